@@ -1,0 +1,114 @@
+"""ctypes binding of libdvgr_hip.so (C ABI declared in include/dvgr.h).
+
+There is NO fallback: if the HIP library is missing this module raises, and so does every
+product entry point that needs it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdvgr_hip.so")
+
+DVGR_F32, DVGR_BF16 = 0, 1
+
+# enum dvgr_param_kind
+(P_QA_W1, P_QA_B1, P_QA_W2, P_QA_B2, P_WQ, P_BQ, P_GAT_W, P_GAT_B, P_GAT_A, P_GAT_C,
+ P_SF_P1, P_SF_BP, P_SF_P2, P_MFB_W0, P_MFB_B0, P_MFB_W1, P_MFB_B1, P_MFB_WO, P_MFB_BO, P_KINDS) = range(20)
+# enum dvgr_saved_kind
+(S_QA_D, S_QA_NRM, S_QA_A, S_QA_AH, S_QA_S, S_QA_Q, S_P, S_S, S_X, S_WH, S_U, S_V, S_TN, S_BETA,
+ S_MFB_X0, S_MFB_X1, S_MFB_Z, S_KINDS) = range(18)
+
+ERRORS = {-1: "DVGR_E_DIMS (unsupported dimensions)", -2: "DVGR_E_NULL (null pointer)",
+          -3: "DVGR_E_WORKSPACE (saved/workspace buffer too small)", -4: "DVGR_E_ALIGN (pointer not 16-byte aligned)",
+          -5: "DVGR_E_KIND (unknown tensor kind)"}
+
+
+class Dims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "N", "T", "D", "Wd", "L", "G", "dtype")]
+
+
+class IO(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("A", "M", "dq", "words", "qlen", "vis", "aq_embed", "mq_embed",
+                                          "com_app", "com_mot", "aq_fusion", "mq_fusion")]
+
+
+class Grads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("g_vis", "g_aq_embed", "g_mq_embed", "g_com_app", "g_com_mot",
+                                          "g_aq_fusion", "g_mq_fusion", "gA", "gM", "gdq", "gwords", "gparams")]
+
+
+# every symbol include/dvgr.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("dvgr_version", C.c_char_p, []),
+    ("dvgr_check_dims", C.c_int, [C.POINTER(Dims)]),
+    ("dvgr_param_count", C.c_int64, [C.POINTER(Dims)]),
+    ("dvgr_param_offset", C.c_int, [C.POINTER(Dims), C.c_int, C.c_int, C.c_int,
+                                    C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("dvgr_param_layer_range", C.c_int, [C.POINTER(Dims), C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("dvgr_saved_bytes", C.c_size_t, [C.POINTER(Dims)]),
+    ("dvgr_saved_offset", C.c_int, [C.POINTER(Dims), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    ("dvgr_workspace_bytes", C.c_size_t, [C.POINTER(Dims)]),
+    ("dvgr_pack_weights", C.c_int, [C.POINTER(Dims), C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("dvgr_unit_forward", C.c_int, [C.POINTER(Dims), C.c_void_p, C.c_void_p, C.POINTER(IO), C.c_void_p, C.c_size_t,
+                                    C.c_void_p, C.c_size_t, C.c_int, C.c_uint64, C.c_void_p]),
+    ("dvgr_unit_backward", C.c_int, [C.POINTER(Dims), C.c_void_p, C.c_void_p, C.POINTER(IO), C.POINTER(Grads),
+                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_uint64,
+                                     C.POINTER(C.c_void_p), C.c_void_p]),
+]
+
+# test hooks declared in include/dvgr_debug.h
+SYMBOLS += [
+    ("dvgr_dbg_gemm", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
+                                C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int,
+                                C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
+    ("dvgr_dbg_colsum", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("dvgr_dbg_keep_mask", C.c_int, [C.c_uint32, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("dvgr_dbg_site_key", C.c_uint32, [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int]),
+]
+
+_lib = None
+
+
+def load():
+    """Load libdvgr_hip.so (once).  Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()' "
+            "or make -C dualvgr-videoqa_amd/csrc).  There is no CPU/eager fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, restype, argtypes in SYMBOLS:
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str):
+    if code == 0:
+        return
+    if code < 0:
+        raise RuntimeError(f"{what} failed: {ERRORS.get(code, code)}")
+    raise RuntimeError(f"{what} failed: hipError_t {code}")
+
+
+def make_dims(B, N, T, D, Wd, L, G=1, dtype=DVGR_F32) -> Dims:
+    return Dims(B, N, T, D, Wd, L, G, dtype)
+
+
+def param_offset(dims: Dims, kind: int, layer: int = 0, mod: int = 0):
+    off, rows, cols = C.c_int64(), C.c_int64(), C.c_int64()
+    check(load().dvgr_param_offset(C.byref(dims), kind, layer, mod, C.byref(off), C.byref(rows), C.byref(cols)),
+          "dvgr_param_offset")
+    return off.value, rows.value, cols.value
+
+
+def saved_offset(dims: Dims, kind: int, layer: int = 0, mod: int = 0) -> int:
+    off = C.c_size_t()
+    check(load().dvgr_saved_offset(C.byref(dims), kind, layer, mod, C.byref(off)), "dvgr_saved_offset")
+    return off.value

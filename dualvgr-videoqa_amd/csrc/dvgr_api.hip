@@ -1,0 +1,597 @@
+// dvgr_api.hip -- C ABI (include/dvgr.h): layouts, argument checks and the stage schedules of the
+// forward and backward passes.  Host code only; all device work is enqueued on the caller's stream.
+#include <string.h>
+
+#include "dvgr_gemm.h"
+#include "dvgr_stages.h"
+
+using namespace dvgr;
+
+namespace dvgr { size_t gat_lds_bytes_max(int N, int F); }
+
+#define DVGR_TRY(expr)                 \
+  do {                                 \
+    const int _e = (expr);             \
+    if (_e != 0) return _e;            \
+  } while (0)
+
+namespace {
+
+struct FwdWs { int64_t Y, total; };
+FwdWs fwd_ws(const dvgr_dims& d) {
+  FwdWs w{};
+  int64_t o = 0;
+  w.Y = o; o += round64((int64_t)d.L * d.B * d.T * d.D);
+  w.total = o;
+  return w;
+}
+
+struct BwdWs {
+  int64_t dpo, dzf, dp0, dp1, dw[2], dpre[2], dz[2], dWh[2], ds_part[2], da_part[2], dc_part[2];
+  int64_t dp_cat, dqbar, dr, dy, total;
+};
+BwdWs bwd_ws(const dvgr_dims& d) {
+  BwdWs w{};
+  const int64_t BN = (int64_t)d.B * d.N, D = d.D, F = d.D / 4;
+  int64_t o = 0;
+  w.dpo = o; o += round64(BN * D);
+  w.dzf = o; o += round64(BN * kMfbPooled);
+  w.dp0 = o; o += round64(BN * kMfbHidden);
+  w.dp1 = o; o += round64(BN * kMfbHidden);
+  for (int m = 0; m < 2; ++m) {
+    w.dw[m] = o;      o += round64(2 * BN);
+    w.dpre[m] = o;    o += round64(2 * BN * D);
+    w.dz[m] = o;      o += round64(2 * BN * D);
+    w.dWh[m] = o;     o += round64(BN * kHeads * F);
+    w.ds_part[m] = o; o += round64((int64_t)d.B * kHeads * d.N);
+    w.da_part[m] = o; o += round64((int64_t)d.B * kHeads * 2 * F);
+    w.dc_part[m] = o; o += round64((int64_t)d.B * kHeads);
+  }
+  w.dp_cat = o; o += round64((int64_t)d.B * 2 * D);
+  w.dqbar = o;  o += round64((int64_t)d.B * d.Wd);
+  w.dr = o;     o += round64((int64_t)d.B * d.T);
+  w.dy = o;     o += round64((int64_t)d.B * d.T * D);
+  w.total = o;
+  return w;
+}
+
+inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// C = act(A[M,K] . B[N,K]^T + bias)                      (forward Linear)
+GemmProblem nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+               const float* bias, int M, int N, int K, int act, uint32_t drop_a = 0) {
+  GemmProblem p{};
+  p.A = operand(A, lda, drop_a); p.B = operand(B, ldb);
+  p.C = C; p.ldc = ldc; p.bias = bias; p.M = M; p.N = N; p.K = K; p.kseg = K; p.act = act;
+  return p;
+}
+// C (+)= A[M,K] . B[K,N]                                  (backward data)
+GemmProblem nn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+               int M, int N, int K, int accumulate, uint32_t drop_c = 0) {
+  GemmProblem p{};
+  p.A = operand(A, lda); p.B = operand(B, ldb);
+  p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.kseg = K; p.accumulate = accumulate; p.drop_key_c = drop_c;
+  return p;
+}
+// C = A[K,M]^T . B[K,N]                                   (backward weight)
+GemmProblem tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+               int M, int N, int K, uint32_t drop_b = 0) {
+  GemmProblem p{};
+  p.A = operand(A, lda); p.B = operand(B, ldb, drop_b);
+  p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.kseg = K;
+  return p;
+}
+
+struct Keys {          // dropout keys of one layer (0 in eval mode)
+  uint32_t x[2][2], out[2][2], alpha[2][8];
+};
+Keys layer_keys(int train, uint64_t seed, int l) {
+  Keys k{};
+  if (!train) return k;
+  for (int m = 0; m < 2; ++m)
+    for (int g = 0; g < 2; ++g) {
+      k.x[m][g] = site_key(seed, drop_site(l, m, g, 0));
+      k.out[m][g] = site_key(seed, drop_site(l, m, g, 5));
+      for (int h = 0; h < 4; ++h) k.alpha[m][g * 4 + h] = site_key(seed, drop_site(l, m, g, 1 + h));
+    }
+  return k;
+}
+
+int check_common(const dvgr_dims* d, const void* params, const dvgr_io* io, const void* saved, size_t saved_bytes,
+                 const void* ws, size_t ws_bytes) {
+  if (!d) return DVGR_E_NULL;
+  DVGR_TRY(dvgr_check_dims(d));
+  if (!params || !io || !saved || !ws) return DVGR_E_NULL;
+  if (!io->A || !io->M || !io->dq || !io->words || !io->qlen || !io->vis || !io->aq_embed || !io->mq_embed ||
+      !io->com_app || !io->com_mot || !io->aq_fusion || !io->mq_fusion)
+    return DVGR_E_NULL;
+  if (saved_bytes < dvgr_saved_bytes(d) || ws_bytes < dvgr_workspace_bytes(d)) return DVGR_E_WORKSPACE;
+  const void* ptrs[] = {params, io->A, io->M, io->dq, io->words, io->vis, io->aq_embed, io->mq_embed,
+                        io->com_app, io->com_mot, io->aq_fusion, io->mq_fusion, saved, ws};
+  for (const void* p : ptrs)
+    if (!aligned16(p)) return DVGR_E_ALIGN;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dvgr_version(void) { return "dvgr-hip 0.1.0 gfx950"; }
+
+int dvgr_check_dims(const dvgr_dims* d) {
+  if (!d) return DVGR_E_NULL;
+  if (d->B < 1 || d->N < 1 || d->T < 1 || d->L < 1) return DVGR_E_DIMS;
+  if (d->G != 1) return DVGR_E_DIMS;
+  if (d->D < 64 || d->D % 64) return DVGR_E_DIMS;
+  if (d->Wd < 4 || d->Wd % 4) return DVGR_E_DIMS;
+  if (d->N > 64 || d->T > 256) return DVGR_E_DIMS;
+  if (d->dtype != DVGR_F32 && d->dtype != DVGR_BF16) return DVGR_E_DIMS;
+  if (gat_lds_bytes_max(d->N, d->D / 4) > 160 * 1024) return DVGR_E_DIMS;
+  if ((int64_t)d->B * d->N * d->D * 2 >= (1ll << 32)) return DVGR_E_DIMS;   // 32-bit dropout counters
+  return 0;
+}
+
+int64_t dvgr_param_count(const dvgr_dims* d) { return d ? param_layout(*d).total : 0; }
+
+int dvgr_param_offset(const dvgr_dims* d, int kind, int layer, int mod, int64_t* offset, int64_t* rows, int64_t* cols) {
+  if (!d || !offset || !rows || !cols) return DVGR_E_NULL;
+  const ParamLayout p = param_layout(*d);
+  const int64_t D = d->D, Wd = d->Wd, F = d->D / 4;
+  if (kind < 0 || kind >= DVGR_P_KINDS) return DVGR_E_KIND;
+  if (kind < DVGR_P_MFB_W0 && (layer < 0 || layer >= d->L || mod < 0 || mod > 1)) return DVGR_E_KIND;
+  const int64_t lb = p.layer_stride * layer, mb = lb + p.mod_base + p.mod_stride * mod;
+  switch (kind) {
+    case DVGR_P_QA_W1: *offset = lb + p.qa_w1; *rows = D; *cols = D; break;
+    case DVGR_P_QA_B1: *offset = lb + p.qa_b1; *rows = 1; *cols = D; break;
+    case DVGR_P_QA_W2: *offset = lb + p.qa_w2; *rows = 1; *cols = D; break;
+    case DVGR_P_QA_B2: *offset = lb + p.qa_b2; *rows = 1; *cols = 1; break;
+    case DVGR_P_WQ: *offset = mb + p.wq; *rows = D; *cols = Wd; break;
+    case DVGR_P_BQ: *offset = mb + p.bq; *rows = 1; *cols = D; break;
+    case DVGR_P_GAT_W: *offset = mb + p.gat_w; *rows = kHeads * F; *cols = D; break;
+    case DVGR_P_GAT_B: *offset = mb + p.gat_b; *rows = 1; *cols = kHeads * F; break;
+    case DVGR_P_GAT_A: *offset = mb + p.gat_a; *rows = kHeads; *cols = 2 * F; break;
+    case DVGR_P_GAT_C: *offset = mb + p.gat_c; *rows = 1; *cols = kHeads; break;
+    case DVGR_P_SF_P1: *offset = mb + p.sf_p1; *rows = D; *cols = D; break;
+    case DVGR_P_SF_BP: *offset = mb + p.sf_bp; *rows = 1; *cols = D; break;
+    case DVGR_P_SF_P2: *offset = mb + p.sf_p2; *rows = 1; *cols = D; break;
+    case DVGR_P_MFB_W0: *offset = p.mfb_w0; *rows = kMfbHidden; *cols = D; break;
+    case DVGR_P_MFB_B0: *offset = p.mfb_b0; *rows = 1; *cols = kMfbHidden; break;
+    case DVGR_P_MFB_W1: *offset = p.mfb_w1; *rows = kMfbHidden; *cols = D; break;
+    case DVGR_P_MFB_B1: *offset = p.mfb_b1; *rows = 1; *cols = kMfbHidden; break;
+    case DVGR_P_MFB_WO: *offset = p.mfb_wo; *rows = D; *cols = kMfbPooled; break;
+    case DVGR_P_MFB_BO: *offset = p.mfb_bo; *rows = 1; *cols = D; break;
+    default: return DVGR_E_KIND;
+  }
+  return 0;
+}
+
+int dvgr_param_layer_range(const dvgr_dims* d, int layer, int64_t* first, int64_t* last) {
+  if (!d || !first || !last) return DVGR_E_NULL;
+  const ParamLayout p = param_layout(*d);
+  if (layer < 0 || layer > d->L) return DVGR_E_KIND;
+  if (layer == d->L) { *first = p.mfb_base; *last = p.total; }
+  else { *first = p.layer_stride * layer; *last = p.layer_stride * (layer + 1); }
+  return 0;
+}
+
+size_t dvgr_saved_bytes(const dvgr_dims* d) { return d ? (size_t)saved_layout(*d).total * sizeof(float) : 0; }
+
+int dvgr_saved_offset(const dvgr_dims* d, int kind, int layer, int mod, size_t* offset_bytes) {
+  if (!d || !offset_bytes) return DVGR_E_NULL;
+  const SavedLayout s = saved_layout(*d);
+  if (kind < 0 || kind >= DVGR_S_KINDS) return DVGR_E_KIND;
+  if (kind < DVGR_S_MFB_X0 && (layer < 0 || layer >= d->L || mod < 0 || mod > 1)) return DVGR_E_KIND;
+  const int64_t lb = s.layer_stride * layer, mb = lb + s.mod_base + s.mod_stride * mod;
+  int64_t o;
+  switch (kind) {
+    case DVGR_S_QA_D: o = lb + s.qa_d; break;
+    case DVGR_S_QA_NRM: o = lb + s.qa_nrm; break;
+    case DVGR_S_QA_A: o = lb + s.qa_a; break;
+    case DVGR_S_QA_AH: o = lb + s.qa_ah; break;
+    case DVGR_S_QA_S: o = lb + s.qa_s; break;
+    case DVGR_S_QA_Q: o = lb + s.qa_q; break;
+    case DVGR_S_P: o = mb + s.p; break;
+    case DVGR_S_S: o = mb + s.s; break;
+    case DVGR_S_X: o = mb + s.x; break;
+    case DVGR_S_WH: o = mb + s.wh; break;
+    case DVGR_S_U: o = mb + s.u; break;
+    case DVGR_S_V: o = mb + s.v; break;
+    case DVGR_S_TN: o = mb + s.tn; break;
+    case DVGR_S_BETA: o = mb + s.beta; break;
+    case DVGR_S_MFB_X0: o = s.mfb_x0; break;
+    case DVGR_S_MFB_X1: o = s.mfb_x1; break;
+    case DVGR_S_MFB_Z: o = s.mfb_z; break;
+    default: return DVGR_E_KIND;
+  }
+  *offset_bytes = (size_t)o * sizeof(float);
+  return 0;
+}
+
+size_t dvgr_workspace_bytes(const dvgr_dims* d) {
+  if (!d) return 0;
+  const int64_t f = fwd_ws(*d).total, b = bwd_ws(*d).total;
+  return (size_t)(f > b ? f : b) * sizeof(float);
+}
+
+int dvgr_pack_weights(const dvgr_dims* d, const float* params, void* params_lp, void* stream) {
+  if (!d || !params || !params_lp) return DVGR_E_NULL;
+  DVGR_TRY(dvgr_check_dims(d));
+  return to_bf16((hipStream_t)stream, params, params_lp, param_layout(*d).total);
+}
+
+// =================================================================================================
+// Forward schedule (stages S0..S6 of oracle/unit_manual.py)
+// =================================================================================================
+int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* params_lp, const dvgr_io* io,
+                      void* saved_v, size_t saved_bytes, void* ws_v, size_t ws_bytes, int train, uint64_t seed,
+                      void* stream) {
+  (void)params_lp;
+  DVGR_TRY(check_common(dp, params, io, saved_v, saved_bytes, ws_v, ws_bytes));
+  const dvgr_dims d = *dp;
+  hipStream_t st = (hipStream_t)stream;
+  const ParamLayout P = param_layout(d);
+  const SavedLayout S = saved_layout(d);
+  const FwdWs W = fwd_ws(d);
+  float* saved = (float*)saved_v;
+  float* ws = (float*)ws_v;
+  const int B = d.B, N = d.N, T = d.T, D = d.D, Wd = d.Wd, L = d.L, F = D / 4, HF = kHeads * F;
+  const int BN = B * N, BT = B * T;
+  const int64_t BND = (int64_t)BN * D;
+  auto lp = [&](int l) { return params + P.layer_stride * l; };
+  auto mp = [&](int l, int m) { return params + P.layer_stride * l + P.mod_base + P.mod_stride * m; };
+  auto ls = [&](int l) { return saved + S.layer_stride * l; };
+  auto ms = [&](int l, int m) { return saved + S.layer_stride * l + S.mod_base + S.mod_stride * m; };
+
+  // ---- S0: query side of every layer (does not depend on A / M) ---------------------------------
+  for (int l0 = 0; l0 < L; l0 += kMaxBatch) {
+    GemmBatch gb{};
+    for (int l = l0; l < L && l < l0 + kMaxBatch; ++l)
+      gb.p[gb.n++] = nt(io->dq, D, lp(l) + P.qa_w1, D, ws + W.Y + (int64_t)l * BT * D, D, lp(l) + P.qa_b1, BT, D, D, ACT_NONE);
+    DVGR_TRY(gemm_launch(st, KC, KC, gb));
+  }
+  {
+    QaRowsArgs a{};
+    a.Y = ws + W.Y; a.params = params; a.off_w2 = P.qa_w2; a.off_b2 = P.qa_b2; a.layer_stride = P.layer_stride;
+    a.words = io->words; a.qlen = io->qlen; a.saved = saved; a.s_layer_stride = S.layer_stride;
+    a.s_d = S.qa_d; a.s_nrm = S.qa_nrm; a.s_a = S.qa_a; a.s_ah = S.qa_ah; a.s_S = S.qa_s; a.s_q = S.qa_q;
+    a.B = B; a.T = T; a.D = D; a.Wd = Wd; a.L = L;
+    DVGR_TRY(qa_rows_fwd(st, a));
+  }
+  {
+    GemmBatch gb{};
+    for (int l = 0; l < L; ++l)
+      for (int m = 0; m < 2; ++m) {
+        gb.p[gb.n++] = nt(ls(l) + S.qa_q, Wd, mp(l, m) + P.wq, Wd, ms(l, m) + S.p, D, mp(l, m) + P.bq, B, D, Wd, ACT_NONE);
+        if (gb.n == kMaxBatch || (l == L - 1 && m == 1)) { DVGR_TRY(gemm_launch(st, KC, KC, gb)); gb.n = 0; }
+      }
+  }
+
+  // ---- layers ---------------------------------------------------------------------------------------
+  for (int l = 0; l < L; ++l) {
+    const Keys K = layer_keys(train, seed, l);
+    const float* Xin[2] = {l == 0 ? io->A : ms(l - 1, 0) + S.x, l == 0 ? io->M : ms(l - 1, 1) + S.x};
+    float* outc[2] = {io->com_app + l * BND, io->com_mot + l * BND};
+    float* outs[2] = {io->aq_fusion + l * BND, io->mq_fusion + l * BND};
+    // S1
+    DVGR_TRY(punish_fwd(st, Xin[0], Xin[1], ms(l, 0) + S.p, ms(l, 1) + S.p, ms(l, 0) + S.s, ms(l, 1) + S.s, B, N, D));
+    // S2: Wh = drop_x(X) . Wcat^T + bcat
+    {
+      GemmBatch gb{};
+      for (int m = 0; m < 2; ++m) {
+        if (!train) {
+          gb.p[gb.n++] = nt(Xin[m], D, mp(l, m) + P.gat_w, D, ms(l, m) + S.wh, HF, mp(l, m) + P.gat_b, BN, HF, D, ACT_NONE);
+        } else {
+          for (int g = 0; g < 2; ++g)
+            gb.p[gb.n++] = nt(Xin[m], D, mp(l, m) + P.gat_w + (int64_t)g * 4 * F * D, D, ms(l, m) + S.wh + g * 4 * F, HF,
+                              mp(l, m) + P.gat_b + g * 4 * F, BN, 4 * F, D, ACT_NONE, K.x[m][g]);
+        }
+      }
+      DVGR_TRY(gemm_launch(st, KC, KC, gb));
+    }
+    // S3
+    {
+      GatAttnArgs a{};
+      for (int m = 0; m < 2; ++m) {
+        a.Wh[m] = ms(l, m) + S.wh; a.s[m] = ms(l, m) + S.s;
+        a.gat_a[m] = mp(l, m) + P.gat_a; a.gat_c[m] = mp(l, m) + P.gat_c;
+        a.u[m] = ms(l, m) + S.u; a.v[m] = ms(l, m) + S.v;
+        a.out_c[m] = outc[m]; a.out_s[m] = outs[m];
+        for (int h = 0; h < 8; ++h) a.key_alpha[m][h] = K.alpha[m][h];
+        for (int g = 0; g < 2; ++g) a.key_out[m][g] = K.out[m][g];
+      }
+      a.B = B; a.N = N; a.D = D;
+      DVGR_TRY(gat_attn_fwd(st, a));
+    }
+    // S4: tn_v = tanh(z_v . P1^T + bP)
+    {
+      GemmBatch gb{};
+      for (int m = 0; m < 2; ++m) {
+        gb.p[gb.n++] = nt(outc[m], D, mp(l, m) + P.sf_p1, D, ms(l, m) + S.tn, D, mp(l, m) + P.sf_bp, BN, D, D, ACT_TANH);
+        gb.p[gb.n++] = nt(outs[m], D, mp(l, m) + P.sf_p1, D, ms(l, m) + S.tn + BND, D, mp(l, m) + P.sf_bp, BN, D, D, ACT_TANH);
+      }
+      DVGR_TRY(gemm_launch(st, KC, KC, gb));
+    }
+    // S5
+    {
+      SfCombineArgs a{};
+      for (int m = 0; m < 2; ++m) {
+        a.X[m] = Xin[m]; a.z0[m] = outc[m]; a.z1[m] = outs[m]; a.tn[m] = ms(l, m) + S.tn;
+        a.p2[m] = mp(l, m) + P.sf_p2; a.beta[m] = ms(l, m) + S.beta; a.Xout[m] = ms(l, m) + S.x;
+        a.o[m] = (l == L - 1) ? (m == 0 ? io->aq_embed : io->mq_embed) : nullptr;
+      }
+      a.rows = BN; a.D = D;
+      DVGR_TRY(sf_combine_fwd(st, a));
+    }
+  }
+
+  // ---- S6: MFB ------------------------------------------------------------------------------------------
+  {
+    GemmBatch gb{};
+    gb.p[gb.n++] = nt(ms(L - 1, 0) + S.x, D, params + P.mfb_w0, D, saved + S.mfb_x0, kMfbHidden, params + P.mfb_b0, BN, kMfbHidden, D, ACT_ELU);
+    gb.p[gb.n++] = nt(ms(L - 1, 1) + S.x, D, params + P.mfb_w1, D, saved + S.mfb_x1, kMfbHidden, params + P.mfb_b1, BN, kMfbHidden, D, ACT_ELU);
+    DVGR_TRY(gemm_launch(st, KC, KC, gb));
+    DVGR_TRY(mfb_pool_fwd(st, saved + S.mfb_x0, saved + S.mfb_x1, saved + S.mfb_z, BN));
+    GemmBatch go{};
+    go.p[go.n++] = nt(saved + S.mfb_z, kMfbPooled, params + P.mfb_wo, kMfbPooled, io->vis, D, params + P.mfb_bo, BN, D, kMfbPooled, ACT_ELU);
+    DVGR_TRY(gemm_launch(st, KC, KC, go));
+  }
+  return 0;
+}
+
+// =================================================================================================
+// Backward schedule
+// =================================================================================================
+int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* params_lp, const dvgr_io* io,
+                       const dvgr_grads* g, const void* saved_v, size_t saved_bytes, void* ws_v, size_t ws_bytes,
+                       int train, uint64_t seed, void* const* layer_done_events, void* stream) {
+  (void)params_lp;
+  DVGR_TRY(check_common(dp, params, io, saved_v, saved_bytes, ws_v, ws_bytes));
+  if (!g || !g->gA || !g->gM || !g->gdq || !g->gwords || !g->gparams) return DVGR_E_NULL;
+  if (!aligned16(g->gA) || !aligned16(g->gM) || !aligned16(g->gdq) || !aligned16(g->gwords) || !aligned16(g->gparams))
+    return DVGR_E_ALIGN;
+  const dvgr_dims d = *dp;
+  hipStream_t st = (hipStream_t)stream;
+  const ParamLayout P = param_layout(d);
+  const SavedLayout S = saved_layout(d);
+  const BwdWs W = bwd_ws(d);
+  const float* saved = (const float*)saved_v;
+  float* ws = (float*)ws_v;
+  float* gp = g->gparams;
+  const int B = d.B, N = d.N, T = d.T, D = d.D, Wd = d.Wd, L = d.L, F = D / 4, HF = kHeads * F;
+  const int BN = B * N, BT = B * T;
+  const int64_t BND = (int64_t)BN * D;
+  auto lp = [&](int l) { return params + P.layer_stride * l; };
+  auto mp = [&](int l, int m) { return params + P.layer_stride * l + P.mod_base + P.mod_stride * m; };
+  auto glp = [&](int l) { return gp + P.layer_stride * l; };
+  auto gmp = [&](int l, int m) { return gp + P.layer_stride * l + P.mod_base + P.mod_stride * m; };
+  auto ls = [&](int l) { return saved + S.layer_stride * l; };
+  auto ms = [&](int l, int m) { return saved + S.layer_stride * l + S.mod_base + S.mod_stride * m; };
+  float* dXacc[2] = {g->gA, g->gM};     // running gradient w.r.t. the current layer boundary
+
+  // every element of gparams is written: the tensors below, zeros in the alignment padding
+  {
+    const hipError_t e = hipMemsetAsync(gp, 0, (size_t)P.total * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+  }
+
+  // ---- S6 backward ------------------------------------------------------------------------------------
+  DVGR_TRY(elu_bwd(st, g->g_vis, io->vis, ws + W.dpo, BND));
+  {
+    GemmBatch gb{};   // dWo = dpo^T . z
+    gb.p[gb.n++] = tn(ws + W.dpo, D, saved + S.mfb_z, kMfbPooled, gp + P.mfb_wo, kMfbPooled, D, kMfbPooled, BN);
+    DVGR_TRY(gemm_launch(st, IC, IC, gb));
+    GemmBatch gd{};   // dz = dpo . Wo
+    gd.p[gd.n++] = nn(ws + W.dpo, D, params + P.mfb_wo, kMfbPooled, ws + W.dzf, kMfbPooled, BN, kMfbPooled, D, 0);
+    DVGR_TRY(gemm_launch(st, KC, IC, gd));
+  }
+  DVGR_TRY(mfb_pool_bwd(st, ws + W.dzf, saved + S.mfb_x0, saved + S.mfb_x1, ws + W.dp0, ws + W.dp1, BN));
+  {
+    GemmBatch gb{};   // dW0 = dp0^T . A_final, dW1 = dp1^T . M_final
+    gb.p[gb.n++] = tn(ws + W.dp0, kMfbHidden, ms(L - 1, 0) + S.x, D, gp + P.mfb_w0, D, kMfbHidden, D, BN);
+    gb.p[gb.n++] = tn(ws + W.dp1, kMfbHidden, ms(L - 1, 1) + S.x, D, gp + P.mfb_w1, D, kMfbHidden, D, BN);
+    DVGR_TRY(gemm_launch(st, IC, IC, gb));
+    GemmBatch gd{};   // dA = dp0 . W0, dM = dp1 . W1
+    gd.p[gd.n++] = nn(ws + W.dp0, kMfbHidden, params + P.mfb_w0, D, dXacc[0], D, BN, D, kMfbHidden, 0);
+    gd.p[gd.n++] = nn(ws + W.dp1, kMfbHidden, params + P.mfb_w1, D, dXacc[1], D, BN, D, kMfbHidden, 0);
+    DVGR_TRY(gemm_launch(st, KC, IC, gd));
+    ColsumBatch cb{};
+    cb.j[cb.n++] = ColsumJob{ws + W.dpo, nullptr, nullptr, nullptr, BN, 0, D, D, gp + P.mfb_bo};
+    cb.j[cb.n++] = ColsumJob{ws + W.dp0, nullptr, nullptr, nullptr, BN, 0, kMfbHidden, kMfbHidden, gp + P.mfb_b0};
+    cb.j[cb.n++] = ColsumJob{ws + W.dp1, nullptr, nullptr, nullptr, BN, 0, kMfbHidden, kMfbHidden, gp + P.mfb_b1};
+    DVGR_TRY(colsum(st, cb));
+  }
+  if (layer_done_events && layer_done_events[L]) {
+    const hipError_t e = hipEventRecord((hipEvent_t)layer_done_events[L], st);
+    if (e != hipSuccess) return (int)e;
+  }
+
+  // ---- layers, last to first -----------------------------------------------------------------------
+  for (int l = L - 1; l >= 0; --l) {
+    const Keys K = layer_keys(train, seed, l);
+    const float* Xin[2] = {l == 0 ? io->A : ms(l - 1, 0) + S.x, l == 0 ? io->M : ms(l - 1, 1) + S.x};
+    const float* outc[2] = {io->com_app + l * BND, io->com_mot + l * BND};
+    const float* outs[2] = {io->aq_fusion + l * BND, io->mq_fusion + l * BND};
+    ColsumBatch cb{};
+    // S5/S4 backward, row part
+    {
+      SfBwdArgs a{};
+      for (int m = 0; m < 2; ++m) {
+        a.dX[m] = dXacc[m];
+        a.g_embed[m] = (l == L - 1) ? (m == 0 ? g->g_aq_embed : g->g_mq_embed) : nullptr;
+        a.z0[m] = outc[m]; a.z1[m] = outs[m]; a.tn[m] = ms(l, m) + S.tn; a.beta[m] = ms(l, m) + S.beta;
+        a.p2[m] = mp(l, m) + P.sf_p2;
+        const float* gc = m == 0 ? g->g_com_app : g->g_com_mot;
+        const float* gs = m == 0 ? g->g_aq_fusion : g->g_mq_fusion;
+        a.g_z0[m] = gc ? gc + l * BND : nullptr;
+        a.g_z1[m] = gs ? gs + l * BND : nullptr;
+        a.dw[m] = ws + W.dw[m]; a.dpre[m] = ws + W.dpre[m]; a.dz[m] = ws + W.dz[m];
+      }
+      a.rows = BN; a.D = D;
+      DVGR_TRY(sf_bwd(st, a));
+    }
+    for (int m = 0; m < 2; ++m) {
+      cb.j[cb.n++] = ColsumJob{ms(l, m) + S.tn, nullptr, ws + W.dw[m], nullptr, 2 * BN, 0, D, D, gmp(l, m) + P.sf_p2};
+      cb.j[cb.n++] = ColsumJob{ws + W.dpre[m], nullptr, nullptr, nullptr, 2 * BN, 0, D, D, gmp(l, m) + P.sf_bp};
+    }
+    {
+      GemmBatch gb{};   // dP1 = sum_v dpre_v^T . z_v   (reduction over the two views = two row segments)
+      for (int m = 0; m < 2; ++m) {
+        GemmProblem p = tn(ws + W.dpre[m], D, outc[m], D, gmp(l, m) + P.sf_p1, D, D, D, 2 * BN);
+        p.kseg = BN;
+        p.A.p1 = ws + W.dpre[m] + BND;
+        p.B.p1 = outs[m];
+        gb.p[gb.n++] = p;
+      }
+      DVGR_TRY(gemm_launch(st, IC, IC, gb));
+      GemmBatch gd{};   // dz_v += dpre_v . P1
+      for (int m = 0; m < 2; ++m)
+        gd.p[gd.n++] = nn(ws + W.dpre[m], D, mp(l, m) + P.sf_p1, D, ws + W.dz[m], D, 2 * BN, D, D, 1);
+      DVGR_TRY(gemm_launch(st, KC, IC, gd));
+    }
+    // S3 backward
+    {
+      GatAttnBwdArgs a{};
+      for (int m = 0; m < 2; ++m) {
+        a.dz[m] = ws + W.dz[m]; a.out_c[m] = outc[m]; a.out_s[m] = outs[m];
+        a.Wh[m] = ms(l, m) + S.wh; a.s[m] = ms(l, m) + S.s; a.u[m] = ms(l, m) + S.u; a.v[m] = ms(l, m) + S.v;
+        a.gat_a[m] = mp(l, m) + P.gat_a; a.gat_c[m] = mp(l, m) + P.gat_c;
+        a.dWh[m] = ws + W.dWh[m]; a.ds_part[m] = ws + W.ds_part[m]; a.da_part[m] = ws + W.da_part[m];
+        a.dc_part[m] = ws + W.dc_part[m];
+        for (int h = 0; h < 8; ++h) a.key_alpha[m][h] = K.alpha[m][h];
+        for (int gi = 0; gi < 2; ++gi) a.key_out[m][gi] = K.out[m][gi];
+      }
+      a.B = B; a.N = N; a.D = D;
+      DVGR_TRY(gat_attn_bwd(st, a));
+    }
+    for (int m = 0; m < 2; ++m) {
+      cb.j[cb.n++] = ColsumJob{ws + W.da_part[m], nullptr, nullptr, nullptr, B, 0, kHeads * 2 * F, kHeads * 2 * F, gmp(l, m) + P.gat_a};
+      cb.j[cb.n++] = ColsumJob{ws + W.dc_part[m], nullptr, nullptr, nullptr, B, 0, kHeads, kHeads, gmp(l, m) + P.gat_c};
+      cb.j[cb.n++] = ColsumJob{ws + W.dWh[m], nullptr, nullptr, nullptr, BN, 0, HF, HF, gmp(l, m) + P.gat_b};
+    }
+    // S2 backward: dWcat = dWh^T . drop_x(X);  dX += drop_x(dWh . Wcat)
+    {
+      GemmBatch gb{};
+      for (int m = 0; m < 2; ++m) {
+        if (!train) {
+          gb.p[gb.n++] = tn(ws + W.dWh[m], HF, Xin[m], D, gmp(l, m) + P.gat_w, D, HF, D, BN);
+        } else {
+          for (int gi = 0; gi < 2; ++gi)
+            gb.p[gb.n++] = tn(ws + W.dWh[m] + gi * 4 * F, HF, Xin[m], D, gmp(l, m) + P.gat_w + (int64_t)gi * 4 * F * D, D,
+                              4 * F, D, BN, K.x[m][gi]);
+        }
+      }
+      DVGR_TRY(gemm_launch(st, IC, IC, gb));
+      if (!train) {
+        GemmBatch gd{};
+        for (int m = 0; m < 2; ++m)
+          gd.p[gd.n++] = nn(ws + W.dWh[m], HF, mp(l, m) + P.gat_w, D, dXacc[m], D, BN, D, HF, 1);
+        DVGR_TRY(gemm_launch(st, KC, IC, gd));
+      } else {
+        for (int gi = 0; gi < 2; ++gi) {   // the two GATs dropped x with different masks: two passes
+          GemmBatch gd{};
+          for (int m = 0; m < 2; ++m)
+            gd.p[gd.n++] = nn(ws + W.dWh[m] + gi * 4 * F, HF, mp(l, m) + P.gat_w + (int64_t)gi * 4 * F * D, D, dXacc[m], D,
+                              BN, D, 4 * F, 1, K.x[m][gi]);
+          DVGR_TRY(gemm_launch(st, KC, IC, gd));
+        }
+      }
+    }
+    // S1 backward
+    {
+      PunishBwdArgs a{};
+      for (int m = 0; m < 2; ++m) {
+        a.ds_part[m] = ws + W.ds_part[m]; a.s[m] = ms(l, m) + S.s; a.p[m] = ms(l, m) + S.p;
+        a.X[m] = Xin[m]; a.dX[m] = dXacc[m];
+      }
+      a.dp_cat = ws + W.dp_cat; a.B = B; a.N = N; a.D = D;
+      DVGR_TRY(punish_bwd(st, a));
+    }
+    {
+      GemmBatch gb{};   // dWq[m] = dp[m]^T . q
+      for (int m = 0; m < 2; ++m)
+        gb.p[gb.n++] = tn(ws + W.dp_cat + m * D, 2 * D, ls(l) + S.qa_q, Wd, gmp(l, m) + P.wq, Wd, D, Wd, B);
+      DVGR_TRY(gemm_launch(st, IC, IC, gb));
+      for (int m = 0; m < 2; ++m)
+        cb.j[cb.n++] = ColsumJob{ws + W.dp_cat + m * D, nullptr, nullptr, nullptr, B, 0, D, 2 * D, gmp(l, m) + P.bq};
+      GemmBatch gd{};   // dqbar = [dp_app | dp_mot] . [Wq_app ; Wq_mot]
+      GemmProblem p = nn(ws + W.dp_cat, 2 * D, mp(l, 0) + P.wq, Wd, ws + W.dqbar, Wd, B, Wd, 2 * D, 0);
+      p.kseg = D;
+      p.B.p1 = mp(l, 1) + P.wq;
+      gd.p[gd.n++] = p;
+      DVGR_TRY(gemm_launch(st, KC, IC, gd));
+    }
+    // S0 backward for this layer
+    {
+      QaBwdArgs a{};
+      a.dqbar = ws + W.dqbar; a.words = io->words; a.qlen = io->qlen;
+      a.params = lp(l); a.off_w2 = P.qa_w2; a.layer_stride = 0;
+      a.saved = ls(l); a.s_layer_stride = 0; a.s_d = S.qa_d; a.s_nrm = S.qa_nrm; a.s_a = S.qa_a; a.s_ah = S.qa_ah; a.s_S = S.qa_s;
+      a.gwords = g->gwords; a.dr = ws + W.dr; a.dy = ws + W.dy;
+      a.B = B; a.T = T; a.D = D; a.Wd = Wd; a.L = 1;
+      a.first = (l == L - 1) ? 1 : 0;
+      DVGR_TRY(qa_bwd(st, a));
+      GemmBatch gb{};   // dW1 = dy^T . dq
+      gb.p[gb.n++] = tn(ws + W.dy, D, io->dq, D, glp(l) + P.qa_w1, D, D, D, BT);
+      DVGR_TRY(gemm_launch(st, IC, IC, gb));
+      GemmBatch gd{};   // d(dq) (+)= dy . W1
+      gd.p[gd.n++] = nn(ws + W.dy, D, lp(l) + P.qa_w1, D, g->gdq, D, BT, D, D, l == L - 1 ? 0 : 1);
+      DVGR_TRY(gemm_launch(st, KC, IC, gd));
+      cb.j[cb.n++] = ColsumJob{ws + W.dy, nullptr, nullptr, nullptr, BT, 0, D, D, glp(l) + P.qa_b1};
+      cb.j[cb.n++] = ColsumJob{ls(l) + S.qa_d, nullptr, ws + W.dr, nullptr, BT, 0, D, D, glp(l) + P.qa_w2};
+      cb.j[cb.n++] = ColsumJob{ws + W.dr, nullptr, nullptr, nullptr, BT, 0, 1, 1, glp(l) + P.qa_b2};
+    }
+    DVGR_TRY(colsum(st, cb));
+    if (layer_done_events && layer_done_events[l]) {
+      const hipError_t e = hipEventRecord((hipEvent_t)layer_done_events[l], st);
+      if (e != hipSuccess) return (int)e;
+    }
+  }
+  return 0;
+}
+
+}  // extern "C"
+
+// =================================================================================================
+// Test hooks (include/dvgr_debug.h)
+// =================================================================================================
+#include "../../include/dvgr_debug.h"
+
+namespace dvgr { int keep_mask_launch(hipStream_t st, uint32_t key, int64_t n, float* keep); }
+
+extern "C" {
+
+int dvgr_dbg_gemm(int mode, int M, int N, int K, int kseg, const float* A, const float* A2, int64_t lda,
+                  const float* B, const float* B2, int64_t ldb, float* C, int64_t ldc, const float* bias, int act,
+                  int accumulate, uint32_t drop_key_a, uint32_t drop_key_b, uint32_t drop_key_c, void* stream) {
+  if (!A || !B || !C) return DVGR_E_NULL;
+  GemmBatch gb{};
+  GemmProblem p{};
+  p.A = operand(A, lda, drop_key_a);
+  p.B = operand(B, ldb, drop_key_b);
+  if (A2) p.A.p1 = A2;
+  if (B2) p.B.p1 = B2;
+  p.C = C; p.ldc = ldc; p.bias = bias; p.M = M; p.N = N; p.K = K; p.kseg = (kseg > 0 && kseg < K) ? kseg : K;
+  p.act = act; p.accumulate = accumulate; p.drop_key_c = drop_key_c;
+  gb.p[gb.n++] = p;
+  const int la = mode == 2 ? IC : KC, lb = mode == 0 ? KC : IC;
+  return gemm_launch((hipStream_t)stream, la, lb, gb);
+}
+
+int dvgr_dbg_colsum(const float* M, const float* w, int rows, int cols, int64_t ld, float* out, void* stream) {
+  if (!M || !out) return DVGR_E_NULL;
+  ColsumBatch cb{};
+  cb.j[cb.n++] = ColsumJob{M, nullptr, w, nullptr, rows, 0, cols, ld, out};
+  return colsum((hipStream_t)stream, cb);
+}
+
+int dvgr_dbg_keep_mask(uint32_t key, int64_t n, float* keep, void* stream) {
+  if (!keep) return DVGR_E_NULL;
+  return keep_mask_launch((hipStream_t)stream, key, n, keep);
+}
+
+uint32_t dvgr_dbg_site_key(uint64_t seed, int layer, int mod, int gat, int which) {
+  return site_key(seed, drop_site(layer, mod, gat, which));
+}
+
+}  // extern "C"

@@ -1,0 +1,157 @@
+// dvgr_common.h -- layouts (host) and device helpers shared by every translation unit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/dvgr.h"
+
+namespace dvgr {
+
+constexpr int kHeads = 8;          // 4 common-GAT heads + 4 specific-GAT heads per modality
+constexpr int kMfbHidden = 512;    // mm_dim * factor   (model/fusions/fusions.py:384-395 defaults)
+constexpr int kMfbPooled = 256;    // mm_dim
+constexpr float kDropP = 0.15f;    // model/models.py:95-100
+constexpr float kKeepScale = 1.0f / (1.0f - 0.15f);
+constexpr uint32_t kDropThresh16 = 9830;  // floor(0.15 * 65536): keep iff 16-bit field >= this
+constexpr float kSlope = 0.01f;    // LeakyReLU slope, model/models.py:95-100
+
+// ---------------------------------------------------------------------------------------------
+// Flat parameter layout.  Every tensor starts at a multiple of 64 floats.
+// ---------------------------------------------------------------------------------------------
+struct ParamLayout {
+  int64_t layer_stride;            // floats per unit layer
+  int64_t mod_stride;              // floats per modality block inside a layer
+  int64_t qa_w1, qa_b1, qa_w2, qa_b2;                       // offsets inside a layer block
+  int64_t mod_base;                                          // first modality block inside a layer
+  int64_t wq, bq, gat_w, gat_b, gat_a, gat_c, sf_p1, sf_bp, sf_p2;  // offsets inside a modality block
+  int64_t mfb_base, mfb_w0, mfb_b0, mfb_w1, mfb_b1, mfb_wo, mfb_bo;  // absolute offsets
+  int64_t total;
+};
+
+__host__ __device__ inline int64_t round64(int64_t x) { return (x + 63) / 64 * 64; }
+
+inline ParamLayout param_layout(const dvgr_dims& d) {
+  ParamLayout p{};
+  const int64_t D = d.D, Wd = d.Wd, F = d.D / 4;
+  int64_t o = 0;
+  p.qa_w1 = o; o += round64(D * D);
+  p.qa_b1 = o; o += round64(D);
+  p.qa_w2 = o; o += round64(D);
+  p.qa_b2 = o; o += 64;
+  p.mod_base = o;
+  int64_t m = 0;
+  p.wq = m;    m += round64(D * Wd);
+  p.bq = m;    m += round64(D);
+  p.gat_w = m; m += round64(kHeads * F * D);
+  p.gat_b = m; m += round64(kHeads * F);
+  p.gat_a = m; m += round64(kHeads * 2 * F);
+  p.gat_c = m; m += 64;
+  p.sf_p1 = m; m += round64(D * D);
+  p.sf_bp = m; m += round64(D);
+  p.sf_p2 = m; m += round64(D);
+  p.mod_stride = m;
+  p.layer_stride = o + 2 * m;
+  p.mfb_base = p.layer_stride * d.L;
+  int64_t q = p.mfb_base;
+  p.mfb_w0 = q; q += round64((int64_t)kMfbHidden * D);
+  p.mfb_b0 = q; q += round64(kMfbHidden);
+  p.mfb_w1 = q; q += round64((int64_t)kMfbHidden * D);
+  p.mfb_b1 = q; q += round64(kMfbHidden);
+  p.mfb_wo = q; q += round64(D * (int64_t)kMfbPooled);
+  p.mfb_bo = q; q += round64(D);
+  p.total = q;
+  return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Saved-for-backward layout (float offsets).
+// ---------------------------------------------------------------------------------------------
+struct SavedLayout {
+  int64_t layer_stride, mod_stride, mod_base;
+  int64_t qa_d, qa_nrm, qa_a, qa_ah, qa_s, qa_q;              // inside a layer block
+  int64_t p, s, x, wh, u, v, tn, beta;                        // inside a modality block
+  int64_t mfb_base, mfb_x0, mfb_x1, mfb_z;                    // absolute
+  int64_t total;
+};
+
+inline SavedLayout saved_layout(const dvgr_dims& d) {
+  SavedLayout s{};
+  const int64_t B = d.B, N = d.N, T = d.T, D = d.D, Wd = d.Wd, F = d.D / 4;
+  int64_t o = 0;
+  s.qa_d = o;   o += round64(B * T * D);
+  s.qa_nrm = o; o += round64(B * T);
+  s.qa_a = o;   o += round64(B * T);
+  s.qa_ah = o;  o += round64(B * T);
+  s.qa_s = o;   o += round64(B);
+  s.qa_q = o;   o += round64(B * Wd);
+  s.mod_base = o;
+  int64_t m = 0;
+  s.p = m;    m += round64(B * D);
+  s.s = m;    m += round64(B * N);
+  s.x = m;    m += round64(B * N * D);
+  s.wh = m;   m += round64(B * N * kHeads * F);
+  s.u = m;    m += round64(B * kHeads * N);
+  s.v = m;    m += round64(B * kHeads * N);
+  s.tn = m;   m += round64(2 * B * N * D);
+  s.beta = m; m += round64(B * N * 2);
+  s.mod_stride = m;
+  s.layer_stride = o + 2 * m;
+  s.mfb_base = s.layer_stride * d.L;
+  int64_t q = s.mfb_base;
+  s.mfb_x0 = q; q += round64(B * N * kMfbHidden);
+  s.mfb_x1 = q; q += round64(B * N * kMfbHidden);
+  s.mfb_z = q;  q += round64(B * N * kMfbPooled);
+  s.total = q;
+  return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dropout: counter-based, stateless.  site = ((layer*2 + mod)*2 + gat)*6 + {0: x, 1..4: alpha of
+// head 0..3, 5: out}; `key` = site_key(seed, site) is computed on the host and passed by value.
+// keep(key, idx): one 32-bit hash serves two consecutive elements (16-bit fields).
+// dualvgr-videoqa_amd/dropout.py replicates this bit for bit in numpy.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return x;
+}
+inline uint32_t site_key(uint64_t seed, uint32_t site) {
+  uint32_t k = mix32(site + 0x9E3779B1u);
+  k = mix32(k ^ (uint32_t)(seed >> 32));
+  k = mix32(k ^ (uint32_t)seed);
+  return k | 1u;  // never 0: key 0 means "no dropout at this site"
+}
+inline uint32_t drop_site(int layer, int mod, int gat, int which) {
+  return (uint32_t)(((layer * 2 + mod) * 2 + gat) * 6 + which);
+}
+__device__ __forceinline__ bool drop_keep(uint32_t key, uint32_t idx) {
+  const uint32_t r = mix32(((idx >> 1) * 0x9E3779B1u) ^ key);
+  const uint32_t f = (idx & 1u) ? (r >> 16) : (r & 0xFFFFu);
+  return f >= kDropThresh16;
+}
+// scaled keep factor: 1/(1-p) or 0; key == 0 -> 1 (eval mode)
+__device__ __forceinline__ float drop_factor(uint32_t key, uint32_t idx) {
+  if (key == 0u) return 1.0f;
+  return drop_keep(key, idx) ? kKeepScale : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Small device helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float elu_f(float x) { return x > 0.0f ? x : expm1f(x); }
+// d ELU(P)/dP from the output value O = ELU(P)
+__device__ __forceinline__ float elu_grad_from_out(float o) { return o > 0.0f ? 1.0f : o + 1.0f; }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+}  // namespace dvgr

@@ -1,0 +1,55 @@
+// dvgr_gemm.h -- the one dense-contraction engine of the unit: C (+)= act(A x B + bias).
+//
+// Every contraction on the hot path is one of three shapes:
+//   NT  Y = X . W^T      forward Linear           A = X [m][k] (KC)   B = W  [n][k] (KC)
+//   NN  dX = dY . W      backward-data            A = dY[m][k] (KC)   B = W  [k][n] (IC)
+//   TN  dW = dY^T . X    backward-weight          A = dY[k][m] (IC)   B = X  [k][n] (IC)
+// KC = the reduction index k is contiguous in memory, IC = the tile index is contiguous.
+//
+// CDNA4 mapping: 256 threads = 4 waves (2 x 2), each wave owns a (BM/2) x (BN/2) block of
+// 16x16 accumulator tiles and issues v_mfma_f32_16x16x4_f32 (exact fp32, = fmaf chain).
+// Operand tiles are staged HBM -> registers -> LDS (double-buffered, one barrier per K-tile) so
+// the dropout keep-mask of the x-site can be applied while the data passes through registers.
+// LDS images: KC tile [rows][BK+4] read with ds_read_b128 (lane (r,g) takes k = 4g..4g+3 of row r
+// and feeds MFMA j with element j: the k order inside a 16-block is permuted identically for A and
+// B, which a sum does not care about); IC tile [BK][cols+4] read with 4 ds_read_b32.
+#pragma once
+#include "dvgr_common.h"
+
+namespace dvgr {
+
+enum : int { KC = 0, IC = 1 };
+enum : int { ACT_NONE = 0, ACT_TANH = 1, ACT_ELU = 2 };
+
+struct GemmOperand {
+  const float* p0;     // rows [0, kseg) of the reduction (IC) / the whole matrix (KC)
+  const float* p1;     // rows [kseg, K) of the reduction (IC only; used when kseg < K)
+  int64_t ld;          // leading dimension (floats); multiple of 4
+  uint32_t drop_key;   // 0 = none; keep index = row * ld + col of the source matrix
+};
+
+struct GemmProblem {
+  GemmOperand A, B;
+  float* C;
+  int64_t ldc;
+  const float* bias;   // per output column, nullable
+  int M, N, K, kseg;   // kseg == K when the reduction is one segment
+  int act;             // ACT_*
+  int accumulate;      // C += result instead of C = result
+  uint32_t drop_key_c; // keep mask applied to the result (index row * ldc + col), 0 = none
+};
+
+constexpr int kMaxBatch = 4;
+struct GemmBatch {
+  GemmProblem p[kMaxBatch];
+  int n;
+};
+
+// Enqueue the batch on `stream`.  la / lb in {KC, IC}.  Returns hipError_t as int.
+int gemm_launch(hipStream_t stream, int la, int lb, const GemmBatch& batch);
+
+inline GemmOperand operand(const float* p, int64_t ld, uint32_t drop_key = 0) {
+  GemmOperand o; o.p0 = p; o.p1 = p; o.ld = ld; o.drop_key = drop_key; return o;
+}
+
+}  // namespace dvgr

@@ -1,0 +1,146 @@
+// dvgr_stages.h -- launchers of the non-GEMM kernels of the unit (row-wise, attention and
+// element-wise stages).  Every function enqueues on `st` and returns a hipError_t as int.
+#pragma once
+#include "dvgr_common.h"
+
+namespace dvgr {
+
+// ---- forward ------------------------------------------------------------------------------------
+// S0 (rows): per (b, layer): y -> d = y / max(||y||, 1e-12); r = d.w2 + b2; softmax over all T;
+// mask t < len; renormalise with +1e-5; q = sum_t ah_t words_t.   model/utils.py:68-82
+struct QaRowsArgs {
+  const float* Y;        // [L][B*T][D]  feat_enhance output (workspace)
+  const float* params;   // flat parameter buffer
+  int64_t off_w2, off_b2, layer_stride;
+  const float* words;    // (B, T, Wd)
+  const int64_t* qlen;   // (B)
+  float* saved;          // base of the saved buffer
+  int64_t s_layer_stride, s_d, s_nrm, s_a, s_ah, s_S, s_q;
+  int B, T, D, Wd, L;
+};
+int qa_rows_fwd(hipStream_t st, const QaRowsArgs& a);
+
+// S1: s[mod][b][n] = sigmoid(X[mod][b][n][:] . p[mod][b][:])                model/utils.py:101-103
+int punish_fwd(hipStream_t st, const float* X0, const float* X1, const float* p0, const float* p1,
+               float* s0, float* s1, int B, int N, int D);
+
+// S3: per (b, head, mod): logits, softmax over j, punish-scaled aggregation, ELU, dropout.
+struct GatAttnArgs {
+  const float* Wh[2];    // (B*N, 8F) per modality
+  const float* s[2];     // (B*N)
+  const float* gat_a[2]; // (8, 2F)   [a_l | a_r] per head
+  const float* gat_c[2]; // (8)
+  float* u[2];           // (B, 8, N) saved
+  float* v[2];
+  float* out_c[2];       // common-GAT output   (B, N, D)
+  float* out_s[2];       // specific-GAT output (B, N, D)
+  uint32_t key_alpha[2][8];  // dropout keys (0 = eval)
+  uint32_t key_out[2][2];    // [mod][gat]
+  int B, N, D;
+};
+int gat_attn_fwd(hipStream_t st, const GatAttnArgs& a);
+
+// S5: w_v = tn_v . p2; beta = softmax over the two views; o = sum_v beta_v z_v; X' = X + o.
+struct SfCombineArgs {
+  const float* X[2];     // layer input (B*N, D)
+  const float* z0[2];    // common output
+  const float* z1[2];    // specific output
+  const float* tn[2];    // (2, B*N, D)
+  const float* p2[2];    // (D)
+  float* beta[2];        // (B*N, 2) saved
+  float* o[2];           // fused embedding (B*N, D); nullable
+  float* Xout[2];        // X' (B*N, D)
+  int rows, D;
+};
+int sf_combine_fwd(hipStream_t st, const SfCombineArgs& a);
+
+// S6 middle: z[r][k] = x0[r][2k] x1[r][2k] + x0[r][2k+1] x1[r][2k+1]   model/fusions/fusions.py:430-440
+int mfb_pool_fwd(hipStream_t st, const float* x0, const float* x1, float* z, int rows);
+
+// ---- backward -----------------------------------------------------------------------------------
+// out[i] = g[i] * ELU'(from output y[i]); g == nullptr -> zeros
+int elu_bwd(hipStream_t st, const float* g, const float* y, float* out, int64_t n);
+// dp0 = dz[k/2] * x1 * ELU'(x0), dp1 = dz[k/2] * x0 * ELU'(x1)
+int mfb_pool_bwd(hipStream_t st, const float* dz, const float* x0, const float* x1, float* dp0, float* dp1, int rows);
+
+struct SfBwdArgs {
+  const float* dX[2];      // grad wrt X' (B*N, D)
+  const float* g_embed[2]; // direct upstream grad of the fused embedding (last layer) or nullptr
+  const float* z0[2];
+  const float* z1[2];
+  const float* tn[2];
+  const float* beta[2];
+  const float* p2[2];
+  const float* g_z0[2];    // direct upstream grads of the list outputs, nullable
+  const float* g_z1[2];
+  float* dw[2];            // (2, B*N)
+  float* dpre[2];          // (2, B*N, D)
+  float* dz[2];            // (2, B*N, D)  = beta_v * do + g_z_v   (GEMM adds dpre . P1)
+  int rows, D;
+};
+int sf_bwd(hipStream_t st, const SfBwdArgs& a);
+
+struct GatAttnBwdArgs {
+  const float* dz[2];      // (2, B*N, D): view 0 = grad of common output, view 1 = specific
+  const float* out_c[2];   // saved outputs
+  const float* out_s[2];
+  const float* Wh[2];
+  const float* s[2];
+  const float* u[2];
+  const float* v[2];
+  const float* gat_a[2];
+  const float* gat_c[2];
+  float* dWh[2];           // (B*N, 8F)
+  float* ds_part[2];       // (B, 8, N)
+  float* da_part[2];       // (B, 8, 2F)
+  float* dc_part[2];       // (B, 8)
+  uint32_t key_alpha[2][8];
+  uint32_t key_out[2][2];
+  int B, N, D;
+};
+int gat_attn_bwd(hipStream_t st, const GatAttnBwdArgs& a);
+
+// S1 backward: ds = sum_h ds_part; dtau = ds s (1-s); dX += dtau p; dp = sum_n dtau X.
+struct PunishBwdArgs {
+  const float* ds_part[2];
+  const float* s[2];
+  const float* p[2];
+  const float* X[2];
+  float* dX[2];            // accumulated in place
+  float* dp_cat;           // (B, 2D): cols [mod*D, (mod+1)*D)
+  int B, N, D;
+};
+int punish_bwd(hipStream_t st, const PunishBwdArgs& a);
+
+// S0 backward (rows), all layers, one workgroup per batch element.
+struct QaBwdArgs {
+  const float* dqbar;      // [L][B][Wd]
+  const float* words;
+  const int64_t* qlen;
+  const float* params; int64_t off_w2, layer_stride;
+  const float* saved; int64_t s_layer_stride, s_d, s_nrm, s_a, s_ah, s_S;
+  float* gwords;           // (B, T, Wd) fully written
+  float* dr;               // [L][B*T]
+  float* dy;               // [L][B*T][D]
+  int B, T, D, Wd, L;
+  int first;               // 1: this launch initialises gwords, 0: it accumulates
+};
+int qa_bwd(hipStream_t st, const QaBwdArgs& a);
+
+// Column sums (bias / vector-parameter gradients): out[c] = sum_r w[r] * M[r][c] over one or two row
+// segments; deterministic order.
+struct ColsumJob {
+  const float* M0; const float* M1;   // row segments (M1 nullable)
+  const float* w0; const float* w1;   // per-row weights, nullable = 1
+  int rows0, rows1, cols;
+  int64_t ld;
+  float* out;
+};
+constexpr int kMaxColsumJobs = 16;
+struct ColsumBatch { ColsumJob j[kMaxColsumJobs]; int n; };
+int colsum(hipStream_t st, const ColsumBatch& b);
+
+// fp32 -> bf16 shadow copy (round to nearest even)
+int to_bf16(hipStream_t st, const float* src, void* dst, int64_t n);
+
+}  // namespace dvgr

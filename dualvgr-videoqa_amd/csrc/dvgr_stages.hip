@@ -1,0 +1,603 @@
+// dvgr_stages.hip -- row-wise, attention and element-wise kernels of the DualVGR unit.
+// Algebra: SURVEY.md Appendix A (restated and checked in oracle/unit_manual.py).
+#include "dvgr_stages.h"
+
+namespace dvgr {
+
+#define DVGR_LAUNCH_CHECK() return (int)hipGetLastError()
+
+// =================================================================================================
+// S0 rows forward.  grid (B, L), 256 threads.  model/utils.py:68-82
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_qa_rows_fwd(const QaRowsArgs a) {
+  __shared__ float sh_r[256];
+  __shared__ float sh_ah[256];
+  const int b = blockIdx.x, l = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int T = a.T, D = a.D, Wd = a.Wd;
+  const float* w2 = a.params + (int64_t)l * a.layer_stride + a.off_w2;
+  const float b2 = a.params[(int64_t)l * a.layer_stride + a.off_b2];
+  float* sav = a.saved + (int64_t)l * a.s_layer_stride;
+  const float* Y = a.Y + ((int64_t)l * a.B + b) * T * D;
+  float* dsv = sav + a.s_d + (int64_t)b * T * D;
+  for (int t = wave; t < T; t += 4) {
+    const float* y = Y + (int64_t)t * D;
+    float ss = 0.f;
+    for (int k = lane; k < D; k += 64) ss += y[k] * y[k];
+    ss = wave_sum(ss);
+    const float nrm = fmaxf(sqrtf(ss), 1e-12f);            // F.normalize eps
+    float rr = 0.f;
+    for (int k = lane; k < D; k += 64) {
+      const float dv = y[k] / nrm;
+      dsv[(int64_t)t * D + k] = dv;
+      rr += dv * w2[k];
+    }
+    rr = wave_sum(rr) + b2;
+    if (lane == 0) { sh_r[t] = rr; sav[a.s_nrm + b * T + t] = nrm; }
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int t = 0; t < T; ++t) mx = fmaxf(mx, sh_r[t]);
+  float sum = 0.f;
+  for (int t = 0; t < T; ++t) sum += expf(sh_r[t] - mx);
+  const int len = (int)a.qlen[b];
+  float S = 0.f;
+  for (int t = 0; t < T && t < len; ++t) S += expf(sh_r[t] - mx) / sum;
+  S += 1e-5f;
+  if (tid < T) {
+    const float av = expf(sh_r[tid] - mx) / sum;             // softmax over ALL T (padding included)
+    const float ah = (tid < len ? av : 0.f) / S;             // mask, renormalise
+    sav[a.s_a + b * T + tid] = av;
+    sav[a.s_ah + b * T + tid] = ah;
+    sh_ah[tid] = ah;
+  }
+  if (tid == 0) sav[a.s_S + b] = S;
+  __syncthreads();
+  for (int w = tid; w < Wd; w += 256) {
+    float q = 0.f;
+    for (int t = 0; t < T; ++t) q += sh_ah[t] * a.words[((int64_t)b * T + t) * Wd + w];
+    sav[a.s_q + (int64_t)b * Wd + w] = q;
+  }
+}
+
+int qa_rows_fwd(hipStream_t st, const QaRowsArgs& a) {
+  hipLaunchKernelGGL(k_qa_rows_fwd, dim3(a.B, a.L), dim3(256), 0, st, a);
+  DVGR_LAUNCH_CHECK();
+}
+
+// =================================================================================================
+// S1 forward: punish gate.  One wave per (b, n) row.  model/utils.py:101-103
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_punish_fwd(const float* X0, const float* X1, const float* p0,
+                                                    const float* p1, float* s0, float* s1, int rows, int N, int D) {
+  const int mod = blockIdx.y;
+  const float* X = mod ? X1 : X0;
+  const float* p = mod ? p1 : p0;
+  float* s = mod ? s1 : s0;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* x = X + (int64_t)row * D;
+  const float* pb = p + (int64_t)(row / N) * D;
+  float acc = 0.f;
+  for (int k = lane; k < D; k += 64) acc += x[k] * pb[k];
+  acc = wave_sum(acc);
+  if (lane == 0) s[row] = sigmoid_f(acc);
+}
+
+int punish_fwd(hipStream_t st, const float* X0, const float* X1, const float* p0, const float* p1,
+               float* s0, float* s1, int B, int N, int D) {
+  const int rows = B * N;
+  hipLaunchKernelGGL(k_punish_fwd, dim3((rows + 3) / 4, 2), dim3(256), 0, st, X0, X1, p0, p1, s0, s1, rows, N, D);
+  DVGR_LAUNCH_CHECK();
+}
+
+// =================================================================================================
+// S3 forward: one workgroup per (b, head, modality).  model/GraphNN.py:97-111 in factorised form.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_gat_attn_fwd(const GatAttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int b = blockIdx.x, h = blockIdx.y, mod = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = a.N, D = a.D, F = D / 4, FS = F + 1, NS = N + 1, HF = kHeads * F;
+  float* shW = sm;                // [N][FS]  Wh tile, later s_j * Wh_j
+  float* shA = shW + N * FS;      // [N][NS]  dropped attention
+  float* shAl = shA + N * NS;     // [F]
+  float* shAr = shAl + F;         // [F]
+  float* shS = shAr + F;          // [N]
+  float* shU = shS + N;           // [N]
+  float* shV = shU + N;           // [N]
+  const float* Wh = a.Wh[mod];
+  for (int e = tid; e < N * F; e += 256) {
+    const int j = e / F, f = e - j * F;
+    shW[j * FS + f] = Wh[((int64_t)b * N + j) * HF + h * F + f];
+  }
+  for (int f = tid; f < F; f += 256) {
+    shAl[f] = a.gat_a[mod][h * 2 * F + f];
+    shAr[f] = a.gat_a[mod][h * 2 * F + F + f];
+  }
+  if (tid < N) shS[tid] = a.s[mod][b * N + tid];
+  __syncthreads();
+  for (int i = wave; i < N; i += 4) {                       // u_i = a_l . Wh_i, v_i = a_r . Wh_i
+    float pu = 0.f, pv = 0.f;
+    for (int f = lane; f < F; f += 64) {
+      const float w = shW[i * FS + f];
+      pu += w * shAl[f];
+      pv += w * shAr[f];
+    }
+    pu = wave_sum(pu); pv = wave_sum(pv);
+    if (lane == 0) {
+      shU[i] = pu; shV[i] = pv;
+      a.u[mod][((int64_t)b * kHeads + h) * N + i] = pu;
+      a.v[mod][((int64_t)b * kHeads + h) * N + i] = pv;
+    }
+  }
+  __syncthreads();
+  if (tid < N) {                                            // softmax over j of LeakyReLU(u_i + v_j + c)
+    const int i = tid;
+    const float ui = shU[i] + a.gat_c[mod][h];
+    float mx = -INFINITY;
+    for (int j = 0; j < N; ++j) {
+      float e = ui + shV[j];
+      e = e > 0.f ? e : kSlope * e;
+      mx = fmaxf(mx, e);
+    }
+    float sum = 0.f;
+    for (int j = 0; j < N; ++j) {
+      float e = ui + shV[j];
+      e = e > 0.f ? e : kSlope * e;
+      sum += expf(e - mx);
+    }
+    const uint32_t key = a.key_alpha[mod][h];
+    for (int j = 0; j < N; ++j) {
+      float e = ui + shV[j];
+      e = e > 0.f ? e : kSlope * e;
+      const float al = expf(e - mx) / sum;
+      shA[i * NS + j] = al * drop_factor(key, (uint32_t)((b * N + i) * N + j));
+    }
+  }
+  for (int e = tid; e < N * F; e += 256) {                  // punish AFTER the logits (GraphNN.py:102-104)
+    const int j = e / F, f = e - j * F;
+    shW[j * FS + f] *= shS[j];
+  }
+  __syncthreads();
+  const int g = h >> 2, hl = h & 3;
+  float* out = g ? a.out_s[mod] : a.out_c[mod];
+  const uint32_t ko = a.key_out[mod][g];
+  for (int f = tid; f < F; f += 256) {
+    for (int i = 0; i < N; ++i) {
+      float acc = 0.f;
+      for (int j = 0; j < N; ++j) acc += shA[i * NS + j] * shW[j * FS + f];
+      const int64_t o = ((int64_t)b * N + i) * D + hl * F + f;
+      out[o] = elu_f(acc) * drop_factor(ko, (uint32_t)o);
+    }
+  }
+}
+
+static size_t gat_fwd_lds(int N, int F) { return sizeof(float) * ((size_t)N * (F + 1) + (size_t)N * (N + 1) + 2 * F + 3 * N); }
+
+int gat_attn_fwd(hipStream_t st, const GatAttnArgs& a) {
+  const size_t lds = gat_fwd_lds(a.N, a.D / 4);
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gat_attn_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_gat_attn_fwd, dim3(a.B, kHeads, 2), dim3(256), lds, st, a);
+  DVGR_LAUNCH_CHECK();
+}
+
+// =================================================================================================
+// S5 forward: one wave per (b, n) row.  model/Attention.py:20-23 + model/models.py:168-169
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_sf_combine_fwd(const SfCombineArgs a) {
+  const int mod = blockIdx.y;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= a.rows) return;
+  const int D = a.D;
+  const float* t0 = a.tn[mod] + (int64_t)row * D;
+  const float* t1 = a.tn[mod] + ((int64_t)a.rows + row) * D;
+  const float* p2 = a.p2[mod];
+  float w0 = 0.f, w1 = 0.f;
+  for (int k = lane; k < D; k += 64) { w0 += t0[k] * p2[k]; w1 += t1[k] * p2[k]; }
+  w0 = wave_sum(w0); w1 = wave_sum(w1);
+  const float mx = fmaxf(w0, w1);
+  const float e0 = expf(w0 - mx), e1 = expf(w1 - mx);
+  const float b0 = e0 / (e0 + e1), b1 = e1 / (e0 + e1);
+  if (lane == 0) { a.beta[mod][row * 2] = b0; a.beta[mod][row * 2 + 1] = b1; }
+  const float* z0 = a.z0[mod] + (int64_t)row * D;
+  const float* z1 = a.z1[mod] + (int64_t)row * D;
+  const float* x = a.X[mod] + (int64_t)row * D;
+  float* xo = a.Xout[mod] + (int64_t)row * D;
+  float* oo = a.o[mod] ? a.o[mod] + (int64_t)row * D : nullptr;
+  for (int k = lane; k < D; k += 64) {
+    const float o = b0 * z0[k] + b1 * z1[k];
+    if (oo) oo[k] = o;
+    xo[k] = x[k] + o;
+  }
+}
+
+int sf_combine_fwd(hipStream_t st, const SfCombineArgs& a) {
+  hipLaunchKernelGGL(k_sf_combine_fwd, dim3((a.rows + 3) / 4, 2), dim3(256), 0, st, a);
+  DVGR_LAUNCH_CHECK();
+}
+
+// =================================================================================================
+// S6 pooling.  model/fusions/fusions.py:430-440
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_mfb_pool_fwd(const float* x0, const float* x1, float* z, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // index into z (rows * 256)
+  if (i >= n) return;
+  const float2 a = reinterpret_cast<const float2*>(x0)[i];
+  const float2 b = reinterpret_cast<const float2*>(x1)[i];
+  z[i] = a.x * b.x + a.y * b.y;
+}
+int mfb_pool_fwd(hipStream_t st, const float* x0, const float* x1, float* z, int rows) {
+  const int64_t n = (int64_t)rows * kMfbPooled;
+  hipLaunchKernelGGL(k_mfb_pool_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x0, x1, z, n);
+  DVGR_LAUNCH_CHECK();
+}
+
+// =================================================================================================
+// Backward element-wise pieces
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_elu_bwd(const float* g, const float* y, float* out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  out[i] = g ? g[i] * elu_grad_from_out(y[i]) : 0.f;
+}
+int elu_bwd(hipStream_t st, const float* g, const float* y, float* out, int64_t n) {
+  hipLaunchKernelGGL(k_elu_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, y, out, n);
+  DVGR_LAUNCH_CHECK();
+}
+
+__global__ __launch_bounds__(256) void k_mfb_pool_bwd(const float* dz, const float* x0, const float* x1,
+                                                      float* dp0, float* dp1, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // index into dz (rows * 256)
+  if (i >= n) return;
+  const float d = dz[i];
+  const float2 a = reinterpret_cast<const float2*>(x0)[i];
+  const float2 b = reinterpret_cast<const float2*>(x1)[i];
+  float2 r0, r1;
+  r0.x = d * b.x * elu_grad_from_out(a.x); r0.y = d * b.y * elu_grad_from_out(a.y);
+  r1.x = d * a.x * elu_grad_from_out(b.x); r1.y = d * a.y * elu_grad_from_out(b.y);
+  reinterpret_cast<float2*>(dp0)[i] = r0;
+  reinterpret_cast<float2*>(dp1)[i] = r1;
+}
+int mfb_pool_bwd(hipStream_t st, const float* dz, const float* x0, const float* x1, float* dp0, float* dp1, int rows) {
+  const int64_t n = (int64_t)rows * kMfbPooled;
+  hipLaunchKernelGGL(k_mfb_pool_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dz, x0, x1, dp0, dp1, n);
+  DVGR_LAUNCH_CHECK();
+}
+
+// =================================================================================================
+// S5/S4 backward (row part).  One wave per row.  SURVEY.md Appendix A.4
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_sf_bwd(const SfBwdArgs a) {
+  const int mod = blockIdx.y;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= a.rows) return;
+  const int D = a.D;
+  const int64_t r0 = (int64_t)row * D, r1 = ((int64_t)a.rows + row) * D;
+  const float* dX = a.dX[mod] + r0;
+  const float* ge = a.g_embed[mod] ? a.g_embed[mod] + r0 : nullptr;
+  const float* z0 = a.z0[mod] + r0;
+  const float* z1 = a.z1[mod] + r0;
+  float db0 = 0.f, db1 = 0.f;
+  for (int k = lane; k < D; k += 64) {
+    const float d = dX[k] + (ge ? ge[k] : 0.f);
+    db0 += d * z0[k];
+    db1 += d * z1[k];
+  }
+  db0 = wave_sum(db0); db1 = wave_sum(db1);
+  const float b0 = a.beta[mod][row * 2], b1 = a.beta[mod][row * 2 + 1];
+  const float mean = b0 * db0 + b1 * db1;
+  const float dw0 = b0 * (db0 - mean), dw1 = b1 * (db1 - mean);
+  if (lane == 0) { a.dw[mod][row] = dw0; a.dw[mod][a.rows + row] = dw1; }
+  const float* t0 = a.tn[mod] + r0;
+  const float* t1 = a.tn[mod] + r1;
+  const float* p2 = a.p2[mod];
+  const float* g0 = a.g_z0[mod] ? a.g_z0[mod] + r0 : nullptr;
+  const float* g1 = a.g_z1[mod] ? a.g_z1[mod] + r0 : nullptr;
+  float* dpre = a.dpre[mod];
+  float* dz = a.dz[mod];
+  for (int k = lane; k < D; k += 64) {
+    const float d = dX[k] + (ge ? ge[k] : 0.f);
+    const float ta = t0[k], tb = t1[k];
+    dpre[r0 + k] = dw0 * p2[k] * (1.f - ta * ta);
+    dpre[r1 + k] = dw1 * p2[k] * (1.f - tb * tb);
+    dz[r0 + k] = b0 * d + (g0 ? g0[k] : 0.f);
+    dz[r1 + k] = b1 * d + (g1 ? g1[k] : 0.f);
+  }
+}
+int sf_bwd(hipStream_t st, const SfBwdArgs& a) {
+  hipLaunchKernelGGL(k_sf_bwd, dim3((a.rows + 3) / 4, 2), dim3(256), 0, st, a);
+  DVGR_LAUNCH_CHECK();
+}
+
+// =================================================================================================
+// S3 backward: one workgroup per (b, head, modality).  SURVEY.md Appendix A.3
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int b = blockIdx.x, h = blockIdx.y, mod = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = a.N, D = a.D, F = D / 4, FS = F + 1, NS = N + 1, HF = kHeads * F;
+  const int g = h >> 2, hl = h & 3;
+  float* shW = sm;                 // [N][FS] Wh (unscaled)
+  float* shP = shW + N * FS;       // [N][FS] dP
+  float* shA = shP + N * FS;       // [N][NS] alpha
+  float* shAd = shA + N * NS;      // [N][NS] alpha * keep
+  float* shG = shAd + N * NS;      // [N][NS] dalpha, then dpre
+  float* shAl = shG + N * NS;      // [F]
+  float* shAr = shAl + F;          // [F]
+  float* shS = shAr + F;           // [N]
+  float* shU = shS + N;            // [N]
+  float* shV = shU + N;            // [N]
+  float* shDu = shV + N;           // [N]
+  float* shDv = shDu + N;          // [N]
+  float* shRow = shDv + N;         // [N]   per-row sum of dpre (for dc)
+  float* shRed = shRow + N;        // [N][4] per-wave partials of ds_j
+  const float* Wh = a.Wh[mod];
+  const float* dz = a.dz[mod] + (int64_t)g * a.B * N * D;   // view g of (2, B*N, D)
+  const float* outp = g ? a.out_s[mod] : a.out_c[mod];
+  const uint32_t ko = a.key_out[mod][g];
+  const uint32_t ka = a.key_alpha[mod][h];
+  for (int e = tid; e < N * F; e += 256) {
+    const int i = e / F, f = e - i * F;
+    shW[i * FS + f] = Wh[((int64_t)b * N + i) * HF + h * F + f];
+    const int64_t o = ((int64_t)b * N + i) * D + hl * F + f;
+    const float kf = drop_factor(ko, (uint32_t)o);
+    const float Oh = ko ? outp[o] * (1.0f - kDropP) : outp[o];   // un-dropped ELU output where kept
+    shP[i * FS + f] = dz[o] * kf * elu_grad_from_out(Oh);
+  }
+  for (int f = tid; f < F; f += 256) {
+    shAl[f] = a.gat_a[mod][h * 2 * F + f];
+    shAr[f] = a.gat_a[mod][h * 2 * F + F + f];
+  }
+  if (tid < N) {
+    shS[tid] = a.s[mod][b * N + tid];
+    shU[tid] = a.u[mod][((int64_t)b * kHeads + h) * N + tid];
+    shV[tid] = a.v[mod][((int64_t)b * kHeads + h) * N + tid];
+  }
+  __syncthreads();
+  const float c = a.gat_c[mod][h];
+  if (tid < N) {                                            // recompute alpha and alpha_d
+    const int i = tid;
+    const float ui = shU[i] + c;
+    float mx = -INFINITY;
+    for (int j = 0; j < N; ++j) { float e = ui + shV[j]; e = e > 0.f ? e : kSlope * e; mx = fmaxf(mx, e); }
+    float sum = 0.f;
+    for (int j = 0; j < N; ++j) { float e = ui + shV[j]; e = e > 0.f ? e : kSlope * e; sum += expf(e - mx); }
+    for (int j = 0; j < N; ++j) {
+      float e = ui + shV[j]; e = e > 0.f ? e : kSlope * e;
+      const float al = expf(e - mx) / sum;
+      shA[i * NS + j] = al;
+      shAd[i * NS + j] = al * drop_factor(ka, (uint32_t)((b * N + i) * N + j));
+    }
+  }
+  __syncthreads();
+  for (int pr = tid; pr < N * N; pr += 256) {               // dalpha_ij = keep_ij * s_j * (dP_i . Wh_j)
+    const int i = pr / N, j = pr - i * N;
+    float acc = 0.f;
+    for (int f = 0; f < F; ++f) acc += shP[i * FS + f] * shW[j * FS + f];
+    shG[i * NS + j] = acc * shS[j] * drop_factor(ka, (uint32_t)((b * N + i) * N + j));
+  }
+  __syncthreads();
+  if (tid < N) {                                            // softmax and LeakyReLU backward, du_i
+    const int i = tid;
+    float rowdot = 0.f;
+    for (int j = 0; j < N; ++j) rowdot += shA[i * NS + j] * shG[i * NS + j];
+    const float ui = shU[i] + c;
+    float du = 0.f;
+    for (int j = 0; j < N; ++j) {
+      const float de = shA[i * NS + j] * (shG[i * NS + j] - rowdot);
+      const float pre = ui + shV[j];
+      const float dpre = de * (pre > 0.f ? 1.f : kSlope);
+      shG[i * NS + j] = dpre;
+      du += dpre;
+    }
+    shDu[i] = du;
+    shRow[i] = du;
+  }
+  __syncthreads();
+  if (tid < N) {                                            // dv_j
+    float dv = 0.f;
+    for (int i = 0; i < N; ++i) dv += shG[i * NS + tid];
+    shDv[tid] = dv;
+  }
+  if (tid == 0) {
+    float dc = 0.f;
+    for (int i = 0; i < N; ++i) dc += shRow[i];
+    a.dc_part[mod][b * kHeads + h] = dc;
+  }
+  __syncthreads();
+  float* dWh = a.dWh[mod];
+  for (int f0 = 0; f0 < F; f0 += 256) {                     // uniform trip count: wave_sum needs all lanes
+    const int f = f0 + tid;
+    const bool act = f < F;
+    float dal = 0.f, dar = 0.f;
+    for (int j = 0; j < N; ++j) {
+      float dZ = 0.f, w = 0.f;
+      if (act) {
+        for (int i = 0; i < N; ++i) dZ += shAd[i * NS + j] * shP[i * FS + f];
+        w = shW[j * FS + f];
+        dWh[((int64_t)b * N + j) * HF + h * F + f] = shS[j] * dZ + shDu[j] * shAl[f] + shDv[j] * shAr[f];
+        dal += shDu[j] * w;
+        dar += shDv[j] * w;
+      }
+      const float part = wave_sum(dZ * w);                  // ds_j partial of this wave
+      if (lane == 0) {
+        if (f0 == 0) shRed[j * 4 + wave] = part; else shRed[j * 4 + wave] += part;
+      }
+    }
+    if (act) {
+      a.da_part[mod][((int64_t)b * kHeads + h) * 2 * F + f] = dal;
+      a.da_part[mod][((int64_t)b * kHeads + h) * 2 * F + F + f] = dar;
+    }
+  }
+  __syncthreads();
+  if (tid < N)
+    a.ds_part[mod][((int64_t)b * kHeads + h) * N + tid] =
+        shRed[tid * 4] + shRed[tid * 4 + 1] + shRed[tid * 4 + 2] + shRed[tid * 4 + 3];
+}
+
+static size_t gat_bwd_lds(int N, int F) {
+  return sizeof(float) * (2 * (size_t)N * (F + 1) + 3 * (size_t)N * (N + 1) + 2 * F + 10 * N);
+}
+size_t gat_lds_bytes_max(int N, int F) { return gat_bwd_lds(N, F); }
+
+int gat_attn_bwd(hipStream_t st, const GatAttnBwdArgs& a) {
+  const size_t lds = gat_bwd_lds(a.N, a.D / 4);
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gat_attn_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_gat_attn_bwd, dim3(a.B, kHeads, 2), dim3(256), lds, st, a);
+  DVGR_LAUNCH_CHECK();
+}
+
+// =================================================================================================
+// S1 backward.  grid (B, 2).  SURVEY.md Appendix A.2
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_punish_bwd(const PunishBwdArgs a) {
+  __shared__ float shT[64];
+  const int b = blockIdx.x, mod = blockIdx.y, tid = threadIdx.x;
+  const int N = a.N, D = a.D;
+  if (tid < N) {
+    float ds = 0.f;
+    for (int h = 0; h < kHeads; ++h) ds += a.ds_part[mod][((int64_t)b * kHeads + h) * N + tid];
+    const float s = a.s[mod][b * N + tid];
+    shT[tid] = ds * s * (1.f - s);
+  }
+  __syncthreads();
+  const float* X = a.X[mod] + (int64_t)b * N * D;
+  float* dX = a.dX[mod] + (int64_t)b * N * D;
+  const float* p = a.p[mod] + (int64_t)b * D;
+  for (int d = tid; d < D; d += 256) {
+    const float pd = p[d];
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) {
+      acc += shT[n] * X[(int64_t)n * D + d];
+      dX[(int64_t)n * D + d] += shT[n] * pd;
+    }
+    a.dp_cat[(int64_t)b * 2 * D + mod * D + d] = acc;
+  }
+}
+int punish_bwd(hipStream_t st, const PunishBwdArgs& a) {
+  hipLaunchKernelGGL(k_punish_bwd, dim3(a.B, 2), dim3(256), 0, st, a);
+  DVGR_LAUNCH_CHECK();
+}
+
+// =================================================================================================
+// S0 backward rows.  grid (B), loops over layers.  SURVEY.md Appendix A.1
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_qa_bwd(const QaBwdArgs a) {
+  __shared__ float sh_dah[256], sh_c[256], sh_ah[256], sh_a[256], sh_da[256], sh_dr[256];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int T = a.T, D = a.D, Wd = a.Wd;
+  const int len = (int)a.qlen[b];
+  for (int l = 0; l < a.L; ++l) {
+    const float* sav = a.saved + (int64_t)l * a.s_layer_stride;
+    const float* w2 = a.params + (int64_t)l * a.layer_stride + a.off_w2;
+    const float* dqb = a.dqbar + ((int64_t)l * a.B + b) * Wd;
+    const float* dsv = sav + a.s_d + (int64_t)b * T * D;
+    for (int t = wave; t < T; t += 4) {
+      float s1 = 0.f, s2 = 0.f;
+      const float* wrow = a.words + ((int64_t)b * T + t) * Wd;
+      for (int w = lane; w < Wd; w += 64) s1 += wrow[w] * dqb[w];
+      for (int k = lane; k < D; k += 64) s2 += dsv[(int64_t)t * D + k] * w2[k];
+      s1 = wave_sum(s1); s2 = wave_sum(s2);
+      if (lane == 0) { sh_dah[t] = s1; sh_c[t] = s2; }
+    }
+    if (tid < T) { sh_ah[tid] = sav[a.s_ah + b * T + tid]; sh_a[tid] = sav[a.s_a + b * T + tid]; }
+    __syncthreads();
+    float dot = 0.f;
+    for (int t = 0; t < T; ++t) dot += sh_dah[t] * sh_ah[t];
+    const float S = sav[a.s_S + b];
+    if (tid < T) sh_da[tid] = (tid < len) ? (sh_dah[tid] - dot) / S : 0.f;
+    __syncthreads();
+    float adot = 0.f;
+    for (int t = 0; t < T; ++t) adot += sh_a[t] * sh_da[t];
+    if (tid < T) {
+      const float dr = sh_a[tid] * (sh_da[tid] - adot);
+      sh_dr[tid] = dr;
+      a.dr[(int64_t)l * a.B * T + b * T + tid] = dr;
+    }
+    __syncthreads();
+    for (int e = tid; e < T * Wd; e += 256) {               // dwords_t += ah_t * dqbar
+      const int t = e / Wd, w = e - t * Wd;
+      const float val = sh_ah[t] * dqb[w];
+      float* dst = a.gwords + (int64_t)b * T * Wd + e;
+      *dst = (a.first && l == 0) ? val : (*dst + val);
+    }
+    float* dy = a.dy + ((int64_t)l * a.B + b) * T * D;
+    for (int e = tid; e < T * D; e += 256) {                // dy = (dd - d (d.dd)) / nrm, dd = dr * w2
+      const int t = e / D, k = e - t * D;
+      const float nrm = sav[a.s_nrm + b * T + t];
+      dy[e] = sh_dr[t] * (w2[k] - dsv[e] * sh_c[t]) / nrm;
+    }
+    __syncthreads();
+  }
+}
+int qa_bwd(hipStream_t st, const QaBwdArgs& a) {
+  hipLaunchKernelGGL(k_qa_bwd, dim3(a.B), dim3(256), 0, st, a);
+  DVGR_LAUNCH_CHECK();
+}
+
+// =================================================================================================
+// Column sums: grid (ceil(cols / 64), jobs), 1024 threads = 16 waves; lane -> column, wave -> rows.
+// =================================================================================================
+__global__ __launch_bounds__(1024) void k_colsum(const ColsumBatch b) {
+  __shared__ float red[16][64];
+  const ColsumJob& J = b.j[blockIdx.y];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  if (blockIdx.x * 64 >= J.cols) return;                    // uniform per workgroup
+  float acc = 0.f;
+  if (c < J.cols) {
+    for (int r = wave; r < J.rows0; r += 16) acc += (J.w0 ? J.w0[r] : 1.f) * J.M0[(int64_t)r * J.ld + c];
+    if (J.M1)
+      for (int r = wave; r < J.rows1; r += 16) acc += (J.w1 ? J.w1[r] : 1.f) * J.M1[(int64_t)r * J.ld + c];
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && c < J.cols) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += red[w][lane];
+    J.out[c] = s;
+  }
+}
+int colsum(hipStream_t st, const ColsumBatch& b) {
+  if (b.n < 1 || b.n > kMaxColsumJobs) return DVGR_E_DIMS;
+  int maxc = 0;
+  for (int i = 0; i < b.n; ++i) maxc = b.j[i].cols > maxc ? b.j[i].cols : maxc;
+  hipLaunchKernelGGL(k_colsum, dim3((maxc + 63) / 64, b.n), dim3(1024), 0, st, b);
+  DVGR_LAUNCH_CHECK();
+}
+
+// =================================================================================================
+// bf16 shadow copy
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_to_bf16(const float* src, uint16_t* dst, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t u = __float_as_uint(src[i]);
+  uint32_t r;
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) r = (u >> 16) | 0x40u;          // keep NaN a NaN
+  else r = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;                       // round to nearest even
+  dst[i] = (uint16_t)r;
+}
+int to_bf16(hipStream_t st, const float* src, void* dst, int64_t n) {
+  hipLaunchKernelGGL(k_to_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, (uint16_t*)dst, n);
+  DVGR_LAUNCH_CHECK();
+}
+
+}  // namespace dvgr
+
+// test hook: materialise the keep decisions of one dropout site
+namespace dvgr {
+__global__ __launch_bounds__(256) void k_keep_mask(uint32_t key, int64_t n, float* keep) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) keep[i] = drop_keep(key, (uint32_t)i) ? 1.0f : 0.0f;
+}
+int keep_mask_launch(hipStream_t st, uint32_t key, int64_t n, float* keep) {
+  hipLaunchKernelGGL(k_keep_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, key, n, keep);
+  return (int)hipGetLastError();
+}
+}  // namespace dvgr

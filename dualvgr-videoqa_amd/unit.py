@@ -1,0 +1,356 @@
+"""Host side of the MI355X-native DualVGR reasoning unit.
+
+`DualVGRUnit_multiple` keeps the constructor / forward() signature, the 7-tuple return and the
+state_dict names of the reference module (model/models.py:86-173) but owns no arithmetic: the
+forward and the backward of the whole stacked unit are the hand-written HIP kernels behind the C
+ABI of include/dvgr.h (libdvgr_hip.so).  PyTorch is used for device memory, the current stream
+and autograd bookkeeping only.  There is no eager fallback: without the HIP library, or with
+tensors that are not on a ROCm device, the module raises.
+
+Parameter storage: all parameters live in ONE flat fp32 buffer laid out for the kernels (the 8
+head matrices of a modality are one contiguous (8F, D) block, etc. -- dvgr_param_offset); every
+named nn.Parameter is a view into it, so optimizers update the kernel-side weights in place and
+the gradient is one flat buffer (one RCCL all-reduce bucket per layer for data parallelism).
+
+Deliberate deviations from the reference: the four list outputs stay on the
+device (the reference moves them to the CPU, model/models.py:153-160); no hard-coded 'cuda:1';
+graph_layers must be 1 (every reference config uses 1).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L_
+
+N_HEADS = 4
+DROP_P = 0.15
+
+
+def param_table(dims: L_.Dims) -> List[Tuple[str, Tuple[int, ...], int]]:
+    """(reference state_dict name, shape, element offset in the flat buffer) for every parameter."""
+    D, Wd, Fh, L = dims.D, dims.Wd, dims.D // 4, dims.L
+    tab = []
+    for l in range(L):
+        o, _, _ = L_.param_offset(dims, L_.P_QA_W1, l)
+        tab.append((f"queryAttn.{l}.feat_enhance.weight", (D, D), o))
+        o, _, _ = L_.param_offset(dims, L_.P_QA_B1, l)
+        tab.append((f"queryAttn.{l}.feat_enhance.bias", (D,), o))
+        o, _, _ = L_.param_offset(dims, L_.P_QA_W2, l)
+        tab.append((f"queryAttn.{l}.fc.weight", (1, D), o))
+        o, _, _ = L_.param_offset(dims, L_.P_QA_B2, l)
+        tab.append((f"queryAttn.{l}.fc.bias", (1,), o))
+        for mod, (qp, com, spec, att) in enumerate((("queryPunish_appear", "acGCN", "appearance_GCN", "attention_appearance"),
+                                                     ("queryPunish_motion", "mcGCN", "motion_GCN", "attention_motion"))):
+            o, _, _ = L_.param_offset(dims, L_.P_WQ, l, mod)
+            tab.append((f"{qp}.{l}.query_weight.weight", (D, Wd), o))
+            o, _, _ = L_.param_offset(dims, L_.P_BQ, l, mod)
+            tab.append((f"{qp}.{l}.query_weight.bias", (D,), o))
+            ow, _, _ = L_.param_offset(dims, L_.P_GAT_W, l, mod)
+            ob, _, _ = L_.param_offset(dims, L_.P_GAT_B, l, mod)
+            oa, _, _ = L_.param_offset(dims, L_.P_GAT_A, l, mod)
+            oc, _, _ = L_.param_offset(dims, L_.P_GAT_C, l, mod)
+            for g, fam in enumerate((com, spec)):
+                for h in range(N_HEADS):
+                    hh = g * N_HEADS + h
+                    tab.append((f"{fam}.{l}.attention_{h}.W.weight", (Fh, D), ow + hh * Fh * D))
+                    tab.append((f"{fam}.{l}.attention_{h}.W.bias", (Fh,), ob + hh * Fh))
+                    tab.append((f"{fam}.{l}.attention_{h}.a.weight", (1, 2 * Fh), oa + hh * 2 * Fh))
+                    tab.append((f"{fam}.{l}.attention_{h}.a.bias", (1,), oc + hh))
+            o, _, _ = L_.param_offset(dims, L_.P_SF_P1, l, mod)
+            tab.append((f"{att}.{l}.project.0.weight", (D, D), o))
+            o, _, _ = L_.param_offset(dims, L_.P_SF_BP, l, mod)
+            tab.append((f"{att}.{l}.project.0.bias", (D,), o))
+            o, _, _ = L_.param_offset(dims, L_.P_SF_P2, l, mod)
+            tab.append((f"{att}.{l}.project.2.weight", (1, D), o))
+    for nm, kw, kb, shp in (("linear0", L_.P_MFB_W0, L_.P_MFB_B0, (512, D)), ("linear1", L_.P_MFB_W1, L_.P_MFB_B1, (512, D)),
+                            ("linear_out", L_.P_MFB_WO, L_.P_MFB_BO, (D, 256))):
+        o, _, _ = L_.param_offset(dims, kw)
+        tab.append((f"visualfusion.{nm}.weight", shp, o))
+        o, _, _ = L_.param_offset(dims, kb)
+        tab.append((f"visualfusion.{nm}.bias", (shp[0],), o))
+    return tab
+
+
+class _Holder(nn.Module):
+    """Parameter container with nn.Linear's attribute names (weight / bias); it never computes."""
+
+    def __init__(self, out_f: int, in_f: int, bias: bool = True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(out_f, in_f))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_f))
+        else:
+            self.register_parameter("bias", None)
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter holder: the arithmetic runs in the HIP kernels")
+
+
+class _Head(nn.Module):
+    def __init__(self, D, Fh):
+        super().__init__()
+        self.W = _Holder(Fh, D)
+        self.a = _Holder(1, 2 * Fh)
+
+
+class _GAT(nn.Module):
+    def __init__(self, D, Fh):
+        super().__init__()
+        for h in range(N_HEADS):
+            self.add_module(f"attention_{h}", _Head(D, Fh))
+
+
+class _QueryAttn(nn.Module):
+    def __init__(self, D):
+        super().__init__()
+        self.feat_enhance = _Holder(D, D)
+        self.fc = _Holder(1, D)
+
+
+class _QueryPunish(nn.Module):
+    def __init__(self, Wd, D):
+        super().__init__()
+        self.query_weight = _Holder(D, Wd)
+
+
+class _SFAttn(nn.Module):
+    def __init__(self, D):
+        super().__init__()
+        self.project = nn.Sequential(_Holder(D, D), nn.Identity(), _Holder(1, D, bias=False))
+
+
+class _MFB(nn.Module):
+    def __init__(self, D):
+        super().__init__()
+        self.linear0 = _Holder(512, D)
+        self.linear1 = _Holder(512, D)
+        self.linear_out = _Holder(D, 256)
+
+
+class _UnitFn(torch.autograd.Function):
+    """Forward / backward of the whole stacked unit through the C ABI."""
+
+    @staticmethod
+    def forward(ctx, mod: "DualVGRUnit_multiple", A, M, dq, words, qlen, *params):
+        lib = L_.load()
+        if not A.is_cuda:
+            raise RuntimeError("DualVGRUnit_multiple runs on a ROCm device only (no CPU fallback); move the module "
+                               "and its inputs to 'cuda'")
+        A, M, dq, words = (t.contiguous().float() for t in (A, M, dq, words))
+        qlen = qlen.to(device=A.device, dtype=torch.int64).contiguous()
+        B, N, D = A.shape
+        T, Wd = dq.shape[1], words.shape[2]
+        if M.shape != A.shape or dq.shape != (B, T, D) or words.shape[:2] != (B, T) or qlen.shape != (B,):
+            raise RuntimeError("inconsistent input shapes for DualVGRUnit_multiple.forward")
+        if D != mod.module_dim or Wd != mod.word_dim:
+            raise RuntimeError(f"feature sizes {D}/{Wd} do not match the module ({mod.module_dim}/{mod.word_dim})")
+        dims = L_.make_dims(B, N, T, D, Wd, mod.layers, 1, mod.dtype_code)
+        L_.check(lib.dvgr_check_dims(C.byref(dims)), "dvgr_check_dims")
+        flat = mod.flat_params()
+        dev = A.device
+        Lr = mod.layers
+        vis = torch.empty((B, N, D), device=dev, dtype=torch.float32)
+        aqe = torch.empty_like(vis)
+        mqe = torch.empty_like(vis)
+        lists = [torch.empty((Lr, B, N, D), device=dev, dtype=torch.float32) for _ in range(4)]
+        saved = torch.empty(lib.dvgr_saved_bytes(C.byref(dims)), device=dev, dtype=torch.uint8)
+        ws = mod.workspace(lib.dvgr_workspace_bytes(C.byref(dims)), dev)
+        train = bool(mod.training)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if train else 0
+        if mod.forced_seed is not None:
+            seed = int(mod.forced_seed)
+        io = L_.IO(A.data_ptr(), M.data_ptr(), dq.data_ptr(), words.data_ptr(), qlen.data_ptr(), vis.data_ptr(),
+                   aqe.data_ptr(), mqe.data_ptr(), lists[0].data_ptr(), lists[1].data_ptr(), lists[2].data_ptr(),
+                   lists[3].data_ptr())
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        L_.check(lib.dvgr_unit_forward(C.byref(dims), flat.data_ptr(), mod.lowp_ptr(), C.byref(io), saved.data_ptr(),
+                                       saved.numel(), ws.data_ptr(), ws.numel(), int(train), seed, stream),
+                 "dvgr_unit_forward")
+        ctx.mod, ctx.dims, ctx.train, ctx.seed = mod, dims, train, seed
+        ctx.save_for_backward(A, M, dq, words, qlen, vis, aqe, mqe, *lists, saved, flat)
+        mod.last_saved = saved if mod.keep_saved else None
+        return (vis, aqe, mqe, *lists)
+
+    @staticmethod
+    def backward(ctx, g_vis, g_aqe, g_mqe, g_ca, g_cm, g_aq, g_mq):
+        lib = L_.load()
+        mod, dims = ctx.mod, ctx.dims
+        A, M, dq, words, qlen, vis, aqe, mqe, l0, l1, l2, l3, saved, flat = ctx.saved_tensors
+        dev = A.device
+        ups = [None if g is None else g.contiguous().float() for g in (g_vis, g_aqe, g_mqe, g_ca, g_cm, g_aq, g_mq)]
+        gA = torch.empty_like(A)
+        gM = torch.empty_like(M)
+        gdq = torch.empty_like(dq)
+        gwords = torch.empty_like(words)
+        gflat = torch.empty_like(flat)
+        ws = mod.workspace(lib.dvgr_workspace_bytes(C.byref(dims)), dev)
+        io = L_.IO(A.data_ptr(), M.data_ptr(), dq.data_ptr(), words.data_ptr(), qlen.data_ptr(), vis.data_ptr(),
+                   aqe.data_ptr(), mqe.data_ptr(), l0.data_ptr(), l1.data_ptr(), l2.data_ptr(), l3.data_ptr())
+        gr = L_.Grads(*[None if u is None else u.data_ptr() for u in ups],
+                      gA.data_ptr(), gM.data_ptr(), gdq.data_ptr(), gwords.data_ptr(), gflat.data_ptr())
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        events = mod.layer_events_ptr()
+        L_.check(lib.dvgr_unit_backward(C.byref(dims), flat.data_ptr(), mod.lowp_ptr(), C.byref(io), C.byref(gr),
+                                        saved.data_ptr(), saved.numel(), ws.data_ptr(), ws.numel(), int(ctx.train),
+                                        ctx.seed, events, stream), "dvgr_unit_backward")
+        mod.last_flat_grad = gflat
+        pgrads = [gflat[o:o + n].view(shape) for (o, n, shape) in mod.param_slices]
+        return (None, gA, gM, gdq, gwords, None, *pgrads)
+
+
+class DualVGRUnit_multiple(nn.Module):
+    """Drop-in for the reference `DualVGRUnit_multiple` (model/models.py:86-173).
+
+    Same constructor arguments and defaults (model/models.py:87); `dtype` ('fp32' | 'bf16') selects
+    the MFMA operand precision of the kernels and is the only addition."""
+
+    def __init__(self, word_dim=300, module_dim=512, num_of_nodes=8, appearance_graph_layers=1,
+                 motion_graph_layers=1, graph_module='GAT', unit_layers=3, dtype='fp32'):
+        super().__init__()
+        if graph_module != 'GAT':
+            # the reference builds no GNN lists for any other value and then fails in forward
+            raise ValueError("graph_module must be 'GAT' (model/models.py:94)")
+        if appearance_graph_layers != 1 or motion_graph_layers != 1:
+            raise NotImplementedError("graph_layers > 1 is not supported by the HIP path (all reference configs use 1)")
+        if module_dim % 64 or word_dim % 4:
+            raise ValueError("module_dim must be a multiple of 64 and word_dim a multiple of 4")
+        self.layers = unit_layers
+        self.module_dim = module_dim
+        self.word_dim = word_dim
+        self.num_of_nodes = num_of_nodes
+        self.num_of_appearance_graph_layers = appearance_graph_layers
+        self.num_of_motion_graph_layers = motion_graph_layers
+        self.dtype_code = {'fp32': L_.DVGR_F32, 'bf16': L_.DVGR_BF16}[dtype]
+        D, Wd, Fh, Lr = module_dim, word_dim, module_dim // 4, unit_layers
+        self.queryAttn = nn.ModuleList([_QueryAttn(D) for _ in range(Lr)])
+        self.queryPunish_appear = nn.ModuleList([_QueryPunish(Wd, D) for _ in range(Lr)])
+        self.queryPunish_motion = nn.ModuleList([_QueryPunish(Wd, D) for _ in range(Lr)])
+        self.appearance_GCN = nn.ModuleList([_GAT(D, Fh) for _ in range(Lr)])
+        self.motion_GCN = nn.ModuleList([_GAT(D, Fh) for _ in range(Lr)])
+        self.acGCN = nn.ModuleList([_GAT(D, Fh) for _ in range(Lr)])
+        self.mcGCN = nn.ModuleList([_GAT(D, Fh) for _ in range(Lr)])
+        self.attention_appearance = nn.ModuleList([_SFAttn(D) for _ in range(Lr)])
+        self.attention_motion = nn.ModuleList([_SFAttn(D) for _ in range(Lr)])
+        self.visualfusion = _MFB(D)
+        # normalised all-ones adjacency, kept for API compatibility only (it is strictly positive, so
+        # the reference's `adj > 0` mask never fires: model/models.py:114-119, model/GraphNN.py:100-101)
+        adj = torch.full((num_of_nodes, num_of_nodes), 1.0 / (num_of_nodes + 1))
+        adj += torch.eye(num_of_nodes) / (num_of_nodes + 1)
+        self.appearance_adj = adj
+        self.motion_adj = adj.clone()
+
+        self._dims0 = L_.make_dims(1, num_of_nodes, 1, D, Wd, Lr, 1, self.dtype_code)
+        L_.load()       # raises with the build instructions when libdvgr_hip.so is missing
+        self._table = param_table(self._dims0)
+        named = dict(self.named_parameters())
+        assert set(named) == {n for n, _, _ in self._table}, "parameter inventory mismatch"
+        self._names = [n for n, _, _ in self._table]
+        self._plist = [named[n] for n in self._names]      # Parameter objects are stable across .to()
+        self.param_slices = [(o, int(torch.tensor(s).prod()), s) for _, s, o in self._table]
+        self._flat = None
+        self._lowp = None
+        self._lowp_version = None
+        self._ws = None
+        self._events = None
+        self.forced_seed = None      # tests: fix the dropout seed of the next forward
+        self.keep_saved = False      # tests: keep a handle on the saved-for-backward buffer
+        self.last_saved = None
+        self.last_flat_grad = None
+        self._reset_parameters()
+        self._flatten()
+
+    # ---- initialisation as the reference constructs the same sub-modules --------------------------
+    def _reset_parameters(self):
+        named = dict(self.named_parameters())
+        for name, p in named.items():
+            with torch.no_grad():
+                if name.startswith("visualfusion"):
+                    # model/init_weight.py:4-13 via model/fusions/fusions.py:412-417
+                    if name.endswith("weight"):
+                        nn.init.normal_(p, mean=0.0, std=0.01)
+                    else:
+                        nn.init.zeros_(p)
+                elif ".attention_" in name and name.endswith("weight"):
+                    nn.init.xavier_uniform_(p, gain=1.414)      # model/GraphNN.py:90,92
+                elif name.endswith("weight"):
+                    nn.init.kaiming_uniform_(p, a=5 ** 0.5)     # nn.Linear default
+                else:
+                    fan_in = named[name[:-4] + "weight"].shape[1]
+                    bound = 1.0 / fan_in ** 0.5
+                    nn.init.uniform_(p, -bound, bound)
+
+    # ---- flat storage ----------------------------------------------------------------------------------
+    def _flatten(self):
+        dev = self._plist[0].device
+        total = L_.load().dvgr_param_count(C.byref(self._dims0))
+        flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        for p, (name, shape, off) in zip(self._plist, self._table):
+            n = p.numel()
+            flat[off:off + n].copy_(p.detach().reshape(-1).float())
+            p.data = flat[off:off + n].view(shape)
+        self._flat = flat
+        self._ptrs = tuple(p.data_ptr() for p in self._plist)
+        self._lowp = None
+        self._lowp_version = None
+
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)
+        if getattr(self, "_table", None) is not None:
+            self._flatten()     # .to()/.cuda() gave every parameter its own storage: re-alias them
+        return out
+
+    def flat_params(self) -> torch.Tensor:
+        if tuple(p.data_ptr() for p in self._plist) != self._ptrs:
+            self._flatten()  # someone re-pointed .data (e.g. an external load that replaced tensors)
+        return self._flat
+
+    def lowp_ptr(self):
+        """bf16 shadow copy of the parameters for DVGR_BF16, refreshed when the weights changed."""
+        if self.dtype_code != L_.DVGR_BF16:
+            return None
+        flat = self._flat
+        ver = tuple(p._version for p in self._plist)
+        if self._lowp is None or self._lowp.device != flat.device or ver != self._lowp_version:
+            if self._lowp is None or self._lowp.device != flat.device:
+                self._lowp = torch.empty(flat.numel(), device=flat.device, dtype=torch.bfloat16)
+            L_.check(L_.load().dvgr_pack_weights(C.byref(self._dims0), flat.data_ptr(), self._lowp.data_ptr(),
+                                                 torch.cuda.current_stream(flat.device).cuda_stream), "dvgr_pack_weights")
+            self._lowp_version = ver
+        return self._lowp.data_ptr()
+
+    def workspace(self, nbytes: int, dev) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
+            self._ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        return self._ws
+
+    def set_layer_events(self, events):
+        """events: list of L+1 torch.cuda.Event (recorded by the backward as each layer's parameter
+        gradients become final; index L = the MFB block).  None disables."""
+        self._events = events
+
+    def layer_events_ptr(self):
+        if not self._events:
+            return None
+        arr = (C.c_void_p * (self.layers + 1))()
+        for i, e in enumerate(self._events):
+            arr[i] = e.cuda_event
+        return arr
+
+    def layer_param_range(self, layer: int) -> Tuple[int, int]:
+        a, b = C.c_int64(), C.c_int64()
+        L_.check(L_.load().dvgr_param_layer_range(C.byref(self._dims0), layer, C.byref(a), C.byref(b)),
+                 "dvgr_param_layer_range")
+        return a.value, b.value
+
+    # ---- forward: the reference signature (model/models.py:121) ---------------------------------------
+    def forward(self, appearance_video_feat, motion_video_feat, dynamic_question_embedding, word_embedding,
+                question_len):
+        params = self._plist
+        vis, aqe, mqe, ca, cm, aq, mq = _UnitFn.apply(self, appearance_video_feat, motion_video_feat,
+                                                       dynamic_question_embedding, word_embedding, question_len,
+                                                       *params)
+        return (vis, aqe, mqe, list(ca.unbind(0)), list(cm.unbind(0)), list(aq.unbind(0)), list(mq.unbind(0)))

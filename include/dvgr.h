@@ -1,0 +1,170 @@
+/*
+ * dvgr.h -- C ABI of the MI355X-native DualVGR reasoning unit (libdvgr_hip.so).
+ *
+ * The reference (NJUPT-MCC/DualVGR-VideoQA) has no FFI or plugin layer: the hot path sits behind a
+ * PyTorch nn.Module contract.  Each entry point below names the reference interface it replaces
+ * (paths relative to the reference repository).  The Python host side
+ * (dualvgr-videoqa_amd/unit.py) binds these with ctypes and exposes the reference's own
+ * `DualVGRUnit_multiple` constructor / forward() signature (model/models.py:87,121).
+ *
+ * Conventions
+ *   - every tensor is fp32, contiguous, row-major, last dimension fastest, resident in HBM;
+ *   - the library never allocates, frees or retains device memory and never synchronises the
+ *     device: it only enqueues kernels on the stream it is given (safe under hipGraph capture);
+ *   - functions return 0 on success, a negative DVGR_E_* code for invalid arguments, or the
+ *     positive hipError_t value of a failed launch;
+ *   - no mutable global state: calls are re-entrant (autograd calls backward from its own thread).
+ */
+#ifndef DVGR_H
+#define DVGR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVGR_F32 0  /* fp32 operands on v_mfma_f32_16x16x4_f32 (exact fp32; parity mode)           */
+#define DVGR_BF16 1 /* bf16 operands (rounded on chip) on v_mfma_f32_16x16x32_bf16, fp32 accumulate */
+
+#define DVGR_E_DIMS (-1)      /* unsupported dimension (see dvgr_check_dims)            */
+#define DVGR_E_NULL (-2)      /* a required pointer is NULL                             */
+#define DVGR_E_WORKSPACE (-3) /* saved/workspace buffer too small                       */
+#define DVGR_E_ALIGN (-4)     /* a pointer is not 16-byte aligned                       */
+#define DVGR_E_KIND (-5)      /* unknown parameter / saved-tensor kind                  */
+
+/* Problem dimensions.  Mirrors the constructor arguments of DualVGRUnit_multiple
+ * (model/models.py:87) plus the run-time batch shape of its forward (model/models.py:121-133). */
+typedef struct dvgr_dims {
+  int32_t B;     /* batch size (QA pairs)                                            */
+  int32_t N;     /* num_of_nodes = clips per video (configs yml: train.num_of_nodes) */
+  int32_t T;     /* padded question length of this batch                             */
+  int32_t D;     /* module_dim (768); multiple of 64                                 */
+  int32_t Wd;    /* word_dim (300); multiple of 4                                    */
+  int32_t L;     /* unit_layers                                                      */
+  int32_t G;     /* graph_layers; only 1 is supported (all reference configs use 1)  */
+  int32_t dtype; /* DVGR_F32 or DVGR_BF16                                            */
+} dvgr_dims;
+
+/* Kinds of parameter tensors inside the flat parameter buffer.  `mod` = 0 appearance, 1 motion.
+ * Reference state_dict names each kind aliases:
+ *   QA_W1/B1  queryAttn.l.feat_enhance.{weight,bias}      QA_W2/B2  queryAttn.l.fc.{weight,bias}
+ *   WQ/BQ     queryPunish_{appear,motion}.l.query_weight.{weight,bias}
+ *   GAT_W     rows [h*F,(h+1)*F) = {acGCN|mcGCN}.l.attention_h.W.weight for h<4 (common GAT),
+ *             rows [(4+h)*F, ...) = {appearance_GCN|motion_GCN}.l.attention_h.W.weight (specific)
+ *   GAT_B     same packing of the W.bias vectors;  GAT_A  row h = a.weight (1, 2F);  GAT_C  a.bias
+ *   SF_P1/BP  attention_{appearance,motion}.l.project.0.{weight,bias}   SF_P2  project.2.weight
+ *   MFB_*     visualfusion.{linear0,linear1,linear_out}.{weight,bias}  (layer/mod ignored)      */
+enum dvgr_param_kind {
+  DVGR_P_QA_W1 = 0, DVGR_P_QA_B1, DVGR_P_QA_W2, DVGR_P_QA_B2,
+  DVGR_P_WQ, DVGR_P_BQ,
+  DVGR_P_GAT_W, DVGR_P_GAT_B, DVGR_P_GAT_A, DVGR_P_GAT_C,
+  DVGR_P_SF_P1, DVGR_P_SF_BP, DVGR_P_SF_P2,
+  DVGR_P_MFB_W0, DVGR_P_MFB_B0, DVGR_P_MFB_W1, DVGR_P_MFB_B1, DVGR_P_MFB_WO, DVGR_P_MFB_BO,
+  DVGR_P_KINDS
+};
+
+/* Kinds of tensors the forward saves for the backward (introspection for the parity tests). */
+enum dvgr_saved_kind {
+  DVGR_S_QA_D = 0,   /* (B*T, D)  L2-normalised feat_enhance output                 per layer     */
+  DVGR_S_QA_NRM,     /* (B*T)     max(||y||, 1e-12)                                                */
+  DVGR_S_QA_A,       /* (B*T)     softmax over all T                                               */
+  DVGR_S_QA_AH,      /* (B*T)     masked + renormalised attention                                  */
+  DVGR_S_QA_S,       /* (B)       sum of masked attention + 1e-5                                   */
+  DVGR_S_QA_Q,       /* (B, Wd)   cycle question vector                                            */
+  DVGR_S_P,          /* (B, D)    query_weight(q)                                   per layer, mod */
+  DVGR_S_S,          /* (B*N)     punish gate sigmoid(X.p)                                         */
+  DVGR_S_X,          /* (B*N, D)  layer OUTPUT X' = X + o (input of layer l+1 / of the MFB)        */
+  DVGR_S_WH,         /* (B*N, 8F) packed head projections                                          */
+  DVGR_S_U,          /* (B, 8, N) a_l . Wh_i                                                       */
+  DVGR_S_V,          /* (B, 8, N) a_r . Wh_j                                                       */
+  DVGR_S_TN,         /* (2, B*N, D) tanh(project.0(z_v)), v = 0 common, 1 specific                 */
+  DVGR_S_BETA,       /* (B*N, 2)  softmax over the two views                                       */
+  DVGR_S_MFB_X0,     /* (B*N, 512) ELU(linear0(A))                                  once           */
+  DVGR_S_MFB_X1,     /* (B*N, 512) ELU(linear1(M))                                                 */
+  DVGR_S_MFB_Z,      /* (B*N, 256) pair-summed product                                             */
+  DVGR_S_KINDS
+};
+
+/* Inputs and outputs of DualVGRUnit_multiple.forward (model/models.py:121-173). */
+typedef struct dvgr_io {
+  const float *A;       /* appearance_video_feat       (B, N, D)  */
+  const float *M;       /* motion_video_feat           (B, N, D)  */
+  const float *dq;      /* dynamic_question_embedding  (B, T, D)  */
+  const float *words;   /* word_embedding              (B, T, Wd) */
+  const int64_t *qlen;  /* question_len                (B) int64  */
+  float *vis;           /* visual_feature              (B, N, D)  */
+  float *aq_embed;      /* last layer's fused appearance embedding (B, N, D) */
+  float *mq_embed;      /* last layer's fused motion embedding     (B, N, D) */
+  float *com_app;       /* com_app_list    as one (L, B, N, D) tensor */
+  float *com_mot;       /* com_motion_list as one (L, B, N, D) tensor */
+  float *aq_fusion;     /* aq_fusion_list  as one (L, B, N, D) tensor */
+  float *mq_fusion;     /* mq_fusion_list  as one (L, B, N, D) tensor */
+} dvgr_io;
+
+/* Upstream gradients (any may be NULL = zero) and gradient outputs of the backward pass. */
+typedef struct dvgr_grads {
+  const float *g_vis, *g_aq_embed, *g_mq_embed;                 /* (B, N, D)    */
+  const float *g_com_app, *g_com_mot, *g_aq_fusion, *g_mq_fusion; /* (L, B, N, D) */
+  float *gA, *gM;       /* (B, N, D)  */
+  float *gdq;           /* (B, T, D)  */
+  float *gwords;        /* (B, T, Wd) */
+  float *gparams;       /* flat, same layout as the parameter buffer; every element is written */
+} dvgr_grads;
+
+/* Library version string "dvgr-hip <semver> gfx950". */
+const char *dvgr_version(void);
+
+/* 0 when `d` is supported: B,N,T,L >= 1, G == 1, D % 64 == 0, Wd % 4 == 0, N <= 64, T <= 256. */
+int dvgr_check_dims(const dvgr_dims *d);
+
+/* Number of fp32 elements of the flat parameter buffer (replaces the nn.ModuleList storage built
+ * by DualVGRUnit_multiple.__init__, model/models.py:87-112). */
+int64_t dvgr_param_count(const dvgr_dims *d);
+
+/* Element offset and 2-D shape (rows, cols; vectors have rows = 1) of one parameter tensor inside
+ * the flat buffer.  Every offset is a multiple of 64 elements. */
+int dvgr_param_offset(const dvgr_dims *d, int kind, int layer, int mod,
+                      int64_t *offset, int64_t *rows, int64_t *cols);
+
+/* Bytes the forward writes into `saved` for the backward, and the byte offset of one saved tensor. */
+size_t dvgr_saved_bytes(const dvgr_dims *d);
+int dvgr_saved_offset(const dvgr_dims *d, int kind, int layer, int mod, size_t *offset_bytes);
+
+/* Scratch bytes needed by forward / backward (contents undefined between calls). */
+size_t dvgr_workspace_bytes(const dvgr_dims *d);
+
+/* bf16 shadow copy of the parameters for DVGR_BF16 (same element offsets, 2 bytes per element);
+ * call after every optimizer step.  `params_lp` must hold dvgr_param_count() * 2 bytes. */
+int dvgr_pack_weights(const dvgr_dims *d, const float *params, void *params_lp, void *stream);
+
+/* Forward of the whole stacked unit: replaces DualVGRUnit_multiple.forward (model/models.py:
+ * 121-173) and, inside it, QueryAttn/QueryPunish.forward (model/utils.py:66-105), punishGAT /
+ * PunishGraphAttentionLayer.forward (model/GraphNN.py:95-178), AttentionSFGCN.forward
+ * (model/Attention.py:20-23) and MFB.forward (model/fusions/fusions.py:419-453).
+ * `train` != 0 enables the 24 dropout sites per layer (p = 0.15) with a counter-based RNG keyed
+ * by `seed` (masks are recomputed, never stored).  `params_lp` may be NULL for DVGR_F32. */
+int dvgr_unit_forward(const dvgr_dims *d, const float *params, const void *params_lp,
+                      const dvgr_io *io, void *saved, size_t saved_bytes,
+                      void *workspace, size_t workspace_bytes,
+                      int train, uint64_t seed, void *stream);
+
+/* Backward of the same: replaces the autograd graph PyTorch builds for the modules above.
+ * `layer_done_events` (nullable) is an array of L+1 hipEvent_t: event[L] is recorded when the MFB
+ * parameter gradients are final, event[l] when layer l's are, so a data-parallel caller can start
+ * the RCCL all-reduce of that slice of `gparams` while earlier layers are still running. */
+int dvgr_unit_backward(const dvgr_dims *d, const float *params, const void *params_lp,
+                       const dvgr_io *io, const dvgr_grads *g,
+                       const void *saved, size_t saved_bytes,
+                       void *workspace, size_t workspace_bytes,
+                       int train, uint64_t seed, void *const *layer_done_events, void *stream);
+
+/* [first, last) element range of the flat buffer that holds layer `layer`'s parameters
+ * (layer == L: the MFB block). */
+int dvgr_param_layer_range(const dvgr_dims *d, int layer, int64_t *first, int64_t *last);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVGR_H */

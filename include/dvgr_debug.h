@@ -1,0 +1,37 @@
+/*
+ * dvgr_debug.h -- test hooks of libdvgr_hip.so: the building-block kernels behind single calls so
+ * the parity tests can localise a mismatch (tests/test_hip_blocks.py).  Not part of the drop-in
+ * surface; same conventions as dvgr.h (device pointers, caller's stream, 0 = success).
+ */
+#ifndef DVGR_DEBUG_H
+#define DVGR_DEBUG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* One contraction C (+)= act(op(A) . op(B) + bias) on the MFMA engine (csrc/dvgr_gemm.h).
+ *   mode 0 (NT): A[M,K] lda, B[N,K] ldb      -- forward Linear  (nn.Linear: y = x W^T + b)
+ *   mode 1 (NN): A[M,K] lda, B[K,N] ldb      -- backward data
+ *   mode 2 (TN): A[K,M] lda, B[K,N] ldb      -- backward weight; rows >= kseg of A/B come from A2/B2
+ * act: 0 none, 1 tanh, 2 ELU.  drop_key_* = 0 disables the dropout masks. */
+int dvgr_dbg_gemm(int mode, int M, int N, int K, int kseg, const float *A, const float *A2, int64_t lda,
+                  const float *B, const float *B2, int64_t ldb, float *C, int64_t ldc, const float *bias,
+                  int act, int accumulate, uint32_t drop_key_a, uint32_t drop_key_b, uint32_t drop_key_c,
+                  void *stream);
+
+/* out[c] = sum_r w[r] * M[r][c]  (w nullable) */
+int dvgr_dbg_colsum(const float *M, const float *w, int rows, int cols, int64_t ld, float *out, void *stream);
+
+/* keep[i] = 1.0f / 0.0f for i in [0, n): the dropout keep decision of the device RNG for `key`. */
+int dvgr_dbg_keep_mask(uint32_t key, int64_t n, float *keep, void *stream);
+
+/* site key of (seed, layer, mod, gat, which) exactly as the forward derives it. */
+uint32_t dvgr_dbg_site_key(uint64_t seed, int layer, int mod, int gat, int which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVGR_DEBUG_H */

