@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Benchmark of the DualVGR reasoning unit on MI355X: QA-pairs/sec (forward+backward) per GPU,
+SVQA num_clips=20 (BASELINE.json).  One step = one forward + one backward of the stacked unit
+over one batch of synthetic inputs already resident in HBM (training mode, dropout on).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]           # N > 1 via torch.distributed.run
+
+Prints ONE JSON line on rank 0 (contract in the task statement): whole-job QA-pairs/s, the
+roofline of the dominant kernel (forward GAT projection GEMM, timed live with HIP events on the
+launch stream) and the CPU baseline (the oracle's op-for-op PyTorch-CPU restatement of the
+reference, timed on this box's host cores, rank 0 at N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+# BASELINE.json `configs` (per-GPU batch; D = 768, Wd = 300, T = 15 as in SURVEY.md section 8)
+CONFIGS = {
+    "c1": dict(B=8, N=20, L=1, T=15, name="SVQA num_clips=20 unit_layers=1 batch=8"),
+    "c2": dict(B=64, N=20, L=3, T=15, name="SVQA num_clips=20 unit_layers=3 batch=64"),
+    "c3": dict(B=128, N=8, L=3, T=15, name="MSVD-QA num_clips=8 unit_layers=3 batch=128"),
+    "c4": dict(B=32, N=16, L=6, T=15, name="MSRVTT-QA num_clips=16 unit_layers=6 batch=256/8 per GPU"),
+    "c5": dict(B=64, N=64, L=12, T=15, name="stress num_clips=64 unit_layers=12 batch=512/8 per GPU"),
+}
+D, WD = 768, 300
+PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}     # /opt/skills/guides/MI355X_MICROARCH.md, dense MFMA
+
+
+def f_fwd(N, L, T):
+    """Algorithmic GEMM FLOPs per QA pair, forward."""
+    return L * (16 * N * D * D + 2 * T * D * D + 8 * N * N * D + 28 * N * D + 2 * T * D + 2 * T * WD + 4 * WD * D) + 2560 * N * D
+
+
+def cpu_baseline(cfg, seconds=15.0):
+    """Reference CPU path (oracle = op-for-op port, kind 'port') on the host cores: forward+backward
+    of the unit at the benchmark's N / L / T on a bounded sample of the batch."""
+    from oracle import unit_torch as O          # test infrastructure, used only as the timed baseline
+    from dualvgr_videoqa_amd import synth
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    Bs = 8
+    sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in
+          synth.xavier_state_dict(O.param_shapes(WD, D, cfg["L"]), seed=666).items()}
+    inp = synth.unit_inputs(Bs, cfg["N"], cfg["T"], D, WD, seed=666)
+    t = {k: torch.from_numpy(v) for k, v in inp.items()}
+    masks = None
+
+    def step():
+        for p in sd.values():
+            p.grad = None
+        outs = O.unit_forward(sd, t["A"], t["M"], t["dq"], t["words"], t["qlen"], cfg["L"], 1, masks=masks, naive=True)
+        O.bench_scalar_loss(outs, cfg["N"]).backward()
+
+    step()
+    t0 = time.perf_counter()
+    step()
+    one = time.perf_counter() - t0
+    n = int(max(3, min(200, seconds / max(one, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    dt = (time.perf_counter() - t0) / n
+    model = "?"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except Exception:
+        pass
+    return {"value": Bs / dt, "unit": "QA-pairs/s", "cores": cores, "kind": "port",
+            "sample": f"B={Bs} of the {cfg['B']}-pair batch, N={cfg['N']} L={cfg['L']} T={cfg['T']} fp32 eval-mode "
+                      f"forward+backward, naive (B,N,N,2F) form, 2 warm-up + {n} timed steps, {dt * 1e3:.1f} ms/step, "
+                      f"{cores} threads on {model}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--eval-mode", action="store_true", help="dropout off (default: training mode, dropout on)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--probe", default="fwd_gat_gemm")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (there is no CPU fallback of the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import dualvgr_videoqa_amd as dv
+    from dualvgr_videoqa_amd import _lib as L_
+    from dualvgr_videoqa_amd import losses, parallel, synth
+
+    cfg = CONFIGS[args.config]
+    B, N, Lr, T = cfg["B"], cfg["N"], cfg["L"], cfg["T"]
+    shapes = {n: s for n, s, _ in dv.param_table(L_.make_dims(1, N, 1, D, WD, Lr))}
+    sd_np = synth.xavier_state_dict(shapes, seed=666)          # same weights on every rank (as after a broadcast)
+    m = dv.DualVGRUnit_multiple(word_dim=WD, module_dim=D, num_of_nodes=N, unit_layers=Lr, dtype=args.dtype)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    m = m.to(dev)
+    m.train(not args.eval_mode)
+    inp = synth.unit_inputs(B, N, T, D, WD, seed=666 + rank)  # each rank owns its own QA pairs (weak scaling)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
+    for k in ("A", "M", "dq", "words"):
+        t[k].requires_grad_(True)                              # the encoders upstream need these gradients
+
+    # upstream gradients of every output: the true gradient of the scope-U loss
+    # sum(vis) + common + 1e-8 * HSIC at the first forward, held fixed for the timed
+    # steps (the auxiliary-loss arithmetic is caller code, not the path: SURVEY.md 8f row f1)
+    raw = m.forward_raw(t["A"], t["M"], t["dq"], t["words"], t["qlen"])
+    det = [r.detach().clone().requires_grad_(True) for r in raw]
+    loss0 = losses.scope_u_loss((det[0], det[1], det[2], list(det[3].unbind(0)), list(det[4].unbind(0)),
+                                 list(det[5].unbind(0)), list(det[6].unbind(0))), N, world_size=world)
+    ups = list(torch.autograd.grad(loss0, det, allow_unused=True))
+    ups = [u if u is not None else torch.zeros_like(r) for u, r in zip(ups, raw)]
+    del raw, det, loss0
+
+    events = None
+    reducer = None
+    if world > 1:
+        events = [torch.cuda.Event() for _ in range(Lr + 1)]
+        m.set_layer_events(events)
+        reducer = parallel.LayerBucketReducer(parallel.layer_buckets(m), device=dev)
+        ev_order = [events[Lr]] + [events[l] for l in range(Lr - 1, -1, -1)]
+
+    probe_sites = {"fwd_gat_gemm": (L_.PROBE_FWD_GAT_GEMM, 8 * B * N * D * D, "gemm_kernel<KC,KC,*,*,TAG_FWD_GAT=1> (Wh = X.Wcat^T, both modalities)"),
+                   "fwd_sf_gemm": (L_.PROBE_FWD_SF_GEMM, 8 * B * N * D * D, "gemm_kernel<KC,KC,*,*,TAG_FWD_SF=2>"),
+                   "bwd_gat_dw": (L_.PROBE_BWD_GAT_DW, 8 * B * N * D * D, "gemm_kernel<IC,IC,*,*,TAG_BWD_GAT_DW=3>"),
+                   "bwd_gat_dx": (L_.PROBE_BWD_GAT_DX, 8 * B * N * D * D, "gemm_kernel<KC,IC,*,*,TAG_BWD_GAT_DX=4>")}
+    site, probe_flops, probe_name = probe_sites[args.probe]
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i=None):
+        if i is not None:
+            m.set_probe(site, 0, pairs[i][0], pairs[i][1])
+        m.zero_grad_flat()
+        for k in ("A", "M", "dq", "words"):
+            t[k].grad = None
+        raw = m.forward_raw(t["A"], t["M"], t["dq"], t["words"], t["qlen"])
+        torch.autograd.backward(raw, ups)
+        if reducer is not None:
+            reducer.reduce(m.last_flat_grad, ev_order)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    m.set_probe(0)
+
+    ms_step = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+    probe_ms = float(np.mean([a.elapsed_time(b) for a, b in pairs]))
+    achieved = probe_flops / (probe_ms * 1e-3) / 1e12
+    peak = PEAK_TFLOPS[args.dtype]
+    f_train = 3 * f_fwd(N, Lr, T)
+    out = {
+        "metric": "QA-pairs/sec (forward+backward) per GPU, SVQA num_clips=20",
+        "value": value, "unit": "QA-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
+        "config": {"workload": f"{cfg['name']}: DualVGR unit forward+backward, per-GPU batch {B}, D={D}, word_dim={WD}, "
+                               f"T={T}, {'eval' if args.eval_mode else 'training (dropout 0.15 on)'}",
+                   "global_batch": world * B, "parallelism": f"dp{world}",
+                   "loss": "upstream gradients of sum(vis)+common+1e-8*HSIC for all 3+4L outputs, precomputed once",
+                   "algorithmic_gflop_per_qa_train": f_train / 1e9,
+                   "unit_tflops": value / world * f_train / 1e12,
+                   "unit_frac_of_mfma_peak": value / world * f_train / 1e12 / peak},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                     "traffic": None, "kernel": probe_name, "launch_ms": probe_ms,
+                     "algorithmic_gflop_per_launch": probe_flops / 1e9},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -39,6 +39,16 @@ class Grads(C.Structure):
                                           "g_aq_fusion", "g_mq_fusion", "gA", "gM", "gdq", "gwords", "gparams")]
 
 
+class Opts(C.Structure):
+    _fields_ = [("train", C.c_int32), ("probe_site", C.c_int32), ("probe_layer", C.c_int32), ("reserved", C.c_int32),
+                ("seed", C.c_uint64), ("probe_begin", C.c_void_p), ("probe_end", C.c_void_p),
+                ("layer_done_events", C.POINTER(C.c_void_p))]
+
+
+# enum dvgr_probe_site
+(PROBE_NONE, PROBE_FWD_QA_GEMM, PROBE_FWD_GAT_GEMM, PROBE_FWD_GAT_ATTN, PROBE_FWD_SF_GEMM, PROBE_FWD_MFB_GEMM,
+ PROBE_BWD_SF_DW, PROBE_BWD_SF_DX, PROBE_BWD_GAT_ATTN, PROBE_BWD_GAT_DW, PROBE_BWD_GAT_DX, PROBE_SITES) = range(12)
+
 # every symbol include/dvgr.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("dvgr_version", C.c_char_p, []),
@@ -52,10 +62,9 @@ SYMBOLS = [
     ("dvgr_workspace_bytes", C.c_size_t, [C.POINTER(Dims)]),
     ("dvgr_pack_weights", C.c_int, [C.POINTER(Dims), C.c_void_p, C.c_void_p, C.c_void_p]),
     ("dvgr_unit_forward", C.c_int, [C.POINTER(Dims), C.c_void_p, C.c_void_p, C.POINTER(IO), C.c_void_p, C.c_size_t,
-                                    C.c_void_p, C.c_size_t, C.c_int, C.c_uint64, C.c_void_p]),
+                                    C.c_void_p, C.c_size_t, C.POINTER(Opts), C.c_void_p]),
     ("dvgr_unit_backward", C.c_int, [C.POINTER(Dims), C.c_void_p, C.c_void_p, C.POINTER(IO), C.POINTER(Grads),
-                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_uint64,
-                                     C.POINTER(C.c_void_p), C.c_void_p]),
+                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(Opts), C.c_void_p]),
 ]
 
 # test hooks declared in include/dvgr_debug.h

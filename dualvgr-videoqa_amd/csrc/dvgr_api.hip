@@ -97,6 +97,15 @@ Keys layer_keys(int train, uint64_t seed, int l) {
   return k;
 }
 
+// Brackets one launch site with the caller's hipEvents (dvgr_opts.probe_*).
+struct Probe {
+  const dvgr_opts& o;
+  hipStream_t st;
+  bool hit(int site, int layer) const { return o.probe_site == site && o.probe_layer == layer && o.probe_begin && o.probe_end; }
+  int begin(int site, int layer) const { return hit(site, layer) ? (int)hipEventRecord((hipEvent_t)o.probe_begin, st) : 0; }
+  int end(int site, int layer) const { return hit(site, layer) ? (int)hipEventRecord((hipEvent_t)o.probe_end, st) : 0; }
+};
+
 int check_common(const dvgr_dims* d, const void* params, const dvgr_io* io, const void* saved, size_t saved_bytes,
                  const void* ws, size_t ws_bytes) {
   if (!d) return DVGR_E_NULL;
@@ -224,12 +233,17 @@ int dvgr_pack_weights(const dvgr_dims* d, const float* params, void* params_lp, 
 // Forward schedule (stages S0..S6 of oracle/unit_manual.py)
 // =================================================================================================
 int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* params_lp, const dvgr_io* io,
-                      void* saved_v, size_t saved_bytes, void* ws_v, size_t ws_bytes, int train, uint64_t seed,
+                      void* saved_v, size_t saved_bytes, void* ws_v, size_t ws_bytes, const dvgr_opts* opts,
                       void* stream) {
   (void)params_lp;
   DVGR_TRY(check_common(dp, params, io, saved_v, saved_bytes, ws_v, ws_bytes));
   const dvgr_dims d = *dp;
   hipStream_t st = (hipStream_t)stream;
+  const dvgr_opts o0{};
+  const dvgr_opts& O = opts ? *opts : o0;
+  const int train = O.train;
+  const uint64_t seed = O.seed;
+  const Probe probe{O, st};
   const ParamLayout P = param_layout(d);
   const SavedLayout S = saved_layout(d);
   const FwdWs W = fwd_ws(d);
@@ -248,7 +262,9 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
     GemmBatch gb{};
     for (int l = l0; l < L && l < l0 + kMaxBatch; ++l)
       gb.p[gb.n++] = nt(io->dq, D, lp(l) + P.qa_w1, D, ws + W.Y + (int64_t)l * BT * D, D, lp(l) + P.qa_b1, BT, D, D, ACT_NONE);
+    DVGR_TRY(probe.begin(DVGR_PROBE_FWD_QA_GEMM, l0));
     DVGR_TRY(gemm_launch(st, KC, KC, gb));
+    DVGR_TRY(probe.end(DVGR_PROBE_FWD_QA_GEMM, l0));
   }
   {
     QaRowsArgs a{};
@@ -287,7 +303,9 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
                               mp(l, m) + P.gat_b + g * 4 * F, BN, 4 * F, D, ACT_NONE, K.x[m][g]);
         }
       }
-      DVGR_TRY(gemm_launch(st, KC, KC, gb));
+      DVGR_TRY(probe.begin(DVGR_PROBE_FWD_GAT_GEMM, l));
+      DVGR_TRY(gemm_launch(st, KC, KC, gb, TAG_FWD_GAT));
+      DVGR_TRY(probe.end(DVGR_PROBE_FWD_GAT_GEMM, l));
     }
     // S3
     {
@@ -301,7 +319,9 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
         for (int g = 0; g < 2; ++g) a.key_out[m][g] = K.out[m][g];
       }
       a.B = B; a.N = N; a.D = D;
+      DVGR_TRY(probe.begin(DVGR_PROBE_FWD_GAT_ATTN, l));
       DVGR_TRY(gat_attn_fwd(st, a));
+      DVGR_TRY(probe.end(DVGR_PROBE_FWD_GAT_ATTN, l));
     }
     // S4: tn_v = tanh(z_v . P1^T + bP)
     {
@@ -310,7 +330,9 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
         gb.p[gb.n++] = nt(outc[m], D, mp(l, m) + P.sf_p1, D, ms(l, m) + S.tn, D, mp(l, m) + P.sf_bp, BN, D, D, ACT_TANH);
         gb.p[gb.n++] = nt(outs[m], D, mp(l, m) + P.sf_p1, D, ms(l, m) + S.tn + BND, D, mp(l, m) + P.sf_bp, BN, D, D, ACT_TANH);
       }
-      DVGR_TRY(gemm_launch(st, KC, KC, gb));
+      DVGR_TRY(probe.begin(DVGR_PROBE_FWD_SF_GEMM, l));
+      DVGR_TRY(gemm_launch(st, KC, KC, gb, TAG_FWD_SF));
+      DVGR_TRY(probe.end(DVGR_PROBE_FWD_SF_GEMM, l));
     }
     // S5
     {
@@ -330,7 +352,9 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
     GemmBatch gb{};
     gb.p[gb.n++] = nt(ms(L - 1, 0) + S.x, D, params + P.mfb_w0, D, saved + S.mfb_x0, kMfbHidden, params + P.mfb_b0, BN, kMfbHidden, D, ACT_ELU);
     gb.p[gb.n++] = nt(ms(L - 1, 1) + S.x, D, params + P.mfb_w1, D, saved + S.mfb_x1, kMfbHidden, params + P.mfb_b1, BN, kMfbHidden, D, ACT_ELU);
+    DVGR_TRY(probe.begin(DVGR_PROBE_FWD_MFB_GEMM, 0));
     DVGR_TRY(gemm_launch(st, KC, KC, gb));
+    DVGR_TRY(probe.end(DVGR_PROBE_FWD_MFB_GEMM, 0));
     DVGR_TRY(mfb_pool_fwd(st, saved + S.mfb_x0, saved + S.mfb_x1, saved + S.mfb_z, BN));
     GemmBatch go{};
     go.p[go.n++] = nt(saved + S.mfb_z, kMfbPooled, params + P.mfb_wo, kMfbPooled, io->vis, D, params + P.mfb_bo, BN, D, kMfbPooled, ACT_ELU);
@@ -344,14 +368,20 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
 // =================================================================================================
 int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* params_lp, const dvgr_io* io,
                        const dvgr_grads* g, const void* saved_v, size_t saved_bytes, void* ws_v, size_t ws_bytes,
-                       int train, uint64_t seed, void* const* layer_done_events, void* stream) {
+                       const dvgr_opts* opts, void* stream) {
   (void)params_lp;
+  const dvgr_opts o0{};
+  const dvgr_opts& O = opts ? *opts : o0;
+  const int train = O.train;
+  const uint64_t seed = O.seed;
+  void* const* layer_done_events = O.layer_done_events;
   DVGR_TRY(check_common(dp, params, io, saved_v, saved_bytes, ws_v, ws_bytes));
   if (!g || !g->gA || !g->gM || !g->gdq || !g->gwords || !g->gparams) return DVGR_E_NULL;
   if (!aligned16(g->gA) || !aligned16(g->gM) || !aligned16(g->gdq) || !aligned16(g->gwords) || !aligned16(g->gparams))
     return DVGR_E_ALIGN;
   const dvgr_dims d = *dp;
   hipStream_t st = (hipStream_t)stream;
+  const Probe probe{O, st};
   const ParamLayout P = param_layout(d);
   const SavedLayout S = saved_layout(d);
   const BwdWs W = bwd_ws(d);
@@ -443,11 +473,15 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
         p.B.p1 = outs[m];
         gb.p[gb.n++] = p;
       }
-      DVGR_TRY(gemm_launch(st, IC, IC, gb));
+      DVGR_TRY(probe.begin(DVGR_PROBE_BWD_SF_DW, l));
+      DVGR_TRY(gemm_launch(st, IC, IC, gb, TAG_BWD_SF_DW));
+      DVGR_TRY(probe.end(DVGR_PROBE_BWD_SF_DW, l));
       GemmBatch gd{};   // dz_v += dpre_v . P1
       for (int m = 0; m < 2; ++m)
         gd.p[gd.n++] = nn(ws + W.dpre[m], D, mp(l, m) + P.sf_p1, D, ws + W.dz[m], D, 2 * BN, D, D, 1);
-      DVGR_TRY(gemm_launch(st, KC, IC, gd));
+      DVGR_TRY(probe.begin(DVGR_PROBE_BWD_SF_DX, l));
+      DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_BWD_SF_DX));
+      DVGR_TRY(probe.end(DVGR_PROBE_BWD_SF_DX, l));
     }
     // S3 backward
     {
@@ -462,7 +496,9 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
         for (int gi = 0; gi < 2; ++gi) a.key_out[m][gi] = K.out[m][gi];
       }
       a.B = B; a.N = N; a.D = D;
+      DVGR_TRY(probe.begin(DVGR_PROBE_BWD_GAT_ATTN, l));
       DVGR_TRY(gat_attn_bwd(st, a));
+      DVGR_TRY(probe.end(DVGR_PROBE_BWD_GAT_ATTN, l));
     }
     for (int m = 0; m < 2; ++m) {
       cb.j[cb.n++] = ColsumJob{ws + W.da_part[m], nullptr, nullptr, nullptr, B, 0, kHeads * 2 * F, kHeads * 2 * F, gmp(l, m) + P.gat_a};
@@ -481,19 +517,25 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
                               4 * F, D, BN, K.x[m][gi]);
         }
       }
-      DVGR_TRY(gemm_launch(st, IC, IC, gb));
+      DVGR_TRY(probe.begin(DVGR_PROBE_BWD_GAT_DW, l));
+      DVGR_TRY(gemm_launch(st, IC, IC, gb, TAG_BWD_GAT_DW));
+      DVGR_TRY(probe.end(DVGR_PROBE_BWD_GAT_DW, l));
       if (!train) {
         GemmBatch gd{};
         for (int m = 0; m < 2; ++m)
           gd.p[gd.n++] = nn(ws + W.dWh[m], HF, mp(l, m) + P.gat_w, D, dXacc[m], D, BN, D, HF, 1);
-        DVGR_TRY(gemm_launch(st, KC, IC, gd));
+        DVGR_TRY(probe.begin(DVGR_PROBE_BWD_GAT_DX, l));
+        DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_BWD_GAT_DX));
+        DVGR_TRY(probe.end(DVGR_PROBE_BWD_GAT_DX, l));
       } else {
         for (int gi = 0; gi < 2; ++gi) {   // the two GATs dropped x with different masks: two passes
           GemmBatch gd{};
           for (int m = 0; m < 2; ++m)
             gd.p[gd.n++] = nn(ws + W.dWh[m] + gi * 4 * F, HF, mp(l, m) + P.gat_w + (int64_t)gi * 4 * F * D, D, dXacc[m], D,
                               BN, D, 4 * F, 1, K.x[m][gi]);
-          DVGR_TRY(gemm_launch(st, KC, IC, gd));
+          if (gi == 0) DVGR_TRY(probe.begin(DVGR_PROBE_BWD_GAT_DX, l));
+          DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_BWD_GAT_DX));
+          if (gi == 1) DVGR_TRY(probe.end(DVGR_PROBE_BWD_GAT_DX, l));
         }
       }
     }

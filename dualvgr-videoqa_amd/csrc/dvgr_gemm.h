@@ -45,8 +45,12 @@ struct GemmBatch {
   int n;
 };
 
+// Launch-site tags: each tag is a separate instantiation (= its own kernel symbol in a profile).
+enum : int { TAG_GENERIC = 0, TAG_FWD_GAT = 1, TAG_FWD_SF = 2, TAG_BWD_GAT_DW = 3, TAG_BWD_GAT_DX = 4,
+             TAG_BWD_SF_DW = 5, TAG_BWD_SF_DX = 6 };
+
 // Enqueue the batch on `stream`.  la / lb in {KC, IC}.  Returns hipError_t as int.
-int gemm_launch(hipStream_t stream, int la, int lb, const GemmBatch& batch);
+int gemm_launch(hipStream_t stream, int la, int lb, const GemmBatch& batch, int tag = TAG_GENERIC);
 
 inline GemmOperand operand(const float* p, int64_t ld, uint32_t drop_key = 0) {
   GemmOperand o; o.p0 = p; o.p1 = p; o.ld = ld; o.drop_key = drop_key; return o;

@@ -80,7 +80,8 @@ __device__ __forceinline__ f32x4 load_frag(const float* sm, int idx16, int kk, i
   }
 }
 
-template <int LA, int LB, int BM, int BN>
+// TAG only gives a launch site its own kernel symbol (rocprofv3 then reports it separately).
+template <int LA, int LB, int BM, int BN, int TAG>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch batch) {
   const GemmProblem& P = batch.p[blockIdx.z];
   const int tiles_n = (P.N + BN - 1) / BN;
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch batch) {
   }
 }
 
-template <int LA, int LB, int BM, int BN>
+template <int LA, int LB, int BM, int BN, int TAG>
 static int launch_cfg(hipStream_t stream, const GemmBatch& b) {
   int tiles = 0;
   for (int i = 0; i < b.n; ++i) {
@@ -177,21 +178,21 @@ static int launch_cfg(hipStream_t stream, const GemmBatch& b) {
     tiles = t > tiles ? t : tiles;
   }
   if (tiles == 0) return 0;
-  hipLaunchKernelGGL((gemm_kernel<LA, LB, BM, BN>), dim3(tiles, 1, b.n), dim3(256), 0, stream, b);
+  hipLaunchKernelGGL((gemm_kernel<LA, LB, BM, BN, TAG>), dim3(tiles, 1, b.n), dim3(256), 0, stream, b);
   return (int)hipGetLastError();
 }
 
-template <int LA, int LB>
+template <int LA, int LB, int TAG>
 static int launch_layout(hipStream_t stream, const GemmBatch& b) {
   // 128x128 tiles when they already give every CU a workgroup, else 64x64 (M = B*N is small:
   // 1280 rows at the headline configuration, so tile quantisation decides the CU fill).
   long wg128 = 0;
   for (int i = 0; i < b.n; ++i) wg128 += (long)((b.p[i].M + 127) / 128) * ((b.p[i].N + 127) / 128);
-  if (wg128 >= 200) return launch_cfg<LA, LB, 128, 128>(stream, b);
-  return launch_cfg<LA, LB, 64, 64>(stream, b);
+  if (wg128 >= 200) return launch_cfg<LA, LB, 128, 128, TAG>(stream, b);
+  return launch_cfg<LA, LB, 64, 64, TAG>(stream, b);
 }
 
-int gemm_launch(hipStream_t stream, int la, int lb, const GemmBatch& b) {
+int gemm_launch(hipStream_t stream, int la, int lb, const GemmBatch& b, int tag) {
   if (b.n < 1 || b.n > kMaxBatch) return DVGR_E_DIMS;
   for (int i = 0; i < b.n; ++i) {
     const GemmProblem& p = b.p[i];
@@ -202,9 +203,21 @@ int gemm_launch(hipStream_t stream, int la, int lb, const GemmBatch& b) {
     if (lb == KC && (p.K & 3)) return DVGR_E_DIMS;
     if (lb == IC && (p.N & 3)) return DVGR_E_DIMS;
   }
-  if (la == KC && lb == KC) return launch_layout<KC, KC>(stream, b);
-  if (la == KC && lb == IC) return launch_layout<KC, IC>(stream, b);
-  if (la == IC && lb == IC) return launch_layout<IC, IC>(stream, b);
+  if (la == KC && lb == KC) {
+    if (tag == TAG_FWD_GAT) return launch_layout<KC, KC, TAG_FWD_GAT>(stream, b);
+    if (tag == TAG_FWD_SF) return launch_layout<KC, KC, TAG_FWD_SF>(stream, b);
+    return launch_layout<KC, KC, TAG_GENERIC>(stream, b);
+  }
+  if (la == KC && lb == IC) {
+    if (tag == TAG_BWD_GAT_DX) return launch_layout<KC, IC, TAG_BWD_GAT_DX>(stream, b);
+    if (tag == TAG_BWD_SF_DX) return launch_layout<KC, IC, TAG_BWD_SF_DX>(stream, b);
+    return launch_layout<KC, IC, TAG_GENERIC>(stream, b);
+  }
+  if (la == IC && lb == IC) {
+    if (tag == TAG_BWD_GAT_DW) return launch_layout<IC, IC, TAG_BWD_GAT_DW>(stream, b);
+    if (tag == TAG_BWD_SF_DW) return launch_layout<IC, IC, TAG_BWD_SF_DW>(stream, b);
+    return launch_layout<IC, IC, TAG_GENERIC>(stream, b);
+  }
   return DVGR_E_DIMS;
 }
 

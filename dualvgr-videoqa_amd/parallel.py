@@ -1,0 +1,68 @@
+"""Data parallelism for the unit: one process per GPU, gradients all-reduced over RCCL (xGMI).
+
+The path shards by independent QA pairs: every rank runs the same kernels on
+its own slice of the batch and the only exchange step is the gradient all-reduce.  Because the
+backward writes ONE flat gradient buffer whose layer blocks become final in the order
+MFB, L-1, ..., 0, the natural bucket is a layer block: `LayerBucketReducer` starts the all-reduce of
+a block on a side stream as soon as the backward has recorded that block's event
+(dvgr_opts.layer_done_events), overlapping communication with the remaining backward kernels.
+
+Backends: "nccl" (= RCCL on ROCm) on GPUs; the same code runs over "gloo" on CPU tensors, which is
+how tests/test_parallel_gloo.py covers it without GPUs.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def layer_buckets(module) -> List[Tuple[int, int]]:
+    """[first, last) element ranges of the flat gradient buffer, in the order the backward
+    finalises them: MFB block first, then layers L-1 .. 0."""
+    L = module.layers
+    return [module.layer_param_range(l) for l in [L] + list(range(L - 1, -1, -1))]
+
+
+class LayerBucketReducer:
+    """Averages a flat gradient buffer across ranks, one all-reduce per layer bucket."""
+
+    def __init__(self, buckets: Sequence[Tuple[int, int]], group=None, device: Optional[torch.device] = None):
+        self.buckets = list(buckets)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.stream = None
+        if device is not None and device.type == "cuda":
+            self.stream = torch.cuda.Stream(device=device)
+
+    def reduce(self, flat_grad: torch.Tensor, events: Optional[Sequence] = None) -> None:
+        """In-place average of `flat_grad`.  `events[i]` (torch.cuda.Event or None) gates bucket i
+        on the communication stream; with no events every bucket waits for the current stream."""
+        if self.world == 1:
+            return
+        if flat_grad.is_cuda and self.stream is not None:
+            cur = torch.cuda.current_stream(flat_grad.device)
+            works = []
+            with torch.cuda.stream(self.stream):
+                for i, (a, b) in enumerate(self.buckets):
+                    if events is not None and events[i] is not None:
+                        self.stream.wait_event(events[i])
+                    else:
+                        self.stream.wait_stream(cur)
+                    works.append(dist.all_reduce(flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                for w in works:
+                    w.wait()
+                flat_grad.mul_(1.0 / self.world)
+            cur.wait_stream(self.stream)
+        else:
+            for (a, b) in self.buckets:
+                dist.all_reduce(flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group)
+            flat_grad.mul_(1.0 / self.world)
+
+
+def shard_batch(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [first, last) slice of `n_items` independent QA pairs owned by `rank`."""
+    base, rem = divmod(n_items, world)
+    first = rank * base + min(rank, rem)
+    return first, first + base + (1 if rank < rem else 0)

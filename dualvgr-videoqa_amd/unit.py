@@ -135,7 +135,9 @@ class _UnitFn(torch.autograd.Function):
     """Forward / backward of the whole stacked unit through the C ABI."""
 
     @staticmethod
-    def forward(ctx, mod: "DualVGRUnit_multiple", A, M, dq, words, qlen, *params):
+    def forward(ctx, mod: "DualVGRUnit_multiple", A, M, dq, words, qlen, anchor, *params):
+        # `anchor` is a 1-element leaf that requires grad: it keeps this node in the autograd graph when
+        # the parameter gradients are deposited directly (grad_mode='flat') and the inputs need no grad.
         lib = L_.load()
         if not A.is_cuda:
             raise RuntimeError("DualVGRUnit_multiple runs on a ROCm device only (no CPU fallback); move the module "
@@ -167,8 +169,9 @@ class _UnitFn(torch.autograd.Function):
                    aqe.data_ptr(), mqe.data_ptr(), lists[0].data_ptr(), lists[1].data_ptr(), lists[2].data_ptr(),
                    lists[3].data_ptr())
         stream = torch.cuda.current_stream(dev).cuda_stream
+        opts = mod.make_opts(train, seed, backward=False)
         L_.check(lib.dvgr_unit_forward(C.byref(dims), flat.data_ptr(), mod.lowp_ptr(), C.byref(io), saved.data_ptr(),
-                                       saved.numel(), ws.data_ptr(), ws.numel(), int(train), seed, stream),
+                                       saved.numel(), ws.data_ptr(), ws.numel(), C.byref(opts), stream),
                  "dvgr_unit_forward")
         ctx.mod, ctx.dims, ctx.train, ctx.seed = mod, dims, train, seed
         ctx.save_for_backward(A, M, dq, words, qlen, vis, aqe, mqe, *lists, saved, flat)
@@ -186,31 +189,44 @@ class _UnitFn(torch.autograd.Function):
         gM = torch.empty_like(M)
         gdq = torch.empty_like(dq)
         gwords = torch.empty_like(words)
-        gflat = torch.empty_like(flat)
+        flat_mode = mod.grad_mode == "flat"
+        gflat, deposit = mod._grad_target(flat) if flat_mode else (torch.empty_like(flat), None)
         ws = mod.workspace(lib.dvgr_workspace_bytes(C.byref(dims)), dev)
         io = L_.IO(A.data_ptr(), M.data_ptr(), dq.data_ptr(), words.data_ptr(), qlen.data_ptr(), vis.data_ptr(),
                    aqe.data_ptr(), mqe.data_ptr(), l0.data_ptr(), l1.data_ptr(), l2.data_ptr(), l3.data_ptr())
         gr = L_.Grads(*[None if u is None else u.data_ptr() for u in ups],
                       gA.data_ptr(), gM.data_ptr(), gdq.data_ptr(), gwords.data_ptr(), gflat.data_ptr())
         stream = torch.cuda.current_stream(dev).cuda_stream
-        events = mod.layer_events_ptr()
+        opts = mod.make_opts(ctx.train, ctx.seed, backward=True)
         L_.check(lib.dvgr_unit_backward(C.byref(dims), flat.data_ptr(), mod.lowp_ptr(), C.byref(io), C.byref(gr),
-                                        saved.data_ptr(), saved.numel(), ws.data_ptr(), ws.numel(), int(ctx.train),
-                                        ctx.seed, events, stream), "dvgr_unit_backward")
+                                        saved.data_ptr(), saved.numel(), ws.data_ptr(), ws.numel(), C.byref(opts),
+                                        stream), "dvgr_unit_backward")
+        if flat_mode:
+            mod._deposit_grad(gflat, deposit)
+            return (None, gA, gM, gdq, gwords, None, None)
         mod.last_flat_grad = gflat
         pgrads = [gflat[o:o + n].view(shape) for (o, n, shape) in mod.param_slices]
-        return (None, gA, gM, gdq, gwords, None, *pgrads)
+        return (None, gA, gM, gdq, gwords, None, None, *pgrads)
 
 
 class DualVGRUnit_multiple(nn.Module):
     """Drop-in for the reference `DualVGRUnit_multiple` (model/models.py:86-173).
 
-    Same constructor arguments and defaults (model/models.py:87); `dtype` ('fp32' | 'bf16') selects
-    the MFMA operand precision of the kernels and is the only addition."""
+    Same constructor arguments and defaults (model/models.py:87).  Additions: `dtype` ('fp32' |
+    'bf16') selects the MFMA operand precision of the kernels; `grad_mode` selects how parameter
+    gradients reach `.grad`:
+      'flat'     (default) the backward writes ONE flat gradient buffer and every `p.grad` is a view
+                 into it (no per-parameter kernels; `zero_grad_flat()` marks it reusable in place).
+                 Works with `loss.backward()` + any optimizer; the parameters are not autograd inputs,
+                 so `torch.autograd.grad(loss, params)` needs 'autograd'.
+      'autograd' every parameter is an input of the autograd node (plain PyTorch semantics)."""
 
     def __init__(self, word_dim=300, module_dim=512, num_of_nodes=8, appearance_graph_layers=1,
-                 motion_graph_layers=1, graph_module='GAT', unit_layers=3, dtype='fp32'):
+                 motion_graph_layers=1, graph_module='GAT', unit_layers=3, dtype='fp32', grad_mode='flat'):
         super().__init__()
+        if grad_mode not in ('flat', 'autograd'):
+            raise ValueError("grad_mode must be 'flat' or 'autograd'")
+        self.grad_mode = grad_mode
         if graph_module != 'GAT':
             # the reference builds no GNN lists for any other value and then fails in forward
             raise ValueError("graph_module must be 'GAT' (model/models.py:94)")
@@ -256,12 +272,53 @@ class DualVGRUnit_multiple(nn.Module):
         self._lowp_version = None
         self._ws = None
         self._events = None
+        self._events_arr = None
+        self._probe = None
         self.forced_seed = None      # tests: fix the dropout seed of the next forward
         self.keep_saved = False      # tests: keep a handle on the saved-for-backward buffer
         self.last_saved = None
         self.last_flat_grad = None
+        self._grad_flat = None       # persistent flat gradient buffer (grad_mode='flat')
+        self._grad_fresh = False     # True: the next backward may overwrite _grad_flat in place
+        self._anchor = torch.zeros(1, requires_grad=True)
         self._reset_parameters()
         self._flatten()
+
+    # ---- flat gradients ----------------------------------------------------------------------------------
+    def _grads_alias_flat(self) -> bool:
+        gf = self._grad_flat
+        if gf is None:
+            return False
+        for idx in (0, -1):
+            p, (o, _, _) = self._plist[idx], self.param_slices[idx]
+            if p.grad is None or p.grad.data_ptr() != gf.data_ptr() + 4 * o:
+                return False
+        return True
+
+    def _grad_target(self, flat):
+        """Buffer the backward writes into and what to do afterwards: 'inplace' (persistent buffer,
+        views already installed), 'accumulate' (add a temporary into it) or 'install' (new buffer)."""
+        if self._grads_alias_flat() and self._grad_flat.device == flat.device:
+            if self._grad_fresh:
+                return self._grad_flat, "inplace"
+            return torch.empty_like(flat), "accumulate"
+        return torch.empty_like(flat), "install"
+
+    def _deposit_grad(self, gflat, how):
+        if how == "accumulate":
+            self._grad_flat.add_(gflat)
+        elif how == "install":
+            self._grad_flat = gflat
+            for p, (o, n, shape) in zip(self._plist, self.param_slices):
+                p.grad = gflat[o:o + n].view(shape)
+        self._grad_fresh = False
+        self.last_flat_grad = self._grad_flat
+
+    def zero_grad_flat(self):
+        """Fast replacement of optimizer.zero_grad() for grad_mode='flat': no memset, no re-aliasing --
+        the next backward simply overwrites the persistent flat gradient buffer (it writes every
+        element).  Until then the old values stay readable."""
+        self._grad_fresh = True
 
     # ---- initialisation as the reference constructs the same sub-modules --------------------------
     def _reset_parameters(self):
@@ -332,13 +389,26 @@ class DualVGRUnit_multiple(nn.Module):
         gradients become final; index L = the MFB block).  None disables."""
         self._events = events
 
-    def layer_events_ptr(self):
-        if not self._events:
-            return None
-        arr = (C.c_void_p * (self.layers + 1))()
-        for i, e in enumerate(self._events):
-            arr[i] = e.cuda_event
-        return arr
+    def set_probe(self, site: int, layer: int = 0, begin=None, end=None):
+        """Bracket one launch site (enum dvgr_probe_site) of the following calls with two
+        torch.cuda.Event(enable_timing=True); site 0 disables.  Used by bench.py."""
+        self._probe = (int(site), int(layer), begin, end) if site else None
+
+    def make_opts(self, train: bool, seed: int, backward: bool) -> "L_.Opts":
+        o = L_.Opts()
+        o.train, o.seed = int(bool(train)), int(seed)
+        if self._probe is not None:
+            site, layer, b, e = self._probe
+            if (site >= L_.PROBE_BWD_SF_DW) == backward:
+                o.probe_site, o.probe_layer = site, layer
+                o.probe_begin, o.probe_end = b.cuda_event, e.cuda_event
+        if backward and self._events:
+            arr = (C.c_void_p * (self.layers + 1))()
+            for i, ev in enumerate(self._events):
+                arr[i] = ev.cuda_event
+            self._events_arr = arr               # keep alive for the duration of the call
+            o.layer_done_events = C.cast(arr, C.POINTER(C.c_void_p))
+        return o
 
     def layer_param_range(self, layer: int) -> Tuple[int, int]:
         a, b = C.c_int64(), C.c_int64()
@@ -349,8 +419,13 @@ class DualVGRUnit_multiple(nn.Module):
     # ---- forward: the reference signature (model/models.py:121) ---------------------------------------
     def forward(self, appearance_video_feat, motion_video_feat, dynamic_question_embedding, word_embedding,
                 question_len):
-        params = self._plist
-        vis, aqe, mqe, ca, cm, aq, mq = _UnitFn.apply(self, appearance_video_feat, motion_video_feat,
-                                                       dynamic_question_embedding, word_embedding, question_len,
-                                                       *params)
+        vis, aqe, mqe, ca, cm, aq, mq = self.forward_raw(appearance_video_feat, motion_video_feat,
+                                                         dynamic_question_embedding, word_embedding, question_len)
         return (vis, aqe, mqe, list(ca.unbind(0)), list(cm.unbind(0)), list(aq.unbind(0)), list(mq.unbind(0)))
+
+    def forward_raw(self, appearance_video_feat, motion_video_feat, dynamic_question_embedding, word_embedding,
+                    question_len):
+        """Same as forward() but the four lists come back as (L, B, N, D) tensors (what the kernels write)."""
+        params = self._plist if self.grad_mode == "autograd" else ()
+        return _UnitFn.apply(self, appearance_video_feat, motion_video_feat, dynamic_question_embedding,
+                             word_embedding, question_len, self._anchor, *params)

@@ -139,26 +139,56 @@ size_t dvgr_workspace_bytes(const dvgr_dims *d);
  * call after every optimizer step.  `params_lp` must hold dvgr_param_count() * 2 bytes. */
 int dvgr_pack_weights(const dvgr_dims *d, const float *params, void *params_lp, void *stream);
 
+/* Launch sites a caller can bracket with a pair of hipEvents (dvgr_opts.probe): the events are
+ * recorded on the launch stream immediately before / after that one kernel launch, which is how
+ * bench.py measures the dominant kernel's duration live inside the timed region. */
+enum dvgr_probe_site {
+  DVGR_PROBE_NONE = 0,
+  DVGR_PROBE_FWD_QA_GEMM,    /* S0  feat_enhance of all layers            (forward)  */
+  DVGR_PROBE_FWD_GAT_GEMM,   /* S2  Wh = X . Wcat^T, both modalities      (forward)  */
+  DVGR_PROBE_FWD_GAT_ATTN,   /* S3  attention + aggregation               (forward)  */
+  DVGR_PROBE_FWD_SF_GEMM,    /* S4  tanh(z . P1^T), 2 views x 2 modalities (forward) */
+  DVGR_PROBE_FWD_MFB_GEMM,   /* S6  linear0 / linear1                     (forward)  */
+  DVGR_PROBE_BWD_SF_DW,      /* dP1 = dpre^T . z                          (backward) */
+  DVGR_PROBE_BWD_SF_DX,      /* dz += dpre . P1                           (backward) */
+  DVGR_PROBE_BWD_GAT_ATTN,   /* attention backward                        (backward) */
+  DVGR_PROBE_BWD_GAT_DW,     /* dWcat = dWh^T . X                         (backward) */
+  DVGR_PROBE_BWD_GAT_DX,     /* dX += dWh . Wcat                          (backward) */
+  DVGR_PROBE_SITES
+};
+
+/* Per-call options of forward / backward (all fields may be zero). */
+typedef struct dvgr_opts {
+  int32_t train;       /* != 0: the 24 dropout sites per layer are active (p = 0.15, F.dropout semantics) */
+  int32_t probe_site;  /* enum dvgr_probe_site, bracketed at layer `probe_layer`                           */
+  int32_t probe_layer;
+  int32_t reserved;
+  uint64_t seed;       /* key of the counter-based dropout RNG; masks are recomputed, never stored         */
+  void *probe_begin;   /* hipEvent_t, recorded before the probed launch (nullable)                         */
+  void *probe_end;     /* hipEvent_t, recorded after it                                                    */
+  void *const *layer_done_events; /* backward only, nullable: L+1 hipEvent_t; event[L] is recorded when the
+                          MFB parameter gradients are final, event[l] when layer l's are, so a data-parallel
+                          caller can start the RCCL all-reduce of that slice of `gparams` while the earlier
+                          layers are still running */
+} dvgr_opts;
+
 /* Forward of the whole stacked unit: replaces DualVGRUnit_multiple.forward (model/models.py:
  * 121-173) and, inside it, QueryAttn/QueryPunish.forward (model/utils.py:66-105), punishGAT /
  * PunishGraphAttentionLayer.forward (model/GraphNN.py:95-178), AttentionSFGCN.forward
  * (model/Attention.py:20-23) and MFB.forward (model/fusions/fusions.py:419-453).
- * `train` != 0 enables the 24 dropout sites per layer (p = 0.15) with a counter-based RNG keyed
- * by `seed` (masks are recomputed, never stored).  `params_lp` may be NULL for DVGR_F32. */
+ * `params_lp` may be NULL for DVGR_F32; `opts` may be NULL (eval mode, no probe). */
 int dvgr_unit_forward(const dvgr_dims *d, const float *params, const void *params_lp,
                       const dvgr_io *io, void *saved, size_t saved_bytes,
                       void *workspace, size_t workspace_bytes,
-                      int train, uint64_t seed, void *stream);
+                      const dvgr_opts *opts, void *stream);
 
 /* Backward of the same: replaces the autograd graph PyTorch builds for the modules above.
- * `layer_done_events` (nullable) is an array of L+1 hipEvent_t: event[L] is recorded when the MFB
- * parameter gradients are final, event[l] when layer l's are, so a data-parallel caller can start
- * the RCCL all-reduce of that slice of `gparams` while earlier layers are still running. */
+ * `opts->train` and `opts->seed` must equal the forward's. */
 int dvgr_unit_backward(const dvgr_dims *d, const float *params, const void *params_lp,
                        const dvgr_io *io, const dvgr_grads *g,
                        const void *saved, size_t saved_bytes,
                        void *workspace, size_t workspace_bytes,
-                       int train, uint64_t seed, void *const *layer_done_events, void *stream);
+                       const dvgr_opts *opts, void *stream);
 
 /* [first, last) element range of the flat buffer that holds layer `layer`'s parameters
  * (layer == L: the MFB block). */

@@ -56,11 +56,11 @@ def test_null_and_small_buffers_are_refused_without_touching_the_gpu():
     lib = L.load()
     d = L.make_dims(2, 5, 6, 64, 32, 2)
     io = L.IO()
-    assert lib.dvgr_unit_forward(C.byref(d), None, None, C.byref(io), None, 0, None, 0, 0, 0, None) == -2
+    assert lib.dvgr_unit_forward(C.byref(d), None, None, C.byref(io), None, 0, None, 0, None, None) == -2
     buf = (C.c_char * 64)()
     io = L.IO(*([C.addressof(buf) // 16 * 16 + 16] * 12))
     p = C.addressof(buf) // 16 * 16 + 16
-    assert lib.dvgr_unit_forward(C.byref(d), p, None, C.byref(io), p, 16, p, 16, 0, 0, None) == -3
+    assert lib.dvgr_unit_forward(C.byref(d), p, None, C.byref(io), p, 16, p, 16, None, None) == -3
 
 
 @pytest.mark.parametrize("D,Wd,Lr", [(64, 32, 2), (768, 300, 1), (768, 300, 3)])

@@ -66,7 +66,7 @@ def test_gemm_tn_exact_integers(M, N, K):
 
 
 def test_gemm_tn_two_row_segments():
-    K0, K1, M, N = 37, 50, 64, 96
+    K0, K1, M, N = 37, 51, 64, 96
     A0, A1, B0, B1 = _ints((K0, M), seed=7), _ints((K1, M), seed=8), _ints((K0, N), seed=9), _ints((K1, N), seed=10)
     got = _gemm(2, A0, B0, M, N, K0 + K1, A2=A1, B2=B1, kseg=K0)
     want = (A0.double().T @ B0.double() + A1.double().T @ B1.double()).float()
