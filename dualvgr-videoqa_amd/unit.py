@@ -387,11 +387,17 @@ class DualVGRUnit_multiple(nn.Module):
     def set_layer_events(self, events):
         """events: list of L+1 torch.cuda.Event (recorded by the backward as each layer's parameter
         gradients become final; index L = the MFB block).  None disables."""
+        for ev in events or []:
+            if not ev.cuda_event:
+                ev.record()          # torch creates the hipEvent lazily at the first record
         self._events = events
 
     def set_probe(self, site: int, layer: int = 0, begin=None, end=None):
         """Bracket one launch site (enum dvgr_probe_site) of the following calls with two
         torch.cuda.Event(enable_timing=True); site 0 disables.  Used by bench.py."""
+        for ev in (begin, end):
+            if site and not ev.cuda_event:
+                ev.record()          # torch creates the hipEvent lazily at the first record
         self._probe = (int(site), int(layer), begin, end) if site else None
 
     def make_opts(self, train: bool, seed: int, backward: bool) -> "L_.Opts":
