@@ -14,7 +14,8 @@ struct Tile {
   static constexpr int kVec = BT * BK / 4 / 256;                          // float4 per thread
 };
 
-// HBM -> registers (zero-filled outside the matrix; x-site dropout applied on the fly).
+// HBM -> registers (zero-filled outside the matrix).  Nothing here depends on the loaded VALUES, so
+// the compiler leaves all loads in flight until store_tile consumes them after the MFMA block.
 template <int LAYOUT, int BT>
 __device__ __forceinline__ void load_tile(const GemmOperand& op, int idx0, int k0, int dim, int K,
                                           int kseg, int tid, float4 (&reg)[Tile<LAYOUT, BT>::kVec]) {
@@ -25,41 +26,44 @@ __device__ __forceinline__ void load_tile(const GemmOperand& op, int idx0, int k
     if (LAYOUT == KC) {
       const int r = f / (BK / 4), c = (f % (BK / 4)) * 4;
       const int gi = idx0 + r, gk = k0 + c;
-      if (gi < dim && gk < K) {
-        v = *reinterpret_cast<const float4*>(op.p0 + (int64_t)gi * op.ld + gk);
-        if (op.drop_key) {
-          const uint32_t e = (uint32_t)((int64_t)gi * op.ld + gk);
-          v.x *= drop_factor(op.drop_key, e);     v.y *= drop_factor(op.drop_key, e + 1);
-          v.z *= drop_factor(op.drop_key, e + 2); v.w *= drop_factor(op.drop_key, e + 3);
-        }
-      }
+      if (gi < dim && gk < K) v = *reinterpret_cast<const float4*>(op.p0 + (int64_t)gi * op.ld + gk);
     } else {
       const int r = f / (BT / 4), c = (f % (BT / 4)) * 4;
       const int gk = k0 + r, gi = idx0 + c;
       if (gk < K && gi < dim) {
         const float* row = (gk < kseg) ? op.p0 + (int64_t)gk * op.ld : op.p1 + (int64_t)(gk - kseg) * op.ld;
         v = *reinterpret_cast<const float4*>(row + gi);
-        if (op.drop_key) {
-          const uint32_t e = (uint32_t)((int64_t)gk * op.ld + gi);
-          v.x *= drop_factor(op.drop_key, e);     v.y *= drop_factor(op.drop_key, e + 1);
-          v.z *= drop_factor(op.drop_key, e + 2); v.w *= drop_factor(op.drop_key, e + 3);
-        }
       }
     }
     reg[i] = v;
   }
 }
 
-// registers -> LDS stage
+// registers -> LDS stage; the x-site dropout keep-mask (index = row * ld + col of the source
+// matrix) is applied here, on the way through the registers.
 template <int LAYOUT, int BT>
-__device__ __forceinline__ void store_tile(float* sm, int tid, const float4 (&reg)[Tile<LAYOUT, BT>::kVec]) {
+__device__ __forceinline__ void store_tile(float* sm, int tid, const float4 (&reg)[Tile<LAYOUT, BT>::kVec],
+                                           const GemmOperand& op, int idx0, int k0) {
 #pragma unroll
   for (int i = 0; i < Tile<LAYOUT, BT>::kVec; ++i) {
     const int f = tid + 256 * i;
     int r, c;
     if (LAYOUT == KC) { r = f / (BK / 4); c = (f % (BK / 4)) * 4; }
     else              { r = f / (BT / 4); c = (f % (BT / 4)) * 4; }
-    *reinterpret_cast<float4*>(sm + r * Tile<LAYOUT, BT>::kStride + c) = reg[i];
+    float4 v = reg[i];
+    if (op.drop_key) {
+      // zero-filled (out of range) elements stay zero whatever the mask says
+      const int64_t row = (LAYOUT == KC) ? (idx0 + r) : (k0 + r);
+      const int64_t col = (LAYOUT == KC) ? (k0 + c) : (idx0 + c);
+      const uint32_t e = (uint32_t)(row * op.ld + col);
+      const uint32_t h0 = mix32(((e >> 1) * 0x9E3779B1u) ^ op.drop_key);         // elements e, e+1 (e is even)
+      const uint32_t h1 = mix32((((e >> 1) + 1u) * 0x9E3779B1u) ^ op.drop_key);  // elements e+2, e+3
+      v.x *= ((h0 & 0xFFFFu) >= kDropThresh16) ? kKeepScale : 0.f;
+      v.y *= ((h0 >> 16) >= kDropThresh16) ? kKeepScale : 0.f;
+      v.z *= ((h1 & 0xFFFFu) >= kDropThresh16) ? kKeepScale : 0.f;
+      v.w *= ((h1 >> 16) >= kDropThresh16) ? kKeepScale : 0.f;
+    }
+    *reinterpret_cast<float4*>(sm + r * Tile<LAYOUT, BT>::kStride + c) = v;
   }
 }
 
@@ -83,7 +87,7 @@ __device__ __forceinline__ f32x4 load_frag(const float* sm, int idx16, int kk, i
 // TAG only gives a launch site its own kernel symbol (rocprofv3 then reports it separately).
 template <int LA, int LB, int BM, int BN, int TAG>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch batch) {
-  const GemmProblem& P = batch.p[blockIdx.z];
+  const GemmProblem P = batch.p[blockIdx.z];   // by value: the fields live in SGPRs for the whole kernel
   const int tiles_n = (P.N + BN - 1) / BN;
   const int tiles_m = (P.M + BM - 1) / BM;
   const int tile = blockIdx.x;
@@ -110,8 +114,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch batch) {
   const int nk = (P.K + BK - 1) / BK;
   load_tile<LA, BM>(P.A, m0, 0, P.M, P.K, P.kseg, tid, ra);
   load_tile<LB, BN>(P.B, n0, 0, P.N, P.K, P.kseg, tid, rb);
-  store_tile<LA, BM>(smem, tid, ra);
-  store_tile<LB, BN>(smem + TA::kFloats, tid, rb);
+  store_tile<LA, BM>(smem, tid, ra, P.A, m0, 0);
+  store_tile<LB, BN>(smem + TA::kFloats, tid, rb, P.B, n0, 0);
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
@@ -139,8 +143,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch batch) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
     }
     if (kt + 1 < nk) {
-      store_tile<LA, BM>(nxtA, tid, ra);
-      store_tile<LB, BN>(nxtB, tid, rb);
+      store_tile<LA, BM>(nxtA, tid, ra, P.A, m0, (kt + 1) * BK);
+      store_tile<LB, BN>(nxtB, tid, rb, P.B, n0, (kt + 1) * BK);
     }
     __syncthreads();
   }
