@@ -34,7 +34,7 @@ CONFIGS = {
     "c5": dict(B=64, N=64, L=12, T=15, name="stress num_clips=64 unit_layers=12 batch=512/8 per GPU"),
 }
 D, WD = 768, 300
-PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}     # /opt/skills/guides/MI355X_MICROARCH.md, dense MFMA
+PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0}     # /opt/skills/guides/MI355X_MICROARCH.md, dense MFMA
 
 
 def f_fwd(N, L, T):
@@ -107,7 +107,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16x3", "bf16"])
     ap.add_argument("--eval-mode", action="store_true", help="dropout off (default: training mode, dropout on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -211,7 +211,7 @@ def main():
         "metric": "QA-pairs/sec (forward+backward) per GPU, SVQA num_clips=20",
         "value": value, "unit": "QA-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
+        "dtype": {"fp32": "f32", "bf16": "bf16", "bf16x3": "bf16x3 (fp32 split hi+lo, 3 bf16 MFMAs, fp32 accumulate)"}[args.dtype], "data": "synthetic",
         "config": {"workload": f"{cfg['name']}: DualVGR unit forward+backward, per-GPU batch {B}, D={D}, word_dim={WD}, "
                                f"T={T}, {'eval' if args.eval_mode else 'training (dropout 0.15 on)'}",
                    "global_batch": world * B, "parallelism": f"dp{world}",

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdvgr_hip.so")
 
-DVGR_F32, DVGR_BF16 = 0, 1
+DVGR_F32, DVGR_BF16, DVGR_BF16X3 = 0, 1, 2
 
 # enum dvgr_param_kind
 (P_QA_W1, P_QA_B1, P_QA_W2, P_QA_B2, P_WQ, P_BQ, P_GAT_W, P_GAT_B, P_GAT_A, P_GAT_C,
@@ -71,7 +71,7 @@ SYMBOLS = [
 SYMBOLS += [
     ("dvgr_dbg_gemm", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
                                 C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int,
-                                C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
+                                C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]),
     ("dvgr_dbg_colsum", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
     ("dvgr_dbg_keep_mask", C.c_int, [C.c_uint32, C.c_int64, C.c_void_p, C.c_void_p]),
     ("dvgr_dbg_site_key", C.c_uint32, [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int]),

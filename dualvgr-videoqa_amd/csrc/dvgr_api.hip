@@ -135,7 +135,7 @@ int dvgr_check_dims(const dvgr_dims* d) {
   if (d->D < 64 || d->D % 64) return DVGR_E_DIMS;
   if (d->Wd < 4 || d->Wd % 4) return DVGR_E_DIMS;
   if (d->N > 64 || d->T > 256) return DVGR_E_DIMS;
-  if (d->dtype != DVGR_F32 && d->dtype != DVGR_BF16) return DVGR_E_DIMS;
+  if (d->dtype != DVGR_F32 && d->dtype != DVGR_BF16 && d->dtype != DVGR_BF16X3) return DVGR_E_DIMS;
   if (gat_lds_bytes_max(d->N, d->D / 4) > 160 * 1024) return DVGR_E_DIMS;
   if ((int64_t)d->B * d->N * d->D * 2 >= (1ll << 32)) return DVGR_E_DIMS;   // 32-bit dropout counters
   return 0;
@@ -244,6 +244,7 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
   const int train = O.train;
   const uint64_t seed = O.seed;
   const Probe probe{O, st};
+  const int prec = dp->dtype;
   const ParamLayout P = param_layout(d);
   const SavedLayout S = saved_layout(d);
   const FwdWs W = fwd_ws(d);
@@ -263,7 +264,7 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
     for (int l = l0; l < L && l < l0 + kMaxBatch; ++l)
       gb.p[gb.n++] = nt(io->dq, D, lp(l) + P.qa_w1, D, ws + W.Y + (int64_t)l * BT * D, D, lp(l) + P.qa_b1, BT, D, D, ACT_NONE);
     DVGR_TRY(probe.begin(DVGR_PROBE_FWD_QA_GEMM, l0));
-    DVGR_TRY(gemm_launch(st, KC, KC, gb));
+    DVGR_TRY(gemm_launch(st, KC, KC, gb, TAG_GENERIC, prec));
     DVGR_TRY(probe.end(DVGR_PROBE_FWD_QA_GEMM, l0));
   }
   {
@@ -279,7 +280,7 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
     for (int l = 0; l < L; ++l)
       for (int m = 0; m < 2; ++m) {
         gb.p[gb.n++] = nt(ls(l) + S.qa_q, Wd, mp(l, m) + P.wq, Wd, ms(l, m) + S.p, D, mp(l, m) + P.bq, B, D, Wd, ACT_NONE);
-        if (gb.n == kMaxBatch || (l == L - 1 && m == 1)) { DVGR_TRY(gemm_launch(st, KC, KC, gb)); gb.n = 0; }
+        if (gb.n == kMaxBatch || (l == L - 1 && m == 1)) { DVGR_TRY(gemm_launch(st, KC, KC, gb, TAG_GENERIC, prec)); gb.n = 0; }
       }
   }
 
@@ -304,7 +305,7 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
         }
       }
       DVGR_TRY(probe.begin(DVGR_PROBE_FWD_GAT_GEMM, l));
-      DVGR_TRY(gemm_launch(st, KC, KC, gb, TAG_FWD_GAT));
+      DVGR_TRY(gemm_launch(st, KC, KC, gb, TAG_FWD_GAT, prec));
       DVGR_TRY(probe.end(DVGR_PROBE_FWD_GAT_GEMM, l));
     }
     // S3
@@ -331,7 +332,7 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
         gb.p[gb.n++] = nt(outs[m], D, mp(l, m) + P.sf_p1, D, ms(l, m) + S.tn + BND, D, mp(l, m) + P.sf_bp, BN, D, D, ACT_TANH);
       }
       DVGR_TRY(probe.begin(DVGR_PROBE_FWD_SF_GEMM, l));
-      DVGR_TRY(gemm_launch(st, KC, KC, gb, TAG_FWD_SF));
+      DVGR_TRY(gemm_launch(st, KC, KC, gb, TAG_FWD_SF, prec));
       DVGR_TRY(probe.end(DVGR_PROBE_FWD_SF_GEMM, l));
     }
     // S5
@@ -353,12 +354,12 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
     gb.p[gb.n++] = nt(ms(L - 1, 0) + S.x, D, params + P.mfb_w0, D, saved + S.mfb_x0, kMfbHidden, params + P.mfb_b0, BN, kMfbHidden, D, ACT_ELU);
     gb.p[gb.n++] = nt(ms(L - 1, 1) + S.x, D, params + P.mfb_w1, D, saved + S.mfb_x1, kMfbHidden, params + P.mfb_b1, BN, kMfbHidden, D, ACT_ELU);
     DVGR_TRY(probe.begin(DVGR_PROBE_FWD_MFB_GEMM, 0));
-    DVGR_TRY(gemm_launch(st, KC, KC, gb));
+    DVGR_TRY(gemm_launch(st, KC, KC, gb, TAG_GENERIC, prec));
     DVGR_TRY(probe.end(DVGR_PROBE_FWD_MFB_GEMM, 0));
     DVGR_TRY(mfb_pool_fwd(st, saved + S.mfb_x0, saved + S.mfb_x1, saved + S.mfb_z, BN));
     GemmBatch go{};
     go.p[go.n++] = nt(saved + S.mfb_z, kMfbPooled, params + P.mfb_wo, kMfbPooled, io->vis, D, params + P.mfb_bo, BN, D, kMfbPooled, ACT_ELU);
-    DVGR_TRY(gemm_launch(st, KC, KC, go));
+    DVGR_TRY(gemm_launch(st, KC, KC, go, TAG_GENERIC, prec));
   }
   return 0;
 }
@@ -382,6 +383,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
   const dvgr_dims d = *dp;
   hipStream_t st = (hipStream_t)stream;
   const Probe probe{O, st};
+  const int prec = dp->dtype;
   const ParamLayout P = param_layout(d);
   const SavedLayout S = saved_layout(d);
   const BwdWs W = bwd_ws(d);
@@ -410,21 +412,21 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
   {
     GemmBatch gb{};   // dWo = dpo^T . z
     gb.p[gb.n++] = tn(ws + W.dpo, D, saved + S.mfb_z, kMfbPooled, gp + P.mfb_wo, kMfbPooled, D, kMfbPooled, BN);
-    DVGR_TRY(gemm_launch(st, IC, IC, gb));
+    DVGR_TRY(gemm_launch(st, IC, IC, gb, TAG_GENERIC, prec));
     GemmBatch gd{};   // dz = dpo . Wo
     gd.p[gd.n++] = nn(ws + W.dpo, D, params + P.mfb_wo, kMfbPooled, ws + W.dzf, kMfbPooled, BN, kMfbPooled, D, 0);
-    DVGR_TRY(gemm_launch(st, KC, IC, gd));
+    DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_GENERIC, prec));
   }
   DVGR_TRY(mfb_pool_bwd(st, ws + W.dzf, saved + S.mfb_x0, saved + S.mfb_x1, ws + W.dp0, ws + W.dp1, BN));
   {
     GemmBatch gb{};   // dW0 = dp0^T . A_final, dW1 = dp1^T . M_final
     gb.p[gb.n++] = tn(ws + W.dp0, kMfbHidden, ms(L - 1, 0) + S.x, D, gp + P.mfb_w0, D, kMfbHidden, D, BN);
     gb.p[gb.n++] = tn(ws + W.dp1, kMfbHidden, ms(L - 1, 1) + S.x, D, gp + P.mfb_w1, D, kMfbHidden, D, BN);
-    DVGR_TRY(gemm_launch(st, IC, IC, gb));
+    DVGR_TRY(gemm_launch(st, IC, IC, gb, TAG_GENERIC, prec));
     GemmBatch gd{};   // dA = dp0 . W0, dM = dp1 . W1
     gd.p[gd.n++] = nn(ws + W.dp0, kMfbHidden, params + P.mfb_w0, D, dXacc[0], D, BN, D, kMfbHidden, 0);
     gd.p[gd.n++] = nn(ws + W.dp1, kMfbHidden, params + P.mfb_w1, D, dXacc[1], D, BN, D, kMfbHidden, 0);
-    DVGR_TRY(gemm_launch(st, KC, IC, gd));
+    DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_GENERIC, prec));
     ColsumBatch cb{};
     cb.j[cb.n++] = ColsumJob{ws + W.dpo, nullptr, nullptr, nullptr, BN, 0, D, D, gp + P.mfb_bo};
     cb.j[cb.n++] = ColsumJob{ws + W.dp0, nullptr, nullptr, nullptr, BN, 0, kMfbHidden, kMfbHidden, gp + P.mfb_b0};
@@ -474,13 +476,13 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
         gb.p[gb.n++] = p;
       }
       DVGR_TRY(probe.begin(DVGR_PROBE_BWD_SF_DW, l));
-      DVGR_TRY(gemm_launch(st, IC, IC, gb, TAG_BWD_SF_DW));
+      DVGR_TRY(gemm_launch(st, IC, IC, gb, TAG_BWD_SF_DW, prec));
       DVGR_TRY(probe.end(DVGR_PROBE_BWD_SF_DW, l));
       GemmBatch gd{};   // dz_v += dpre_v . P1
       for (int m = 0; m < 2; ++m)
         gd.p[gd.n++] = nn(ws + W.dpre[m], D, mp(l, m) + P.sf_p1, D, ws + W.dz[m], D, 2 * BN, D, D, 1);
       DVGR_TRY(probe.begin(DVGR_PROBE_BWD_SF_DX, l));
-      DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_BWD_SF_DX));
+      DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_BWD_SF_DX, prec));
       DVGR_TRY(probe.end(DVGR_PROBE_BWD_SF_DX, l));
     }
     // S3 backward
@@ -518,14 +520,14 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
         }
       }
       DVGR_TRY(probe.begin(DVGR_PROBE_BWD_GAT_DW, l));
-      DVGR_TRY(gemm_launch(st, IC, IC, gb, TAG_BWD_GAT_DW));
+      DVGR_TRY(gemm_launch(st, IC, IC, gb, TAG_BWD_GAT_DW, prec));
       DVGR_TRY(probe.end(DVGR_PROBE_BWD_GAT_DW, l));
       if (!train) {
         GemmBatch gd{};
         for (int m = 0; m < 2; ++m)
           gd.p[gd.n++] = nn(ws + W.dWh[m], HF, mp(l, m) + P.gat_w, D, dXacc[m], D, BN, D, HF, 1);
         DVGR_TRY(probe.begin(DVGR_PROBE_BWD_GAT_DX, l));
-        DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_BWD_GAT_DX));
+        DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_BWD_GAT_DX, prec));
         DVGR_TRY(probe.end(DVGR_PROBE_BWD_GAT_DX, l));
       } else {
         for (int gi = 0; gi < 2; ++gi) {   // the two GATs dropped x with different masks: two passes
@@ -534,7 +536,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
             gd.p[gd.n++] = nn(ws + W.dWh[m] + gi * 4 * F, HF, mp(l, m) + P.gat_w + (int64_t)gi * 4 * F * D, D, dXacc[m], D,
                               BN, D, 4 * F, 1, K.x[m][gi]);
           if (gi == 0) DVGR_TRY(probe.begin(DVGR_PROBE_BWD_GAT_DX, l));
-          DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_BWD_GAT_DX));
+          DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_BWD_GAT_DX, prec));
           if (gi == 1) DVGR_TRY(probe.end(DVGR_PROBE_BWD_GAT_DX, l));
         }
       }
@@ -553,7 +555,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       GemmBatch gb{};   // dWq[m] = dp[m]^T . q
       for (int m = 0; m < 2; ++m)
         gb.p[gb.n++] = tn(ws + W.dp_cat + m * D, 2 * D, ls(l) + S.qa_q, Wd, gmp(l, m) + P.wq, Wd, D, Wd, B);
-      DVGR_TRY(gemm_launch(st, IC, IC, gb));
+      DVGR_TRY(gemm_launch(st, IC, IC, gb, TAG_GENERIC, prec));
       for (int m = 0; m < 2; ++m)
         cb.j[cb.n++] = ColsumJob{ws + W.dp_cat + m * D, nullptr, nullptr, nullptr, B, 0, D, 2 * D, gmp(l, m) + P.bq};
       GemmBatch gd{};   // dqbar = [dp_app | dp_mot] . [Wq_app ; Wq_mot]
@@ -561,7 +563,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       p.kseg = D;
       p.B.p1 = mp(l, 1) + P.wq;
       gd.p[gd.n++] = p;
-      DVGR_TRY(gemm_launch(st, KC, IC, gd));
+      DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_GENERIC, prec));
     }
     // S0 backward for this layer
     {
@@ -575,10 +577,10 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       DVGR_TRY(qa_bwd(st, a));
       GemmBatch gb{};   // dW1 = dy^T . dq
       gb.p[gb.n++] = tn(ws + W.dy, D, io->dq, D, glp(l) + P.qa_w1, D, D, D, BT);
-      DVGR_TRY(gemm_launch(st, IC, IC, gb));
+      DVGR_TRY(gemm_launch(st, IC, IC, gb, TAG_GENERIC, prec));
       GemmBatch gd{};   // d(dq) (+)= dy . W1
       gd.p[gd.n++] = nn(ws + W.dy, D, lp(l) + P.qa_w1, D, g->gdq, D, BT, D, D, l == L - 1 ? 0 : 1);
-      DVGR_TRY(gemm_launch(st, KC, IC, gd));
+      DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_GENERIC, prec));
       cb.j[cb.n++] = ColsumJob{ws + W.dy, nullptr, nullptr, nullptr, BT, 0, D, D, glp(l) + P.qa_b1};
       cb.j[cb.n++] = ColsumJob{ls(l) + S.qa_d, nullptr, ws + W.dr, nullptr, BT, 0, D, D, glp(l) + P.qa_w2};
       cb.j[cb.n++] = ColsumJob{ws + W.dr, nullptr, nullptr, nullptr, BT, 0, 1, 1, glp(l) + P.qa_b2};
@@ -605,7 +607,8 @@ extern "C" {
 
 int dvgr_dbg_gemm(int mode, int M, int N, int K, int kseg, const float* A, const float* A2, int64_t lda,
                   const float* B, const float* B2, int64_t ldb, float* C, int64_t ldc, const float* bias, int act,
-                  int accumulate, uint32_t drop_key_a, uint32_t drop_key_b, uint32_t drop_key_c, void* stream) {
+                  int accumulate, uint32_t drop_key_a, uint32_t drop_key_b, uint32_t drop_key_c, int prec,
+                  void* stream) {
   if (!A || !B || !C) return DVGR_E_NULL;
   GemmBatch gb{};
   GemmProblem p{};
@@ -614,10 +617,10 @@ int dvgr_dbg_gemm(int mode, int M, int N, int K, int kseg, const float* A, const
   if (A2) p.A.p1 = A2;
   if (B2) p.B.p1 = B2;
   p.C = C; p.ldc = ldc; p.bias = bias; p.M = M; p.N = N; p.K = K; p.kseg = (kseg > 0 && kseg < K) ? kseg : K;
-  p.act = act; p.accumulate = accumulate; p.drop_key_c = drop_key_c;
+  p.act = act & 15; p.dbg = act >> 4; p.accumulate = accumulate; p.drop_key_c = drop_key_c;
   gb.p[gb.n++] = p;
   const int la = mode == 2 ? IC : KC, lb = mode == 0 ? KC : IC;
-  return gemm_launch((hipStream_t)stream, la, lb, gb);
+  return gemm_launch((hipStream_t)stream, la, lb, gb, TAG_GENERIC, prec);
 }
 
 int dvgr_dbg_colsum(const float* M, const float* w, int rows, int cols, int64_t ld, float* out, void* stream) {

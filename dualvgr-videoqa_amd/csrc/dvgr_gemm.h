@@ -37,6 +37,7 @@ struct GemmProblem {
   int act;             // ACT_*
   int accumulate;      // C += result instead of C = result
   uint32_t drop_key_c; // keep mask applied to the result (index row * ldc + col), 0 = none
+  int dbg;             // profiling aid (tools/): bit 0 skip the epilogue, bit 1 skip the K loop; 0 in production
 };
 
 constexpr int kMaxBatch = 4;
@@ -50,7 +51,7 @@ enum : int { TAG_GENERIC = 0, TAG_FWD_GAT = 1, TAG_FWD_SF = 2, TAG_BWD_GAT_DW = 
              TAG_BWD_SF_DW = 5, TAG_BWD_SF_DX = 6 };
 
 // Enqueue the batch on `stream`.  la / lb in {KC, IC}.  Returns hipError_t as int.
-int gemm_launch(hipStream_t stream, int la, int lb, const GemmBatch& batch, int tag = TAG_GENERIC);
+int gemm_launch(hipStream_t stream, int la, int lb, const GemmBatch& batch, int tag = TAG_GENERIC, int prec = DVGR_F32);
 
 inline GemmOperand operand(const float* p, int64_t ld, uint32_t drop_key = 0) {
   GemmOperand o; o.p0 = p; o.p1 = p; o.ld = ld; o.drop_key = drop_key; return o;

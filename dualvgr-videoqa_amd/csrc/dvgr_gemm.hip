@@ -1,10 +1,44 @@
-// dvgr_gemm.hip -- MFMA contraction kernel (see dvgr_gemm.h for the design notes).
+// dvgr_gemm.hip -- MFMA contraction kernels (see dvgr_gemm.h for the design notes).
+//
+// Two kernels share the HBM loader and the epilogue:
+//   gemm_kernel     fp32 operands in LDS, v_mfma_f32_16x16x4_f32 (exact fp32)
+//   gemm_lp_kernel  operands rounded to bf16 on the way into LDS, v_mfma_f32_16x16x32_bf16, fp32
+//                   accumulate; TERMS = 1 (plain bf16) or 3 ("bf16x3": x = hi + lo with hi = bf16(x),
+//                   lo = bf16(x - hi); a.b ~ hi.hi + hi.lo + lo.hi, relative error ~2^-16 per product,
+//                   i.e. fp32-grade results at 3/16 of the fp32-MFMA cost).
 #include "dvgr_gemm.h"
 
 namespace dvgr {
 
-constexpr int BK = 32;  // reduction depth of one LDS stage (floats)
+constexpr int BK = 32;  // reduction depth of one LDS stage
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// XCD-aware workgroup -> output-tile map.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and
+// b + 8 share an L2), and each XCD's L2 is only 4 MiB: give every XCD a CONTIGUOUS chunk of the tile list,
+// ordered in column groups of width w ~ sqrt(chunk) so that a chunk is a compact ~(chunk/w) x w rectangle
+// whose A and B panels fit one L2 instead of every XCD streaming every panel.  A wrong guess about the
+// placement costs speed only.  gridDim.x = 8 * ceil(tiles / 8); returns false for the padding workgroups.
+__host__ __device__ inline int isqrt_floor(int x) { int r = 1; while ((r + 1) * (r + 1) <= x) ++r; return r; }
+__device__ __forceinline__ bool tile_coords(int M, int N, int BM, int BN, int* m0, int* n0) {
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const int tiles = tiles_m * tiles_n;
+  const int chunk = (int)gridDim.x >> 3;                 // tiles per XCD (grid is 8 * chunk wide)
+  const int t = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+  const int pchunk = (tiles + 7) >> 3;                   // this problem's own chunk (batched problems differ)
+  const int tt = (int)(blockIdx.x & 7) * pchunk + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= pchunk || tt >= tiles) return false;
+  (void)t;
+  const int w = isqrt_floor(pchunk);
+  const int per_group = w * tiles_m;
+  const int group = tt / per_group, local = tt - group * per_group;
+  const int first_n = group * w;
+  const int gw = (tiles_n - first_n) < w ? (tiles_n - first_n) : w;
+  *m0 = (local / gw) * BM;
+  *n0 = (first_n + local % gw) * BN;
+  return true;
+}
 
 template <int LAYOUT, int BT>
 struct Tile {
@@ -39,8 +73,25 @@ __device__ __forceinline__ void load_tile(const GemmOperand& op, int idx0, int k
   }
 }
 
-// registers -> LDS stage; the x-site dropout keep-mask (index = row * ld + col of the source
-// matrix) is applied here, on the way through the registers.
+// x-site dropout keep-mask (index = row * ld + col of the source matrix) applied on the way
+// through the registers; zero-filled (out of range) elements stay zero whatever the mask says.
+template <int LAYOUT>
+__device__ __forceinline__ float4 drop4(float4 v, const GemmOperand& op, int idx0, int k0, int r, int c) {
+  if (op.drop_key) {
+    const int64_t row = (LAYOUT == KC) ? (idx0 + r) : (k0 + r);
+    const int64_t col = (LAYOUT == KC) ? (k0 + c) : (idx0 + c);
+    const uint32_t e = (uint32_t)(row * op.ld + col);
+    const uint32_t h0 = mix32(((e >> 1) * 0x9E3779B1u) ^ op.drop_key);         // elements e, e+1 (e is even)
+    const uint32_t h1 = mix32((((e >> 1) + 1u) * 0x9E3779B1u) ^ op.drop_key);  // elements e+2, e+3
+    v.x *= ((h0 & 0xFFFFu) >= kDropThresh16) ? kKeepScale : 0.f;
+    v.y *= ((h0 >> 16) >= kDropThresh16) ? kKeepScale : 0.f;
+    v.z *= ((h1 & 0xFFFFu) >= kDropThresh16) ? kKeepScale : 0.f;
+    v.w *= ((h1 >> 16) >= kDropThresh16) ? kKeepScale : 0.f;
+  }
+  return v;
+}
+
+// registers -> LDS stage (fp32 image)
 template <int LAYOUT, int BT>
 __device__ __forceinline__ void store_tile(float* sm, int tid, const float4 (&reg)[Tile<LAYOUT, BT>::kVec],
                                            const GemmOperand& op, int idx0, int k0) {
@@ -50,20 +101,7 @@ __device__ __forceinline__ void store_tile(float* sm, int tid, const float4 (&re
     int r, c;
     if (LAYOUT == KC) { r = f / (BK / 4); c = (f % (BK / 4)) * 4; }
     else              { r = f / (BT / 4); c = (f % (BT / 4)) * 4; }
-    float4 v = reg[i];
-    if (op.drop_key) {
-      // zero-filled (out of range) elements stay zero whatever the mask says
-      const int64_t row = (LAYOUT == KC) ? (idx0 + r) : (k0 + r);
-      const int64_t col = (LAYOUT == KC) ? (k0 + c) : (idx0 + c);
-      const uint32_t e = (uint32_t)(row * op.ld + col);
-      const uint32_t h0 = mix32(((e >> 1) * 0x9E3779B1u) ^ op.drop_key);         // elements e, e+1 (e is even)
-      const uint32_t h1 = mix32((((e >> 1) + 1u) * 0x9E3779B1u) ^ op.drop_key);  // elements e+2, e+3
-      v.x *= ((h0 & 0xFFFFu) >= kDropThresh16) ? kKeepScale : 0.f;
-      v.y *= ((h0 >> 16) >= kDropThresh16) ? kKeepScale : 0.f;
-      v.z *= ((h1 & 0xFFFFu) >= kDropThresh16) ? kKeepScale : 0.f;
-      v.w *= ((h1 >> 16) >= kDropThresh16) ? kKeepScale : 0.f;
-    }
-    *reinterpret_cast<float4*>(sm + r * Tile<LAYOUT, BT>::kStride + c) = v;
+    *reinterpret_cast<float4*>(sm + r * Tile<LAYOUT, BT>::kStride + c) = drop4<LAYOUT>(reg[i], op, idx0, k0, r, c);
   }
 }
 
@@ -84,15 +122,98 @@ __device__ __forceinline__ f32x4 load_frag(const float* sm, int idx16, int kk, i
   }
 }
 
-// TAG only gives a launch site its own kernel symbol (rocprofv3 then reports it separately).
+// Epilogue shared by both kernels.  C/D fragment map of the 16x16 MFMAs (dtype independent):
+// col = lane & 15, row = (lane >> 4) * 4 + reg.
+template <int MT, int NT>
+__device__ __forceinline__ void epilogue(const GemmProblem& P, const f32x4 (&acc)[MT][NT], int row0, int col0, int lane) {
+  const int col_l = lane & 15, row_l = (lane >> 4) * 4;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = col0 + j * 16 + col_l;
+    if (col >= P.N) continue;
+    const float bv = P.bias ? P.bias[col] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + i * 16 + row_l + r;
+        if (row >= P.M) continue;
+        float v = acc[i][j][r] + bv;
+        if (P.act == ACT_TANH) v = tanhf(v);
+        else if (P.act == ACT_ELU) v = elu_f(v);
+        const int64_t o = (int64_t)row * P.ldc + col;
+        if (P.drop_key_c) v *= drop_factor(P.drop_key_c, (uint32_t)o);
+        if (P.accumulate) v += P.C[o];
+        P.C[o] = v;
+      }
+    }
+  }
+}
+
+// Vectorised epilogue.  The 16x16 accumulator layout gives each lane ONE column of four rows, so storing
+// it directly costs 64 four-byte store instructions per lane that each touch four 64-byte row pieces --
+// measured 8-14 us per 128x128 tile, more than the whole K loop of a bf16 contraction.  Instead each wave
+// transposes its sub-tile through its own slice of the (now idle) LDS stage buffers, two 16-row tile bands at a
+// time, and writes whole rows: 16 bytes per lane, 256 contiguous bytes per row per wave-instruction.
+// Callers put a workgroup barrier between the last fragment read of the K loop and this function.
+template <int MT, int NT>
+__device__ __forceinline__ void epilogue_rows(const GemmProblem& P, const f32x4 (&acc)[MT][NT], int row0, int col0,
+                                              int lane, float* scratch /* wave-private, >= 32 * (16*NT + 4) floats */) {
+  constexpr int W = NT * 16, STR = W + 4;          // sub-tile width, padded LDS row stride (floats)
+  constexpr int MCH = MT < 2 ? MT : 2;             // tile bands per pass
+  constexpr int CPR = W / 4;                       // float4 chunks per row
+  constexpr int RPI = 64 / CPR;                    // rows covered by one wave-instruction
+  const int c = lane & 15, g = lane >> 4;
+  const bool vec_ok = ((P.ldc & 3) == 0) && ((((uintptr_t)P.C) & 15) == 0) && ((col0 & 3) == 0);
+  if (!vec_ok) { epilogue<MT, NT>(P, acc, row0, col0, lane); return; }
+#pragma unroll
+  for (int i0 = 0; i0 < MT; i0 += MCH) {
+#pragma unroll
+    for (int ii = 0; ii < MCH; ++ii)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) scratch[(ii * 16 + 4 * g + r) * STR + j * 16 + c] = acc[i0 + ii][j][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // LDS ops of one wave execute in order; keep the compiler in line
+#pragma unroll
+    for (int it = 0; it < MCH * 16 / RPI; ++it) {
+      const int rr = it * RPI + lane / CPR, cc = (lane % CPR) * 4;
+      const int row = row0 + i0 * 16 + rr, col = col0 + cc;
+      float4 v = *reinterpret_cast<const float4*>(scratch + rr * STR + cc);
+      if (row < P.M && col < P.N) {
+        const int64_t o = (int64_t)row * P.ldc + col;
+        const int nv = (P.N - col) < 4 ? (P.N - col) : 4;    // valid columns of this chunk
+        float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (P.bias && e < nv) x[e] += P.bias[col + e];
+          if (P.act == ACT_TANH) x[e] = tanhf(x[e]);
+          else if (P.act == ACT_ELU) x[e] = elu_f(x[e]);
+          if (P.drop_key_c) x[e] *= drop_factor(P.drop_key_c, (uint32_t)(o + e));
+        }
+        if (nv == 4) {
+          if (P.accumulate) {
+            const float4 old = *reinterpret_cast<const float4*>(P.C + o);
+            x[0] += old.x; x[1] += old.y; x[2] += old.z; x[3] += old.w;
+          }
+          *reinterpret_cast<float4*>(P.C + o) = make_float4(x[0], x[1], x[2], x[3]);
+        } else {
+          for (int e = 0; e < nv; ++e) P.C[o + e] = P.accumulate ? P.C[o + e] + x[e] : x[e];
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  }
+}
+
+// =================================================================================================
+// fp32 kernel.  TAG only gives a launch site its own kernel symbol (rocprofv3 then reports it separately).
+// =================================================================================================
 template <int LA, int LB, int BM, int BN, int TAG>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch batch) {
   const GemmProblem P = batch.p[blockIdx.z];   // by value: the fields live in SGPRs for the whole kernel
-  const int tiles_n = (P.N + BN - 1) / BN;
-  const int tiles_m = (P.M + BM - 1) / BM;
-  const int tile = blockIdx.x;
-  if (tile >= tiles_m * tiles_n) return;            // uniform per workgroup, before any barrier
-  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  int m0, n0;
+  if (!tile_coords(P.M, P.N, BM, BN, &m0, &n0)) return;   // uniform per workgroup, before any barrier
 
   using TA = Tile<LA, BM>;
   using TB = Tile<LB, BN>;
@@ -148,55 +269,366 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch batch) {
     }
     __syncthreads();
   }
+  epilogue_rows<MT, NT>(P, acc, m0 + wm, n0 + wn, lane, smem + wave * (32 * (16 * NT + 4)));
+}
 
-  // epilogue: C/D fragment map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
-  const int col_l = lane & 15, row_l = (lane >> 4) * 4;
+// =================================================================================================
+// bf16 / bf16x3 kernel.  LDS images hold bf16: k-contiguous operands [rows][32 + 16 pad] (96-byte rows:
+// the ds_read_b128 of a fragment is bank-conflict free), index-contiguous operands [32][cols + 8 pad]
+// read with ds_read_b64_tr_b16 (the hardware transposes 4 k-rows x 16 columns per 16-lane group).
+// Lane (r = lane & 15, g = lane >> 4) of an MFMA operand holds k = 8g .. 8g+7 of row/column r.
+// =================================================================================================
+template <int LAYOUT, int BT>
+struct TileLP {
+  static constexpr int kStride = (LAYOUT == KC) ? (BK + 16) : (BT + 8);   // bf16 elements per LDS row
+  static constexpr int kRows = (LAYOUT == KC) ? BT : BK;
+  static constexpr int kElems = kRows * kStride;
+};
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 v = {(__bf16)a, (__bf16)b};                 // v_cvt_pk_bf16_f32 (round to nearest even)
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float bf16_lo_as_f32(uint32_t p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf16_hi_as_f32(uint32_t p) { return __uint_as_float(p & 0xFFFF0000u); }
+
+template <int LAYOUT, int BT, int TERMS>
+__device__ __forceinline__ void store_tile_lp(uint16_t* sm_hi, uint16_t* sm_lo, int tid,
+                                              const float4 (&reg)[Tile<LAYOUT, BT>::kVec], const GemmOperand& op,
+                                              int idx0, int k0) {
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int col = n0 + wn + j * 16 + col_l;
-    if (col >= P.N) continue;
-    const float bv = P.bias ? P.bias[col] : 0.0f;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wm + i * 16 + row_l + r;
-        if (row >= P.M) continue;
-        float v = acc[i][j][r] + bv;
-        if (P.act == ACT_TANH) v = tanhf(v);
-        else if (P.act == ACT_ELU) v = elu_f(v);
-        const int64_t o = (int64_t)row * P.ldc + col;
-        if (P.drop_key_c) v *= drop_factor(P.drop_key_c, (uint32_t)o);
-        if (P.accumulate) v += P.C[o];
-        P.C[o] = v;
-      }
+  for (int i = 0; i < Tile<LAYOUT, BT>::kVec; ++i) {
+    const int f = tid + 256 * i;
+    int r, c;
+    if (LAYOUT == KC) { r = f / (BK / 4); c = (f % (BK / 4)) * 4; }
+    else              { r = f / (BT / 4); c = (f % (BT / 4)) * 4; }
+    const float4 v = drop4<LAYOUT>(reg[i], op, idx0, k0, r, c);
+    const uint32_t h01 = pack_bf16(v.x, v.y), h23 = pack_bf16(v.z, v.w);
+    const int o = r * TileLP<LAYOUT, BT>::kStride + c;
+    *reinterpret_cast<uint2*>(sm_hi + o) = make_uint2(h01, h23);
+    if (TERMS == 3) {
+      const uint32_t l01 = pack_bf16(v.x - bf16_lo_as_f32(h01), v.y - bf16_hi_as_f32(h01));
+      const uint32_t l23 = pack_bf16(v.z - bf16_lo_as_f32(h23), v.w - bf16_hi_as_f32(h23));
+      *reinterpret_cast<uint2*>(sm_lo + o) = make_uint2(l01, l23);
     }
   }
 }
 
+template <int LAYOUT, int BT>
+__device__ __forceinline__ bf16x8 load_frag_lp(const uint16_t* sm, int idx16, int lane) {
+  const int r = lane & 15, g = lane >> 4;
+  if (LAYOUT == KC) {
+    return *reinterpret_cast<const bf16x8*>(sm + (idx16 + r) * TileLP<LAYOUT, BT>::kStride + g * 8);
+  } else {
+    // lane 4q+p of the 16-lane group addresses row q, columns 4p..4p+3 of a 4 x 16 block and receives
+    // column (lane & 15) of its 4 rows: two blocks give k = 8g..8g+3 and 8g+4..8g+7.
+    const int q = r >> 2, p = r & 3;
+    typedef __attribute__((address_space(3))) s16x4* lds_ptr;
+    const uint16_t* a0 = sm + (g * 8 + q) * TileLP<LAYOUT, BT>::kStride + idx16 + 4 * p;
+    const uint16_t* a1 = a0 + 4 * TileLP<LAYOUT, BT>::kStride;
+    const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a0));
+    const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a1));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 t = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+    return __builtin_bit_cast(bf16x8, t);
+  }
+}
+
+template <int LA, int LB, int BM, int BN, int TAG, int TERMS>
+__global__ __launch_bounds__(256) void gemm_lp_kernel(const GemmBatch batch) {
+  const GemmProblem P = batch.p[blockIdx.z];
+  int m0, n0;
+  if (!tile_coords(P.M, P.N, BM, BN, &m0, &n0)) return;   // uniform per workgroup, before any barrier
+
+  using TA = TileLP<LA, BM>;
+  using TB = TileLP<LB, BN>;
+  constexpr int kPlanes = (TERMS == 3) ? 2 : 1;
+  constexpr int kStage = kPlanes * (TA::kElems + TB::kElems);   // [A hi | A lo | B hi | B lo]
+  __shared__ __attribute__((aligned(16))) uint16_t smem[2 * kStage];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+  constexpr int MT = BM / 32, NT = BN / 32;
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float4 ra[Tile<LA, BM>::kVec], rb[Tile<LB, BN>::kVec];
+  const int nk = (P.K + BK - 1) / BK;
+  load_tile<LA, BM>(P.A, m0, 0, P.M, P.K, P.kseg, tid, ra);
+  load_tile<LB, BN>(P.B, n0, 0, P.N, P.K, P.kseg, tid, rb);
+  store_tile_lp<LA, BM, TERMS>(smem, smem + TA::kElems, tid, ra, P.A, m0, 0);
+  store_tile_lp<LB, BN, TERMS>(smem + kPlanes * TA::kElems, smem + kPlanes * TA::kElems + TB::kElems, tid, rb, P.B, n0, 0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const uint16_t* curA = smem + (kt & 1) * kStage;
+    const uint16_t* curB = curA + kPlanes * TA::kElems;
+    uint16_t* nxtA = smem + ((kt + 1) & 1) * kStage;
+    uint16_t* nxtB = nxtA + kPlanes * TA::kElems;
+    if (kt + 1 < nk) {
+      load_tile<LA, BM>(P.A, m0, (kt + 1) * BK, P.M, P.K, P.kseg, tid, ra);
+      load_tile<LB, BN>(P.B, n0, (kt + 1) * BK, P.N, P.K, P.kseg, tid, rb);
+    }
+    {
+      bf16x8 ah[MT], bh[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) ah[i] = load_frag_lp<LA, BM>(curA, wm + i * 16, lane);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bh[j] = load_frag_lp<LB, BN>(curB, wn + j * 16, lane);
+      if (TERMS == 3) {
+        bf16x8 al[MT], bl[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) al[i] = load_frag_lp<LA, BM>(curA + TA::kElems, wm + i * 16, lane);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bl[j] = load_frag_lp<LB, BN>(curB + TB::kElems, wn + j * 16, lane);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          }
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      store_tile_lp<LA, BM, TERMS>(nxtA, nxtA + TA::kElems, tid, ra, P.A, m0, (kt + 1) * BK);
+      store_tile_lp<LB, BN, TERMS>(nxtB, nxtB + TB::kElems, tid, rb, P.B, n0, (kt + 1) * BK);
+    }
+    __syncthreads();
+  }
+  epilogue_rows<MT, NT>(P, acc, m0 + wm, n0 + wn, lane, reinterpret_cast<float*>(smem) + wave * (32 * (16 * NT + 4)));
+}
+
+// =================================================================================================
+// Ring kernel: 128x128 tile, 4-slot LDS ring filled by LDS-DMA (global_load_lds_dwordx4), three
+// K-tiles (96 KB) in flight per CU behind a COUNTED s_waitcnt vmcnt + one raw s_barrier per K-tile.
+// The register-staged kernels above keep one 32 KB tile in flight per CU and are latency-bound at
+// these sizes (M = B*N = 1280 gives ~1 workgroup per CU); this one is for every contraction whose
+// K is a multiple of 32 and whose operands carry no dropout mask.
+//   LDS images are fp32 and lane-linear per wave-instruction (the DMA writes base + lane*16), so the
+//   bank-conflict swizzle is applied to the SOURCE address and undone by the fragment reads:
+//     KC tile [128 rows][8 chunks of 4 floats]: chunk slot = chunk ^ ((row >> 1) & 7)
+//     IC tile [32 k][32 chunks]:                chunk slot = chunk ^ (((k >> 2) & 1) << 2)
+//   Lane (r, g) of an MFMA operand owns k = 4g+j and 16+4g+j (j = 0..3) of row/column r, for A and B
+//   alike.  Operands are converted fp32 -> bf16 (hi [+ lo]) in registers right before the MFMAs.
+// =================================================================================================
+constexpr int RS = 4;                       // ring slots
+constexpr int RT = 128;                     // tile extent (M and N)
+constexpr int kRingTile = RT * BK;          // floats per operand tile (16 KB)
+constexpr int kRingSlot = 2 * kRingTile;    // A tile + B tile
+
+template <int LAYOUT>
+__device__ __forceinline__ void ring_issue(const GemmOperand& op, int idx0, int k0, int dim, int kseg, int wave,
+                                           int lane, float* lds_tile) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {             // 1024 16-byte slots per tile = 4 waves x 4 instructions x 64 lanes
+    const int S0 = (wave * 4 + i) * 64;     // first 16-byte slot written by this wave-instruction
+    const float* src;
+    if (LAYOUT == KC) {
+      const int row = (S0 >> 3) + (lane >> 3), slot = lane & 7;
+      const int chunk = slot ^ ((row >> 1) & 7);
+      int gi = idx0 + row;
+      gi = gi < dim ? gi : dim - 1;         // rows past the matrix: any valid row (their outputs are never stored)
+      src = op.p0 + (int64_t)gi * op.ld + k0 + chunk * 4;
+    } else {
+      const int krow = (S0 >> 5) + (lane >> 5), slot = lane & 31;
+      const int chunk = slot ^ (((krow >> 2) & 1) << 2);
+      const int gk = k0 + krow;
+      int gi = idx0 + chunk * 4;
+      gi = gi < dim ? gi : dim - 4;
+      const float* rowp = (gk < kseg) ? op.p0 + (int64_t)gk * op.ld : op.p1 + (int64_t)(gk - kseg) * op.ld;
+      src = rowp + gi;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(lds_tile + S0 * 4), 16, 0, 0);
+  }
+}
+
+template <int LAYOUT>
+__device__ __forceinline__ void ring_frag(const float* tile, int idx16, int lane, float (&v)[8]) {
+  const int r = lane & 15, g = lane >> 4;
+  if (LAYOUT == KC) {
+    const int row = idx16 + r, f = (row >> 1) & 7;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(tile + row * BK + ((g ^ f) << 2));
+    const f32x4 b = *reinterpret_cast<const f32x4*>(tile + row * BK + (((g + 4) ^ f) << 2));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+  } else {
+    const int idx = idx16 + r;
+    const int col = ((((idx >> 2) ^ ((g & 1) << 2))) << 2) + (idx & 3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[j] = tile[(4 * g + j) * RT + col];
+      v[4 + j] = tile[(16 + 4 * g + j) * RT + col];
+    }
+  }
+}
+
+template <bool LO>
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 h, l;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    h[p] = pack_bf16(v[2 * p], v[2 * p + 1]);
+    if (LO) l[p] = pack_bf16(v[2 * p] - bf16_lo_as_f32(h[p]), v[2 * p + 1] - bf16_hi_as_f32(h[p]));
+  }
+  hi = __builtin_bit_cast(bf16x8, h);
+  if (LO) lo = __builtin_bit_cast(bf16x8, l);
+}
+
+template <int LA, int LB, int TAG, int PREC>
+__global__ __launch_bounds__(256) void gemm_ring_kernel(const GemmBatch batch) {
+  const GemmProblem P = batch.p[blockIdx.z];
+  int m0, n0;
+  if (!tile_coords(P.M, P.N, RT, RT, &m0, &n0)) return;
+
+  __shared__ __attribute__((aligned(16))) float smem[RS * kRingSlot];   // 128 KB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  constexpr int MT = 4, NT = 4;
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = P.K / BK;
+#pragma unroll
+  for (int s = 0; s < RS - 1; ++s)
+    if (s < nk) {
+      ring_issue<LA>(P.A, m0, s * BK, P.M, P.kseg, wave, lane, smem + s * kRingSlot);
+      ring_issue<LB>(P.B, n0, s * BK, P.N, P.kseg, wave, lane, smem + s * kRingSlot + kRingTile);
+    }
+
+  for (int kt = 0; kt < ((P.dbg & 2) ? 0 : nk); ++kt) {
+    // this wave issued 8 DMA instructions per K-tile (4 A + 4 B), in order: wait until tile kt has landed
+    // while leaving the (up to two) younger tiles in flight, then meet the other waves
+    const int younger = nk - 1 - kt;
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // every wave has finished reading slot (kt-1) % RS: refill it with tile kt + RS - 1
+    if (kt + RS - 1 < nk) {
+      float* dst = smem + ((kt + RS - 1) % RS) * kRingSlot;
+      ring_issue<LA>(P.A, m0, (kt + RS - 1) * BK, P.M, P.kseg, wave, lane, dst);
+      ring_issue<LB>(P.B, n0, (kt + RS - 1) * BK, P.N, P.kseg, wave, lane, dst + kRingTile);
+    }
+    const float* curA = smem + (kt % RS) * kRingSlot;
+    const float* curB = curA + kRingTile;
+    if (PREC == DVGR_F32) {
+      float fa[MT][8], fb[NT][8];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) ring_frag<LA>(curA, wm + i * 16, lane, fa[i]);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) ring_frag<LB>(curB, wn + j * 16, lane, fb[j]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+    } else {
+      constexpr bool X3 = (PREC == DVGR_BF16X3);
+      bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        float v[8];
+        ring_frag<LA>(curA, wm + i * 16, lane, v);
+        split8<X3>(v, ah[i], al[i]);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        float v[8];
+        ring_frag<LB>(curB, wn + j * 16, lane, v);
+        split8<X3>(v, bh[j], bl[j]);
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          if (X3) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+  if (P.dbg & 1) { if (acc[0][0][0] == 12345.678f) P.C[0] = 1.f; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+  __syncthreads();     // every wave is done reading the ring (all DMA landed: vmcnt(0) in the last iteration)
+  epilogue_rows<MT, NT>(P, acc, m0 + wm, n0 + wn, lane, smem + wave * (32 * (16 * NT + 4)));
+}
+
+template <int LA, int LB, int TAG>
+static int launch_ring(hipStream_t stream, const GemmBatch& b, int prec) {
+  int tiles = 0;
+  for (int i = 0; i < b.n; ++i) {
+    const int t = ((b.p[i].M + RT - 1) / RT) * ((b.p[i].N + RT - 1) / RT);
+    tiles = t > tiles ? t : tiles;
+  }
+  if (tiles == 0) return 0;
+  const dim3 grid(8 * ((tiles + 7) / 8), 1, b.n), block(256);
+  if (prec == DVGR_BF16X3) hipLaunchKernelGGL((gemm_ring_kernel<LA, LB, TAG, DVGR_BF16X3>), grid, block, 0, stream, b);
+  else if (prec == DVGR_BF16) hipLaunchKernelGGL((gemm_ring_kernel<LA, LB, TAG, DVGR_BF16>), grid, block, 0, stream, b);
+  else hipLaunchKernelGGL((gemm_ring_kernel<LA, LB, TAG, DVGR_F32>), grid, block, 0, stream, b);
+  return (int)hipGetLastError();
+}
+
+static bool ring_eligible(const GemmBatch& b) {
+  for (int i = 0; i < b.n; ++i) {
+    const GemmProblem& p = b.p[i];
+    if (p.K < BK || (p.K % BK) || p.A.drop_key || p.B.drop_key) return false;
+    if (p.M < 4 || p.N < 4) return false;
+  }
+  return true;
+}
+
+// =================================================================================================
+// Launch
+// =================================================================================================
 template <int LA, int LB, int BM, int BN, int TAG>
-static int launch_cfg(hipStream_t stream, const GemmBatch& b) {
+static int launch_cfg(hipStream_t stream, const GemmBatch& b, int prec) {
   int tiles = 0;
   for (int i = 0; i < b.n; ++i) {
     const int t = ((b.p[i].M + BM - 1) / BM) * ((b.p[i].N + BN - 1) / BN);
     tiles = t > tiles ? t : tiles;
   }
   if (tiles == 0) return 0;
-  hipLaunchKernelGGL((gemm_kernel<LA, LB, BM, BN, TAG>), dim3(tiles, 1, b.n), dim3(256), 0, stream, b);
+  const dim3 grid(8 * ((tiles + 7) / 8), 1, b.n), block(256);
+  if (prec == DVGR_BF16X3) hipLaunchKernelGGL((gemm_lp_kernel<LA, LB, BM, BN, TAG, 3>), grid, block, 0, stream, b);
+  else if (prec == DVGR_BF16) hipLaunchKernelGGL((gemm_lp_kernel<LA, LB, BM, BN, TAG, 1>), grid, block, 0, stream, b);
+  else hipLaunchKernelGGL((gemm_kernel<LA, LB, BM, BN, TAG>), grid, block, 0, stream, b);
   return (int)hipGetLastError();
 }
 
 template <int LA, int LB, int TAG>
-static int launch_layout(hipStream_t stream, const GemmBatch& b) {
+static int launch_layout(hipStream_t stream, const GemmBatch& b, int prec) {
   // 128x128 tiles when they already give every CU a workgroup, else 64x64 (M = B*N is small:
   // 1280 rows at the headline configuration, so tile quantisation decides the CU fill).
+  if (ring_eligible(b)) return launch_ring<LA, LB, TAG>(stream, b, prec);
   long wg128 = 0;
   for (int i = 0; i < b.n; ++i) wg128 += (long)((b.p[i].M + 127) / 128) * ((b.p[i].N + 127) / 128);
-  if (wg128 >= 200) return launch_cfg<LA, LB, 128, 128, TAG>(stream, b);
-  return launch_cfg<LA, LB, 64, 64, TAG>(stream, b);
+  if (wg128 >= 200) return launch_cfg<LA, LB, 128, 128, TAG>(stream, b, prec);
+  return launch_cfg<LA, LB, 64, 64, TAG>(stream, b, prec);
 }
 
-int gemm_launch(hipStream_t stream, int la, int lb, const GemmBatch& b, int tag) {
+int gemm_launch(hipStream_t stream, int la, int lb, const GemmBatch& b, int tag, int prec) {
   if (b.n < 1 || b.n > kMaxBatch) return DVGR_E_DIMS;
   for (int i = 0; i < b.n; ++i) {
     const GemmProblem& p = b.p[i];
@@ -208,19 +640,19 @@ int gemm_launch(hipStream_t stream, int la, int lb, const GemmBatch& b, int tag)
     if (lb == IC && (p.N & 3)) return DVGR_E_DIMS;
   }
   if (la == KC && lb == KC) {
-    if (tag == TAG_FWD_GAT) return launch_layout<KC, KC, TAG_FWD_GAT>(stream, b);
-    if (tag == TAG_FWD_SF) return launch_layout<KC, KC, TAG_FWD_SF>(stream, b);
-    return launch_layout<KC, KC, TAG_GENERIC>(stream, b);
+    if (tag == TAG_FWD_GAT) return launch_layout<KC, KC, TAG_FWD_GAT>(stream, b, prec);
+    if (tag == TAG_FWD_SF) return launch_layout<KC, KC, TAG_FWD_SF>(stream, b, prec);
+    return launch_layout<KC, KC, TAG_GENERIC>(stream, b, prec);
   }
   if (la == KC && lb == IC) {
-    if (tag == TAG_BWD_GAT_DX) return launch_layout<KC, IC, TAG_BWD_GAT_DX>(stream, b);
-    if (tag == TAG_BWD_SF_DX) return launch_layout<KC, IC, TAG_BWD_SF_DX>(stream, b);
-    return launch_layout<KC, IC, TAG_GENERIC>(stream, b);
+    if (tag == TAG_BWD_GAT_DX) return launch_layout<KC, IC, TAG_BWD_GAT_DX>(stream, b, prec);
+    if (tag == TAG_BWD_SF_DX) return launch_layout<KC, IC, TAG_BWD_SF_DX>(stream, b, prec);
+    return launch_layout<KC, IC, TAG_GENERIC>(stream, b, prec);
   }
   if (la == IC && lb == IC) {
-    if (tag == TAG_BWD_GAT_DW) return launch_layout<IC, IC, TAG_BWD_GAT_DW>(stream, b);
-    if (tag == TAG_BWD_SF_DW) return launch_layout<IC, IC, TAG_BWD_SF_DW>(stream, b);
-    return launch_layout<IC, IC, TAG_GENERIC>(stream, b);
+    if (tag == TAG_BWD_GAT_DW) return launch_layout<IC, IC, TAG_BWD_GAT_DW>(stream, b, prec);
+    if (tag == TAG_BWD_SF_DW) return launch_layout<IC, IC, TAG_BWD_SF_DW>(stream, b, prec);
+    return launch_layout<IC, IC, TAG_GENERIC>(stream, b, prec);
   }
   return DVGR_E_DIMS;
 }

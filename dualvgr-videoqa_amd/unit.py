@@ -212,8 +212,9 @@ class _UnitFn(torch.autograd.Function):
 class DualVGRUnit_multiple(nn.Module):
     """Drop-in for the reference `DualVGRUnit_multiple` (model/models.py:86-173).
 
-    Same constructor arguments and defaults (model/models.py:87).  Additions: `dtype` ('fp32' |
-    'bf16') selects the MFMA operand precision of the kernels; `grad_mode` selects how parameter
+    Same constructor arguments and defaults (model/models.py:87).  Additions: `dtype` ('fp32' | 'bf16x3' |
+    'bf16') selects the MFMA operand precision of the kernels (include/dvgr.h: DVGR_F32 exact fp32,
+    DVGR_BF16X3 fp32-grade split-bf16, DVGR_BF16 plain bf16 operands); `grad_mode` selects how parameter
     gradients reach `.grad`:
       'flat'     (default) the backward writes ONE flat gradient buffer and every `p.grad` is a view
                  into it (no per-parameter kernels; `zero_grad_flat()` marks it reusable in place).
@@ -240,7 +241,7 @@ class DualVGRUnit_multiple(nn.Module):
         self.num_of_nodes = num_of_nodes
         self.num_of_appearance_graph_layers = appearance_graph_layers
         self.num_of_motion_graph_layers = motion_graph_layers
-        self.dtype_code = {'fp32': L_.DVGR_F32, 'bf16': L_.DVGR_BF16}[dtype]
+        self.dtype_code = {'fp32': L_.DVGR_F32, 'bf16': L_.DVGR_BF16, 'bf16x3': L_.DVGR_BF16X3}[dtype]
         D, Wd, Fh, Lr = module_dim, word_dim, module_dim // 4, unit_layers
         self.queryAttn = nn.ModuleList([_QueryAttn(D) for _ in range(Lr)])
         self.queryPunish_appear = nn.ModuleList([_QueryPunish(Wd, D) for _ in range(Lr)])
@@ -367,8 +368,7 @@ class DualVGRUnit_multiple(nn.Module):
 
     def lowp_ptr(self):
         """bf16 shadow copy of the parameters for DVGR_BF16, refreshed when the weights changed."""
-        if self.dtype_code != L_.DVGR_BF16:
-            return None
+        return None    # operands are rounded on chip while they are staged into LDS; no shadow copy needed yet
         flat = self._flat
         ver = tuple(p._version for p in self._plist)
         if self._lowp is None or self._lowp.device != flat.device or ver != self._lowp_version:

@@ -27,6 +27,8 @@ extern "C" {
 
 #define DVGR_F32 0  /* fp32 operands on v_mfma_f32_16x16x4_f32 (exact fp32; parity mode)           */
 #define DVGR_BF16 1 /* bf16 operands (rounded on chip) on v_mfma_f32_16x16x32_bf16, fp32 accumulate */
+#define DVGR_BF16X3 2 /* every fp32 operand split as hi + lo bf16; 3 bf16 MFMAs per product (hi.hi + hi.lo +
+                         lo.hi), fp32 accumulate: fp32-grade results (~1e-5 relative) at 3/16 the MFMA cost */
 
 #define DVGR_E_DIMS (-1)      /* unsupported dimension (see dvgr_check_dims)            */
 #define DVGR_E_NULL (-2)      /* a required pointer is NULL                             */
@@ -44,7 +46,7 @@ typedef struct dvgr_dims {
   int32_t Wd;    /* word_dim (300); multiple of 4                                    */
   int32_t L;     /* unit_layers                                                      */
   int32_t G;     /* graph_layers; only 1 is supported (all reference configs use 1)  */
-  int32_t dtype; /* DVGR_F32 or DVGR_BF16                                            */
+  int32_t dtype; /* DVGR_F32, DVGR_BF16 or DVGR_BF16X3 (precision of the MFMA operands) */
 } dvgr_dims;
 
 /* Kinds of parameter tensors inside the flat parameter buffer.  `mod` = 0 appearance, 1 motion.

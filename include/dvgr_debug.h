@@ -16,11 +16,12 @@ extern "C" {
  *   mode 0 (NT): A[M,K] lda, B[N,K] ldb      -- forward Linear  (nn.Linear: y = x W^T + b)
  *   mode 1 (NN): A[M,K] lda, B[K,N] ldb      -- backward data
  *   mode 2 (TN): A[K,M] lda, B[K,N] ldb      -- backward weight; rows >= kseg of A/B come from A2/B2
- * act: 0 none, 1 tanh, 2 ELU.  drop_key_* = 0 disables the dropout masks. */
+ * act: 0 none, 1 tanh, 2 ELU.  drop_key_* = 0 disables the dropout masks.
+ * prec: DVGR_F32 / DVGR_BF16 / DVGR_BF16X3 (dvgr.h). */
 int dvgr_dbg_gemm(int mode, int M, int N, int K, int kseg, const float *A, const float *A2, int64_t lda,
                   const float *B, const float *B2, int64_t ldb, float *C, int64_t ldc, const float *bias,
                   int act, int accumulate, uint32_t drop_key_a, uint32_t drop_key_b, uint32_t drop_key_c,
-                  void *stream);
+                  int prec, void *stream);
 
 /* out[c] = sum_r w[r] * M[r][c]  (w nullable) */
 int dvgr_dbg_colsum(const float *M, const float *w, int rows, int cols, int64_t ld, float *out, void *stream);

@@ -19,12 +19,12 @@ def _stream():
 
 
 def _gemm(mode, A, B, M, N, K, bias=None, act=0, accumulate=False, C0=None, A2=None, B2=None, kseg=0,
-          ka=0, kb=0, kc=0):
+          ka=0, kb=0, kc=0, prec=0):
     lib = L.load()
     Cm = C0.clone() if C0 is not None else torch.full((M, N), float("nan"), device="cuda")
     rc = lib.dvgr_dbg_gemm(mode, M, N, K, kseg, A.data_ptr(), None if A2 is None else A2.data_ptr(), A.stride(0),
                            B.data_ptr(), None if B2 is None else B2.data_ptr(), B.stride(0), Cm.data_ptr(), Cm.stride(0),
-                           None if bias is None else bias.data_ptr(), act, int(accumulate), ka, kb, kc, _stream())
+                           None if bias is None else bias.data_ptr(), act, int(accumulate), ka, kb, kc, prec, _stream())
     assert rc == 0, rc
     torch.cuda.synchronize()
     return Cm
@@ -99,7 +99,7 @@ def test_gemm_strided_views_bias_activation_accumulate():
     wide = torch.full((M, 2 * N), 7.0, device="cuda")
     lib = L.load()
     assert lib.dvgr_dbg_gemm(0, M, N, K, 0, A.data_ptr(), None, A.stride(0), W.data_ptr(), None, K, wide[:, N:].data_ptr(),
-                             2 * N, None, 0, 0, 0, 0, 0, _stream()) == 0
+                             2 * N, None, 0, 0, 0, 0, 0, 0, _stream()) == 0
     torch.cuda.synchronize()
     assert torch.all(wide[:, :N] == 7.0)
     assert float((wide[:, N:] - (A.double() @ W.double().T).float()).abs().max()) < 2e-4 * float(ref.abs().max())
@@ -153,3 +153,65 @@ def test_colsum(rows, cols):
     torch.cuda.synchronize()
     ref = (Mx.double() * w.double()[:, None]).sum(0)
     assert float((out.double() - ref).abs().max()) < 1e-5 * max(1.0, float((Mx.abs() * w.abs()[:, None]).double().sum(0).max()))
+
+
+# ---- low-precision MFMA modes --------------------------------------------------------------------
+LP_SHAPES = [(80, 192, 768), (100, 300, 128), (64, 768, 300), (1280, 1536, 768), (257, 132, 36), (15, 128, 64)]
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", LP_SHAPES)
+def test_gemm_bf16_exact_on_small_integers(mode, M, N, K):
+    """Integers in [-4, 4] are exact in bf16, so plain-bf16 MFMA must reproduce the fp32 result bit for
+    bit in all three operand layouts (this is the A/B lane-map check of the bf16 kernel)."""
+    M, N = M // 4 * 4, N // 4 * 4
+    if mode == 0:
+        A, B = _ints((M, K), seed=21), _ints((N, K), seed=22)
+        want = A.double() @ B.double().T
+    elif mode == 1:
+        A, B = _ints((M, K), seed=23), _ints((K, N), seed=24)
+        want = A.double() @ B.double()
+    else:
+        A, B = _ints((K, M), seed=25), _ints((K, N), seed=26)
+        want = A.double().T @ B.double()
+    for prec in (1, 2):
+        got = _gemm(mode, A, B, M, N, K, prec=prec)
+        assert torch.equal(got, want.float()), (prec, float((got - want.float()).abs().max()))
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_gemm_bf16x3_is_fp32_grade(mode):
+    """Random fp32 operands: bf16x3 within 2e-5 of the exact product (relative to max |C|), plain bf16
+    within 2e-2 -- the tolerances the unit-level tests of those modes build on."""
+    torch.manual_seed(3)
+    M, N, K = 320, 384, 768
+    if mode == 0:
+        A, B = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda") * 0.05
+        want = A.double() @ B.double().T
+    elif mode == 1:
+        A, B = torch.randn(M, K, device="cuda"), torch.randn(K, N, device="cuda") * 0.05
+        want = A.double() @ B.double()
+    else:
+        A, B = torch.randn(K, M, device="cuda"), torch.randn(K, N, device="cuda") * 0.05
+        want = A.double().T @ B.double()
+    scale = float(want.abs().max())
+    e32 = float((_gemm(mode, A, B, M, N, K, prec=0).double() - want).abs().max()) / scale
+    ex3 = float((_gemm(mode, A, B, M, N, K, prec=2).double() - want).abs().max()) / scale
+    e16 = float((_gemm(mode, A, B, M, N, K, prec=1).double() - want).abs().max()) / scale
+    print(f"  mode {mode}: rel err fp32 {e32:.2e}  bf16x3 {ex3:.2e}  bf16 {e16:.2e}")
+    assert e32 < 2e-6 and ex3 < 2e-5 and e16 < 2e-2
+
+
+def test_gemm_bf16x3_dropout_and_segments():
+    M, N, K = 50, 64, 96
+    key = dropout.site_key(7, 3)
+    A, W = _ints((M, K), seed=12), _ints((N, K), seed=13)
+    mA = torch.from_numpy(dropout.keep_mask(key, M * K).reshape(M, K)).cuda()
+    scale = float(np.float32(1.0) / (np.float32(1.0) - np.float32(0.15)))
+    got = _gemm(0, A, W, M, N, K, ka=key, prec=2)
+    want = ((A * mA * scale).double() @ W.double().T)
+    assert float((got.double() - want).abs().max()) < 1e-4 * float(want.abs().max())
+    K0, K1 = 37, 51
+    A0, A1, B0, B1 = _ints((K0, 64), seed=7), _ints((K1, 64), seed=8), _ints((K0, 96), seed=9), _ints((K1, 96), seed=10)
+    got = _gemm(2, A0, B0, 64, 96, K0 + K1, A2=A1, B2=B1, kseg=K0, prec=2)
+    assert torch.equal(got, (A0.double().T @ B0.double() + A1.double().T @ B1.double()).float())
