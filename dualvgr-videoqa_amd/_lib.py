@@ -18,7 +18,7 @@ DVGR_F32, DVGR_BF16, DVGR_BF16X3 = 0, 1, 2
  P_SF_P1, P_SF_BP, P_SF_P2, P_MFB_W0, P_MFB_B0, P_MFB_W1, P_MFB_B1, P_MFB_WO, P_MFB_BO, P_KINDS) = range(20)
 # enum dvgr_saved_kind
 (S_QA_D, S_QA_NRM, S_QA_A, S_QA_AH, S_QA_S, S_QA_Q, S_P, S_S, S_X, S_WH, S_U, S_V, S_TN, S_BETA,
- S_MFB_X0, S_MFB_X1, S_MFB_Z, S_KINDS) = range(18)
+ S_MFB_X0, S_MFB_X1, S_MFB_Z, S_XD, S_KINDS) = range(19)
 
 ERRORS = {-1: "DVGR_E_DIMS (unsupported dimensions)", -2: "DVGR_E_NULL (null pointer)",
           -3: "DVGR_E_WORKSPACE (saved/workspace buffer too small)", -4: "DVGR_E_ALIGN (pointer not 16-byte aligned)",

@@ -79,6 +79,7 @@ GemmProblem tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* 
   GemmProblem p{};
   p.A = operand(A, lda); p.B = operand(B, ldb, drop_b);
   p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.kseg = K;
+  p.atomic_ok = 1;   // every weight gradient lands in gparams, which the backward zeroes first
   return p;
 }
 
@@ -190,7 +191,7 @@ int dvgr_saved_offset(const dvgr_dims* d, int kind, int layer, int mod, size_t* 
   if (!d || !offset_bytes) return DVGR_E_NULL;
   const SavedLayout s = saved_layout(*d);
   if (kind < 0 || kind >= DVGR_S_KINDS) return DVGR_E_KIND;
-  if (kind < DVGR_S_MFB_X0 && (layer < 0 || layer >= d->L || mod < 0 || mod > 1)) return DVGR_E_KIND;
+  if ((kind < DVGR_S_MFB_X0 || kind == DVGR_S_XD) && (layer < 0 || layer >= d->L || mod < 0 || mod > 1)) return DVGR_E_KIND;
   const int64_t lb = s.layer_stride * layer, mb = lb + s.mod_base + s.mod_stride * mod;
   int64_t o;
   switch (kind) {
@@ -211,6 +212,7 @@ int dvgr_saved_offset(const dvgr_dims* d, int kind, int layer, int mod, size_t* 
     case DVGR_S_MFB_X0: o = s.mfb_x0; break;
     case DVGR_S_MFB_X1: o = s.mfb_x1; break;
     case DVGR_S_MFB_Z: o = s.mfb_z; break;
+    case DVGR_S_XD: o = mb + s.xd; break;
     default: return DVGR_E_KIND;
   }
   *offset_bytes = (size_t)o * sizeof(float);
@@ -292,16 +294,19 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
     float* outs[2] = {io->aq_fusion + l * BND, io->mq_fusion + l * BND};
     // S1
     DVGR_TRY(punish_fwd(st, Xin[0], Xin[1], ms(l, 0) + S.p, ms(l, 1) + S.p, ms(l, 0) + S.s, ms(l, 1) + S.s, B, N, D));
-    // S2: Wh = drop_x(X) . Wcat^T + bcat
+    // S2: Wh = drop_x(X) . Wcat^T + bcat.  Training: the two GATs of a modality see differently dropped
+    // copies of X, materialised once (saved: the backward needs them for dWcat) so that the contraction
+    // itself carries no mask and can run on the LDS-DMA ring kernel.
     {
       GemmBatch gb{};
+      if (train) DVGR_TRY(drop_x(st, Xin[0], Xin[1], ms(l, 0) + S.xd, ms(l, 1) + S.xd, K.x, BND));
       for (int m = 0; m < 2; ++m) {
         if (!train) {
           gb.p[gb.n++] = nt(Xin[m], D, mp(l, m) + P.gat_w, D, ms(l, m) + S.wh, HF, mp(l, m) + P.gat_b, BN, HF, D, ACT_NONE);
         } else {
           for (int g = 0; g < 2; ++g)
-            gb.p[gb.n++] = nt(Xin[m], D, mp(l, m) + P.gat_w + (int64_t)g * 4 * F * D, D, ms(l, m) + S.wh + g * 4 * F, HF,
-                              mp(l, m) + P.gat_b + g * 4 * F, BN, 4 * F, D, ACT_NONE, K.x[m][g]);
+            gb.p[gb.n++] = nt(ms(l, m) + S.xd + g * BND, D, mp(l, m) + P.gat_w + (int64_t)g * 4 * F * D, D,
+                              ms(l, m) + S.wh + g * 4 * F, HF, mp(l, m) + P.gat_b + g * 4 * F, BN, 4 * F, D, ACT_NONE);
         }
       }
       DVGR_TRY(probe.begin(DVGR_PROBE_FWD_GAT_GEMM, l));
@@ -401,9 +406,11 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
   auto ms = [&](int l, int m) { return saved + S.layer_stride * l + S.mod_base + S.mod_stride * m; };
   float* dXacc[2] = {g->gA, g->gM};     // running gradient w.r.t. the current layer boundary
 
-  // every element of gparams is written: the tensors below, zeros in the alignment padding
+  // every element of gparams is written: the tensors below, zeros in the alignment padding.  gdq is the sum
+  // over layers of split-K partial tiles, so it starts from zero as well.
   {
-    const hipError_t e = hipMemsetAsync(gp, 0, (size_t)P.total * sizeof(float), st);
+    hipError_t e = hipMemsetAsync(gp, 0, (size_t)P.total * sizeof(float), st);
+    if (e == hipSuccess) e = hipMemsetAsync(g->gdq, 0, (size_t)BT * D * sizeof(float), st);
     if (e != hipSuccess) return (int)e;
   }
 
@@ -431,6 +438,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     cb.j[cb.n++] = ColsumJob{ws + W.dpo, nullptr, nullptr, nullptr, BN, 0, D, D, gp + P.mfb_bo};
     cb.j[cb.n++] = ColsumJob{ws + W.dp0, nullptr, nullptr, nullptr, BN, 0, kMfbHidden, kMfbHidden, gp + P.mfb_b0};
     cb.j[cb.n++] = ColsumJob{ws + W.dp1, nullptr, nullptr, nullptr, BN, 0, kMfbHidden, kMfbHidden, gp + P.mfb_b1};
+    cb.chunks = 8;
     DVGR_TRY(colsum(st, cb));
   }
   if (layer_done_events && layer_done_events[L]) {
@@ -515,8 +523,8 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
           gb.p[gb.n++] = tn(ws + W.dWh[m], HF, Xin[m], D, gmp(l, m) + P.gat_w, D, HF, D, BN);
         } else {
           for (int gi = 0; gi < 2; ++gi)
-            gb.p[gb.n++] = tn(ws + W.dWh[m] + gi * 4 * F, HF, Xin[m], D, gmp(l, m) + P.gat_w + (int64_t)gi * 4 * F * D, D,
-                              4 * F, D, BN, K.x[m][gi]);
+            gb.p[gb.n++] = tn(ws + W.dWh[m] + gi * 4 * F, HF, ms(l, m) + S.xd + gi * BND, D,
+                              gmp(l, m) + P.gat_w + (int64_t)gi * 4 * F * D, D, 4 * F, D, BN);
         }
       }
       DVGR_TRY(probe.begin(DVGR_PROBE_BWD_GAT_DW, l));
@@ -562,6 +570,12 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       GemmProblem p = nn(ws + W.dp_cat, 2 * D, mp(l, 0) + P.wq, Wd, ws + W.dqbar, Wd, B, Wd, 2 * D, 0);
       p.kseg = D;
       p.B.p1 = mp(l, 1) + P.wq;
+      p.atomic_ok = 1;                       // 3 output tiles x 48 K-tiles: split K, partials added atomically
+      p.accumulate = 1;
+      {
+        const hipError_t e = hipMemsetAsync(ws + W.dqbar, 0, (size_t)B * Wd * sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+      }
       gd.p[gd.n++] = p;
       DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_GENERIC, prec));
     }
@@ -579,12 +593,14 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       gb.p[gb.n++] = tn(ws + W.dy, D, io->dq, D, glp(l) + P.qa_w1, D, D, D, BT);
       DVGR_TRY(gemm_launch(st, IC, IC, gb, TAG_GENERIC, prec));
       GemmBatch gd{};   // d(dq) (+)= dy . W1
-      gd.p[gd.n++] = nn(ws + W.dy, D, lp(l) + P.qa_w1, D, g->gdq, D, BT, D, D, l == L - 1 ? 0 : 1);
+      gd.p[gd.n++] = nn(ws + W.dy, D, lp(l) + P.qa_w1, D, g->gdq, D, BT, D, D, 1);
+      gd.p[0].atomic_ok = 1;
       DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_GENERIC, prec));
       cb.j[cb.n++] = ColsumJob{ws + W.dy, nullptr, nullptr, nullptr, BT, 0, D, D, glp(l) + P.qa_b1};
       cb.j[cb.n++] = ColsumJob{ls(l) + S.qa_d, nullptr, ws + W.dr, nullptr, BT, 0, D, D, glp(l) + P.qa_w2};
       cb.j[cb.n++] = ColsumJob{ws + W.dr, nullptr, nullptr, nullptr, BT, 0, 1, 1, glp(l) + P.qa_b2};
     }
+    cb.chunks = 8;
     DVGR_TRY(colsum(st, cb));
     if (layer_done_events && layer_done_events[l]) {
       const hipError_t e = hipEventRecord((hipEvent_t)layer_done_events[l], st);
@@ -618,6 +634,7 @@ int dvgr_dbg_gemm(int mode, int M, int N, int K, int kseg, const float* A, const
   if (B2) p.B.p1 = B2;
   p.C = C; p.ldc = ldc; p.bias = bias; p.M = M; p.N = N; p.K = K; p.kseg = (kseg > 0 && kseg < K) ? kseg : K;
   p.act = act & 15; p.dbg = act >> 4; p.accumulate = accumulate; p.drop_key_c = drop_key_c;
+  p.atomic_ok = accumulate;   // an accumulating output may be produced by split-K partial tiles
   gb.p[gb.n++] = p;
   const int la = mode == 2 ? IC : KC, lb = mode == 0 ? KC : IC;
   return gemm_launch((hipStream_t)stream, la, lb, gb, TAG_GENERIC, prec);

@@ -70,7 +70,7 @@ inline ParamLayout param_layout(const dvgr_dims& d) {
 struct SavedLayout {
   int64_t layer_stride, mod_stride, mod_base;
   int64_t qa_d, qa_nrm, qa_a, qa_ah, qa_s, qa_q;              // inside a layer block
-  int64_t p, s, x, wh, u, v, tn, beta;                        // inside a modality block
+  int64_t p, s, x, wh, u, v, tn, beta, xd;                    // inside a modality block
   int64_t mfb_base, mfb_x0, mfb_x1, mfb_z;                    // absolute
   int64_t total;
 };
@@ -95,6 +95,7 @@ inline SavedLayout saved_layout(const dvgr_dims& d) {
   s.v = m;    m += round64(B * kHeads * N);
   s.tn = m;   m += round64(2 * B * N * D);
   s.beta = m; m += round64(B * N * 2);
+  s.xd = m;   m += round64(2 * B * N * D);   // training mode: x * keep/(1-p) for the common / specific GAT
   s.mod_stride = m;
   s.layer_stride = o + 2 * m;
   s.mfb_base = s.layer_stride * d.L;

@@ -38,6 +38,8 @@ struct GemmProblem {
   int accumulate;      // C += result instead of C = result
   uint32_t drop_key_c; // keep mask applied to the result (index row * ldc + col), 0 = none
   int dbg;             // profiling aid (tools/): bit 0 skip the epilogue, bit 1 skip the K loop; 0 in production
+  int atomic_ok;       // the output is pre-zeroed (or accumulates) and has no bias/act/mask: the launcher may split K
+                       // over several workgroups that add their partial tiles with float atomics
 };
 
 constexpr int kMaxBatch = 4;

@@ -158,14 +158,16 @@ __device__ __forceinline__ void epilogue(const GemmProblem& P, const f32x4 (&acc
 // Callers put a workgroup barrier between the last fragment read of the K loop and this function.
 template <int MT, int NT>
 __device__ __forceinline__ void epilogue_rows(const GemmProblem& P, const f32x4 (&acc)[MT][NT], int row0, int col0,
-                                              int lane, float* scratch /* wave-private, >= 32 * (16*NT + 4) floats */) {
+                                              int lane, float* scratch /* wave-private, >= 32 * (16*NT + 4) floats */,
+                                              bool atomic = false /* split-K partial tile: add with float atomics */) {
   constexpr int W = NT * 16, STR = W + 4;          // sub-tile width, padded LDS row stride (floats)
   constexpr int MCH = MT < 2 ? MT : 2;             // tile bands per pass
   constexpr int CPR = W / 4;                       // float4 chunks per row
   constexpr int RPI = 64 / CPR;                    // rows covered by one wave-instruction
   const int c = lane & 15, g = lane >> 4;
-  const bool vec_ok = ((P.ldc & 3) == 0) && ((((uintptr_t)P.C) & 15) == 0) && ((col0 & 3) == 0);
+  const bool vec_ok = atomic || (((P.ldc & 3) == 0) && ((((uintptr_t)P.C) & 15) == 0) && ((col0 & 3) == 0));
   if (!vec_ok) { epilogue<MT, NT>(P, acc, row0, col0, lane); return; }
+  static_assert(W == 64 || W == 32, "sub-tile width");
 #pragma unroll
   for (int i0 = 0; i0 < MT; i0 += MCH) {
 #pragma unroll
@@ -175,6 +177,19 @@ __device__ __forceinline__ void epilogue_rows(const GemmProblem& P, const f32x4 
 #pragma unroll
         for (int r = 0; r < 4; ++r) scratch[(ii * 16 + 4 * g + r) * STR + j * 16 + c] = acc[i0 + ii][j][r];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // LDS ops of one wave execute in order; keep the compiler in line
+    if (atomic) {
+      // float atomics run at full rate only as 256 contiguous bytes per wave-instruction: one row piece per instruction
+      constexpr int RPA = 64 / W;                  // rows per wave-instruction (1 or 2)
+#pragma unroll
+      for (int it = 0; it < MCH * 16 / RPA; ++it) {
+        const int rr = it * RPA + lane / W, cc = lane % W;
+        const int row = row0 + i0 * 16 + rr, col = col0 + cc;
+        const float x = scratch[rr * STR + cc];
+        if (row < P.M && col < P.N) atomicAdd(P.C + (int64_t)row * P.ldc + col, x);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      continue;
+    }
 #pragma unroll
     for (int it = 0; it < MCH * 16 / RPI; ++it) {
       const int rr = it * RPI + lane / CPR, cc = (lane % CPR) * 4;
@@ -191,7 +206,9 @@ __device__ __forceinline__ void epilogue_rows(const GemmProblem& P, const f32x4 
           else if (P.act == ACT_ELU) x[e] = elu_f(x[e]);
           if (P.drop_key_c) x[e] *= drop_factor(P.drop_key_c, (uint32_t)(o + e));
         }
-        if (nv == 4) {
+        if (atomic) {
+          for (int e = 0; e < nv; ++e) atomicAdd(P.C + o + e, x[e]);   // global_atomic_add_f32, no return
+        } else if (nv == 4) {
           if (P.accumulate) {
             const float4 old = *reinterpret_cast<const float4*>(P.C + o);
             x[0] += old.x; x[1] += old.y; x[2] += old.z; x[3] += old.w;
@@ -428,29 +445,53 @@ constexpr int RT = 128;                     // tile extent (M and N)
 constexpr int kRingTile = RT * BK;          // floats per operand tile (16 KB)
 constexpr int kRingSlot = 2 * kRingTile;    // A tile + B tile
 
+// Per-lane element offsets of the 4 DMA instructions a wave issues per operand tile, relative to the
+// tile's first K position: computed ONCE per workgroup (the K loop only moves a wave-uniform base), so
+// that issuing a K-tile costs a handful of vector instructions -- at one wave per SIMD every VALU
+// instruction costs 4 issue cycles and the address arithmetic was the bottleneck of the first version.
 template <int LAYOUT>
-__device__ __forceinline__ void ring_issue(const GemmOperand& op, int idx0, int k0, int dim, int kseg, int wave,
-                                           int lane, float* lds_tile) {
+__device__ __forceinline__ void ring_prep(const GemmOperand& op, int idx0, int dim, int wave, int lane, uint32_t (&off)[4]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {             // 1024 16-byte slots per tile = 4 waves x 4 instructions x 64 lanes
     const int S0 = (wave * 4 + i) * 64;     // first 16-byte slot written by this wave-instruction
-    const float* src;
     if (LAYOUT == KC) {
       const int row = (S0 >> 3) + (lane >> 3), slot = lane & 7;
       const int chunk = slot ^ ((row >> 1) & 7);
       int gi = idx0 + row;
       gi = gi < dim ? gi : dim - 1;         // rows past the matrix: any valid row (their outputs are never stored)
-      src = op.p0 + (int64_t)gi * op.ld + k0 + chunk * 4;
+      off[i] = (uint32_t)gi * (uint32_t)op.ld + (uint32_t)(chunk * 4);
     } else {
       const int krow = (S0 >> 5) + (lane >> 5), slot = lane & 31;
       const int chunk = slot ^ (((krow >> 2) & 1) << 2);
-      const int gk = k0 + krow;
       int gi = idx0 + chunk * 4;
       gi = gi < dim ? gi : dim - 4;
-      const float* rowp = (gk < kseg) ? op.p0 + (int64_t)gk * op.ld : op.p1 + (int64_t)(gk - kseg) * op.ld;
-      src = rowp + gi;
+      off[i] = (uint32_t)krow * (uint32_t)op.ld + (uint32_t)gi;
     }
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+  }
+}
+
+template <int LAYOUT>
+__device__ __forceinline__ void ring_issue(const GemmOperand& op, int k0, int kseg, int wave, int lane,
+                                           const uint32_t (&off)[4], float* lds_tile) {
+  // wave-uniform bases of this K-tile; an IC tile may straddle the boundary between the two row segments
+  const float* base0;
+  const float* base1;
+  if (LAYOUT == KC) {
+    base0 = op.p0 + k0;
+    base1 = base0;
+  } else {
+    base0 = op.p0 + (int64_t)k0 * op.ld;
+    base1 = op.p1 + (int64_t)(k0 - kseg) * op.ld;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int S0 = (wave * 4 + i) * 64;
+    const float* base = base0;
+    if (LAYOUT == IC) {
+      const int krow = (S0 >> 5) + (lane >> 5);
+      base = (k0 + krow < kseg) ? base0 : base1;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off[i]),
                                      (__attribute__((address_space(3))) void*)(lds_tile + S0 * 4), 16, 0, 0);
   }
 }
@@ -488,46 +529,69 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& 
   if (LO) lo = __builtin_bit_cast(bf16x8, l);
 }
 
+// 8 waves: waves 0-3 own the 2x2 grid of 64x64 accumulator blocks and only compute; waves 4-7 only move
+// data (each issues a quarter of every K-tile's DMA and does the counted vmcnt wait).  An LDS-DMA
+// instruction costs its issuing wave 60-180 cycles: on the computing waves that was a third of the
+// K-tile time.  One s_barrier per K-tile is shared by all 8 waves: it publishes tile kt (the loaders waited for
+// it) and frees slot (kt-1) % RS (the consumers finished reading it).
 template <int LA, int LB, int TAG, int PREC>
-__global__ __launch_bounds__(256) void gemm_ring_kernel(const GemmBatch batch) {
+__global__ __launch_bounds__(512) void gemm_ring_kernel(const GemmBatch batch) {
   const GemmProblem P = batch.p[blockIdx.z];
   int m0, n0;
   if (!tile_coords(P.M, P.N, RT, RT, &m0, &n0)) return;
 
   __shared__ __attribute__((aligned(16))) float smem[RS * kRingSlot];   // 128 KB
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave8 >= 4;
+  const int wave = wave8 & 3;
   constexpr int MT = 4, NT = 4;
 
+  // split-K: gridDim.y workgroups share one output tile, each reducing a contiguous range of K-tiles
+  const int nk_all = P.K / BK;
+  const int per = (nk_all + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int kbeg = (int)blockIdx.y * per;
+  const int nk_real = (nk_all - kbeg) < per ? (nk_all - kbeg) : per;
+  if (nk_real <= 0) return;
+  const int nk = (P.dbg & 2) ? 0 : nk_real;
+
+  if (loader) {
+    uint32_t offA[4], offB[4];
+    ring_prep<LA>(P.A, m0, P.M, wave, lane, offA);
+    ring_prep<LB>(P.B, n0, P.N, wave, lane, offB);
+#pragma unroll
+    for (int s = 0; s < RS - 1; ++s)
+      if (s < nk) {
+        ring_issue<LA>(P.A, (kbeg + s) * BK, P.kseg, wave, lane, offA, smem + s * kRingSlot);
+        ring_issue<LB>(P.B, (kbeg + s) * BK, P.kseg, wave, lane, offB, smem + s * kRingSlot + kRingTile);
+      }
+    for (int kt = 0; kt < nk; ++kt) {
+      // 8 DMA instructions per K-tile from this wave, in order: wait until tile kt has landed while
+      // leaving the (up to two) younger tiles in flight
+      const int younger = nk - 1 - kt;
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + RS - 1 < nk) {            // slot (kt-1) % RS is free now: refill it with tile kt + RS - 1
+        float* dst = smem + ((kt + RS - 1) % RS) * kRingSlot;
+        ring_issue<LA>(P.A, (kbeg + kt + RS - 1) * BK, P.kseg, wave, lane, offA, dst);
+        ring_issue<LB>(P.B, (kbeg + kt + RS - 1) * BK, P.kseg, wave, lane, offB, dst + kRingTile);
+      }
+    }
+    __builtin_amdgcn_s_barrier();        // matches the consumers' barrier in front of the epilogue
+    return;
+  }
+
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   f32x4 acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = P.K / BK;
-#pragma unroll
-  for (int s = 0; s < RS - 1; ++s)
-    if (s < nk) {
-      ring_issue<LA>(P.A, m0, s * BK, P.M, P.kseg, wave, lane, smem + s * kRingSlot);
-      ring_issue<LB>(P.B, n0, s * BK, P.N, P.kseg, wave, lane, smem + s * kRingSlot + kRingTile);
-    }
-
-  for (int kt = 0; kt < ((P.dbg & 2) ? 0 : nk); ++kt) {
-    // this wave issued 8 DMA instructions per K-tile (4 A + 4 B), in order: wait until tile kt has landed
-    // while leaving the (up to two) younger tiles in flight, then meet the other waves
-    const int younger = nk - 1 - kt;
-    if (younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int kt = 0; kt < nk; ++kt) {
     __builtin_amdgcn_s_barrier();
-    // every wave has finished reading slot (kt-1) % RS: refill it with tile kt + RS - 1
-    if (kt + RS - 1 < nk) {
-      float* dst = smem + ((kt + RS - 1) % RS) * kRingSlot;
-      ring_issue<LA>(P.A, m0, (kt + RS - 1) * BK, P.M, P.kseg, wave, lane, dst);
-      ring_issue<LB>(P.B, n0, (kt + RS - 1) * BK, P.N, P.kseg, wave, lane, dst + kRingTile);
-    }
     const float* curA = smem + (kt % RS) * kRingSlot;
     const float* curB = curA + kRingTile;
     if (PREC == DVGR_F32) {
@@ -545,34 +609,50 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(const GemmBatch batch) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
     } else {
       constexpr bool X3 = (PREC == DVGR_BF16X3);
-      bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
+      // column by column: the fp32 -> bf16 (hi, lo) conversion of B column j+1 is independent of the MFMAs of
+      // column j, so the scheduler can slot its VALU work into the MFMA issue gaps
+      bf16x8 ah[MT], al[MT], bh, bl;
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         float v[8];
         ring_frag<LA>(curA, wm + i * 16, lane, v);
         split8<X3>(v, ah[i], al[i]);
       }
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
+      {
         float v[8];
-        ring_frag<LB>(curB, wn + j * 16, lane, v);
-        split8<X3>(v, bh[j], bl[j]);
+        ring_frag<LB>(curB, wn, lane, v);
+        split8<X3>(v, bh, bl);
       }
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          if (X3) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < NT; ++j) {
+        bf16x8 nh = bh, nl = bl;
+        if (j + 1 < NT) {
+          float v[8];
+          ring_frag<LB>(curB, wn + (j + 1) * 16, lane, v);
+          split8<X3>(v, nh, nl);
         }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          if (X3) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+        }
+        if (j + 1 < NT) {
+#pragma unroll
+          for (int q = 0; q < (X3 ? 12 : 4); ++q) {        // MFMA, 2 VALU, MFMA, 2 VALU, ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, X3 ? 2 : 3, 0);
+          }
+        }
+        bh = nh; bl = nl;
+      }
     }
   }
-  if (P.dbg & 1) { if (acc[0][0][0] == 12345.678f) P.C[0] = 1.f; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
-  __syncthreads();     // every wave is done reading the ring (all DMA landed: vmcnt(0) in the last iteration)
-  epilogue_rows<MT, NT>(P, acc, m0 + wm, n0 + wn, lane, smem + wave * (32 * (16 * NT + 4)));
+  __builtin_amdgcn_s_barrier();      // every consumer is done reading the ring; the loaders leave here
+  if (P.dbg & 1) { if (acc[0][0][0] == 12345.678f) P.C[0] = 1.f; return; }
+  epilogue_rows<MT, NT>(P, acc, m0 + wm, n0 + wn, lane, smem + wave * (32 * (16 * NT + 4)), gridDim.y > 1);
 }
 
 template <int LA, int LB, int TAG>
@@ -583,7 +663,26 @@ static int launch_ring(hipStream_t stream, const GemmBatch& b, int prec) {
     tiles = t > tiles ? t : tiles;
   }
   if (tiles == 0) return 0;
-  const dim3 grid(8 * ((tiles + 7) / 8), 1, b.n), block(256);
+  // split-K (float atomics into a pre-zeroed / accumulating output) when the launch would leave most CUs
+  // idle: aim at ~1-2 workgroups per CU, at least 4 K-tiles per split
+  int split = 1;
+  bool atomic_ok = true;
+  long total = 0;
+  int nk_min = 1 << 30;
+  for (int i = 0; i < b.n; ++i) {
+    atomic_ok = atomic_ok && b.p[i].atomic_ok && !b.p[i].bias && b.p[i].act == ACT_NONE && !b.p[i].drop_key_c;
+    total += (long)((b.p[i].M + RT - 1) / RT) * ((b.p[i].N + RT - 1) / RT);
+    nk_min = (b.p[i].K / BK) < nk_min ? (b.p[i].K / BK) : nk_min;
+  }
+  // an atomic epilogue costs ~13 us per workgroup (float atomics run at ~5 GB/s per CU), a K-tile ~0.5-1 us:
+  // split only long K loops, and never into more workgroups than there are CUs
+  if (atomic_ok && total <= 128 && nk_min >= 32) {
+    split = (int)(256 / total);
+    if (split > nk_min / 16) split = nk_min / 16;
+    if (split < 1) split = 1;
+    if (split > 8) split = 8;
+  }
+  const dim3 grid(8 * ((tiles + 7) / 8), split, b.n), block(512);
   if (prec == DVGR_BF16X3) hipLaunchKernelGGL((gemm_ring_kernel<LA, LB, TAG, DVGR_BF16X3>), grid, block, 0, stream, b);
   else if (prec == DVGR_BF16) hipLaunchKernelGGL((gemm_ring_kernel<LA, LB, TAG, DVGR_BF16>), grid, block, 0, stream, b);
   else hipLaunchKernelGGL((gemm_ring_kernel<LA, LB, TAG, DVGR_F32>), grid, block, 0, stream, b);
@@ -595,6 +694,8 @@ static bool ring_eligible(const GemmBatch& b) {
     const GemmProblem& p = b.p[i];
     if (p.K < BK || (p.K % BK) || p.A.drop_key || p.B.drop_key) return false;
     if (p.M < 4 || p.N < 4) return false;
+    // per-lane source offsets are 32-bit element counts
+    if ((int64_t)(p.M > p.K ? p.M : p.K) * p.A.ld >= (1ll << 31) || (int64_t)(p.N > p.K ? p.N : p.K) * p.B.ld >= (1ll << 31)) return false;
   }
   return true;
 }

@@ -24,6 +24,10 @@ int qa_rows_fwd(hipStream_t st, const QaRowsArgs& a);
 int punish_fwd(hipStream_t st, const float* X0, const float* X1, const float* p0, const float* p1,
                float* s0, float* s1, int B, int N, int D);
 
+// x-site dropout of the two GATs of both modalities, materialised once per layer (training mode):
+// out[m][g][i] = X[m][i] * keep(key[m][g], i) / (1 - p).  model/GraphNN.py:175
+int drop_x(hipStream_t st, const float* X0, const float* X1, float* out0, float* out1, const uint32_t (&key)[2][2], int64_t n);
+
 // S3: per (b, head, mod): logits, softmax over j, punish-scaled aggregation, ELU, dropout.
 struct GatAttnArgs {
   const float* Wh[2];    // (B*N, 8F) per modality
@@ -128,7 +132,8 @@ struct QaBwdArgs {
 int qa_bwd(hipStream_t st, const QaBwdArgs& a);
 
 // Column sums (bias / vector-parameter gradients): out[c] = sum_r w[r] * M[r][c] over one or two row
-// segments; deterministic order.
+// segments.  `chunks` > 1 splits the rows over that many workgroups which ADD into a pre-zeroed `out`
+// with float atomics (the gradient buffer is zeroed at the start of the backward).
 struct ColsumJob {
   const float* M0; const float* M1;   // row segments (M1 nullable)
   const float* w0; const float* w1;   // per-row weights, nullable = 1
@@ -137,7 +142,7 @@ struct ColsumJob {
   float* out;
 };
 constexpr int kMaxColsumJobs = 16;
-struct ColsumBatch { ColsumJob j[kMaxColsumJobs]; int n; };
+struct ColsumBatch { ColsumJob j[kMaxColsumJobs]; int n; int chunks; };
 int colsum(hipStream_t st, const ColsumBatch& b);
 
 // fp32 -> bf16 shadow copy (round to nearest even)

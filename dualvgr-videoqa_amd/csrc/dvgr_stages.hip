@@ -548,11 +548,17 @@ __global__ __launch_bounds__(1024) void k_colsum(const ColsumBatch b) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
   if (blockIdx.x * 64 >= J.cols) return;                    // uniform per workgroup
+  const int nch = gridDim.z, ch = blockIdx.z;               // row chunk of this workgroup
   float acc = 0.f;
   if (c < J.cols) {
-    for (int r = wave; r < J.rows0; r += 16) acc += (J.w0 ? J.w0[r] : 1.f) * J.M0[(int64_t)r * J.ld + c];
-    if (J.M1)
-      for (int r = wave; r < J.rows1; r += 16) acc += (J.w1 ? J.w1[r] : 1.f) * J.M1[(int64_t)r * J.ld + c];
+    const int per0 = (J.rows0 + nch - 1) / nch;
+    const int b0 = ch * per0, e0 = (b0 + per0) < J.rows0 ? (b0 + per0) : J.rows0;
+    for (int r = b0 + wave; r < e0; r += 16) acc += (J.w0 ? J.w0[r] : 1.f) * J.M0[(int64_t)r * J.ld + c];
+    if (J.M1) {
+      const int per1 = (J.rows1 + nch - 1) / nch;
+      const int b1 = ch * per1, e1 = (b1 + per1) < J.rows1 ? (b1 + per1) : J.rows1;
+      for (int r = b1 + wave; r < e1; r += 16) acc += (J.w1 ? J.w1[r] : 1.f) * J.M1[(int64_t)r * J.ld + c];
+    }
   }
   red[wave][lane] = acc;
   __syncthreads();
@@ -560,14 +566,43 @@ __global__ __launch_bounds__(1024) void k_colsum(const ColsumBatch b) {
     float s = 0.f;
 #pragma unroll
     for (int w = 0; w < 16; ++w) s += red[w][lane];
-    J.out[c] = s;
+    if (nch > 1) atomicAdd(J.out + c, s); else J.out[c] = s;
   }
 }
 int colsum(hipStream_t st, const ColsumBatch& b) {
   if (b.n < 1 || b.n > kMaxColsumJobs) return DVGR_E_DIMS;
   int maxc = 0;
   for (int i = 0; i < b.n; ++i) maxc = b.j[i].cols > maxc ? b.j[i].cols : maxc;
-  hipLaunchKernelGGL(k_colsum, dim3((maxc + 63) / 64, b.n), dim3(1024), 0, st, b);
+  const int chunks = b.chunks > 1 ? b.chunks : 1;
+  hipLaunchKernelGGL(k_colsum, dim3((maxc + 63) / 64, b.n, chunks), dim3(1024), 0, st, b);
+  DVGR_LAUNCH_CHECK();
+}
+
+__global__ __launch_bounds__(256) void k_drop_x(const float* X0, const float* X1, float* out0, float* out1,
+                                                uint32_t k00, uint32_t k01, uint32_t k10, uint32_t k11, int64_t n4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // float4 index
+  if (i >= n4) return;
+  const int mod = blockIdx.y;
+  const float4 x = reinterpret_cast<const float4*>(mod ? X1 : X0)[i];
+  float* out = mod ? out1 : out0;
+  const uint32_t keys[2] = {mod ? k10 : k00, mod ? k11 : k01};
+  const uint32_t e = (uint32_t)(i * 4);
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const uint32_t h0 = mix32(((e >> 1) * 0x9E3779B1u) ^ keys[g]);
+    const uint32_t h1 = mix32((((e >> 1) + 1u) * 0x9E3779B1u) ^ keys[g]);
+    float4 y;
+    y.x = x.x * (((h0 & 0xFFFFu) >= kDropThresh16) ? kKeepScale : 0.f);
+    y.y = x.y * (((h0 >> 16) >= kDropThresh16) ? kKeepScale : 0.f);
+    y.z = x.z * (((h1 & 0xFFFFu) >= kDropThresh16) ? kKeepScale : 0.f);
+    y.w = x.w * (((h1 >> 16) >= kDropThresh16) ? kKeepScale : 0.f);
+    reinterpret_cast<float4*>(out + (int64_t)g * n4 * 4)[i] = y;
+  }
+}
+int drop_x(hipStream_t st, const float* X0, const float* X1, float* out0, float* out1, const uint32_t (&key)[2][2], int64_t n) {
+  const int64_t n4 = n / 4;
+  hipLaunchKernelGGL(k_drop_x, dim3((unsigned)((n4 + 255) / 256), 2), dim3(256), 0, st, X0, X1, out0, out1,
+                     key[0][0], key[0][1], key[1][0], key[1][1], n4);
   DVGR_LAUNCH_CHECK();
 }
 

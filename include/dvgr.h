@@ -86,6 +86,8 @@ enum dvgr_saved_kind {
   DVGR_S_MFB_X0,     /* (B*N, 512) ELU(linear0(A))                                  once           */
   DVGR_S_MFB_X1,     /* (B*N, 512) ELU(linear1(M))                                                 */
   DVGR_S_MFB_Z,      /* (B*N, 256) pair-summed product                                             */
+  DVGR_S_XD,         /* (2, B*N, D) layer input after the x-site dropout of the common / specific GAT
+                        (training mode only)                                           per layer, mod */
   DVGR_S_KINDS
 };
 

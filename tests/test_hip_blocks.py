@@ -215,3 +215,23 @@ def test_gemm_bf16x3_dropout_and_segments():
     A0, A1, B0, B1 = _ints((K0, 64), seed=7), _ints((K1, 64), seed=8), _ints((K0, 96), seed=9), _ints((K1, 96), seed=10)
     got = _gemm(2, A0, B0, 64, 96, K0 + K1, A2=A1, B2=B1, kseg=K0, prec=2)
     assert torch.equal(got, (A0.double().T @ B0.double() + A1.double().T @ B1.double()).float())
+
+
+@pytest.mark.parametrize("mode,M,N,K", [(2, 768, 768, 2560), (2, 128, 128, 2560), (1, 64, 300, 1536), (0, 256, 128, 640)])
+@pytest.mark.parametrize("prec", [0, 2])
+def test_gemm_splitk_atomic_partials(mode, M, N, K, prec):
+    """Few output tiles + long K: the launcher splits K over several workgroups that add their partial tiles
+    into the (accumulating) output with float atomics.  Integer operands keep every partial exact, so the
+    result is order independent and must match bit for bit."""
+    if mode == 0:
+        A, B = _ints((M, K), seed=31), _ints((N, K), seed=32)
+        want = A.double() @ B.double().T
+    elif mode == 1:
+        A, B = _ints((M, K), seed=33), _ints((K, N), seed=34)
+        want = A.double() @ B.double()
+    else:
+        A, B = _ints((K, M), seed=35), _ints((K, N), seed=36)
+        want = A.double().T @ B.double()
+    C0 = _ints((M, N), seed=37)
+    got = _gemm(mode, A, B, M, N, K, accumulate=True, C0=C0, prec=prec)
+    assert torch.equal(got, (C0.double() + want).float()), float((got.double() - C0.double() - want).abs().max())
