@@ -76,10 +76,13 @@ __global__ __launch_bounds__(256) void k_punish_fwd(const float* X0, const float
   float* s = mod ? s1 : s0;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
-  const float* x = X + (int64_t)row * D;
-  const float* pb = p + (int64_t)(row / N) * D;
+  const float4* x = reinterpret_cast<const float4*>(X + (int64_t)row * D);
+  const float4* pb = reinterpret_cast<const float4*>(p + (int64_t)(row / N) * D);
   float acc = 0.f;
-  for (int k = lane; k < D; k += 64) acc += x[k] * pb[k];
+  for (int k = lane; k < D / 4; k += 64) {
+    const float4 a = x[k], b = pb[k];
+    acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+  }
   acc = wave_sum(acc);
   if (lane == 0) s[row] = sigmoid_f(acc);
 }
@@ -190,26 +193,31 @@ __global__ __launch_bounds__(256) void k_sf_combine_fwd(const SfCombineArgs a) {
   const int mod = blockIdx.y;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= a.rows) return;
-  const int D = a.D;
-  const float* t0 = a.tn[mod] + (int64_t)row * D;
-  const float* t1 = a.tn[mod] + ((int64_t)a.rows + row) * D;
-  const float* p2 = a.p2[mod];
+  const int D4 = a.D / 4;
+  const float4* t0 = reinterpret_cast<const float4*>(a.tn[mod] + (int64_t)row * a.D);
+  const float4* t1 = reinterpret_cast<const float4*>(a.tn[mod] + ((int64_t)a.rows + row) * a.D);
+  const float4* p2 = reinterpret_cast<const float4*>(a.p2[mod]);
   float w0 = 0.f, w1 = 0.f;
-  for (int k = lane; k < D; k += 64) { w0 += t0[k] * p2[k]; w1 += t1[k] * p2[k]; }
+  for (int k = lane; k < D4; k += 64) {
+    const float4 u = t0[k], v = t1[k], p = p2[k];
+    w0 += u.x * p.x + u.y * p.y + u.z * p.z + u.w * p.w;
+    w1 += v.x * p.x + v.y * p.y + v.z * p.z + v.w * p.w;
+  }
   w0 = wave_sum(w0); w1 = wave_sum(w1);
   const float mx = fmaxf(w0, w1);
   const float e0 = expf(w0 - mx), e1 = expf(w1 - mx);
   const float b0 = e0 / (e0 + e1), b1 = e1 / (e0 + e1);
   if (lane == 0) { a.beta[mod][row * 2] = b0; a.beta[mod][row * 2 + 1] = b1; }
-  const float* z0 = a.z0[mod] + (int64_t)row * D;
-  const float* z1 = a.z1[mod] + (int64_t)row * D;
-  const float* x = a.X[mod] + (int64_t)row * D;
-  float* xo = a.Xout[mod] + (int64_t)row * D;
-  float* oo = a.o[mod] ? a.o[mod] + (int64_t)row * D : nullptr;
-  for (int k = lane; k < D; k += 64) {
-    const float o = b0 * z0[k] + b1 * z1[k];
+  const float4* z0 = reinterpret_cast<const float4*>(a.z0[mod] + (int64_t)row * a.D);
+  const float4* z1 = reinterpret_cast<const float4*>(a.z1[mod] + (int64_t)row * a.D);
+  const float4* x = reinterpret_cast<const float4*>(a.X[mod] + (int64_t)row * a.D);
+  float4* xo = reinterpret_cast<float4*>(a.Xout[mod] + (int64_t)row * a.D);
+  float4* oo = a.o[mod] ? reinterpret_cast<float4*>(a.o[mod] + (int64_t)row * a.D) : nullptr;
+  for (int k = lane; k < D4; k += 64) {
+    const float4 u = z0[k], v = z1[k], xx = x[k];
+    const float4 o = make_float4(b0 * u.x + b1 * v.x, b0 * u.y + b1 * v.y, b0 * u.z + b1 * v.z, b0 * u.w + b1 * v.w);
     if (oo) oo[k] = o;
-    xo[k] = x[k] + o;
+    xo[k] = make_float4(xx.x + o.x, xx.y + o.y, xx.z + o.z, xx.w + o.w);
   }
 }
 
@@ -273,37 +281,48 @@ __global__ __launch_bounds__(256) void k_sf_bwd(const SfBwdArgs a) {
   const int mod = blockIdx.y;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= a.rows) return;
-  const int D = a.D;
+  const int D = a.D, D4 = D / 4;
   const int64_t r0 = (int64_t)row * D, r1 = ((int64_t)a.rows + row) * D;
-  const float* dX = a.dX[mod] + r0;
-  const float* ge = a.g_embed[mod] ? a.g_embed[mod] + r0 : nullptr;
-  const float* z0 = a.z0[mod] + r0;
-  const float* z1 = a.z1[mod] + r0;
+  const float4* dX = reinterpret_cast<const float4*>(a.dX[mod] + r0);
+  const float4* ge = a.g_embed[mod] ? reinterpret_cast<const float4*>(a.g_embed[mod] + r0) : nullptr;
+  const float4* z0 = reinterpret_cast<const float4*>(a.z0[mod] + r0);
+  const float4* z1 = reinterpret_cast<const float4*>(a.z1[mod] + r0);
   float db0 = 0.f, db1 = 0.f;
-  for (int k = lane; k < D; k += 64) {
-    const float d = dX[k] + (ge ? ge[k] : 0.f);
-    db0 += d * z0[k];
-    db1 += d * z1[k];
+  for (int k = lane; k < D4; k += 64) {
+    float4 d = dX[k];
+    if (ge) { const float4 e = ge[k]; d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w; }
+    const float4 u = z0[k], v = z1[k];
+    db0 += d.x * u.x + d.y * u.y + d.z * u.z + d.w * u.w;
+    db1 += d.x * v.x + d.y * v.y + d.z * v.z + d.w * v.w;
   }
   db0 = wave_sum(db0); db1 = wave_sum(db1);
   const float b0 = a.beta[mod][row * 2], b1 = a.beta[mod][row * 2 + 1];
   const float mean = b0 * db0 + b1 * db1;
   const float dw0 = b0 * (db0 - mean), dw1 = b1 * (db1 - mean);
   if (lane == 0) { a.dw[mod][row] = dw0; a.dw[mod][a.rows + row] = dw1; }
-  const float* t0 = a.tn[mod] + r0;
-  const float* t1 = a.tn[mod] + r1;
-  const float* p2 = a.p2[mod];
-  const float* g0 = a.g_z0[mod] ? a.g_z0[mod] + r0 : nullptr;
-  const float* g1 = a.g_z1[mod] ? a.g_z1[mod] + r0 : nullptr;
-  float* dpre = a.dpre[mod];
-  float* dz = a.dz[mod];
-  for (int k = lane; k < D; k += 64) {
-    const float d = dX[k] + (ge ? ge[k] : 0.f);
-    const float ta = t0[k], tb = t1[k];
-    dpre[r0 + k] = dw0 * p2[k] * (1.f - ta * ta);
-    dpre[r1 + k] = dw1 * p2[k] * (1.f - tb * tb);
-    dz[r0 + k] = b0 * d + (g0 ? g0[k] : 0.f);
-    dz[r1 + k] = b1 * d + (g1 ? g1[k] : 0.f);
+  const float4* t0 = reinterpret_cast<const float4*>(a.tn[mod] + r0);
+  const float4* t1 = reinterpret_cast<const float4*>(a.tn[mod] + r1);
+  const float4* p2 = reinterpret_cast<const float4*>(a.p2[mod]);
+  const float4* g0 = a.g_z0[mod] ? reinterpret_cast<const float4*>(a.g_z0[mod] + r0) : nullptr;
+  const float4* g1 = a.g_z1[mod] ? reinterpret_cast<const float4*>(a.g_z1[mod] + r0) : nullptr;
+  float4* dpre0 = reinterpret_cast<float4*>(a.dpre[mod] + r0);
+  float4* dpre1 = reinterpret_cast<float4*>(a.dpre[mod] + r1);
+  float4* dz0 = reinterpret_cast<float4*>(a.dz[mod] + r0);
+  float4* dz1 = reinterpret_cast<float4*>(a.dz[mod] + r1);
+  for (int k = lane; k < D4; k += 64) {
+    float4 d = dX[k];
+    if (ge) { const float4 e = ge[k]; d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w; }
+    const float4 ta = t0[k], tb = t1[k], p = p2[k];
+    dpre0[k] = make_float4(dw0 * p.x * (1.f - ta.x * ta.x), dw0 * p.y * (1.f - ta.y * ta.y),
+                           dw0 * p.z * (1.f - ta.z * ta.z), dw0 * p.w * (1.f - ta.w * ta.w));
+    dpre1[k] = make_float4(dw1 * p.x * (1.f - tb.x * tb.x), dw1 * p.y * (1.f - tb.y * tb.y),
+                           dw1 * p.z * (1.f - tb.z * tb.z), dw1 * p.w * (1.f - tb.w * tb.w));
+    float4 o0 = make_float4(b0 * d.x, b0 * d.y, b0 * d.z, b0 * d.w);
+    float4 o1 = make_float4(b1 * d.x, b1 * d.y, b1 * d.z, b1 * d.w);
+    if (g0) { const float4 e = g0[k]; o0.x += e.x; o0.y += e.y; o0.z += e.z; o0.w += e.w; }
+    if (g1) { const float4 e = g1[k]; o1.x += e.x; o1.y += e.y; o1.z += e.z; o1.w += e.w; }
+    dz0[k] = o0;
+    dz1[k] = o1;
   }
 }
 int sf_bwd(hipStream_t st, const SfBwdArgs& a) {
@@ -465,30 +484,30 @@ __global__ __launch_bounds__(256) void k_punish_bwd(const PunishBwdArgs a) {
     shT[tid] = ds * s * (1.f - s);
   }
   __syncthreads();
+  const int d = blockIdx.z * 256 + tid;                     // one feature column per thread
+  if (d >= D) return;
   const float* X = a.X[mod] + (int64_t)b * N * D;
   float* dX = a.dX[mod] + (int64_t)b * N * D;
-  const float* p = a.p[mod] + (int64_t)b * D;
-  for (int d = tid; d < D; d += 256) {
-    const float pd = p[d];
-    float acc = 0.f;
-    for (int n = 0; n < N; ++n) {
-      acc += shT[n] * X[(int64_t)n * D + d];
-      dX[(int64_t)n * D + d] += shT[n] * pd;
-    }
-    a.dp_cat[(int64_t)b * 2 * D + mod * D + d] = acc;
+  const float pd = a.p[mod][(int64_t)b * D + d];
+  float acc = 0.f;
+  for (int n = 0; n < N; ++n) {
+    acc += shT[n] * X[(int64_t)n * D + d];
+    dX[(int64_t)n * D + d] += shT[n] * pd;
   }
+  a.dp_cat[(int64_t)b * 2 * D + mod * D + d] = acc;
 }
 int punish_bwd(hipStream_t st, const PunishBwdArgs& a) {
-  hipLaunchKernelGGL(k_punish_bwd, dim3(a.B, 2), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_punish_bwd, dim3(a.B, 2, (a.D + 255) / 256), dim3(256), 0, st, a);
   DVGR_LAUNCH_CHECK();
 }
 
 // =================================================================================================
 // S0 backward rows.  grid (B), loops over layers.  SURVEY.md Appendix A.1
 // =================================================================================================
+constexpr int kQaChunks = 4;   // workgroups per batch element: each redoes the (tiny) softmax part, then owns 1/4 of the rows
 __global__ __launch_bounds__(256) void k_qa_bwd(const QaBwdArgs a) {
   __shared__ float sh_dah[256], sh_c[256], sh_ah[256], sh_a[256], sh_da[256], sh_dr[256];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = a.T, D = a.D, Wd = a.Wd;
   const int len = (int)a.qlen[b];
   for (int l = 0; l < a.L; ++l) {
@@ -498,9 +517,18 @@ __global__ __launch_bounds__(256) void k_qa_bwd(const QaBwdArgs a) {
     const float* dsv = sav + a.s_d + (int64_t)b * T * D;
     for (int t = wave; t < T; t += 4) {
       float s1 = 0.f, s2 = 0.f;
-      const float* wrow = a.words + ((int64_t)b * T + t) * Wd;
-      for (int w = lane; w < Wd; w += 64) s1 += wrow[w] * dqb[w];
-      for (int k = lane; k < D; k += 64) s2 += dsv[(int64_t)t * D + k] * w2[k];
+      const float4* wrow = reinterpret_cast<const float4*>(a.words + ((int64_t)b * T + t) * Wd);
+      const float4* dq4 = reinterpret_cast<const float4*>(dqb);
+      for (int w = lane; w < Wd / 4; w += 64) {
+        const float4 x = wrow[w], y = dq4[w];
+        s1 += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+      }
+      const float4* drow = reinterpret_cast<const float4*>(dsv + (int64_t)t * D);
+      const float4* w24 = reinterpret_cast<const float4*>(w2);
+      for (int k = lane; k < D / 4; k += 64) {
+        const float4 x = drow[k], y = w24[k];
+        s2 += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+      }
       s1 = wave_sum(s1); s2 = wave_sum(s2);
       if (lane == 0) { sh_dah[t] = s1; sh_c[t] = s2; }
     }
@@ -516,26 +544,27 @@ __global__ __launch_bounds__(256) void k_qa_bwd(const QaBwdArgs a) {
     if (tid < T) {
       const float dr = sh_a[tid] * (sh_da[tid] - adot);
       sh_dr[tid] = dr;
-      a.dr[(int64_t)l * a.B * T + b * T + tid] = dr;
+      if (ch == 0) a.dr[(int64_t)l * a.B * T + b * T + tid] = dr;
     }
     __syncthreads();
-    for (int e = tid; e < T * Wd; e += 256) {               // dwords_t += ah_t * dqbar
-      const int t = e / Wd, w = e - t * Wd;
-      const float val = sh_ah[t] * dqb[w];
-      float* dst = a.gwords + (int64_t)b * T * Wd + e;
-      *dst = (a.first && l == 0) ? val : (*dst + val);
-    }
+    // rows t = ch, ch + kQaChunks, ... of this batch element
     float* dy = a.dy + ((int64_t)l * a.B + b) * T * D;
-    for (int e = tid; e < T * D; e += 256) {                // dy = (dd - d (d.dd)) / nrm, dd = dr * w2
-      const int t = e / D, k = e - t * D;
-      const float nrm = sav[a.s_nrm + b * T + t];
-      dy[e] = sh_dr[t] * (w2[k] - dsv[e] * sh_c[t]) / nrm;
+    for (int t = ch; t < T; t += kQaChunks) {
+      const float aht = sh_ah[t];
+      float* gw = a.gwords + ((int64_t)b * T + t) * Wd;
+      for (int w = tid; w < Wd; w += 256) {                 // dwords_t (+)= ah_t * dqbar
+        const float val = aht * dqb[w];
+        gw[w] = (a.first && l == 0) ? val : (gw[w] + val);
+      }
+      const float nrm = sav[a.s_nrm + b * T + t], drt = sh_dr[t], ct = sh_c[t];
+      for (int k = tid; k < D; k += 256)                    // dy = (dd - d (d.dd)) / nrm, dd = dr * w2
+        dy[(int64_t)t * D + k] = drt * (w2[k] - dsv[(int64_t)t * D + k] * ct) / nrm;
     }
     __syncthreads();
   }
 }
 int qa_bwd(hipStream_t st, const QaBwdArgs& a) {
-  hipLaunchKernelGGL(k_qa_bwd, dim3(a.B), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_qa_bwd, dim3(a.B, kQaChunks), dim3(256), 0, st, a);
   DVGR_LAUNCH_CHECK();
 }
 
