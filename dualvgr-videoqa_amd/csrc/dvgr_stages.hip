@@ -97,24 +97,23 @@ int punish_fwd(hipStream_t st, const float* X0, const float* X1, const float* p0
 // =================================================================================================
 // S3 forward: one workgroup per (b, head, modality).  model/GraphNN.py:97-111 in factorised form.
 // =================================================================================================
+// NB = N rounded up to a compile-time bound: the per-thread accumulators over the N nodes live in registers.
+template <int NB>
 __global__ __launch_bounds__(256) void k_gat_attn_fwd(const GatAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int b = blockIdx.x, h = blockIdx.y, mod = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int N = a.N, D = a.D, F = D / 4, FS = F + 1, NS = N + 1, HF = kHeads * F;
-  float* shW = sm;                // [N][FS]  Wh tile, later s_j * Wh_j
-  float* shA = shW + N * FS;      // [N][NS]  dropped attention
-  float* shAl = shA + N * NS;     // [F]
-  float* shAr = shAl + F;         // [F]
-  float* shS = shAr + F;          // [N]
-  float* shU = shS + N;           // [N]
-  float* shV = shU + N;           // [N]
-  const float* Wh = a.Wh[mod];
-  for (int e = tid; e < N * F; e += 256) {
-    const int j = e / F, f = e - j * F;
-    shW[j * FS + f] = Wh[((int64_t)b * N + j) * HF + h * F + f];
-  }
+  const int N = a.N, D = a.D, F = D / 4, FS = F + 1, HF = kHeads * F;
+  float* shZ = sm;                 // [N][FS]  Wh tile, later s_j * Wh_j
+  float* shAT = shZ + ((N * FS + 3) & ~3);   // [N][NB] dropped attention, TRANSPOSED: shAT[j][i]
+  float* shAl = shAT + N * NB;     // [F]
+  float* shAr = shAl + F;          // [F]
+  float* shS = shAr + F;           // [N]
+  float* shU = shS + N;            // [N]
+  float* shV = shU + N;            // [N]
+  const float* Wh = a.Wh[mod] + (int64_t)b * N * HF + h * F;
   for (int f = tid; f < F; f += 256) {
+    for (int j = 0; j < N; ++j) shZ[j * FS + f] = Wh[(int64_t)j * HF + f];
     shAl[f] = a.gat_a[mod][h * 2 * F + f];
     shAr[f] = a.gat_a[mod][h * 2 * F + F + f];
   }
@@ -123,7 +122,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_fwd(const GatAttnArgs a) {
   for (int i = wave; i < N; i += 4) {                       // u_i = a_l . Wh_i, v_i = a_r . Wh_i
     float pu = 0.f, pv = 0.f;
     for (int f = lane; f < F; f += 64) {
-      const float w = shW[i * FS + f];
+      const float w = shZ[i * FS + f];
       pu += w * shAl[f];
       pv += w * shAr[f];
     }
@@ -135,55 +134,67 @@ __global__ __launch_bounds__(256) void k_gat_attn_fwd(const GatAttnArgs a) {
     }
   }
   __syncthreads();
-  if (tid < N) {                                            // softmax over j of LeakyReLU(u_i + v_j + c)
-    const int i = tid;
-    const float ui = shU[i] + a.gat_c[mod][h];
-    float mx = -INFINITY;
-    for (int j = 0; j < N; ++j) {
-      float e = ui + shV[j];
-      e = e > 0.f ? e : kSlope * e;
-      mx = fmaxf(mx, e);
-    }
-    float sum = 0.f;
-    for (int j = 0; j < N; ++j) {
-      float e = ui + shV[j];
-      e = e > 0.f ? e : kSlope * e;
-      sum += expf(e - mx);
-    }
+  {                                                         // softmax over j of LeakyReLU(u_i + v_j + c): one wave per row
+    const float c = a.gat_c[mod][h];
     const uint32_t key = a.key_alpha[mod][h];
-    for (int j = 0; j < N; ++j) {
-      float e = ui + shV[j];
-      e = e > 0.f ? e : kSlope * e;
-      const float al = expf(e - mx) / sum;
-      shA[i * NS + j] = al * drop_factor(key, (uint32_t)((b * N + i) * N + j));
+    for (int i = wave; i < N; i += 4) {
+      float e = -INFINITY;
+      if (lane < N) { e = shU[i] + shV[lane] + c; e = e > 0.f ? e : kSlope * e; }
+      const float mx = wave_max(e);
+      const float pe = lane < N ? expf(e - mx) : 0.f;
+      const float sum = wave_sum(pe);
+      if (lane < N) shAT[lane * NB + i] = pe / sum * drop_factor(key, (uint32_t)((b * N + i) * N + lane));
     }
   }
-  for (int e = tid; e < N * F; e += 256) {                  // punish AFTER the logits (GraphNN.py:102-104)
-    const int j = e / F, f = e - j * F;
-    shW[j * FS + f] *= shS[j];
-  }
+  for (int f = tid; f < F; f += 256)                        // punish AFTER the logits (GraphNN.py:102-104)
+    for (int j = 0; j < N; ++j) shZ[j * FS + f] *= shS[j];
   __syncthreads();
   const int g = h >> 2, hl = h & 3;
-  float* out = g ? a.out_s[mod] : a.out_c[mod];
+  float* out = (g ? a.out_s[mod] : a.out_c[mod]) + (int64_t)b * N * D + hl * F;
   const uint32_t ko = a.key_out[mod][g];
   for (int f = tid; f < F; f += 256) {
-    for (int i = 0; i < N; ++i) {
-      float acc = 0.f;
-      for (int j = 0; j < N; ++j) acc += shA[i * NS + j] * shW[j * FS + f];
-      const int64_t o = ((int64_t)b * N + i) * D + hl * F + f;
-      out[o] = elu_f(acc) * drop_factor(ko, (uint32_t)o);
+    float acc[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) acc[i] = 0.f;
+    for (int j = 0; j < N; ++j) {
+      const float z = shZ[j * FS + f];
+#pragma unroll
+      for (int i4 = 0; i4 < NB / 4; ++i4) {                 // one broadcast b128 read serves four nodes i
+        const float4 a4 = *reinterpret_cast<const float4*>(shAT + j * NB + 4 * i4);
+        acc[4 * i4 + 0] += a4.x * z; acc[4 * i4 + 1] += a4.y * z;
+        acc[4 * i4 + 2] += a4.z * z; acc[4 * i4 + 3] += a4.w * z;
+      }
     }
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      if (i < N) {
+        const int64_t o = (int64_t)i * D + f;
+        out[o] = elu_f(acc[i]) * drop_factor(ko, (uint32_t)(((int64_t)b * N) * D + hl * F + o));
+      }
   }
 }
 
-static size_t gat_fwd_lds(int N, int F) { return sizeof(float) * ((size_t)N * (F + 1) + (size_t)N * (N + 1) + 2 * F + 3 * N); }
+static size_t gat_fwd_lds(int N, int NB, int F) {
+  return sizeof(float) * ((((size_t)N * (F + 1) + 3) & ~(size_t)3) + (size_t)N * NB + 2 * F + 3 * N);
+}
+static int gat_nb(int N) { return N <= 8 ? 8 : N <= 16 ? 16 : N <= 24 ? 24 : N <= 32 ? 32 : 64; }
 
-int gat_attn_fwd(hipStream_t st, const GatAttnArgs& a) {
-  const size_t lds = gat_fwd_lds(a.N, a.D / 4);
+template <int NB>
+static int gat_attn_fwd_nb(hipStream_t st, const GatAttnArgs& a) {
+  const size_t lds = gat_fwd_lds(a.N, NB, a.D / 4);
   if (lds > 48 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gat_attn_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_gat_attn_fwd, dim3(a.B, kHeads, 2), dim3(256), lds, st, a);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gat_attn_fwd<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_gat_attn_fwd<NB>, dim3(a.B, kHeads, 2), dim3(256), lds, st, a);
   DVGR_LAUNCH_CHECK();
+}
+int gat_attn_fwd(hipStream_t st, const GatAttnArgs& a) {
+  switch (gat_nb(a.N)) {
+    case 8: return gat_attn_fwd_nb<8>(st, a);
+    case 16: return gat_attn_fwd_nb<16>(st, a);
+    case 24: return gat_attn_fwd_nb<24>(st, a);
+    case 32: return gat_attn_fwd_nb<32>(st, a);
+    default: return gat_attn_fwd_nb<64>(st, a);
+  }
 }
 
 // =================================================================================================
@@ -333,40 +344,39 @@ int sf_bwd(hipStream_t st, const SfBwdArgs& a) {
 // =================================================================================================
 // S3 backward: one workgroup per (b, head, modality).  SURVEY.md Appendix A.3
 // =================================================================================================
+template <int NB>
 __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int b = blockIdx.x, h = blockIdx.y, mod = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int N = a.N, D = a.D, F = D / 4, FS = F + 1, NS = N + 1, HF = kHeads * F;
+  const int N = a.N, D = a.D, F = D / 4, FS = F + 4, HF = kHeads * F;   // FS: 16-byte aligned rows (b128 reads)
   const int g = h >> 2, hl = h & 3;
   float* shW = sm;                 // [N][FS] Wh (unscaled)
   float* shP = shW + N * FS;       // [N][FS] dP
-  float* shA = shP + N * FS;       // [N][NS] alpha
-  float* shAd = shA + N * NS;      // [N][NS] alpha * keep
-  float* shG = shAd + N * NS;      // [N][NS] dalpha, then dpre
-  float* shAl = shG + N * NS;      // [F]
+  float* shA = shP + N * FS;       // [N][NB] alpha
+  float* shAd = shA + N * NB;      // [N][NB] alpha * keep
+  float* shG = shAd + N * NB;      // [N][NB] dalpha, then dpre
+  float* shAl = shG + N * NB;      // [F]
   float* shAr = shAl + F;          // [F]
   float* shS = shAr + F;           // [N]
   float* shU = shS + N;            // [N]
   float* shV = shU + N;            // [N]
   float* shDu = shV + N;           // [N]
   float* shDv = shDu + N;          // [N]
-  float* shRow = shDv + N;         // [N]   per-row sum of dpre (for dc)
-  float* shRed = shRow + N;        // [N][4] per-wave partials of ds_j
-  const float* Wh = a.Wh[mod];
-  const float* dz = a.dz[mod] + (int64_t)g * a.B * N * D;   // view g of (2, B*N, D)
-  const float* outp = g ? a.out_s[mod] : a.out_c[mod];
+  float* shRed = shDv + N;         // [NB][4] per-wave partials of ds_j
+  const float* Wh = a.Wh[mod] + (int64_t)b * N * HF + h * F;
+  const float* dz = a.dz[mod] + (int64_t)g * a.B * N * D + (int64_t)b * N * D + hl * F;   // view g of (2, B*N, D)
+  const float* outp = (g ? a.out_s[mod] : a.out_c[mod]) + (int64_t)b * N * D + hl * F;
   const uint32_t ko = a.key_out[mod][g];
   const uint32_t ka = a.key_alpha[mod][h];
-  for (int e = tid; e < N * F; e += 256) {
-    const int i = e / F, f = e - i * F;
-    shW[i * FS + f] = Wh[((int64_t)b * N + i) * HF + h * F + f];
-    const int64_t o = ((int64_t)b * N + i) * D + hl * F + f;
-    const float kf = drop_factor(ko, (uint32_t)o);
-    const float Oh = ko ? outp[o] * (1.0f - kDropP) : outp[o];   // un-dropped ELU output where kept
-    shP[i * FS + f] = dz[o] * kf * elu_grad_from_out(Oh);
-  }
   for (int f = tid; f < F; f += 256) {
+    for (int i = 0; i < N; ++i) {
+      shW[i * FS + f] = Wh[(int64_t)i * HF + f];
+      const int64_t o = (int64_t)i * D + f;
+      const float kf = drop_factor(ko, (uint32_t)(((int64_t)b * N) * D + hl * F + o));
+      const float Oh = ko ? outp[o] * (1.0f - kDropP) : outp[o];   // un-dropped ELU output where kept
+      shP[i * FS + f] = dz[o] * kf * elu_grad_from_out(Oh);
+    }
     shAl[f] = a.gat_a[mod][h * 2 * F + f];
     shAr[f] = a.gat_a[mod][h * 2 * F + F + f];
   }
@@ -377,73 +387,84 @@ __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
   }
   __syncthreads();
   const float c = a.gat_c[mod][h];
-  if (tid < N) {                                            // recompute alpha and alpha_d
-    const int i = tid;
-    const float ui = shU[i] + c;
-    float mx = -INFINITY;
-    for (int j = 0; j < N; ++j) { float e = ui + shV[j]; e = e > 0.f ? e : kSlope * e; mx = fmaxf(mx, e); }
-    float sum = 0.f;
-    for (int j = 0; j < N; ++j) { float e = ui + shV[j]; e = e > 0.f ? e : kSlope * e; sum += expf(e - mx); }
-    for (int j = 0; j < N; ++j) {
-      float e = ui + shV[j]; e = e > 0.f ? e : kSlope * e;
-      const float al = expf(e - mx) / sum;
-      shA[i * NS + j] = al;
-      shAd[i * NS + j] = al * drop_factor(ka, (uint32_t)((b * N + i) * N + j));
+  for (int i = wave; i < N; i += 4) {                       // recompute alpha and alpha * keep: one wave per row
+    float e = -INFINITY;
+    if (lane < N) { e = shU[i] + shV[lane] + c; e = e > 0.f ? e : kSlope * e; }
+    const float mx = wave_max(e);
+    const float pe = lane < N ? expf(e - mx) : 0.f;
+    const float sum = wave_sum(pe);
+    if (lane < N) {
+      const float al = pe / sum;
+      shA[i * NB + lane] = al;
+      shAd[i * NB + lane] = al * drop_factor(ka, (uint32_t)((b * N + i) * N + lane));
     }
   }
-  __syncthreads();
   for (int pr = tid; pr < N * N; pr += 256) {               // dalpha_ij = keep_ij * s_j * (dP_i . Wh_j)
     const int i = pr / N, j = pr - i * N;
+    const float4* pi = reinterpret_cast<const float4*>(shP + i * FS);
+    const float4* wj = reinterpret_cast<const float4*>(shW + j * FS);
     float acc = 0.f;
-    for (int f = 0; f < F; ++f) acc += shP[i * FS + f] * shW[j * FS + f];
-    shG[i * NS + j] = acc * shS[j] * drop_factor(ka, (uint32_t)((b * N + i) * N + j));
+    for (int f4 = 0; f4 < F / 4; ++f4) {
+      const float4 x = pi[f4], y = wj[f4];
+      acc += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    }
+    shG[i * NB + j] = acc * shS[j] * drop_factor(ka, (uint32_t)((b * N + i) * N + j));
   }
   __syncthreads();
-  if (tid < N) {                                            // softmax and LeakyReLU backward, du_i
-    const int i = tid;
-    float rowdot = 0.f;
-    for (int j = 0; j < N; ++j) rowdot += shA[i * NS + j] * shG[i * NS + j];
-    const float ui = shU[i] + c;
-    float du = 0.f;
-    for (int j = 0; j < N; ++j) {
-      const float de = shA[i * NS + j] * (shG[i * NS + j] - rowdot);
-      const float pre = ui + shV[j];
-      const float dpre = de * (pre > 0.f ? 1.f : kSlope);
-      shG[i * NS + j] = dpre;
-      du += dpre;
-    }
-    shDu[i] = du;
-    shRow[i] = du;
+  float dc_w = 0.f;
+  for (int i = wave; i < N; i += 4) {                       // softmax and LeakyReLU backward, du_i: one wave per row
+    const float al = lane < N ? shA[i * NB + lane] : 0.f;
+    const float da = lane < N ? shG[i * NB + lane] : 0.f;
+    const float rowdot = wave_sum(al * da);
+    const float pre = lane < N ? shU[i] + shV[lane] + c : 0.f;
+    const float dpre = al * (da - rowdot) * (pre > 0.f ? 1.f : kSlope);
+    if (lane < N) shG[i * NB + lane] = dpre;
+    const float du = wave_sum(lane < N ? dpre : 0.f);
+    if (lane == 0) shDu[i] = du;
+    dc_w += du;
   }
+  if (lane == 0) shRed[wave] = dc_w;
   __syncthreads();
   if (tid < N) {                                            // dv_j
     float dv = 0.f;
-    for (int i = 0; i < N; ++i) dv += shG[i * NS + tid];
+    for (int i = 0; i < N; ++i) dv += shG[i * NB + tid];
     shDv[tid] = dv;
   }
-  if (tid == 0) {
-    float dc = 0.f;
-    for (int i = 0; i < N; ++i) dc += shRow[i];
-    a.dc_part[mod][b * kHeads + h] = dc;
-  }
+  if (tid == 0) a.dc_part[mod][b * kHeads + h] = shRed[0] + shRed[1] + shRed[2] + shRed[3];
   __syncthreads();
-  float* dWh = a.dWh[mod];
+  float* dWh = a.dWh[mod] + (int64_t)b * N * HF + h * F;
   for (int f0 = 0; f0 < F; f0 += 256) {                     // uniform trip count: wave_sum needs all lanes
     const int f = f0 + tid;
     const bool act = f < F;
-    float dal = 0.f, dar = 0.f;
-    for (int j = 0; j < N; ++j) {
-      float dZ = 0.f, w = 0.f;
-      if (act) {
-        for (int i = 0; i < N; ++i) dZ += shAd[i * NS + j] * shP[i * FS + f];
-        w = shW[j * FS + f];
-        dWh[((int64_t)b * N + j) * HF + h * F + f] = shS[j] * dZ + shDu[j] * shAl[f] + shDv[j] * shAr[f];
-        dal += shDu[j] * w;
-        dar += shDv[j] * w;
+    float dZ[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) dZ[j] = 0.f;
+    if (act) {
+      for (int i = 0; i < N; ++i) {                         // dZ_j = sum_i alpha_d[i][j] dP[i][f]
+        const float pv = shP[i * FS + f];
+#pragma unroll
+        for (int j4 = 0; j4 < NB / 4; ++j4) {
+          const float4 a4 = *reinterpret_cast<const float4*>(shAd + i * NB + 4 * j4);
+          dZ[4 * j4 + 0] += a4.x * pv; dZ[4 * j4 + 1] += a4.y * pv;
+          dZ[4 * j4 + 2] += a4.z * pv; dZ[4 * j4 + 3] += a4.w * pv;
+        }
       }
-      const float part = wave_sum(dZ * w);                  // ds_j partial of this wave
-      if (lane == 0) {
-        if (f0 == 0) shRed[j * 4 + wave] = part; else shRed[j * 4 + wave] += part;
+    }
+    float dal = 0.f, dar = 0.f;
+    const float alf = act ? shAl[f] : 0.f, arf = act ? shAr[f] : 0.f;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      if (j < N) {                                          // N is uniform: no divergence
+        const float w = act ? shW[j * FS + f] : 0.f;
+        if (act) {
+          dWh[(int64_t)j * HF + f] = shS[j] * dZ[j] + shDu[j] * alf + shDv[j] * arf;
+          dal += shDu[j] * w;
+          dar += shDv[j] * w;
+        }
+        const float part = wave_sum(act ? dZ[j] * w : 0.f); // ds_j partial of this wave
+        if (lane == 0) {
+          if (f0 == 0) shRed[4 + j * 4 + wave] = part; else shRed[4 + j * 4 + wave] += part;
+        }
       }
     }
     if (act) {
@@ -454,20 +475,30 @@ __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
   __syncthreads();
   if (tid < N)
     a.ds_part[mod][((int64_t)b * kHeads + h) * N + tid] =
-        shRed[tid * 4] + shRed[tid * 4 + 1] + shRed[tid * 4 + 2] + shRed[tid * 4 + 3];
+        shRed[4 + tid * 4] + shRed[4 + tid * 4 + 1] + shRed[4 + tid * 4 + 2] + shRed[4 + tid * 4 + 3];
 }
 
-static size_t gat_bwd_lds(int N, int F) {
-  return sizeof(float) * (2 * (size_t)N * (F + 1) + 3 * (size_t)N * (N + 1) + 2 * F + 10 * N);
+static size_t gat_bwd_lds(int N, int NB, int F) {
+  return sizeof(float) * (2 * (size_t)N * (F + 4) + 3 * (size_t)N * NB + 2 * F + 5 * N + 4 + 4 * NB);
 }
-size_t gat_lds_bytes_max(int N, int F) { return gat_bwd_lds(N, F); }
+size_t gat_lds_bytes_max(int N, int F) { return gat_bwd_lds(N, gat_nb(N), F); }
 
-int gat_attn_bwd(hipStream_t st, const GatAttnBwdArgs& a) {
-  const size_t lds = gat_bwd_lds(a.N, a.D / 4);
+template <int NB>
+static int gat_attn_bwd_nb(hipStream_t st, const GatAttnBwdArgs& a) {
+  const size_t lds = gat_bwd_lds(a.N, NB, a.D / 4);
   if (lds > 48 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gat_attn_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_gat_attn_bwd, dim3(a.B, kHeads, 2), dim3(256), lds, st, a);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gat_attn_bwd<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_gat_attn_bwd<NB>, dim3(a.B, kHeads, 2), dim3(256), lds, st, a);
   DVGR_LAUNCH_CHECK();
+}
+int gat_attn_bwd(hipStream_t st, const GatAttnBwdArgs& a) {
+  switch (gat_nb(a.N)) {
+    case 8: return gat_attn_bwd_nb<8>(st, a);
+    case 16: return gat_attn_bwd_nb<16>(st, a);
+    case 24: return gat_attn_bwd_nb<24>(st, a);
+    case 32: return gat_attn_bwd_nb<32>(st, a);
+    default: return gat_attn_bwd_nb<64>(st, a);
+  }
 }
 
 // =================================================================================================
