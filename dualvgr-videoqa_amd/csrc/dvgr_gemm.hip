@@ -535,17 +535,19 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& 
 // K-tile time.  One s_barrier per K-tile is shared by all 8 waves: it publishes tile kt (the loaders waited for
 // it) and frees slot (kt-1) % RS (the consumers finished reading it).
 template <int LA, int LB, int TAG, int PREC>
-__global__ __launch_bounds__(512) void gemm_ring_kernel(const GemmBatch batch) {
+__global__ __launch_bounds__(768) void gemm_ring_kernel(const GemmBatch batch) {
   const GemmProblem P = batch.p[blockIdx.z];
   int m0, n0;
   if (!tile_coords(P.M, P.N, RT, RT, &m0, &n0)) return;
 
   __shared__ __attribute__((aligned(16))) float smem[RS * kRingSlot];   // 128 KB
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool loader = wave8 >= 4;
-  const int wave = wave8 & 3;
-  constexpr int MT = 4, NT = 4;
+  // 12 waves: 0-7 compute (two per SIMD: one wave alone issues a VALU instruction every 4 cycles, two share the
+  // SIMD at 2 cycles each, and the fp32 -> bf16 conversion of the operands is VALU work), 8-11 move data
+  const int wave12 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave12 >= 8;
+  const int wave = loader ? wave12 - 8 : wave12;
+  constexpr int MT = 4, NT = 2;        // each computing wave owns a 64 x 32 block of the 128 x 128 tile
 
   // split-K: gridDim.y workgroups share one output tile, each reducing a contiguous range of K-tiles
   const int nk_all = P.K / BK;
@@ -559,9 +561,10 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(const GemmBatch batch) {
     uint32_t offA[4], offB[4];
     ring_prep<LA>(P.A, m0, P.M, wave, lane, offA);
     ring_prep<LB>(P.B, n0, P.N, wave, lane, offB);
+    const bool nodma = (P.dbg & 8) != 0;
 #pragma unroll
     for (int s = 0; s < RS - 1; ++s)
-      if (s < nk) {
+      if (s < nk && !nodma) {
         ring_issue<LA>(P.A, (kbeg + s) * BK, P.kseg, wave, lane, offA, smem + s * kRingSlot);
         ring_issue<LB>(P.B, (kbeg + s) * BK, P.kseg, wave, lane, offB, smem + s * kRingSlot + kRingTile);
       }
@@ -573,7 +576,7 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(const GemmBatch batch) {
       else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if (kt + RS - 1 < nk) {            // slot (kt-1) % RS is free now: refill it with tile kt + RS - 1
+      if (kt + RS - 1 < nk && !nodma) {  // slot (kt-1) % RS is free now: refill it with tile kt + RS - 1
         float* dst = smem + ((kt + RS - 1) % RS) * kRingSlot;
         ring_issue<LA>(P.A, (kbeg + kt + RS - 1) * BK, P.kseg, wave, lane, offA, dst);
         ring_issue<LB>(P.B, (kbeg + kt + RS - 1) * BK, P.kseg, wave, lane, offB, dst + kRingTile);
@@ -583,17 +586,25 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(const GemmBatch batch) {
     return;
   }
 
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int wm = (wave >> 2) * 64, wn = (wave & 3) * 32;
   f32x4 acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  bf16x8 ah[MT], al[MT], bh, bl;       // bf16 modes: operands carried from one K-tile into the next (see below)
+  {
+    const bf16x8 z = __builtin_bit_cast(bf16x8, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+    for (int i = 0; i < MT; ++i) { ah[i] = z; al[i] = z; }
+    bh = z; bl = z;
+  }
   for (int kt = 0; kt < nk; ++kt) {
     __builtin_amdgcn_s_barrier();
     const float* curA = smem + (kt % RS) * kRingSlot;
     const float* curB = curA + kRingTile;
+    if (P.dbg & 4) continue;
     if (PREC == DVGR_F32) {
       float fa[MT][8], fb[NT][8];
 #pragma unroll
@@ -608,28 +619,50 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(const GemmBatch batch) {
           for (int j = 0; j < NT; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
     } else {
+      // Rotated, column-blocked schedule.  Per K-tile a wave converts 8 fragments fp32 -> bf16 hi (+ lo)
+      // (~24 VALU each) and issues 16 x 3 MFMAs; written naively hipcc emits all conversions, then all MFMAs,
+      // and the K-tile costs their SUM.  Here every block pairs 12 MFMAs of one B column with the conversion
+      // of what the NEXT block needs, and the last column of tile kt-1 is multiplied while the A fragments
+      // of tile kt are converted (its operands live in registers; the ring slot of tile kt-1 is already free).
       constexpr bool X3 = (PREC == DVGR_BF16X3);
-      // column by column: the fp32 -> bf16 (hi, lo) conversion of B column j+1 is independent of the MFMAs of
-      // column j, so the scheduler can slot its VALU work into the MFMA issue gaps
-      bf16x8 ah[MT], al[MT], bh, bl;
+      constexpr int MPB = X3 ? 12 : 4;                       // MFMAs per block (4 rows x 3 or 1 terms)
+      bf16x8 nah[MT], nal[MT], nbh, nbl;
+      // block P: column NT-1 of the previous tile  ||  convert A rows 0..3 and B column 0 of this tile
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         float v[8];
         ring_frag<LA>(curA, wm + i * 16, lane, v);
-        split8<X3>(v, ah[i], al[i]);
+        split8<X3>(v, nah[i], nal[i]);
       }
       {
         float v[8];
         ring_frag<LB>(curB, wn, lane, v);
-        split8<X3>(v, bh, bl);
+        split8<X3>(v, nbh, nbl);
       }
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        bf16x8 nh = bh, nl = bl;
-        if (j + 1 < NT) {
+      for (int i = 0; i < MT; ++i) {
+        if (X3) {
+          acc[i][NT - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][NT - 1], 0, 0, 0);
+          acc[i][NT - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][NT - 1], 0, 0, 0);
+        }
+        acc[i][NT - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][NT - 1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < MPB; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, X3 ? 10 : 12, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) { ah[i] = nah[i]; al[i] = nal[i]; }
+      bh = nbh; bl = nbl;
+      // blocks 0 .. NT-2: column j  ||  convert B column j+1
+#pragma unroll
+      for (int j = 0; j + 1 < NT; ++j) {
+        {
           float v[8];
           ring_frag<LB>(curB, wn + (j + 1) * 16, lane, v);
-          split8<X3>(v, nh, nl);
+          split8<X3>(v, nbh, nbl);
         }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -639,15 +672,24 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(const GemmBatch batch) {
           }
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
         }
-        if (j + 1 < NT) {
 #pragma unroll
-          for (int q = 0; q < (X3 ? 12 : 4); ++q) {        // MFMA, 2 VALU, MFMA, 2 VALU, ...
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, X3 ? 2 : 3, 0);
-          }
+        for (int q = 0; q < MPB; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, X3 ? 2 : 6, 0);
         }
-        bh = nh; bl = nl;
+        __builtin_amdgcn_sched_barrier(0);
+        bh = nbh; bl = nbl;
       }
+    }
+  }
+  if (PREC != DVGR_F32) {                                    // the last tile's last column is still pending
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      if (PREC == DVGR_BF16X3) {
+        acc[i][NT - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][NT - 1], 0, 0, 0);
+        acc[i][NT - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][NT - 1], 0, 0, 0);
+      }
+      acc[i][NT - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][NT - 1], 0, 0, 0);
     }
   }
   __builtin_amdgcn_s_barrier();      // every consumer is done reading the ring; the loaders leave here
@@ -682,7 +724,7 @@ static int launch_ring(hipStream_t stream, const GemmBatch& b, int prec) {
     if (split < 1) split = 1;
     if (split > 8) split = 8;
   }
-  const dim3 grid(8 * ((tiles + 7) / 8), split, b.n), block(512);
+  const dim3 grid(8 * ((tiles + 7) / 8), split, b.n), block(768);
   if (prec == DVGR_BF16X3) hipLaunchKernelGGL((gemm_ring_kernel<LA, LB, TAG, DVGR_BF16X3>), grid, block, 0, stream, b);
   else if (prec == DVGR_BF16) hipLaunchKernelGGL((gemm_ring_kernel<LA, LB, TAG, DVGR_BF16>), grid, block, 0, stream, b);
   else hipLaunchKernelGGL((gemm_ring_kernel<LA, LB, TAG, DVGR_F32>), grid, block, 0, stream, b);
