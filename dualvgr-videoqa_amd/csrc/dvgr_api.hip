@@ -55,7 +55,46 @@ BwdWs bwd_ws(const dvgr_dims& d) {
   return w;
 }
 
+int64_t ws_floats(const dvgr_dims& d) {
+  const int64_t f = fwd_ws(d).total, b = bwd_ws(d).total;
+  return f > b ? f : b;
+}
+
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// bf16 hi/lo planes of GEMM operands (DVGR_BF16 / DVGR_BF16X3).  Every fp32 buffer the library owns
+// (parameters, saved, workspace) has a parallel planes region with the same element offsets; tensors owned
+// by the caller (inputs, list outputs) get plane-only slots inside `saved`.  attach() resolves the planes of
+// both operands of a contraction from their fp32 pointers; a problem whose planes are not found simply runs
+// on the converting kernels.
+struct PlaneMap {
+  struct Range { const float* f; int64_t n; const uint16_t* hi; int64_t lo_off; };
+  Range r[64];
+  int n = 0;
+  bool on = false;
+  void add(const float* f, int64_t cnt, const uint16_t* hi, int64_t lo_off) {
+    if (on && hi && n < 64) r[n++] = Range{f, cnt, hi, lo_off};
+  }
+  const uint16_t* find(const float* p, int64_t* lo_off) const {
+    for (int i = 0; i < n; ++i)
+      if (p >= r[i].f && p < r[i].f + r[i].n) { *lo_off = r[i].lo_off; return r[i].hi + (p - r[i].f); }
+    return nullptr;
+  }
+  void attach1(GemmOperand& o) const {
+    int64_t l0 = 0, l1 = 0;
+    const uint16_t* h0 = find(o.p0, &l0);
+    const uint16_t* h1 = find(o.p1, &l1);
+    if (h0 && h1 && l0 == l1) { o.h0 = h0; o.h1 = h1; o.lo_off = l0; }
+  }
+  void attach(GemmProblem& p) const {
+    if (!on) return;
+    attach1(p.A);
+    attach1(p.B);
+  }
+  uint16_t* out(const float* p, int64_t* lo_off) const {     // planes of an OUTPUT tensor (nullable)
+    return on ? const_cast<uint16_t*>(find(p, lo_off)) : nullptr;
+  }
+};
 
 // C = act(A[M,K] . B[N,K]^T + bias)                      (forward Linear)
 GemmProblem nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
@@ -106,6 +145,29 @@ struct Probe {
   int begin(int site, int layer) const { return hit(site, layer) ? (int)hipEventRecord((hipEvent_t)o.probe_begin, st) : 0; }
   int end(int site, int layer) const { return hit(site, layer) ? (int)hipEventRecord((hipEvent_t)o.probe_end, st) : 0; }
 };
+
+PlaneMap make_plane_map(const dvgr_dims& d, const ParamLayout& P, const SavedLayout& S, const float* params,
+                        const void* params_lp, const dvgr_io* io, const float* saved, const float* ws) {
+  PlaneMap pm;
+  pm.on = d.dtype != DVGR_F32 && params_lp != nullptr;
+  if (!pm.on) return pm;
+  const int64_t BND = (int64_t)d.B * d.N * d.D, wsf = ws_floats(d);
+  const uint16_t* sv_hi = reinterpret_cast<const uint16_t*>(saved + S.total);
+  pm.add(params, P.total, reinterpret_cast<const uint16_t*>(params_lp), P.total);
+  pm.add(saved, S.total, sv_hi, S.total);
+  pm.add(ws, wsf, reinterpret_cast<const uint16_t*>(ws + wsf), wsf);
+  pm.add(io->A, BND, sv_hi + S.in_a, S.total);
+  pm.add(io->M, BND, sv_hi + S.in_m, S.total);
+  pm.add(io->dq, (int64_t)d.B * d.T * d.D, sv_hi + S.in_dq, S.total);
+  for (int l = 0; l < d.L && l < 12; ++l) {
+    const int64_t m0 = S.layer_stride * l + S.mod_base, m1 = m0 + S.mod_stride;
+    pm.add(io->com_app + l * BND, BND, sv_hi + m0 + S.zc, S.total);
+    pm.add(io->com_mot + l * BND, BND, sv_hi + m1 + S.zc, S.total);
+    pm.add(io->aq_fusion + l * BND, BND, sv_hi + m0 + S.zs, S.total);
+    pm.add(io->mq_fusion + l * BND, BND, sv_hi + m1 + S.zs, S.total);
+  }
+  return pm;
+}
 
 int check_common(const dvgr_dims* d, const void* params, const dvgr_io* io, const void* saved, size_t saved_bytes,
                  const void* ws, size_t ws_bytes) {
@@ -185,7 +247,8 @@ int dvgr_param_layer_range(const dvgr_dims* d, int layer, int64_t* first, int64_
   return 0;
 }
 
-size_t dvgr_saved_bytes(const dvgr_dims* d) { return d ? (size_t)saved_layout(*d).total * sizeof(float) : 0; }
+// fp32 region + bf16 hi/lo planes region (same element offsets): 8 bytes per float slot
+size_t dvgr_saved_bytes(const dvgr_dims* d) { return d ? (size_t)saved_layout(*d).total * 8 : 0; }
 
 int dvgr_saved_offset(const dvgr_dims* d, int kind, int layer, int mod, size_t* offset_bytes) {
   if (!d || !offset_bytes) return DVGR_E_NULL;
@@ -221,14 +284,17 @@ int dvgr_saved_offset(const dvgr_dims* d, int kind, int layer, int mod, size_t* 
 
 size_t dvgr_workspace_bytes(const dvgr_dims* d) {
   if (!d) return 0;
-  const int64_t f = fwd_ws(*d).total, b = bwd_ws(*d).total;
-  return (size_t)(f > b ? f : b) * sizeof(float);
+  return (size_t)ws_floats(*d) * 8;      // fp32 region + bf16 hi/lo planes region
 }
 
 int dvgr_pack_weights(const dvgr_dims* d, const float* params, void* params_lp, void* stream) {
   if (!d || !params || !params_lp) return DVGR_E_NULL;
   DVGR_TRY(dvgr_check_dims(d));
-  return to_bf16((hipStream_t)stream, params, params_lp, param_layout(*d).total);
+  SplitBatch sb{};
+  const int64_t total = param_layout(*d).total;
+  sb.lo_off = total;
+  sb.j[sb.n++] = SplitJob{params, reinterpret_cast<uint16_t*>(params_lp), total};
+  return split_planes((hipStream_t)stream, sb);
 }
 
 // =================================================================================================
@@ -237,7 +303,6 @@ int dvgr_pack_weights(const dvgr_dims* d, const float* params, void* params_lp, 
 int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* params_lp, const dvgr_io* io,
                       void* saved_v, size_t saved_bytes, void* ws_v, size_t ws_bytes, const dvgr_opts* opts,
                       void* stream) {
-  (void)params_lp;
   DVGR_TRY(check_common(dp, params, io, saved_v, saved_bytes, ws_v, ws_bytes));
   const dvgr_dims d = *dp;
   hipStream_t st = (hipStream_t)stream;
@@ -260,11 +325,25 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
   auto ls = [&](int l) { return saved + S.layer_stride * l; };
   auto ms = [&](int l, int m) { return saved + S.layer_stride * l + S.mod_base + S.mod_stride * m; };
 
+  const PlaneMap PM = make_plane_map(d, P, S, params, params_lp, io, saved, ws);
+  int64_t plo = 0;                       // lo-plane offset of the last PM.out() lookup
+  if (PM.on) {                           // bf16 hi/lo planes of the caller's inputs
+    SplitBatch sb{};
+    sb.lo_off = S.total;
+    uint16_t* sv_hi = reinterpret_cast<uint16_t*>(saved + S.total);
+    sb.j[sb.n++] = SplitJob{io->A, sv_hi + S.in_a, BND};
+    sb.j[sb.n++] = SplitJob{io->M, sv_hi + S.in_m, BND};
+    sb.j[sb.n++] = SplitJob{io->dq, sv_hi + S.in_dq, (int64_t)BT * D};
+    DVGR_TRY(split_planes(st, sb));
+  }
+
   // ---- S0: query side of every layer (does not depend on A / M) ---------------------------------
   for (int l0 = 0; l0 < L; l0 += kMaxBatch) {
     GemmBatch gb{};
-    for (int l = l0; l < L && l < l0 + kMaxBatch; ++l)
-      gb.p[gb.n++] = nt(io->dq, D, lp(l) + P.qa_w1, D, ws + W.Y + (int64_t)l * BT * D, D, lp(l) + P.qa_b1, BT, D, D, ACT_NONE);
+    for (int l = l0; l < L && l < l0 + kMaxBatch; ++l) {
+      gb.p[gb.n] = nt(io->dq, D, lp(l) + P.qa_w1, D, ws + W.Y + (int64_t)l * BT * D, D, lp(l) + P.qa_b1, BT, D, D, ACT_NONE);
+      PM.attach(gb.p[gb.n++]);
+    }
     DVGR_TRY(probe.begin(DVGR_PROBE_FWD_QA_GEMM, l0));
     DVGR_TRY(gemm_launch(st, KC, KC, gb, TAG_GENERIC, prec));
     DVGR_TRY(probe.end(DVGR_PROBE_FWD_QA_GEMM, l0));
@@ -299,14 +378,19 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
     // itself carries no mask and can run on the LDS-DMA ring kernel.
     {
       GemmBatch gb{};
-      if (train) DVGR_TRY(drop_x(st, Xin[0], Xin[1], ms(l, 0) + S.xd, ms(l, 1) + S.xd, K.x, BND));
+      if (train)
+        DVGR_TRY(drop_x(st, Xin[0], Xin[1], ms(l, 0) + S.xd, ms(l, 1) + S.xd, K.x, BND, PM.out(ms(l, 0) + S.xd, &plo),
+                        PM.out(ms(l, 1) + S.xd, &plo), plo));
       for (int m = 0; m < 2; ++m) {
         if (!train) {
-          gb.p[gb.n++] = nt(Xin[m], D, mp(l, m) + P.gat_w, D, ms(l, m) + S.wh, HF, mp(l, m) + P.gat_b, BN, HF, D, ACT_NONE);
+          gb.p[gb.n] = nt(Xin[m], D, mp(l, m) + P.gat_w, D, ms(l, m) + S.wh, HF, mp(l, m) + P.gat_b, BN, HF, D, ACT_NONE);
+          PM.attach(gb.p[gb.n++]);
         } else {
-          for (int g = 0; g < 2; ++g)
-            gb.p[gb.n++] = nt(ms(l, m) + S.xd + g * BND, D, mp(l, m) + P.gat_w + (int64_t)g * 4 * F * D, D,
-                              ms(l, m) + S.wh + g * 4 * F, HF, mp(l, m) + P.gat_b + g * 4 * F, BN, 4 * F, D, ACT_NONE);
+          for (int g = 0; g < 2; ++g) {
+            gb.p[gb.n] = nt(ms(l, m) + S.xd + g * BND, D, mp(l, m) + P.gat_w + (int64_t)g * 4 * F * D, D,
+                            ms(l, m) + S.wh + g * 4 * F, HF, mp(l, m) + P.gat_b + g * 4 * F, BN, 4 * F, D, ACT_NONE);
+            PM.attach(gb.p[gb.n++]);
+          }
         }
       }
       DVGR_TRY(probe.begin(DVGR_PROBE_FWD_GAT_GEMM, l));
@@ -323,7 +407,10 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
         a.out_c[m] = outc[m]; a.out_s[m] = outs[m];
         for (int h = 0; h < 8; ++h) a.key_alpha[m][h] = K.alpha[m][h];
         for (int g = 0; g < 2; ++g) a.key_out[m][g] = K.out[m][g];
+        a.zp_c[m] = PM.out(outc[m], &plo);
+        a.zp_s[m] = PM.out(outs[m], &plo);
       }
+      a.z_lo_off = plo;
       a.B = B; a.N = N; a.D = D;
       DVGR_TRY(probe.begin(DVGR_PROBE_FWD_GAT_ATTN, l));
       DVGR_TRY(gat_attn_fwd(st, a));
@@ -333,8 +420,10 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
     {
       GemmBatch gb{};
       for (int m = 0; m < 2; ++m) {
-        gb.p[gb.n++] = nt(outc[m], D, mp(l, m) + P.sf_p1, D, ms(l, m) + S.tn, D, mp(l, m) + P.sf_bp, BN, D, D, ACT_TANH);
-        gb.p[gb.n++] = nt(outs[m], D, mp(l, m) + P.sf_p1, D, ms(l, m) + S.tn + BND, D, mp(l, m) + P.sf_bp, BN, D, D, ACT_TANH);
+        gb.p[gb.n] = nt(outc[m], D, mp(l, m) + P.sf_p1, D, ms(l, m) + S.tn, D, mp(l, m) + P.sf_bp, BN, D, D, ACT_TANH);
+        PM.attach(gb.p[gb.n++]);
+        gb.p[gb.n] = nt(outs[m], D, mp(l, m) + P.sf_p1, D, ms(l, m) + S.tn + BND, D, mp(l, m) + P.sf_bp, BN, D, D, ACT_TANH);
+        PM.attach(gb.p[gb.n++]);
       }
       DVGR_TRY(probe.begin(DVGR_PROBE_FWD_SF_GEMM, l));
       DVGR_TRY(gemm_launch(st, KC, KC, gb, TAG_FWD_SF, prec));
@@ -347,7 +436,9 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
         a.X[m] = Xin[m]; a.z0[m] = outc[m]; a.z1[m] = outs[m]; a.tn[m] = ms(l, m) + S.tn;
         a.p2[m] = mp(l, m) + P.sf_p2; a.beta[m] = ms(l, m) + S.beta; a.Xout[m] = ms(l, m) + S.x;
         a.o[m] = (l == L - 1) ? (m == 0 ? io->aq_embed : io->mq_embed) : nullptr;
+        a.xp[m] = PM.out(ms(l, m) + S.x, &plo);
       }
+      a.x_lo_off = plo;
       a.rows = BN; a.D = D;
       DVGR_TRY(sf_combine_fwd(st, a));
     }
@@ -356,14 +447,18 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
   // ---- S6: MFB ------------------------------------------------------------------------------------------
   {
     GemmBatch gb{};
-    gb.p[gb.n++] = nt(ms(L - 1, 0) + S.x, D, params + P.mfb_w0, D, saved + S.mfb_x0, kMfbHidden, params + P.mfb_b0, BN, kMfbHidden, D, ACT_ELU);
-    gb.p[gb.n++] = nt(ms(L - 1, 1) + S.x, D, params + P.mfb_w1, D, saved + S.mfb_x1, kMfbHidden, params + P.mfb_b1, BN, kMfbHidden, D, ACT_ELU);
+    gb.p[gb.n] = nt(ms(L - 1, 0) + S.x, D, params + P.mfb_w0, D, saved + S.mfb_x0, kMfbHidden, params + P.mfb_b0, BN, kMfbHidden, D, ACT_ELU);
+    PM.attach(gb.p[gb.n++]);
+    gb.p[gb.n] = nt(ms(L - 1, 1) + S.x, D, params + P.mfb_w1, D, saved + S.mfb_x1, kMfbHidden, params + P.mfb_b1, BN, kMfbHidden, D, ACT_ELU);
+    PM.attach(gb.p[gb.n++]);
     DVGR_TRY(probe.begin(DVGR_PROBE_FWD_MFB_GEMM, 0));
     DVGR_TRY(gemm_launch(st, KC, KC, gb, TAG_GENERIC, prec));
     DVGR_TRY(probe.end(DVGR_PROBE_FWD_MFB_GEMM, 0));
-    DVGR_TRY(mfb_pool_fwd(st, saved + S.mfb_x0, saved + S.mfb_x1, saved + S.mfb_z, BN));
+    uint16_t* zfp = PM.out(saved + S.mfb_z, &plo);
+    DVGR_TRY(mfb_pool_fwd(st, saved + S.mfb_x0, saved + S.mfb_x1, saved + S.mfb_z, BN, zfp, plo));
     GemmBatch go{};
-    go.p[go.n++] = nt(saved + S.mfb_z, kMfbPooled, params + P.mfb_wo, kMfbPooled, io->vis, D, params + P.mfb_bo, BN, D, kMfbPooled, ACT_ELU);
+    go.p[go.n] = nt(saved + S.mfb_z, kMfbPooled, params + P.mfb_wo, kMfbPooled, io->vis, D, params + P.mfb_bo, BN, D, kMfbPooled, ACT_ELU);
+    PM.attach(go.p[go.n++]);
     DVGR_TRY(gemm_launch(st, KC, KC, go, TAG_GENERIC, prec));
   }
   return 0;
@@ -375,7 +470,6 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
 int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* params_lp, const dvgr_io* io,
                        const dvgr_grads* g, const void* saved_v, size_t saved_bytes, void* ws_v, size_t ws_bytes,
                        const dvgr_opts* opts, void* stream) {
-  (void)params_lp;
   const dvgr_opts o0{};
   const dvgr_opts& O = opts ? *opts : o0;
   const int train = O.train;
@@ -405,6 +499,8 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
   auto ls = [&](int l) { return saved + S.layer_stride * l; };
   auto ms = [&](int l, int m) { return saved + S.layer_stride * l + S.mod_base + S.mod_stride * m; };
   float* dXacc[2] = {g->gA, g->gM};     // running gradient w.r.t. the current layer boundary
+  const PlaneMap PM = make_plane_map(d, P, S, params, params_lp, io, saved, ws);
+  int64_t plo = 0;
 
   // every element of gparams is written: the tensors below, zeros in the alignment padding.  gdq is the sum
   // over layers of split-K partial tiles, so it starts from zero as well.
@@ -415,24 +511,37 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
   }
 
   // ---- S6 backward ------------------------------------------------------------------------------------
-  DVGR_TRY(elu_bwd(st, g->g_vis, io->vis, ws + W.dpo, BND));
+  {
+    uint16_t* dpop = PM.out(ws + W.dpo, &plo);
+    DVGR_TRY(elu_bwd(st, g->g_vis, io->vis, ws + W.dpo, BND, dpop, plo));
+  }
   {
     GemmBatch gb{};   // dWo = dpo^T . z
-    gb.p[gb.n++] = tn(ws + W.dpo, D, saved + S.mfb_z, kMfbPooled, gp + P.mfb_wo, kMfbPooled, D, kMfbPooled, BN);
+    gb.p[gb.n] = tn(ws + W.dpo, D, saved + S.mfb_z, kMfbPooled, gp + P.mfb_wo, kMfbPooled, D, kMfbPooled, BN);
+    PM.attach(gb.p[gb.n++]);
     DVGR_TRY(gemm_launch(st, IC, IC, gb, TAG_GENERIC, prec));
     GemmBatch gd{};   // dz = dpo . Wo
-    gd.p[gd.n++] = nn(ws + W.dpo, D, params + P.mfb_wo, kMfbPooled, ws + W.dzf, kMfbPooled, BN, kMfbPooled, D, 0);
+    gd.p[gd.n] = nn(ws + W.dpo, D, params + P.mfb_wo, kMfbPooled, ws + W.dzf, kMfbPooled, BN, kMfbPooled, D, 0);
+    PM.attach(gd.p[gd.n++]);
     DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_GENERIC, prec));
   }
-  DVGR_TRY(mfb_pool_bwd(st, ws + W.dzf, saved + S.mfb_x0, saved + S.mfb_x1, ws + W.dp0, ws + W.dp1, BN));
+  {
+    uint16_t* q0 = PM.out(ws + W.dp0, &plo);
+    uint16_t* q1 = PM.out(ws + W.dp1, &plo);
+    DVGR_TRY(mfb_pool_bwd(st, ws + W.dzf, saved + S.mfb_x0, saved + S.mfb_x1, ws + W.dp0, ws + W.dp1, BN, q0, q1, plo));
+  }
   {
     GemmBatch gb{};   // dW0 = dp0^T . A_final, dW1 = dp1^T . M_final
-    gb.p[gb.n++] = tn(ws + W.dp0, kMfbHidden, ms(L - 1, 0) + S.x, D, gp + P.mfb_w0, D, kMfbHidden, D, BN);
-    gb.p[gb.n++] = tn(ws + W.dp1, kMfbHidden, ms(L - 1, 1) + S.x, D, gp + P.mfb_w1, D, kMfbHidden, D, BN);
+    gb.p[gb.n] = tn(ws + W.dp0, kMfbHidden, ms(L - 1, 0) + S.x, D, gp + P.mfb_w0, D, kMfbHidden, D, BN);
+    PM.attach(gb.p[gb.n++]);
+    gb.p[gb.n] = tn(ws + W.dp1, kMfbHidden, ms(L - 1, 1) + S.x, D, gp + P.mfb_w1, D, kMfbHidden, D, BN);
+    PM.attach(gb.p[gb.n++]);
     DVGR_TRY(gemm_launch(st, IC, IC, gb, TAG_GENERIC, prec));
     GemmBatch gd{};   // dA = dp0 . W0, dM = dp1 . W1
-    gd.p[gd.n++] = nn(ws + W.dp0, kMfbHidden, params + P.mfb_w0, D, dXacc[0], D, BN, D, kMfbHidden, 0);
-    gd.p[gd.n++] = nn(ws + W.dp1, kMfbHidden, params + P.mfb_w1, D, dXacc[1], D, BN, D, kMfbHidden, 0);
+    gd.p[gd.n] = nn(ws + W.dp0, kMfbHidden, params + P.mfb_w0, D, dXacc[0], D, BN, D, kMfbHidden, 0);
+    PM.attach(gd.p[gd.n++]);
+    gd.p[gd.n] = nn(ws + W.dp1, kMfbHidden, params + P.mfb_w1, D, dXacc[1], D, BN, D, kMfbHidden, 0);
+    PM.attach(gd.p[gd.n++]);
     DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_GENERIC, prec));
     ColsumBatch cb{};
     cb.j[cb.n++] = ColsumJob{ws + W.dpo, nullptr, nullptr, nullptr, BN, 0, D, D, gp + P.mfb_bo};
@@ -466,7 +575,9 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
         a.g_z0[m] = gc ? gc + l * BND : nullptr;
         a.g_z1[m] = gs ? gs + l * BND : nullptr;
         a.dw[m] = ws + W.dw[m]; a.dpre[m] = ws + W.dpre[m]; a.dz[m] = ws + W.dz[m];
+        a.dpre_p[m] = PM.out(ws + W.dpre[m], &plo);
       }
+      a.lo_off = plo;
       a.rows = BN; a.D = D;
       DVGR_TRY(sf_bwd(st, a));
     }
@@ -481,14 +592,17 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
         p.kseg = BN;
         p.A.p1 = ws + W.dpre[m] + BND;
         p.B.p1 = outs[m];
+        PM.attach(p);
         gb.p[gb.n++] = p;
       }
       DVGR_TRY(probe.begin(DVGR_PROBE_BWD_SF_DW, l));
       DVGR_TRY(gemm_launch(st, IC, IC, gb, TAG_BWD_SF_DW, prec));
       DVGR_TRY(probe.end(DVGR_PROBE_BWD_SF_DW, l));
       GemmBatch gd{};   // dz_v += dpre_v . P1
-      for (int m = 0; m < 2; ++m)
-        gd.p[gd.n++] = nn(ws + W.dpre[m], D, mp(l, m) + P.sf_p1, D, ws + W.dz[m], D, 2 * BN, D, D, 1);
+      for (int m = 0; m < 2; ++m) {
+        gd.p[gd.n] = nn(ws + W.dpre[m], D, mp(l, m) + P.sf_p1, D, ws + W.dz[m], D, 2 * BN, D, D, 1);
+        PM.attach(gd.p[gd.n++]);
+      }
       DVGR_TRY(probe.begin(DVGR_PROBE_BWD_SF_DX, l));
       DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_BWD_SF_DX, prec));
       DVGR_TRY(probe.end(DVGR_PROBE_BWD_SF_DX, l));
@@ -504,7 +618,9 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
         a.dc_part[m] = ws + W.dc_part[m];
         for (int h = 0; h < 8; ++h) a.key_alpha[m][h] = K.alpha[m][h];
         for (int gi = 0; gi < 2; ++gi) a.key_out[m][gi] = K.out[m][gi];
+        a.dWh_p[m] = PM.out(ws + W.dWh[m], &plo);
       }
+      a.lo_off = plo;
       a.B = B; a.N = N; a.D = D;
       DVGR_TRY(probe.begin(DVGR_PROBE_BWD_GAT_ATTN, l));
       DVGR_TRY(gat_attn_bwd(st, a));
@@ -520,11 +636,14 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       GemmBatch gb{};
       for (int m = 0; m < 2; ++m) {
         if (!train) {
-          gb.p[gb.n++] = tn(ws + W.dWh[m], HF, Xin[m], D, gmp(l, m) + P.gat_w, D, HF, D, BN);
+          gb.p[gb.n] = tn(ws + W.dWh[m], HF, Xin[m], D, gmp(l, m) + P.gat_w, D, HF, D, BN);
+          PM.attach(gb.p[gb.n++]);
         } else {
-          for (int gi = 0; gi < 2; ++gi)
-            gb.p[gb.n++] = tn(ws + W.dWh[m] + gi * 4 * F, HF, ms(l, m) + S.xd + gi * BND, D,
-                              gmp(l, m) + P.gat_w + (int64_t)gi * 4 * F * D, D, 4 * F, D, BN);
+          for (int gi = 0; gi < 2; ++gi) {
+            gb.p[gb.n] = tn(ws + W.dWh[m] + gi * 4 * F, HF, ms(l, m) + S.xd + gi * BND, D,
+                            gmp(l, m) + P.gat_w + (int64_t)gi * 4 * F * D, D, 4 * F, D, BN);
+            PM.attach(gb.p[gb.n++]);
+          }
         }
       }
       DVGR_TRY(probe.begin(DVGR_PROBE_BWD_GAT_DW, l));
@@ -532,17 +651,21 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       DVGR_TRY(probe.end(DVGR_PROBE_BWD_GAT_DW, l));
       if (!train) {
         GemmBatch gd{};
-        for (int m = 0; m < 2; ++m)
-          gd.p[gd.n++] = nn(ws + W.dWh[m], HF, mp(l, m) + P.gat_w, D, dXacc[m], D, BN, D, HF, 1);
+        for (int m = 0; m < 2; ++m) {
+          gd.p[gd.n] = nn(ws + W.dWh[m], HF, mp(l, m) + P.gat_w, D, dXacc[m], D, BN, D, HF, 1);
+          PM.attach(gd.p[gd.n++]);
+        }
         DVGR_TRY(probe.begin(DVGR_PROBE_BWD_GAT_DX, l));
         DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_BWD_GAT_DX, prec));
         DVGR_TRY(probe.end(DVGR_PROBE_BWD_GAT_DX, l));
       } else {
         for (int gi = 0; gi < 2; ++gi) {   // the two GATs dropped x with different masks: two passes
           GemmBatch gd{};
-          for (int m = 0; m < 2; ++m)
-            gd.p[gd.n++] = nn(ws + W.dWh[m] + gi * 4 * F, HF, mp(l, m) + P.gat_w + (int64_t)gi * 4 * F * D, D, dXacc[m], D,
-                              BN, D, 4 * F, 1, K.x[m][gi]);
+          for (int m = 0; m < 2; ++m) {
+            gd.p[gd.n] = nn(ws + W.dWh[m] + gi * 4 * F, HF, mp(l, m) + P.gat_w + (int64_t)gi * 4 * F * D, D, dXacc[m], D,
+                            BN, D, 4 * F, 1, K.x[m][gi]);
+            PM.attach(gd.p[gd.n++]);
+          }
           if (gi == 0) DVGR_TRY(probe.begin(DVGR_PROBE_BWD_GAT_DX, l));
           DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_BWD_GAT_DX, prec));
           if (gi == 1) DVGR_TRY(probe.end(DVGR_PROBE_BWD_GAT_DX, l));
@@ -588,12 +711,16 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       a.gwords = g->gwords; a.dr = ws + W.dr; a.dy = ws + W.dy;
       a.B = B; a.T = T; a.D = D; a.Wd = Wd; a.L = 1;
       a.first = (l == L - 1) ? 1 : 0;
+      a.dy_p = PM.out(ws + W.dy, &plo);
+      a.lo_off = plo;
       DVGR_TRY(qa_bwd(st, a));
       GemmBatch gb{};   // dW1 = dy^T . dq
-      gb.p[gb.n++] = tn(ws + W.dy, D, io->dq, D, glp(l) + P.qa_w1, D, D, D, BT);
+      gb.p[gb.n] = tn(ws + W.dy, D, io->dq, D, glp(l) + P.qa_w1, D, D, D, BT);
+      PM.attach(gb.p[gb.n++]);
       DVGR_TRY(gemm_launch(st, IC, IC, gb, TAG_GENERIC, prec));
       GemmBatch gd{};   // d(dq) (+)= dy . W1
-      gd.p[gd.n++] = nn(ws + W.dy, D, lp(l) + P.qa_w1, D, g->gdq, D, BT, D, D, 1);
+      gd.p[gd.n] = nn(ws + W.dy, D, lp(l) + P.qa_w1, D, g->gdq, D, BT, D, D, 1);
+      PM.attach(gd.p[gd.n++]);
       gd.p[0].atomic_ok = 1;
       DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_GENERIC, prec));
       cb.j[cb.n++] = ColsumJob{ws + W.dy, nullptr, nullptr, nullptr, BT, 0, D, D, glp(l) + P.qa_b1};

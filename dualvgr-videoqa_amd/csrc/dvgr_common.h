@@ -70,9 +70,9 @@ inline ParamLayout param_layout(const dvgr_dims& d) {
 struct SavedLayout {
   int64_t layer_stride, mod_stride, mod_base;
   int64_t qa_d, qa_nrm, qa_a, qa_ah, qa_s, qa_q;              // inside a layer block
-  int64_t p, s, x, wh, u, v, tn, beta, xd;                    // inside a modality block
-  int64_t mfb_base, mfb_x0, mfb_x1, mfb_z;                    // absolute
-  int64_t total;
+  int64_t p, s, x, wh, u, v, tn, beta, xd, zc, zs;            // inside a modality block
+  int64_t mfb_base, mfb_x0, mfb_x1, mfb_z, in_a, in_m, in_dq; // absolute
+  int64_t total;                                              // floats; the bf16 planes region follows (2 x total x 2 bytes)
 };
 
 inline SavedLayout saved_layout(const dvgr_dims& d) {
@@ -96,6 +96,8 @@ inline SavedLayout saved_layout(const dvgr_dims& d) {
   s.tn = m;   m += round64(2 * B * N * D);
   s.beta = m; m += round64(B * N * 2);
   s.xd = m;   m += round64(2 * B * N * D);   // training mode: x * keep/(1-p) for the common / specific GAT
+  s.zc = m;   m += round64(B * N * D);       // plane-only slots: bf16 hi/lo of the common / specific GAT outputs
+  s.zs = m;   m += round64(B * N * D);       //   (their fp32 values live in the caller's list tensors)
   s.mod_stride = m;
   s.layer_stride = o + 2 * m;
   s.mfb_base = s.layer_stride * d.L;
@@ -103,6 +105,9 @@ inline SavedLayout saved_layout(const dvgr_dims& d) {
   s.mfb_x0 = q; q += round64(B * N * kMfbHidden);
   s.mfb_x1 = q; q += round64(B * N * kMfbHidden);
   s.mfb_z = q;  q += round64(B * N * kMfbPooled);
+  s.in_a = q;   q += round64(B * N * D);     // plane-only slots: bf16 hi/lo of the inputs A, M, dq
+  s.in_m = q;   q += round64(B * N * D);
+  s.in_dq = q;  q += round64(B * T * D);
   s.total = q;
   return s;
 }
@@ -154,5 +159,33 @@ __device__ __forceinline__ float elu_f(float x) { return x > 0.0f ? x : expm1f(x
 // d ELU(P)/dP from the output value O = ELU(P)
 __device__ __forceinline__ float elu_grad_from_out(float o) { return o > 0.0f ? 1.0f : o + 1.0f; }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---------------------------------------------------------------------------------------------
+// bf16 "planes": hi = bf16_rne(x), lo = bf16_rne(x - hi).  x ~ hi + lo to 2^-16 relative, and
+// a.b ~ hi.hi + hi.lo + lo.hi is what DVGR_BF16X3 feeds the bf16 MFMA.  Producers of GEMM operands
+// store the planes next to (or instead of) the fp32 values so the contraction kernels convert nothing.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 v = {(__bf16)a, (__bf16)b};                 // v_cvt_pk_bf16_f32 (round to nearest even)
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float bf16_lo_as_f32(uint32_t p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf16_hi_as_f32(uint32_t p) { return __uint_as_float(p & 0xFFFF0000u); }
+// 4 consecutive elements starting at element index idx (multiple of 4); hi == nullptr: no-op
+__device__ __forceinline__ void split_store4(uint16_t* hi, int64_t lo_off, int64_t idx, float4 v) {
+  if (!hi) return;
+  const uint32_t h01 = pack_bf16(v.x, v.y), h23 = pack_bf16(v.z, v.w);
+  *reinterpret_cast<uint2*>(hi + idx) = make_uint2(h01, h23);
+  const uint32_t l01 = pack_bf16(v.x - bf16_lo_as_f32(h01), v.y - bf16_hi_as_f32(h01));
+  const uint32_t l23 = pack_bf16(v.z - bf16_lo_as_f32(h23), v.w - bf16_hi_as_f32(h23));
+  *reinterpret_cast<uint2*>(hi + lo_off + idx) = make_uint2(l01, l23);
+}
+__device__ __forceinline__ void split_store1(uint16_t* hi, int64_t lo_off, int64_t idx, float x) {
+  if (!hi) return;
+  const uint32_t h = pack_bf16(x, 0.f);
+  hi[idx] = (uint16_t)h;
+  hi[lo_off + idx] = (uint16_t)pack_bf16(x - bf16_lo_as_f32(h), 0.f);
+}
 
 }  // namespace dvgr

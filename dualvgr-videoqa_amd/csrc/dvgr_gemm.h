@@ -26,6 +26,12 @@ struct GemmOperand {
   const float* p1;     // rows [kseg, K) of the reduction (IC only; used when kseg < K)
   int64_t ld;          // leading dimension (floats); multiple of 4
   uint32_t drop_key;   // 0 = none; keep index = row * ld + col of the source matrix
+  // Optional pre-split bf16 "planes" of the same matrix (same shape and ld): hi = bf16(x), lo = bf16(x - hi),
+  // written by whoever produced the matrix (split_store in dvgr_common.h).  With planes on both operands the
+  // bf16 modes run on gemm_planes_kernel, which moves bf16 straight into LDS and converts nothing.
+  const uint16_t* h0;  // hi plane of segment 0 (nullptr: no planes)
+  const uint16_t* h1;  // hi plane of segment 1
+  int64_t lo_off;      // lo plane = hi plane + lo_off elements
 };
 
 struct GemmProblem {
@@ -56,7 +62,7 @@ enum : int { TAG_GENERIC = 0, TAG_FWD_GAT = 1, TAG_FWD_SF = 2, TAG_BWD_GAT_DW = 
 int gemm_launch(hipStream_t stream, int la, int lb, const GemmBatch& batch, int tag = TAG_GENERIC, int prec = DVGR_F32);
 
 inline GemmOperand operand(const float* p, int64_t ld, uint32_t drop_key = 0) {
-  GemmOperand o; o.p0 = p; o.p1 = p; o.ld = ld; o.drop_key = drop_key; return o;
+  GemmOperand o; o.p0 = p; o.p1 = p; o.ld = ld; o.drop_key = drop_key; o.h0 = nullptr; o.h1 = nullptr; o.lo_off = 0; return o;
 }
 
 }  // namespace dvgr

@@ -302,13 +302,6 @@ struct TileLP {
   static constexpr int kElems = kRows * kStride;
 };
 
-__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
-  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-  bf16x2 v = {(__bf16)a, (__bf16)b};                 // v_cvt_pk_bf16_f32 (round to nearest even)
-  return __builtin_bit_cast(uint32_t, v);
-}
-__device__ __forceinline__ float bf16_lo_as_f32(uint32_t p) { return __uint_as_float(p << 16); }
-__device__ __forceinline__ float bf16_hi_as_f32(uint32_t p) { return __uint_as_float(p & 0xFFFF0000u); }
 
 template <int LAYOUT, int BT, int TERMS>
 __device__ __forceinline__ void store_tile_lp(uint16_t* sm_hi, uint16_t* sm_lo, int tid,
@@ -697,6 +690,199 @@ __global__ __launch_bounds__(768) void gemm_ring_kernel(const GemmBatch batch) {
   epilogue_rows<MT, NT>(P, acc, m0 + wm, n0 + wn, lane, smem + wave * (32 * (16 * NT + 4)), gridDim.y > 1);
 }
 
+// =================================================================================================
+// Planes kernel: both operands arrive pre-split as bf16 hi / lo planes (GemmOperand::h0), so the K loop is
+// DMA + ds_read + MFMA only -- no conversion, and half the LDS bytes per element.  Same 12-wave ring
+// structure as gemm_ring_kernel (8 computing waves, 4 loaders, counted vmcnt, one s_barrier per K-tile).
+//   LDS stage = [A hi | A lo | B hi | B lo], each a 128 x 32 bf16 tile (8 KB), lane-linear per DMA instruction:
+//     KC tile [128 rows][4 chunks of 8 bf16]:  chunk slot = chunk ^ ((-(row >> 2)) & 3)      (b128 reads conflict free)
+//     IC tile [32 k][16 chunks of 8 bf16]:     chunk slot = chunk ^ swz(k), swz(k) = ((k & 3) | ((k >> 3) & 1) << 2) << 1
+//                                              (ds_read_b64_tr_b16 blocks of 4 k-rows x 16 columns conflict free)
+//   Lane (r, g) of an MFMA operand holds k = 8g .. 8g+7 of row / column r.
+// =================================================================================================
+constexpr int kPlaneTile = RT * BK;          // bf16 elements per plane tile
+
+__device__ __forceinline__ int plane_swz_ic(int k) { return (((k & 3) | (((k >> 3) & 1) << 2)) << 1); }
+
+template <int LAYOUT>
+__device__ __forceinline__ void planes_prep(const GemmOperand& op, int idx0, int dim, int wave, int lane, uint32_t (&off)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {              // 512 16-byte chunks per plane tile = 4 waves x 2 instructions x 64 lanes
+    const int S = (wave * 2 + i) * 64 + lane;
+    if (LAYOUT == KC) {
+      const int row = S >> 2, slot = S & 3;
+      const int chunk = slot ^ ((-(row >> 2)) & 3);
+      int gi = idx0 + row;
+      gi = gi < dim ? gi : dim - 1;
+      off[i] = (uint32_t)gi * (uint32_t)op.ld + (uint32_t)(chunk * 8);
+    } else {
+      const int krow = S >> 4, slot = S & 15;
+      const int chunk = slot ^ plane_swz_ic(krow);
+      int gi = idx0 + chunk * 8;
+      gi = gi < dim ? gi : dim - 8;
+      off[i] = (uint32_t)krow * (uint32_t)op.ld + (uint32_t)gi;
+    }
+  }
+}
+
+template <int LAYOUT, int TERMS>
+__device__ __forceinline__ void planes_issue(const GemmOperand& op, int k0, int kseg, int wave, int lane,
+                                             const uint32_t (&off)[2], uint16_t* lds_hi /* lo tile follows */) {
+  const uint16_t* base0;
+  const uint16_t* base1;
+  if (LAYOUT == KC) {
+    base0 = op.h0 + k0;
+    base1 = base0;
+  } else {
+    base0 = op.h0 + (int64_t)k0 * op.ld;
+    base1 = op.h1 + (int64_t)(k0 - kseg) * op.ld;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int S0 = (wave * 2 + i) * 64;
+    const uint16_t* base = base0;
+    if (LAYOUT == IC) {
+      const int krow = (S0 + lane) >> 4;
+      base = (k0 + krow < kseg) ? base0 : base1;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off[i]),
+                                     (__attribute__((address_space(3))) void*)(lds_hi + S0 * 8), 16, 0, 0);
+    if (TERMS == 3)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + op.lo_off + off[i]),
+                                       (__attribute__((address_space(3))) void*)(lds_hi + kPlaneTile + S0 * 8), 16, 0, 0);
+  }
+}
+
+template <int LAYOUT>
+__device__ __forceinline__ bf16x8 planes_frag(const uint16_t* tile, int idx16, int lane) {
+  const int r = lane & 15, g = lane >> 4;
+  if (LAYOUT == KC) {
+    const int row = idx16 + r;
+    const int slot = g ^ ((-(row >> 2)) & 3);
+    return *reinterpret_cast<const bf16x8*>(tile + row * BK + slot * 8);
+  } else {
+    const int q = r >> 2, p = r & 3;
+    const int k = 8 * g + q;
+    const int c = (idx16 >> 3) + (p >> 1);
+    typedef __attribute__((address_space(3))) s16x4* lds_ptr;
+    const uint16_t* a0 = tile + k * RT + ((c ^ plane_swz_ic(k)) << 3) + 4 * (p & 1);
+    const uint16_t* a1 = a0 + 4 * RT;            // rows k + 4: same swizzle value
+    const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a0));
+    const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a1));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 t = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+    return __builtin_bit_cast(bf16x8, t);
+  }
+}
+
+template <int LA, int LB, int TAG, int TERMS>
+__global__ __launch_bounds__(768) void gemm_planes_kernel(const GemmBatch batch) {
+  const GemmProblem P = batch.p[blockIdx.z];
+  int m0, n0;
+  if (!tile_coords(P.M, P.N, RT, RT, &m0, &n0)) return;
+
+  constexpr int kPlanes = (TERMS == 3) ? 2 : 1;
+  constexpr int kSlot = 2 * kPlanes * kPlaneTile;              // A planes, then B planes
+  constexpr int kEpi = 8 * 32 * (16 * 2 + 4) * 2;              // epilogue scratch (8 waves), in bf16-sized elements
+  constexpr int kLds = (RS * kSlot) > kEpi ? (RS * kSlot) : kEpi;
+  __shared__ __attribute__((aligned(16))) uint16_t smem[kLds];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave12 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave12 >= 8;
+  const int wave = loader ? wave12 - 8 : wave12;
+  constexpr int MT = 4, NT = 2;
+
+  const int nk_all = P.K / BK;
+  const int per = (nk_all + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int kbeg = (int)blockIdx.y * per;
+  const int nk_real = (nk_all - kbeg) < per ? (nk_all - kbeg) : per;
+  if (nk_real <= 0) return;
+  const int nk = (P.dbg & 2) ? 0 : nk_real;
+
+  if (loader) {
+    uint32_t offA[2], offB[2];
+    planes_prep<LA>(P.A, m0, P.M, wave, lane, offA);
+    planes_prep<LB>(P.B, n0, P.N, wave, lane, offB);
+#pragma unroll
+    for (int s = 0; s < RS - 1; ++s)
+      if (s < nk) {
+        planes_issue<LA, TERMS>(P.A, (kbeg + s) * BK, P.kseg, wave, lane, offA, smem + s * kSlot);
+        planes_issue<LB, TERMS>(P.B, (kbeg + s) * BK, P.kseg, wave, lane, offB, smem + s * kSlot + kPlanes * kPlaneTile);
+      }
+    for (int kt = 0; kt < nk; ++kt) {
+      // 4 * kPlanes DMA instructions per K-tile from this wave: keep the (up to two) younger tiles in flight
+      const int younger = nk - 1 - kt;
+      if (TERMS == 3) {
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      if (kt + RS - 1 < nk) {
+        uint16_t* dst = smem + ((kt + RS - 1) % RS) * kSlot;
+        planes_issue<LA, TERMS>(P.A, (kbeg + kt + RS - 1) * BK, P.kseg, wave, lane, offA, dst);
+        planes_issue<LB, TERMS>(P.B, (kbeg + kt + RS - 1) * BK, P.kseg, wave, lane, offB, dst + kPlanes * kPlaneTile);
+      }
+    }
+    __builtin_amdgcn_s_barrier();
+    return;
+  }
+
+  const int wm = (wave >> 2) * 64, wn = (wave & 3) * 32;
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int kt = 0; kt < nk; ++kt) {
+    __builtin_amdgcn_s_barrier();
+    const uint16_t* curA = smem + (kt % RS) * kSlot;
+    const uint16_t* curB = curA + kPlanes * kPlaneTile;
+    bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      ah[i] = planes_frag<LA>(curA, wm + i * 16, lane);
+      if (TERMS == 3) al[i] = planes_frag<LA>(curA + kPlaneTile, wm + i * 16, lane);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      bh[j] = planes_frag<LB>(curB, wn + j * 16, lane);
+      if (TERMS == 3) bl[j] = planes_frag<LB>(curB + kPlaneTile, wn + j * 16, lane);
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if (TERMS == 3) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        }
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      }
+  }
+  __builtin_amdgcn_s_barrier();
+  if (P.dbg & 1) { if (acc[0][0][0] == 12345.678f) P.C[0] = 1.f; return; }
+  epilogue_rows<MT, NT>(P, acc, m0 + wm, n0 + wn, lane, reinterpret_cast<float*>(smem) + wave * (32 * (16 * NT + 4)), gridDim.y > 1);
+}
+
+static bool planes_eligible(const GemmBatch& b, int la, int lb) {
+  for (int i = 0; i < b.n; ++i) {
+    const GemmProblem& p = b.p[i];
+    if (!p.A.h0 || !p.B.h0) return false;
+    if ((p.A.ld & 7) || (p.B.ld & 7)) return false;                     // 16-byte chunks of 8 bf16
+    if (((uintptr_t)p.A.h0 | (uintptr_t)p.A.h1 | (uintptr_t)p.B.h0 | (uintptr_t)p.B.h1) & 15) return false;
+    if ((p.A.lo_off & 7) || (p.B.lo_off & 7)) return false;
+    if (la == IC && ((p.M & 7) || p.M < 8)) return false;
+    if (lb == IC && ((p.N & 7) || p.N < 8)) return false;
+  }
+  return true;
+}
+
 template <int LA, int LB, int TAG>
 static int launch_ring(hipStream_t stream, const GemmBatch& b, int prec) {
   int tiles = 0;
@@ -725,6 +911,11 @@ static int launch_ring(hipStream_t stream, const GemmBatch& b, int prec) {
     if (split > 8) split = 8;
   }
   const dim3 grid(8 * ((tiles + 7) / 8), split, b.n), block(768);
+  if (prec != DVGR_F32 && planes_eligible(b, LA, LB)) {
+    if (prec == DVGR_BF16X3) hipLaunchKernelGGL((gemm_planes_kernel<LA, LB, TAG, 3>), grid, block, 0, stream, b);
+    else hipLaunchKernelGGL((gemm_planes_kernel<LA, LB, TAG, 1>), grid, block, 0, stream, b);
+    return (int)hipGetLastError();
+  }
   if (prec == DVGR_BF16X3) hipLaunchKernelGGL((gemm_ring_kernel<LA, LB, TAG, DVGR_BF16X3>), grid, block, 0, stream, b);
   else if (prec == DVGR_BF16) hipLaunchKernelGGL((gemm_ring_kernel<LA, LB, TAG, DVGR_BF16>), grid, block, 0, stream, b);
   else hipLaunchKernelGGL((gemm_ring_kernel<LA, LB, TAG, DVGR_F32>), grid, block, 0, stream, b);

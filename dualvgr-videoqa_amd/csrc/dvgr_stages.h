@@ -26,7 +26,13 @@ int punish_fwd(hipStream_t st, const float* X0, const float* X1, const float* p0
 
 // x-site dropout of the two GATs of both modalities, materialised once per layer (training mode):
 // out[m][g][i] = X[m][i] * keep(key[m][g], i) / (1 - p).  model/GraphNN.py:175
-int drop_x(hipStream_t st, const float* X0, const float* X1, float* out0, float* out1, const uint32_t (&key)[2][2], int64_t n);
+int drop_x(hipStream_t st, const float* X0, const float* X1, float* out0, float* out1, const uint32_t (&key)[2][2], int64_t n,
+           uint16_t* p0 = nullptr, uint16_t* p1 = nullptr, int64_t lo_off = 0);
+
+// hi/lo bf16 planes of up to 4 fp32 tensors (the unit's inputs)
+struct SplitJob { const float* src; uint16_t* hi; int64_t n; };
+struct SplitBatch { SplitJob j[4]; int n; int64_t lo_off; };
+int split_planes(hipStream_t st, const SplitBatch& b);
 
 // S3: per (b, head, mod): logits, softmax over j, punish-scaled aggregation, ELU, dropout.
 struct GatAttnArgs {
@@ -40,6 +46,9 @@ struct GatAttnArgs {
   float* out_s[2];       // specific-GAT output (B, N, D)
   uint32_t key_alpha[2][8];  // dropout keys (0 = eval)
   uint32_t key_out[2][2];    // [mod][gat]
+  uint16_t* zp_c[2];     // bf16 hi plane of out_c (nullable); lo plane at + z_lo_off
+  uint16_t* zp_s[2];
+  int64_t z_lo_off;
   int B, N, D;
 };
 int gat_attn_fwd(hipStream_t st, const GatAttnArgs& a);
@@ -54,18 +63,21 @@ struct SfCombineArgs {
   float* beta[2];        // (B*N, 2) saved
   float* o[2];           // fused embedding (B*N, D); nullable
   float* Xout[2];        // X' (B*N, D)
+  uint16_t* xp[2];       // bf16 planes of X' (nullable)
+  int64_t x_lo_off;
   int rows, D;
 };
 int sf_combine_fwd(hipStream_t st, const SfCombineArgs& a);
 
 // S6 middle: z[r][k] = x0[r][2k] x1[r][2k] + x0[r][2k+1] x1[r][2k+1]   model/fusions/fusions.py:430-440
-int mfb_pool_fwd(hipStream_t st, const float* x0, const float* x1, float* z, int rows);
+int mfb_pool_fwd(hipStream_t st, const float* x0, const float* x1, float* z, int rows, uint16_t* zp = nullptr, int64_t lo_off = 0);
 
 // ---- backward -----------------------------------------------------------------------------------
 // out[i] = g[i] * ELU'(from output y[i]); g == nullptr -> zeros
-int elu_bwd(hipStream_t st, const float* g, const float* y, float* out, int64_t n);
+int elu_bwd(hipStream_t st, const float* g, const float* y, float* out, int64_t n, uint16_t* op = nullptr, int64_t lo_off = 0);
 // dp0 = dz[k/2] * x1 * ELU'(x0), dp1 = dz[k/2] * x0 * ELU'(x1)
-int mfb_pool_bwd(hipStream_t st, const float* dz, const float* x0, const float* x1, float* dp0, float* dp1, int rows);
+int mfb_pool_bwd(hipStream_t st, const float* dz, const float* x0, const float* x1, float* dp0, float* dp1, int rows,
+                 uint16_t* p0 = nullptr, uint16_t* p1 = nullptr, int64_t lo_off = 0);
 
 struct SfBwdArgs {
   const float* dX[2];      // grad wrt X' (B*N, D)
@@ -80,6 +92,8 @@ struct SfBwdArgs {
   float* dw[2];            // (2, B*N)
   float* dpre[2];          // (2, B*N, D)
   float* dz[2];            // (2, B*N, D)  = beta_v * do + g_z_v   (GEMM adds dpre . P1)
+  uint16_t* dpre_p[2];     // bf16 planes of dpre (nullable)
+  int64_t lo_off;
   int rows, D;
 };
 int sf_bwd(hipStream_t st, const SfBwdArgs& a);
@@ -100,6 +114,8 @@ struct GatAttnBwdArgs {
   float* dc_part[2];       // (B, 8)
   uint32_t key_alpha[2][8];
   uint32_t key_out[2][2];
+  uint16_t* dWh_p[2];      // bf16 planes of dWh (nullable)
+  int64_t lo_off;
   int B, N, D;
 };
 int gat_attn_bwd(hipStream_t st, const GatAttnBwdArgs& a);
@@ -128,6 +144,8 @@ struct QaBwdArgs {
   float* dy;               // [L][B*T][D]
   int B, T, D, Wd, L;
   int first;               // 1: this launch initialises gwords, 0: it accumulates
+  uint16_t* dy_p;          // bf16 planes of dy (nullable)
+  int64_t lo_off;
 };
 int qa_bwd(hipStream_t st, const QaBwdArgs& a);
 

@@ -152,6 +152,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_fwd(const GatAttnArgs a) {
   const int g = h >> 2, hl = h & 3;
   float* out = (g ? a.out_s[mod] : a.out_c[mod]) + (int64_t)b * N * D + hl * F;
   const uint32_t ko = a.key_out[mod][g];
+  uint16_t* zp = g ? a.zp_s[mod] : a.zp_c[mod];
   for (int f = tid; f < F; f += 256) {
     float acc[NB];
 #pragma unroll
@@ -169,7 +170,9 @@ __global__ __launch_bounds__(256) void k_gat_attn_fwd(const GatAttnArgs a) {
     for (int i = 0; i < NB; ++i)
       if (i < N) {
         const int64_t o = (int64_t)i * D + f;
-        out[o] = elu_f(acc[i]) * drop_factor(ko, (uint32_t)(((int64_t)b * N) * D + hl * F + o));
+        const float val = elu_f(acc[i]) * drop_factor(ko, (uint32_t)(((int64_t)b * N) * D + hl * F + o));
+        out[o] = val;
+        split_store1(zp, a.z_lo_off, (int64_t)b * N * D + hl * F + o, val);
       }
   }
 }
@@ -228,7 +231,9 @@ __global__ __launch_bounds__(256) void k_sf_combine_fwd(const SfCombineArgs a) {
     const float4 u = z0[k], v = z1[k], xx = x[k];
     const float4 o = make_float4(b0 * u.x + b1 * v.x, b0 * u.y + b1 * v.y, b0 * u.z + b1 * v.z, b0 * u.w + b1 * v.w);
     if (oo) oo[k] = o;
-    xo[k] = make_float4(xx.x + o.x, xx.y + o.y, xx.z + o.z, xx.w + o.w);
+    const float4 xn = make_float4(xx.x + o.x, xx.y + o.y, xx.z + o.z, xx.w + o.w);
+    xo[k] = xn;
+    split_store4(a.xp[mod], a.x_lo_off, (int64_t)row * a.D + 4 * k, xn);
   }
 }
 
@@ -240,34 +245,47 @@ int sf_combine_fwd(hipStream_t st, const SfCombineArgs& a) {
 // =================================================================================================
 // S6 pooling.  model/fusions/fusions.py:430-440
 // =================================================================================================
-__global__ __launch_bounds__(256) void k_mfb_pool_fwd(const float* x0, const float* x1, float* z, int64_t n) {
+__global__ __launch_bounds__(256) void k_mfb_pool_fwd(const float* x0, const float* x1, float* z, int64_t n,
+                                                      uint16_t* zp, int64_t lo_off) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // index into z (rows * 256)
   if (i >= n) return;
   const float2 a = reinterpret_cast<const float2*>(x0)[i];
   const float2 b = reinterpret_cast<const float2*>(x1)[i];
-  z[i] = a.x * b.x + a.y * b.y;
+  const float v = a.x * b.x + a.y * b.y;
+  z[i] = v;
+  split_store1(zp, lo_off, i, v);
 }
-int mfb_pool_fwd(hipStream_t st, const float* x0, const float* x1, float* z, int rows) {
+int mfb_pool_fwd(hipStream_t st, const float* x0, const float* x1, float* z, int rows, uint16_t* zp, int64_t lo_off) {
   const int64_t n = (int64_t)rows * kMfbPooled;
-  hipLaunchKernelGGL(k_mfb_pool_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x0, x1, z, n);
+  hipLaunchKernelGGL(k_mfb_pool_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x0, x1, z, n, zp, lo_off);
   DVGR_LAUNCH_CHECK();
 }
 
 // =================================================================================================
 // Backward element-wise pieces
 // =================================================================================================
-__global__ __launch_bounds__(256) void k_elu_bwd(const float* g, const float* y, float* out, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  out[i] = g ? g[i] * elu_grad_from_out(y[i]) : 0.f;
+__global__ __launch_bounds__(256) void k_elu_bwd(const float* g, const float* y, float* out, int64_t n4,
+                                                 uint16_t* op, int64_t lo_off) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // float4 index
+  if (i >= n4) return;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g) {
+    const float4 gg = reinterpret_cast<const float4*>(g)[i], yy = reinterpret_cast<const float4*>(y)[i];
+    v = make_float4(gg.x * elu_grad_from_out(yy.x), gg.y * elu_grad_from_out(yy.y), gg.z * elu_grad_from_out(yy.z),
+                    gg.w * elu_grad_from_out(yy.w));
+  }
+  reinterpret_cast<float4*>(out)[i] = v;
+  split_store4(op, lo_off, 4 * i, v);
 }
-int elu_bwd(hipStream_t st, const float* g, const float* y, float* out, int64_t n) {
-  hipLaunchKernelGGL(k_elu_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, y, out, n);
+int elu_bwd(hipStream_t st, const float* g, const float* y, float* out, int64_t n, uint16_t* op, int64_t lo_off) {
+  const int64_t n4 = n / 4;
+  hipLaunchKernelGGL(k_elu_bwd, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, g, y, out, n4, op, lo_off);
   DVGR_LAUNCH_CHECK();
 }
 
 __global__ __launch_bounds__(256) void k_mfb_pool_bwd(const float* dz, const float* x0, const float* x1,
-                                                      float* dp0, float* dp1, int64_t n) {
+                                                      float* dp0, float* dp1, int64_t n, uint16_t* p0, uint16_t* p1,
+                                                      int64_t lo_off) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // index into dz (rows * 256)
   if (i >= n) return;
   const float d = dz[i];
@@ -278,10 +296,13 @@ __global__ __launch_bounds__(256) void k_mfb_pool_bwd(const float* dz, const flo
   r1.x = d * a.x * elu_grad_from_out(b.x); r1.y = d * a.y * elu_grad_from_out(b.y);
   reinterpret_cast<float2*>(dp0)[i] = r0;
   reinterpret_cast<float2*>(dp1)[i] = r1;
+  split_store1(p0, lo_off, 2 * i, r0.x); split_store1(p0, lo_off, 2 * i + 1, r0.y);
+  split_store1(p1, lo_off, 2 * i, r1.x); split_store1(p1, lo_off, 2 * i + 1, r1.y);
 }
-int mfb_pool_bwd(hipStream_t st, const float* dz, const float* x0, const float* x1, float* dp0, float* dp1, int rows) {
+int mfb_pool_bwd(hipStream_t st, const float* dz, const float* x0, const float* x1, float* dp0, float* dp1, int rows,
+                 uint16_t* p0, uint16_t* p1, int64_t lo_off) {
   const int64_t n = (int64_t)rows * kMfbPooled;
-  hipLaunchKernelGGL(k_mfb_pool_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dz, x0, x1, dp0, dp1, n);
+  hipLaunchKernelGGL(k_mfb_pool_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dz, x0, x1, dp0, dp1, n, p0, p1, lo_off);
   DVGR_LAUNCH_CHECK();
 }
 
@@ -324,10 +345,14 @@ __global__ __launch_bounds__(256) void k_sf_bwd(const SfBwdArgs a) {
     float4 d = dX[k];
     if (ge) { const float4 e = ge[k]; d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w; }
     const float4 ta = t0[k], tb = t1[k], p = p2[k];
-    dpre0[k] = make_float4(dw0 * p.x * (1.f - ta.x * ta.x), dw0 * p.y * (1.f - ta.y * ta.y),
-                           dw0 * p.z * (1.f - ta.z * ta.z), dw0 * p.w * (1.f - ta.w * ta.w));
-    dpre1[k] = make_float4(dw1 * p.x * (1.f - tb.x * tb.x), dw1 * p.y * (1.f - tb.y * tb.y),
-                           dw1 * p.z * (1.f - tb.z * tb.z), dw1 * p.w * (1.f - tb.w * tb.w));
+    const float4 q0 = make_float4(dw0 * p.x * (1.f - ta.x * ta.x), dw0 * p.y * (1.f - ta.y * ta.y),
+                                  dw0 * p.z * (1.f - ta.z * ta.z), dw0 * p.w * (1.f - ta.w * ta.w));
+    const float4 q1 = make_float4(dw1 * p.x * (1.f - tb.x * tb.x), dw1 * p.y * (1.f - tb.y * tb.y),
+                                  dw1 * p.z * (1.f - tb.z * tb.z), dw1 * p.w * (1.f - tb.w * tb.w));
+    dpre0[k] = q0;
+    dpre1[k] = q1;
+    split_store4(a.dpre_p[mod], a.lo_off, r0 + 4 * k, q0);
+    split_store4(a.dpre_p[mod], a.lo_off, r1 + 4 * k, q1);
     float4 o0 = make_float4(b0 * d.x, b0 * d.y, b0 * d.z, b0 * d.w);
     float4 o1 = make_float4(b1 * d.x, b1 * d.y, b1 * d.z, b1 * d.w);
     if (g0) { const float4 e = g0[k]; o0.x += e.x; o0.y += e.y; o0.z += e.z; o0.w += e.w; }
@@ -457,7 +482,9 @@ __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
       if (j < N) {                                          // N is uniform: no divergence
         const float w = act ? shW[j * FS + f] : 0.f;
         if (act) {
-          dWh[(int64_t)j * HF + f] = shS[j] * dZ[j] + shDu[j] * alf + shDv[j] * arf;
+          const float dwv = shS[j] * dZ[j] + shDu[j] * alf + shDv[j] * arf;
+          dWh[(int64_t)j * HF + f] = dwv;
+          split_store1(a.dWh_p[mod], a.lo_off, (int64_t)b * N * HF + h * F + (int64_t)j * HF + f, dwv);
           dal += shDu[j] * w;
           dar += shDv[j] * w;
         }
@@ -588,8 +615,11 @@ __global__ __launch_bounds__(256) void k_qa_bwd(const QaBwdArgs a) {
         gw[w] = (a.first && l == 0) ? val : (gw[w] + val);
       }
       const float nrm = sav[a.s_nrm + b * T + t], drt = sh_dr[t], ct = sh_c[t];
-      for (int k = tid; k < D; k += 256)                    // dy = (dd - d (d.dd)) / nrm, dd = dr * w2
-        dy[(int64_t)t * D + k] = drt * (w2[k] - dsv[(int64_t)t * D + k] * ct) / nrm;
+      for (int k = tid; k < D; k += 256) {                  // dy = (dd - d (d.dd)) / nrm, dd = dr * w2
+        const float dyv = drt * (w2[k] - dsv[(int64_t)t * D + k] * ct) / nrm;
+        dy[(int64_t)t * D + k] = dyv;
+        split_store1(a.dy_p, a.lo_off, (((int64_t)l * a.B + b) * T + t) * D + k, dyv);
+      }
     }
     __syncthreads();
   }
@@ -639,7 +669,8 @@ int colsum(hipStream_t st, const ColsumBatch& b) {
 }
 
 __global__ __launch_bounds__(256) void k_drop_x(const float* X0, const float* X1, float* out0, float* out1,
-                                                uint32_t k00, uint32_t k01, uint32_t k10, uint32_t k11, int64_t n4) {
+                                                uint32_t k00, uint32_t k01, uint32_t k10, uint32_t k11, int64_t n4,
+                                                uint16_t* p0, uint16_t* p1, int64_t lo_off) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // float4 index
   if (i >= n4) return;
   const int mod = blockIdx.y;
@@ -657,12 +688,29 @@ __global__ __launch_bounds__(256) void k_drop_x(const float* X0, const float* X1
     y.z = x.z * (((h1 & 0xFFFFu) >= kDropThresh16) ? kKeepScale : 0.f);
     y.w = x.w * (((h1 >> 16) >= kDropThresh16) ? kKeepScale : 0.f);
     reinterpret_cast<float4*>(out + (int64_t)g * n4 * 4)[i] = y;
+    split_store4(mod ? p1 : p0, lo_off, (int64_t)g * n4 * 4 + 4 * i, y);
   }
 }
-int drop_x(hipStream_t st, const float* X0, const float* X1, float* out0, float* out1, const uint32_t (&key)[2][2], int64_t n) {
+int drop_x(hipStream_t st, const float* X0, const float* X1, float* out0, float* out1, const uint32_t (&key)[2][2], int64_t n,
+           uint16_t* p0, uint16_t* p1, int64_t lo_off) {
   const int64_t n4 = n / 4;
   hipLaunchKernelGGL(k_drop_x, dim3((unsigned)((n4 + 255) / 256), 2), dim3(256), 0, st, X0, X1, out0, out1,
-                     key[0][0], key[0][1], key[1][0], key[1][1], n4);
+                     key[0][0], key[0][1], key[1][0], key[1][1], n4, p0, p1, lo_off);
+  DVGR_LAUNCH_CHECK();
+}
+
+__global__ __launch_bounds__(256) void k_split_planes(const SplitBatch b) {
+  const SplitJob& J = b.j[blockIdx.y];
+  const int64_t n4 = J.n / 4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
+    split_store4(J.hi, b.lo_off, 4 * i, reinterpret_cast<const float4*>(J.src)[i]);
+}
+int split_planes(hipStream_t st, const SplitBatch& b) {
+  if (b.n < 1 || b.n > 4) return DVGR_E_DIMS;
+  int64_t mx = 0;
+  for (int i = 0; i < b.n; ++i) mx = b.j[i].n > mx ? b.j[i].n : mx;
+  const int64_t blocks = (mx / 4 + 255) / 256;
+  hipLaunchKernelGGL(k_split_planes, dim3((unsigned)(blocks > 2048 ? 2048 : blocks), b.n), dim3(256), 0, st, b);
   DVGR_LAUNCH_CHECK();
 }
 

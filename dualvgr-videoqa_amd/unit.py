@@ -367,13 +367,15 @@ class DualVGRUnit_multiple(nn.Module):
         return self._flat
 
     def lowp_ptr(self):
-        """bf16 shadow copy of the parameters for DVGR_BF16, refreshed when the weights changed."""
-        return None    # operands are rounded on chip while they are staged into LDS; no shadow copy needed yet
+        """bf16 hi / lo planes of the parameters (2 x param_count bf16) for the bf16 MFMA modes, refreshed
+        whenever a parameter changed (optimizer step, load_state_dict).  None in fp32 mode."""
+        if self.dtype_code == L_.DVGR_F32:
+            return None
         flat = self._flat
-        ver = tuple(p._version for p in self._plist)
+        ver = sum(p._version for p in self._plist)
         if self._lowp is None or self._lowp.device != flat.device or ver != self._lowp_version:
             if self._lowp is None or self._lowp.device != flat.device:
-                self._lowp = torch.empty(flat.numel(), device=flat.device, dtype=torch.bfloat16)
+                self._lowp = torch.empty(2 * flat.numel(), device=flat.device, dtype=torch.bfloat16)
             L_.check(L_.load().dvgr_pack_weights(C.byref(self._dims0), flat.data_ptr(), self._lowp.data_ptr(),
                                                  torch.cuda.current_stream(flat.device).cuda_stream), "dvgr_pack_weights")
             self._lowp_version = ver

@@ -132,15 +132,17 @@ int64_t dvgr_param_count(const dvgr_dims *d);
 int dvgr_param_offset(const dvgr_dims *d, int kind, int layer, int mod,
                       int64_t *offset, int64_t *rows, int64_t *cols);
 
-/* Bytes the forward writes into `saved` for the backward, and the byte offset of one saved tensor. */
+/* Bytes of the `saved` buffer: an fp32 region the forward writes for the backward (dvgr_saved_offset gives
+ * the byte offset of one tensor inside it) followed by a region of bf16 hi / lo planes of the same size. */
 size_t dvgr_saved_bytes(const dvgr_dims *d);
 int dvgr_saved_offset(const dvgr_dims *d, int kind, int layer, int mod, size_t *offset_bytes);
 
-/* Scratch bytes needed by forward / backward (contents undefined between calls). */
+/* Scratch bytes needed by forward / backward (contents undefined between calls); fp32 region + planes region. */
 size_t dvgr_workspace_bytes(const dvgr_dims *d);
 
-/* bf16 shadow copy of the parameters for DVGR_BF16 (same element offsets, 2 bytes per element);
- * call after every optimizer step.  `params_lp` must hold dvgr_param_count() * 2 bytes. */
+/* bf16 hi / lo planes of the parameters for DVGR_BF16 / DVGR_BF16X3: hi = bf16(w) at element offset o,
+ * lo = bf16(w - hi) at dvgr_param_count() + o (same offsets as the fp32 buffer).  Call after every
+ * optimizer step.  `params_lp` must hold 2 * dvgr_param_count() * 2 bytes. */
 int dvgr_pack_weights(const dvgr_dims *d, const float *params, void *params_lp, void *stream);
 
 /* Launch sites a caller can bracket with a pair of hipEvents (dvgr_opts.probe): the events are
