@@ -72,6 +72,10 @@ SYMBOLS += [
     ("dvgr_dbg_gemm", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
                                 C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int,
                                 C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]),
+    ("dvgr_dbg_split", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    ("dvgr_dbg_gemm_planes", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                       C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                       C.c_int, C.c_void_p]),
     ("dvgr_dbg_colsum", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
     ("dvgr_dbg_keep_mask", C.c_int, [C.c_uint32, C.c_int64, C.c_void_p, C.c_void_p]),
     ("dvgr_dbg_site_key", C.c_uint32, [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -767,6 +767,31 @@ int dvgr_dbg_gemm(int mode, int M, int N, int K, int kseg, const float* A, const
   return gemm_launch((hipStream_t)stream, la, lb, gb, TAG_GENERIC, prec);
 }
 
+int dvgr_dbg_split(const float* src, void* hi, int64_t lo_off, int64_t n, void* stream) {
+  if (!src || !hi) return DVGR_E_NULL;
+  SplitBatch sb{};
+  sb.lo_off = lo_off;
+  sb.j[sb.n++] = SplitJob{src, reinterpret_cast<uint16_t*>(hi), n};
+  return split_planes((hipStream_t)stream, sb);
+}
+
+int dvgr_dbg_gemm_planes(int mode, int M, int N, int K, const float* A, const void* A_hi, int64_t lda, int64_t a_lo_off,
+                         const float* B, const void* B_hi, int64_t ldb, int64_t b_lo_off, float* C, int64_t ldc, int act,
+                         int accumulate, int prec, void* stream) {
+  if (!A || !B || !C || !A_hi || !B_hi) return DVGR_E_NULL;
+  GemmBatch gb{};
+  GemmProblem p{};
+  p.A = operand(A, lda);
+  p.B = operand(B, ldb);
+  p.A.h0 = p.A.h1 = reinterpret_cast<const uint16_t*>(A_hi); p.A.lo_off = a_lo_off;
+  p.B.h0 = p.B.h1 = reinterpret_cast<const uint16_t*>(B_hi); p.B.lo_off = b_lo_off;
+  p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.kseg = K;
+  p.act = act & 15; p.dbg = act >> 4; p.accumulate = accumulate; p.atomic_ok = accumulate;
+  gb.p[gb.n++] = p;
+  const int la = mode == 2 ? IC : KC, lb = mode == 0 ? KC : IC;
+  return gemm_launch((hipStream_t)stream, la, lb, gb, TAG_GENERIC, prec);
+}
+
 int dvgr_dbg_colsum(const float* M, const float* w, int rows, int cols, int64_t ld, float* out, void* stream) {
   if (!M || !out) return DVGR_E_NULL;
   ColsumBatch cb{};

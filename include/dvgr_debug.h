@@ -23,6 +23,15 @@ int dvgr_dbg_gemm(int mode, int M, int N, int K, int kseg, const float *A, const
                   int act, int accumulate, uint32_t drop_key_a, uint32_t drop_key_b, uint32_t drop_key_c,
                   int prec, void *stream);
 
+/* bf16 hi / lo planes of an fp32 array: hi[i] = bf16(src[i]), hi[lo_off + i] = bf16(src[i] - hi[i]); n % 4 == 0. */
+int dvgr_dbg_split(const float *src, void *hi, int64_t lo_off, int64_t n, void *stream);
+
+/* dvgr_dbg_gemm with pre-split operands (planes made by dvgr_dbg_split; same shapes / leading dimensions as the
+ * fp32 matrices, which are still passed for the fallback path).  act carries the dbg flags in bits 4.. */
+int dvgr_dbg_gemm_planes(int mode, int M, int N, int K, const float *A, const void *A_hi, int64_t lda, int64_t a_lo_off,
+                         const float *B, const void *B_hi, int64_t ldb, int64_t b_lo_off, float *C, int64_t ldc,
+                         int act, int accumulate, int prec, void *stream);
+
 /* out[c] = sum_r w[r] * M[r][c]  (w nullable) */
 int dvgr_dbg_colsum(const float *M, const float *w, int rows, int cols, int64_t ld, float *out, void *stream);
 

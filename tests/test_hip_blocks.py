@@ -235,3 +235,54 @@ def test_gemm_splitk_atomic_partials(mode, M, N, K, prec):
     C0 = _ints((M, N), seed=37)
     got = _gemm(mode, A, B, M, N, K, accumulate=True, C0=C0, prec=prec)
     assert torch.equal(got, (C0.double() + want).float()), float((got.double() - C0.double() - want).abs().max())
+
+
+# ---- pre-split bf16 planes -------------------------------------------------------------------------
+def _planes(x):
+    lib = L.load()
+    n = x.numel()
+    pl = torch.empty(2 * n, dtype=torch.bfloat16, device="cuda")
+    assert lib.dvgr_dbg_split(x.data_ptr(), pl.data_ptr(), n, n, _stream()) == 0
+    return pl, n
+
+
+def _gemm_planes(mode, A, B, M, N, K, prec, accumulate=False, C0=None):
+    lib = L.load()
+    pa, na = _planes(A)
+    pb, nb = _planes(B)
+    Cm = C0.clone() if C0 is not None else torch.full((M, N), float("nan"), device="cuda")
+    rc = lib.dvgr_dbg_gemm_planes(mode, M, N, K, A.data_ptr(), pa.data_ptr(), A.stride(0), na, B.data_ptr(), pb.data_ptr(),
+                                  B.stride(0), nb, Cm.data_ptr(), Cm.stride(0), 0, int(accumulate), prec, _stream())
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    return Cm
+
+
+def test_split_planes_reconstruct():
+    torch.manual_seed(5)
+    x = torch.randn(4096, device="cuda") * 3
+    pl, n = _planes(x)
+    torch.cuda.synchronize()
+    hi, lo = pl[:n].float(), pl[n:].float()
+    assert torch.equal(hi, x.to(torch.bfloat16).float())                 # hi is the round-to-nearest bf16
+    assert float((hi + lo - x).abs().max()) < 2 ** -15 * float(x.abs().max())
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(80, 192, 768), (1280, 1536, 768), (136, 264, 2560), (128, 128, 32)])
+def test_gemm_planes_kernel(mode, M, N, K):
+    """Operands handed over as hi / lo planes: exact on small integers in both bf16 modes, and bf16x3 keeps
+    fp32-grade accuracy on random operands (same bounds as the converting kernels)."""
+    shapes = {0: ((M, K), (N, K)), 1: ((M, K), (K, N)), 2: ((K, M), (K, N))}[mode]
+    A, B = _ints(shapes[0], seed=41), _ints(shapes[1], seed=42)
+    ref = lambda a, b: (a.double() @ b.double().T) if mode == 0 else (a.double() @ b.double()) if mode == 1 else (a.double().T @ b.double())
+    want = ref(A, B)
+    for prec in (1, 2):
+        got = _gemm_planes(mode, A, B, M, N, K, prec)
+        assert torch.equal(got, want.float()), (prec, float((got - want.float()).abs().max()))
+    torch.manual_seed(6)
+    A, B = torch.randn(shapes[0], device="cuda"), torch.randn(shapes[1], device="cuda") * 0.05
+    want = ref(A, B)
+    scale = float(want.abs().max())
+    assert float((_gemm_planes(mode, A, B, M, N, K, 2).double() - want).abs().max()) / scale < 2e-5
+    assert float((_gemm_planes(mode, A, B, M, N, K, 1).double() - want).abs().max()) / scale < 2e-2
