@@ -107,7 +107,10 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16x3", "bf16"])
+    ap.add_argument("--dtype", default="bf16x3", choices=["fp32", "bf16x3", "bf16"],
+                    help="MFMA operand precision: bf16x3 (default; fp32 split hi+lo, meets the 1e-4 fp32 parity gate), "
+                         "fp32 (exact fp32 MFMA), bf16 (plain bf16 operands, 3e-2 tolerance)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--eval-mode", action="store_true", help="dropout off (default: training mode, dropout on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -121,11 +124,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (there is no CPU fallback of the product path)")
+    local = min(local, torch.cuda.device_count() - 1)          # (testing aid: several ranks may share one GPU with gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     import dualvgr_videoqa_amd as dv
     from dualvgr_videoqa_amd import _lib as L_
@@ -163,7 +170,7 @@ def main():
         reducer = parallel.LayerBucketReducer(parallel.layer_buckets(m), device=dev)
         ev_order = [events[Lr]] + [events[l] for l in range(Lr - 1, -1, -1)]
 
-    probe_sites = {"fwd_gat_gemm": (L_.PROBE_FWD_GAT_GEMM, 8 * B * N * D * D, "gemm_kernel<KC,KC,*,*,TAG_FWD_GAT=1> (Wh = X.Wcat^T, both modalities)"),
+    probe_sites = {"fwd_gat_gemm": (L_.PROBE_FWD_GAT_GEMM, 8 * B * N * D * D, "gemm_planes_kernel<KC,KC,TAG_FWD_GAT=1,TERMS> / gemm_ring_kernel<KC,KC,1,F32> (Wh = X.Wcat^T, both modalities)"),
                    "fwd_sf_gemm": (L_.PROBE_FWD_SF_GEMM, 8 * B * N * D * D, "gemm_kernel<KC,KC,*,*,TAG_FWD_SF=2>"),
                    "bwd_gat_dw": (L_.PROBE_BWD_GAT_DW, 8 * B * N * D * D, "gemm_kernel<IC,IC,*,*,TAG_BWD_GAT_DW=3>"),
                    "bwd_gat_dx": (L_.PROBE_BWD_GAT_DX, 8 * B * N * D * D, "gemm_kernel<KC,IC,*,*,TAG_BWD_GAT_DX=4>")}
