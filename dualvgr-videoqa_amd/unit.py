@@ -275,6 +275,7 @@ class DualVGRUnit_multiple(nn.Module):
         self._events = None
         self._events_arr = None
         self._probe = None
+        self.no_planes = False       # diagnostics: bf16 modes convert inside the contraction kernels instead
         self.forced_seed = None      # tests: fix the dropout seed of the next forward
         self.keep_saved = False      # tests: keep a handle on the saved-for-backward buffer
         self.last_saved = None
@@ -369,7 +370,7 @@ class DualVGRUnit_multiple(nn.Module):
     def lowp_ptr(self):
         """bf16 hi / lo planes of the parameters (2 x param_count bf16) for the bf16 MFMA modes, refreshed
         whenever a parameter changed (optimizer step, load_state_dict).  None in fp32 mode."""
-        if self.dtype_code == L_.DVGR_F32:
+        if self.dtype_code == L_.DVGR_F32 or self.no_planes:
             return None
         flat = self._flat
         ver = sum(p._version for p in self._plist)
