@@ -115,6 +115,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--probe", default="fwd_gat_gemm")
+    ap.add_argument("--loss", default="fused", choices=["fused", "precomputed"],
+                    help="fused: the scope-U loss and its gradients are computed inside every timed step by "
+                         "dvgr_scope_u_loss; precomputed: fixed upstream gradients (unit kernels only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -186,7 +189,12 @@ def main():
         for k in ("A", "M", "dq", "words"):
             t[k].grad = None
         raw = m.forward_raw(t["A"], t["M"], t["dq"], t["words"], t["qlen"])
-        torch.autograd.backward(raw, ups)
+        if args.loss == "fused":
+            # loss value + its gradients w.r.t. all outputs by the fused kernels (csrc/dvgr_loss.hip), every step
+            _, g = losses.fused_scope_u_loss(raw, 1.0, 1e-8, world)
+            torch.autograd.backward([raw[0], *raw[3:]], [g[0], *g[3:]])
+        else:
+            torch.autograd.backward(raw, ups)
         if reducer is not None:
             reducer.reduce(m.last_flat_grad, ev_order)
 
@@ -222,7 +230,9 @@ def main():
         "config": {"workload": f"{cfg['name']}: DualVGR unit forward+backward, per-GPU batch {B}, D={D}, word_dim={WD}, "
                                f"T={T}, {'eval' if args.eval_mode else 'training (dropout 0.15 on)'}",
                    "global_batch": world * B, "parallelism": f"dp{world}",
-                   "loss": "upstream gradients of sum(vis)+common+1e-8*HSIC for all 3+4L outputs, precomputed once",
+                   "loss": ("sum(vis)+common+1e-8*HSIC evaluated with its gradients inside every timed step "
+                            "(fused HIP kernels, dvgr_scope_u_loss)") if args.loss == "fused" else
+                           "upstream gradients of sum(vis)+common+1e-8*HSIC for all 3+4L outputs, precomputed once",
                    "algorithmic_gflop_per_qa_train": f_train / 1e9,
                    "unit_tflops": value / world * f_train / 1e12,
                    "unit_frac_of_mfma_peak": value / world * f_train / 1e12 / peak},

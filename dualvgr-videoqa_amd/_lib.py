@@ -65,6 +65,9 @@ SYMBOLS = [
                                     C.c_void_p, C.c_size_t, C.POINTER(Opts), C.c_void_p]),
     ("dvgr_unit_backward", C.c_int, [C.POINTER(Dims), C.c_void_p, C.c_void_p, C.POINTER(IO), C.POINTER(Grads),
                                      C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(Opts), C.c_void_p]),
+    ("dvgr_scope_u_loss", C.c_int, [C.POINTER(Dims), C.POINTER(IO), C.c_float, C.c_float, C.c_float, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                    C.c_void_p]),
 ]
 
 # test hooks declared in include/dvgr_debug.h

@@ -187,6 +187,12 @@ int check_common(const dvgr_dims* d, const void* params, const dvgr_io* io, cons
 
 }  // namespace
 
+namespace dvgr {
+size_t aux_ws_floats(const dvgr_dims& d);
+int aux_losses(hipStream_t st, const dvgr_dims& d, const dvgr_io* io, float alpha, float beta, float dep_scale,
+               float* loss3, float* g_vis, float* const g[4], float* ws);
+}
+
 extern "C" {
 
 const char* dvgr_version(void) { return "dvgr-hip 0.1.0 gfx950"; }
@@ -735,6 +741,18 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     }
   }
   return 0;
+}
+
+
+int dvgr_scope_u_loss(const dvgr_dims* dp, const dvgr_io* io, float alpha, float beta, float dep_scale,
+                      float* loss3, float* g_vis, float* g_com_app, float* g_com_mot, float* g_aq_fusion,
+                      float* g_mq_fusion, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!dp || !io || !loss3 || !workspace || !g_com_app || !g_com_mot || !g_aq_fusion || !g_mq_fusion) return DVGR_E_NULL;
+  if (!io->vis || !io->com_app || !io->com_mot || !io->aq_fusion || !io->mq_fusion) return DVGR_E_NULL;
+  DVGR_TRY(dvgr_check_dims(dp));
+  if (workspace_bytes < aux_ws_floats(*dp) * sizeof(float)) return DVGR_E_WORKSPACE;
+  float* const g[4] = {g_com_app, g_com_mot, g_aq_fusion, g_mq_fusion};
+  return aux_losses((hipStream_t)stream, *dp, io, alpha, beta, dep_scale, loss3, g_vis, g, reinterpret_cast<float*>(workspace));
 }
 
 }  // extern "C"

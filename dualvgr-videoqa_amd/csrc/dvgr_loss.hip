@@ -1,0 +1,333 @@
+// dvgr_loss.hip -- fused auxiliary losses of the unit's list outputs, value AND gradient in one pass
+// (SURVEY.md section 8f, row f1).  Restates utils.py:10-31 + train.py:148-154 of the reference:
+//   common_l = mean_{b,i,j} (C(com_app_l) - C(com_mot_l))^2,   C(E) = Ehat Ehat^T, Ehat = rows of (E - mean over
+//              nodes) L2-normalised over D (eps 1e-12)
+//   dep_l    = sum_b [ tr(R K(aq_l) R K(com_app_l)) + tr(R K(mq_l) R K(com_mot_l)) ],  K(E) = E E^T, R = I - 1/N
+//   aux      = alpha * mean_l common_l + beta * dep_scale * mean_l dep_l
+// Algebra used: with c = R E (rows centred over the nodes), R K R = c c^T =: G(E) and tr(R K1 R K2) = <G1, G2>;
+// d<G1,G2>/dE1 = 2 G2 c1.  The normalised Gram is C_ij = G_ij / (n_i n_j), n_i = max(sqrt(G_ii), 1e-12), and
+// (ehat_i . dehat_i) = sum_j M_ij C_ij for dehat = M ehat, so every N x N quantity comes from the four centred
+// Grams of a (b, l) pair and the D-wide work is two passes over the rows: Gram, then gradient.
+#include "dvgr_common.h"
+#include "../../include/dvgr.h"
+
+#define DVGR_TRY_HIP(x) do { const int rc_ = (x); if (rc_ != 0) return rc_; } while (0)
+
+namespace dvgr {
+
+struct AuxArgs {
+  const float* t[4];     // com_app, com_mot, aq_fusion, mq_fusion: (L, B, N, D)
+  float* g[4];           // gradients of aux w.r.t. the same tensors
+  float* gram;           // [L][B][4][N][N] centred Grams
+  float* wt;             // [L][B][4][N][NBP] gradient matrices: g_t[i] = sum_j wt_t[j][i] c_t[j]
+  float* loss;           // [3]: sum(vis), mean_l common_l, mean_l dep_l
+  float wc, wh;          // alpha / (L B N^2), beta * dep_scale / L
+  int B, N, D, L, NBP;
+};
+
+// ---- pass 1: centred Gram of one tensor of one (b, l) ---------------------------------------------------
+// c c^T on the fp32 MFMA (v_mfma_f32_16x16x4_f32: exact fp32 products).  A lane holds c[16 I + lane%16][k0 + 4 (lane/16)
+// .. +3]; the same fragment serves as the A operand of row block I and the B operand of column block J, so the four k-steps
+// of one float4 are four MFMAs per (I, J >= I).  The four waves split D and their partial tiles are summed through LDS.
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_aux_gram(const AuxArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int b = blockIdx.x, l = blockIdx.y >> 2, t = blockIdx.y & 3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = a.N, D = a.D;
+  float* mu = sm;                                     // [D]
+  float* red = sm + D;                                // [4][NT*NT][256]
+  const float* E = a.t[t] + ((int64_t)l * a.B + b) * N * D;
+  for (int d4 = tid; d4 < D / 4; d4 += 256) {           // column means, 4 rows in flight per thread
+    const float4* col = reinterpret_cast<const float4*>(E) + d4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int i = 0;
+    for (; i + 4 <= N; i += 4) {
+      const float4 v0 = col[(int64_t)i * (D / 4)], v1 = col[(int64_t)(i + 1) * (D / 4)];
+      const float4 v2 = col[(int64_t)(i + 2) * (D / 4)], v3 = col[(int64_t)(i + 3) * (D / 4)];
+      s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y);
+      s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; i < N; ++i) {
+      const float4 v = col[(int64_t)i * (D / 4)];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const float inv = 1.0f / (float)N;
+    *reinterpret_cast<float4*>(mu + 4 * d4) = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+  }
+  __syncthreads();
+  const int r16 = lane & 15, kq = lane >> 4;
+  floatx4 acc[NT][NT];
+#pragma unroll
+  for (int I = 0; I < NT; ++I)
+#pragma unroll
+    for (int J = 0; J < NT; ++J) acc[I][J] = floatx4{0.f, 0.f, 0.f, 0.f};
+  const int kw = D / 4;                               // D % 64 == 0: every wave owns a multiple of 16 columns
+  const int nk = kw / 16;
+#pragma unroll 4
+  for (int it = 0; it < nk; ++it) {
+    const int k0 = wave * kw + it * 16;
+    const float4 m = *reinterpret_cast<const float4*>(mu + k0 + 4 * kq);
+    float f[NT][4];
+#pragma unroll
+    for (int I = 0; I < NT; ++I) {
+      const int row = 16 * I + r16;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < N) {
+        v = *reinterpret_cast<const float4*>(E + (int64_t)row * D + k0 + 4 * kq);
+        v.x -= m.x; v.y -= m.y; v.z -= m.z; v.w -= m.w;
+      }
+      f[I][0] = v.x; f[I][1] = v.y; f[I][2] = v.z; f[I][3] = v.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int J = I; J < NT; ++J) acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[I][e], f[J][e], acc[I][J], 0, 0, 0);
+  }
+#pragma unroll
+  for (int I = 0; I < NT; ++I)
+#pragma unroll
+    for (int J = I; J < NT; ++J)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[((wave * NT + I) * NT + J) * 256 + r * 64 + lane] = acc[I][J][r];
+  __syncthreads();
+  float* G = a.gram + (((int64_t)l * a.B + b) * 4 + t) * N * N;
+  const int r = tid >> 6;
+#pragma unroll
+  for (int I = 0; I < NT; ++I)
+#pragma unroll
+    for (int J = I; J < NT; ++J) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v += red[((w * NT + I) * NT + J) * 256 + tid];
+      const int row = 16 * I + 4 * (lane >> 4) + r, col = 16 * J + (lane & 15);
+      if (row < N && col < N) { G[row * N + col] = v; G[col * N + row] = v; }
+    }
+}
+
+// ---- pass 2: N x N algebra of one (b, l) ------------------------------------------------------------------------
+// Everything downstream of the Grams is linear in the centred rows c_t, so the whole gradient of tensor t collapses into
+// ONE N x N matrix:  g_t[i] = sum_j W_t[j][i] c_t[j]  with
+//   W_t[j][i] = Mh_t[j][i]                                   HSIC:    2 wh G_partner              (all four tensors)
+//             + Mc_t[j][i] / (n_j n_i) - delta_ij s_i/n_i^2  common:  through the row normalisation (t = com_app, com_mot)
+//             - (1/N) sum_i' [the common part of row j]      ... and through the centring over the nodes
+// where Mc = +-4 wc (C1 - C2), s_i = sum_j Mc_ij C_ij.  Rows are stored padded to NBP floats (32-byte aligned) so that
+// pass 3 can fetch them with scalar loads.
+__global__ __launch_bounds__(256) void k_aux_combine(const AuxArgs a) {
+  extern __shared__ float sm[];
+  const int b = blockIdx.x, l = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = a.N, NN = N * N, NBP = a.NBP;
+  const int64_t bl = (int64_t)l * a.B + b;
+  float* G = sm;                                      // [4][NN]
+  float* A1 = G + 4 * NN;                             // [NN] common part of W for com_app, then com_mot
+  float* A2 = A1 + NN;
+  float* inv = A2 + NN;                               // [2][N] 1 / n_i
+  float* srow = inv + 2 * N;                          // [2][N]
+  float* rmean = srow + 2 * N;                        // [2][N]
+  float* red = rmean + 2 * N;                         // [8]
+  for (int e = tid; e < 4 * NN; e += 256) G[e] = a.gram[bl * 4 * NN + e];
+  __syncthreads();
+  if (tid < 2 * N) {
+    const int t = tid / N, i = tid - t * N;
+    inv[tid] = 1.0f / fmaxf(sqrtf(fmaxf(G[t * NN + i * N + i], 0.f)), 1e-12f);
+  }
+  __syncthreads();
+  float pc = 0.f, ph = 0.f;
+  for (int e = tid; e < NN; e += 256) {
+    const int i = e / N, j = e - i * N;
+    const float c1 = G[e] * (inv[i] * inv[j]), c2 = G[NN + e] * (inv[N + i] * inv[N + j]);
+    const float diff = c1 - c2;
+    pc += diff * diff;
+    ph += G[2 * NN + e] * G[e] + G[3 * NN + e] * G[NN + e];
+    const float m = 4.f * a.wc * diff;                // dehat1 = 2 Gc ehat1 with Gc = 2 wc diff;  dehat2 = -(...)
+    A1[e] = m;                                        // Mc of com_app (com_mot: -m); C recomputed below
+  }
+  pc = wave_sum(pc); ph = wave_sum(ph);
+  if (lane == 0) { red[wave] = pc; red[4 + wave] = ph; }
+  __syncthreads();
+  if (tid < 2 * N) {                                  // s_i = sum_j Mc_ij C_ij
+    const int t = tid / N, i = tid - t * N;
+    float s = 0.f;
+    for (int j = 0; j < N; ++j) {
+      const float c = G[t * NN + i * N + j] * (inv[t * N + i] * inv[t * N + j]);
+      s += (t ? -A1[i * N + j] : A1[i * N + j]) * c;
+    }
+    srow[tid] = s;
+  }
+  __syncthreads();
+  for (int e = tid; e < NN; e += 256) {               // common part: Mc_ji / (n_j n_i) - delta_ij s_i / n_i^2
+    const int j = e / N, i = e - j * N;
+    const float m = A1[e];
+    A2[e] = -m * (inv[N + j] * inv[N + i]) - (i == j ? srow[N + i] * inv[N + i] * inv[N + i] : 0.f);
+    A1[e] = m * (inv[j] * inv[i]) - (i == j ? srow[i] * inv[i] * inv[i] : 0.f);
+  }
+  __syncthreads();
+  if (tid < 2 * N) {
+    const int t = tid / N, j = tid - t * N;
+    const float* A = t ? A2 : A1;
+    float s = 0.f;
+    for (int i = 0; i < N; ++i) s += A[j * N + i];
+    rmean[tid] = s / (float)N;
+  }
+  __syncthreads();
+  float* W = a.wt + bl * 4 * N * NBP;
+  for (int e = tid; e < N * NBP; e += 256) {
+    const int j = e / NBP, i = e - j * NBP;
+    const bool in = i < N;
+    const int q = j * N + (in ? i : 0);
+    W[(0 * N + j) * NBP + i] = in ? 2.f * a.wh * G[2 * NN + q] + A1[q] - rmean[j] : 0.f;       // com_app <- aq
+    W[(1 * N + j) * NBP + i] = in ? 2.f * a.wh * G[3 * NN + q] + A2[q] - rmean[N + j] : 0.f;   // com_mot <- mq
+    W[(2 * N + j) * NBP + i] = in ? 2.f * a.wh * G[q] : 0.f;                                    // aq      <- com_app
+    W[(3 * N + j) * NBP + i] = in ? 2.f * a.wh * G[NN + q] : 0.f;                               // mq      <- com_mot
+  }
+  if (tid == 0) {
+    atomicAdd(a.loss + 1, (red[0] + red[1] + red[2] + red[3]) / ((float)a.B * N * N * a.L));
+    atomicAdd(a.loss + 2, (red[4] + red[5] + red[6] + red[7]) / (float)a.L);
+  }
+}
+
+// ---- pass 3: g_t = W_t^T c_t, one feature column per thread; W rows are wave-uniform -> scalar loads ---------------
+template <int NB, int CPT>
+__global__ __launch_bounds__(256) void k_aux_grad(const AuxArgs a) {
+  extern __shared__ float cs_all[];                   // [CPT][N][256]: each thread's centred columns (one bank per lane)
+  const int b = blockIdx.x, l = blockIdx.y >> 2, t = blockIdx.y & 3, tid = threadIdx.x;
+  const int N = a.N, D = a.D;
+  const int64_t bl = (int64_t)l * a.B + b;
+  // constant address space + wave-uniform index = s_load (the matrix was written by the previous kernel); each fetched
+  // row is used for CPT columns per thread
+  typedef const float __attribute__((address_space(4))) * ConstPtr;
+  ConstPtr W = (ConstPtr)(uintptr_t)(a.wt + (bl * 4 + t) * N * NB);
+  const float* __restrict__ E = a.t[t] + bl * N * D;
+  float* __restrict__ g = a.g[t] + bl * N * D;
+  float* cs = cs_all + tid;
+  for (int d0 = tid; d0 < D; d0 += 256 * CPT) {
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+      const int d = d0 + 256 * q;
+      float c[NB];
+      float mu = 0.f;
+#pragma unroll
+      for (int i = 0; i < NB; ++i) { c[i] = (i < N && d < D) ? E[i * D + d] : 0.f; mu += c[i]; }
+      mu /= (float)N;
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+        if (i < N) cs[(q * N + i) * 256] = c[i] - mu;
+    }
+    float o[CPT][NB];
+#pragma unroll
+    for (int q = 0; q < CPT; ++q)
+#pragma unroll
+      for (int i = 0; i < NB; ++i) o[q][i] = 0.f;
+    ConstPtr Wj = W;
+#pragma unroll 2
+    for (int j = 0; j < N; ++j, Wj += NB) {
+      float cj[CPT];
+#pragma unroll
+      for (int q = 0; q < CPT; ++q) cj[q] = cs[(q * N + j) * 256];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const float w = Wj[i];
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) o[q][i] += w * cj[q];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+      const int d = d0 + 256 * q;
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+        if (i < N && d < D) g[i * D + d] = o[q][i];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_sum_and_ones(const float* x, float* g_ones, int64_t n, float* out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    s += x[i];
+    if (g_ones) g_ones[i] = 1.0f;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+template <int NT>
+static int launch_gram_nt(hipStream_t st, const AuxArgs& a) {
+  const size_t lds = sizeof(float) * ((size_t)a.D + 4 * NT * NT * 256);
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_aux_gram<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_aux_gram<NT>, dim3(a.B, a.L * 4), dim3(256), lds, st, a);
+  return (int)hipGetLastError();
+}
+static int launch_gram(hipStream_t st, const AuxArgs& a) {
+  switch ((a.N + 15) / 16) {
+    case 1: return launch_gram_nt<1>(st, a);
+    case 2: return launch_gram_nt<2>(st, a);
+    case 3: return launch_gram_nt<3>(st, a);
+    default: return launch_gram_nt<4>(st, a);
+  }
+}
+
+static int nb_of(int N) { return N <= 8 ? 8 : N <= 16 ? 16 : N <= 24 ? 24 : N <= 32 ? 32 : 64; }
+
+template <int NB, int CPT>
+static int launch_grad_cpt(hipStream_t st, const AuxArgs& a) {
+  const size_t lds = sizeof(float) * CPT * a.N * 256;
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_aux_grad<NB, CPT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((k_aux_grad<NB, CPT>), dim3(a.B, a.L * 4), dim3(256), lds, st, a);
+  return (int)hipGetLastError();
+}
+template <int NB>
+static int launch_grad(hipStream_t st, const AuxArgs& a) {
+  constexpr int kMaxCpt = NB <= 24 ? 3 : NB <= 32 ? 2 : 1;      // VGPR (CPT * NB accumulators) and LDS (CPT * N KB) budget
+  const int cpt = (a.D + 255) / 256;
+  if (cpt >= 3 && kMaxCpt >= 3) return launch_grad_cpt<NB, kMaxCpt>(st, a);
+  if (cpt >= 2 && kMaxCpt >= 2) return launch_grad_cpt<NB, (kMaxCpt >= 2 ? 2 : 1)>(st, a);
+  return launch_grad_cpt<NB, 1>(st, a);
+}
+
+size_t aux_ws_floats(const dvgr_dims& d) {
+  const size_t LB = (size_t)d.L * d.B, NN = (size_t)d.N * d.N;
+  return LB * 4 * NN + LB * 4 * (size_t)d.N * nb_of(d.N) + 64;
+}
+
+int aux_losses(hipStream_t st, const dvgr_dims& d, const dvgr_io* io, float alpha, float beta, float dep_scale,
+               float* loss3, float* g_vis, float* const g[4], float* ws) {
+  AuxArgs a{};
+  a.t[0] = io->com_app; a.t[1] = io->com_mot; a.t[2] = io->aq_fusion; a.t[3] = io->mq_fusion;
+  for (int i = 0; i < 4; ++i) a.g[i] = g[i];
+  const size_t LB = (size_t)d.L * d.B, NN = (size_t)d.N * d.N;
+  a.gram = ws; a.wt = a.gram + round64((int64_t)(LB * 4 * NN));
+  a.NBP = nb_of(d.N);
+  a.loss = loss3;
+  a.wc = alpha / ((float)d.L * d.B * d.N * d.N);
+  a.wh = beta * dep_scale / (float)d.L;
+  a.B = d.B; a.N = d.N; a.D = d.D; a.L = d.L;
+  hipError_t e = hipMemsetAsync(loss3, 0, 3 * sizeof(float), st);
+  if (e != hipSuccess) return (int)e;
+  const int64_t nv = (int64_t)d.B * d.N * d.D;
+  hipLaunchKernelGGL(k_sum_and_ones, dim3(256), dim3(256), 0, st, io->vis, g_vis, nv, loss3);
+  DVGR_TRY_HIP(launch_gram(st, a));
+  const size_t lds2 = sizeof(float) * (6 * NN + 6 * d.N + 8);
+  if (lds2 > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_aux_combine), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+  hipLaunchKernelGGL(k_aux_combine, dim3(d.B, d.L), dim3(256), lds2, st, a);
+  if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+  switch (nb_of(d.N)) {
+    case 8: return launch_grad<8>(st, a);
+    case 16: return launch_grad<16>(st, a);
+    case 24: return launch_grad<24>(st, a);
+    case 32: return launch_grad<32>(st, a);
+    default: return launch_grad<64>(st, a);
+  }
+}
+
+}  // namespace dvgr

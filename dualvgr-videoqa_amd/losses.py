@@ -1,13 +1,19 @@
 """Auxiliary losses that consume the unit's list outputs -- the caller-side counterpart of
 train.py:146-154 + utils.py:10-31 of the reference.
 
-Plain PyTorch on whatever device the unit's outputs live on (the reference hard-codes `.cuda()`,
-utils.py:22).  These are harness code around the hot path, not part of the HIP kernels yet
-(SURVEY.md section 8f ranks fusing them with the unit's tail as the next row)."""
+Two implementations of the same arithmetic:
+  * common_loss / loss_dependence / unit_aux_losses / scope_u_loss: plain PyTorch on whatever device the unit's
+    outputs live on (the reference hard-codes `.cuda()`, utils.py:22) -- the readable statement, used by tests;
+  * fused_scope_u_loss / ScopeULoss: the HIP kernels of csrc/dvgr_loss.hip through `dvgr_scope_u_loss`
+    (SURVEY.md section 8f row f1): value and gradient in three launches, no N x N autograd graph."""
 from __future__ import annotations
+
+import ctypes as C
 
 import torch
 import torch.nn.functional as F
+
+from . import _lib as L_
 
 
 def common_loss(emb1: torch.Tensor, emb2: torch.Tensor) -> torch.Tensor:
@@ -41,3 +47,50 @@ def scope_u_loss(outs, num_nodes: int, alpha: float = 1.0, beta: float = 1e-8, w
     vis, _, _, ca, cm, aq, mq = outs
     com, dep = unit_aux_losses(ca, cm, aq, mq, num_nodes)
     return vis.sum() + alpha * com + beta * world_size * dep
+
+
+def fused_scope_u_loss(raw, alpha: float = 1.0, beta: float = 1e-8, world_size: int = 1, g_vis=None):
+    """HIP path of scope_u_loss on the tensors `DualVGRUnit_multiple.forward_raw` returns
+    (vis, aq_embed, mq_embed, com_app, com_mot, aq_fusion, mq_fusion; the lists as (L,B,N,D) tensors).
+
+    Returns (terms, ups): `terms` = device tensor [sum(vis), mean_l common, mean_l dependence] and `ups` = the seven
+    upstream gradients of loss = terms[0] + alpha*terms[1] + beta*world_size*terms[2], in forward_raw's order (None
+    for aq_embed / mq_embed), ready for `torch.autograd.backward(raw, ups)`.  `g_vis`: optional preallocated
+    (B,N,D) tensor that receives d loss / d vis (= 1)."""
+    lib = L_.load()
+    vis, _, _, ca, cm, aq, mq = raw
+    if not vis.is_cuda:
+        raise RuntimeError("fused_scope_u_loss runs on a ROCm device only (no CPU fallback)")
+    vis, ca, cm, aq, mq = (t.detach().contiguous() for t in (vis, ca, cm, aq, mq))
+    Lr, B, N, D = ca.shape
+    dims = L_.make_dims(B, N, 1, D, 4, Lr, 1, L_.DVGR_F32)
+    L_.check(lib.dvgr_check_dims(C.byref(dims)), "dvgr_check_dims")
+    dev = vis.device
+    terms = torch.empty(3, device=dev, dtype=torch.float32)
+    if g_vis is None:
+        g_vis = torch.empty_like(vis)
+    grads = [torch.empty_like(t) for t in (ca, cm, aq, mq)]
+    ws = torch.empty(4 * (Lr * B * (4 * N * N + 4 * N * 64) + 128), device=dev, dtype=torch.uint8)
+    io = L_.IO(None, None, None, None, None, vis.data_ptr(), None, None, ca.data_ptr(), cm.data_ptr(), aq.data_ptr(),
+               mq.data_ptr())
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    L_.check(lib.dvgr_scope_u_loss(C.byref(dims), C.byref(io), float(alpha), float(beta), float(world_size),
+                                   terms.data_ptr(), g_vis.data_ptr(), *[g.data_ptr() for g in grads], ws.data_ptr(),
+                                   ws.numel(), stream), "dvgr_scope_u_loss")
+    return terms, [g_vis, None, None, *grads]
+
+
+class ScopeULoss(torch.autograd.Function):
+    """scope_u_loss as one autograd node: forward runs the fused kernels and keeps the gradients they produce,
+    backward scales them by the incoming scalar."""
+
+    @staticmethod
+    def forward(ctx, alpha, beta, world_size, vis, ca, cm, aq, mq):
+        terms, ups = fused_scope_u_loss((vis, None, None, ca, cm, aq, mq), alpha, beta, world_size)
+        ctx.save_for_backward(ups[0], *ups[3:])
+        ctx.mark_non_differentiable(terms)
+        return terms[0] + alpha * terms[1] + beta * world_size * terms[2], terms
+
+    @staticmethod
+    def backward(ctx, g, _):
+        return (None, None, None, *[g * t for t in ctx.saved_tensors])

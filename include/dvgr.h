@@ -200,6 +200,21 @@ int dvgr_unit_backward(const dvgr_dims *d, const float *params, const void *para
  * (layer == L: the MFB block). */
 int dvgr_param_layer_range(const dvgr_dims *d, int layer, int64_t *first, int64_t *last);
 
+/* Scope-U scalar loss on the unit's outputs, value and gradient in one pass:
+ *   loss = sum(vis) + alpha * mean_l common_loss(com_app_l, com_mot_l)
+ *                   + beta * dep_scale * mean_l [loss_dependence(aq_fusion_l, com_app_l)
+ *                                              + loss_dependence(mq_fusion_l, com_mot_l)]
+ * common_loss / loss_dependence restate utils.py:10-31 of the reference; the weighting is train.py:148-154
+ * (there the first term is the cross-entropy of the classifier, which is outside the unit).
+ * `loss3` (device, 3 floats) receives {sum(vis), mean_l common, mean_l dependence}.  The outputs g_vis (B,N,D;
+ * may be NULL) and g_com_app / g_com_mot / g_aq_fusion / g_mq_fusion (L,B,N,D) receive d loss / d tensor and can be
+ * handed to dvgr_unit_backward as the upstream gradients.  Only io->vis and the four list tensors are read.
+ * `workspace` is the unit's workspace (dvgr_workspace_bytes). */
+int dvgr_scope_u_loss(const dvgr_dims *d, const dvgr_io *io, float alpha, float beta, float dep_scale,
+                      float *loss3, float *g_vis, float *g_com_app, float *g_com_mot,
+                      float *g_aq_fusion, float *g_mq_fusion,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
