@@ -40,10 +40,12 @@ class Grads(C.Structure):
 
 
 class Opts(C.Structure):
-    _fields_ = [("train", C.c_int32), ("probe_site", C.c_int32), ("probe_layer", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("train", C.c_int32), ("probe_site", C.c_int32), ("probe_layer", C.c_int32), ("flags", C.c_int32),
                 ("seed", C.c_uint64), ("probe_begin", C.c_void_p), ("probe_end", C.c_void_p),
                 ("layer_done_events", C.POINTER(C.c_void_p))]
 
+
+OPT_SINGLE_STREAM = 1
 
 # enum dvgr_probe_site
 (PROBE_NONE, PROBE_FWD_QA_GEMM, PROBE_FWD_GAT_GEMM, PROBE_FWD_GAT_ATTN, PROBE_FWD_SF_GEMM, PROBE_FWD_MFB_GEMM,

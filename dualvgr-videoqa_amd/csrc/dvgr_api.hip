@@ -26,9 +26,12 @@ FwdWs fwd_ws(const dvgr_dims& d) {
   return w;
 }
 
+// Buffers written by the critical path of layer l and read by the side stream (weight / bias gradients) exist
+// twice, indexed by l & 1: the critical path may run one layer ahead of the side stream.
 struct BwdWs {
-  int64_t dpo, dzf, dp0, dp1, dw[2], dpre[2], dz[2], dWh[2], ds_part[2], da_part[2], dc_part[2];
-  int64_t dp_cat, dqbar, dr, dy, total;
+  int64_t dpo, dzf, dp0, dp1, dz[2];
+  int64_t dw[2][2], dpre[2][2], dWh[2][2], ds_part[2][2], da_part[2][2], dc_part[2][2], dp_cat[2];   // [set][modality]
+  int64_t dqbar, dr, dy, total;
 };
 BwdWs bwd_ws(const dvgr_dims& d) {
   BwdWs w{};
@@ -38,16 +41,18 @@ BwdWs bwd_ws(const dvgr_dims& d) {
   w.dzf = o; o += round64(BN * kMfbPooled);
   w.dp0 = o; o += round64(BN * kMfbHidden);
   w.dp1 = o; o += round64(BN * kMfbHidden);
-  for (int m = 0; m < 2; ++m) {
-    w.dw[m] = o;      o += round64(2 * BN);
-    w.dpre[m] = o;    o += round64(2 * BN * D);
-    w.dz[m] = o;      o += round64(2 * BN * D);
-    w.dWh[m] = o;     o += round64(BN * kHeads * F);
-    w.ds_part[m] = o; o += round64((int64_t)d.B * kHeads * d.N);
-    w.da_part[m] = o; o += round64((int64_t)d.B * kHeads * 2 * F);
-    w.dc_part[m] = o; o += round64((int64_t)d.B * kHeads);
+  for (int m = 0; m < 2; ++m) { w.dz[m] = o; o += round64(2 * BN * D); }
+  for (int s = 0; s < 2; ++s) {
+    for (int m = 0; m < 2; ++m) {
+      w.dw[s][m] = o;      o += round64(2 * BN);
+      w.dpre[s][m] = o;    o += round64(2 * BN * D);
+      w.dWh[s][m] = o;     o += round64(BN * kHeads * F);
+      w.ds_part[s][m] = o; o += round64((int64_t)d.B * kHeads * d.N);
+      w.da_part[s][m] = o; o += round64((int64_t)d.B * kHeads * 2 * F);
+      w.dc_part[s][m] = o; o += round64((int64_t)d.B * kHeads);
+    }
+    w.dp_cat[s] = o; o += round64((int64_t)d.B * 2 * D);
   }
-  w.dp_cat = o; o += round64((int64_t)d.B * 2 * D);
   w.dqbar = o;  o += round64((int64_t)d.B * d.Wd);
   w.dr = o;     o += round64((int64_t)d.B * d.T);
   w.dy = o;     o += round64((int64_t)d.B * d.T * D);
@@ -145,6 +150,43 @@ struct Probe {
   int begin(int site, int layer) const { return hit(site, layer) ? (int)hipEventRecord((hipEvent_t)o.probe_begin, st) : 0; }
   int end(int site, int layer) const { return hit(site, layer) ? (int)hipEventRecord((hipEvent_t)o.probe_end, st) : 0; }
 };
+
+// Side stream of the backward pass: weight / bias gradients and the query branch are off the critical path
+// (the dX chain), so they run on a second, lower-priority stream and fill the CUs the small critical-path
+// kernels leave idle.  One per device, created on first use; events are recycled call after call (every wait
+// on an event is enqueued right after its record, so a later re-record cannot be observed by it).
+struct SideStream {
+  hipStream_t st = nullptr;
+  hipEvent_t ev[256] = {};
+  int used = 0;
+  int init() {
+    if (st) return 0;
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    return (int)hipStreamCreateWithPriority(&st, hipStreamNonBlocking, lo);
+  }
+  hipEvent_t next() {
+    if (used >= 256) used = 0;
+    if (!ev[used] && hipEventCreateWithFlags(&ev[used], hipEventDisableTiming) != hipSuccess) return nullptr;
+    return ev[used++];
+  }
+  // everything enqueued on `from` so far happens before whatever is enqueued on `to` from now on
+  int order(hipStream_t from, hipStream_t to) {
+    hipEvent_t e = next();
+    if (!e) return (int)hipErrorOutOfMemory;
+    hipError_t r = hipEventRecord(e, from);
+    if (r == hipSuccess) r = hipStreamWaitEvent(to, e, 0);
+    return (int)r;
+  }
+};
+SideStream* side_stream() {
+  static thread_local SideStream per_dev[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  SideStream* s = &per_dev[dev];
+  s->used = 0;
+  return s->init() == 0 ? s : nullptr;
+}
 
 PlaneMap make_plane_map(const dvgr_dims& d, const ParamLayout& P, const SavedLayout& S, const float* params,
                         const void* params_lp, const dvgr_io* io, const float* saved, const float* ws) {
@@ -516,58 +558,75 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     if (e != hipSuccess) return (int)e;
   }
 
+  // Two streams: `st` carries the critical path (the dX chain), `hs` the weight / bias gradients and the query
+  // branch.  DVGR_OPT_SINGLE_STREAM (or a missing side stream) folds everything onto `st`.
+  SideStream* side = ((O.flags & DVGR_OPT_SINGLE_STREAM) || 4 * L + 16 > 256) ? nullptr : side_stream();
+  hipStream_t hs = side ? side->st : st;
+  const Probe hprobe{O, hs};
+  auto to_side = [&]() -> int { return side ? side->order(st, hs) : 0; };     // hs continues after st's work so far
+  auto to_main = [&]() -> int { return side ? side->order(hs, st) : 0; };     // st continues after hs's work so far
+  DVGR_TRY(to_side());
+
   // ---- S6 backward ------------------------------------------------------------------------------------
   {
     uint16_t* dpop = PM.out(ws + W.dpo, &plo);
     DVGR_TRY(elu_bwd(st, g->g_vis, io->vis, ws + W.dpo, BND, dpop, plo));
+    DVGR_TRY(to_side());
   }
   {
-    GemmBatch gb{};   // dWo = dpo^T . z
-    gb.p[gb.n] = tn(ws + W.dpo, D, saved + S.mfb_z, kMfbPooled, gp + P.mfb_wo, kMfbPooled, D, kMfbPooled, BN);
-    PM.attach(gb.p[gb.n++]);
-    DVGR_TRY(gemm_launch(st, IC, IC, gb, TAG_GENERIC, prec));
     GemmBatch gd{};   // dz = dpo . Wo
     gd.p[gd.n] = nn(ws + W.dpo, D, params + P.mfb_wo, kMfbPooled, ws + W.dzf, kMfbPooled, BN, kMfbPooled, D, 0);
     PM.attach(gd.p[gd.n++]);
     DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_GENERIC, prec));
+    GemmBatch gb{};   // dWo = dpo^T . z
+    gb.p[gb.n] = tn(ws + W.dpo, D, saved + S.mfb_z, kMfbPooled, gp + P.mfb_wo, kMfbPooled, D, kMfbPooled, BN);
+    PM.attach(gb.p[gb.n++]);
+    DVGR_TRY(gemm_launch(hs, IC, IC, gb, TAG_GENERIC, prec));
   }
   {
     uint16_t* q0 = PM.out(ws + W.dp0, &plo);
     uint16_t* q1 = PM.out(ws + W.dp1, &plo);
     DVGR_TRY(mfb_pool_bwd(st, ws + W.dzf, saved + S.mfb_x0, saved + S.mfb_x1, ws + W.dp0, ws + W.dp1, BN, q0, q1, plo));
+    DVGR_TRY(to_side());
   }
   {
-    GemmBatch gb{};   // dW0 = dp0^T . A_final, dW1 = dp1^T . M_final
-    gb.p[gb.n] = tn(ws + W.dp0, kMfbHidden, ms(L - 1, 0) + S.x, D, gp + P.mfb_w0, D, kMfbHidden, D, BN);
-    PM.attach(gb.p[gb.n++]);
-    gb.p[gb.n] = tn(ws + W.dp1, kMfbHidden, ms(L - 1, 1) + S.x, D, gp + P.mfb_w1, D, kMfbHidden, D, BN);
-    PM.attach(gb.p[gb.n++]);
-    DVGR_TRY(gemm_launch(st, IC, IC, gb, TAG_GENERIC, prec));
     GemmBatch gd{};   // dA = dp0 . W0, dM = dp1 . W1
     gd.p[gd.n] = nn(ws + W.dp0, kMfbHidden, params + P.mfb_w0, D, dXacc[0], D, BN, D, kMfbHidden, 0);
     PM.attach(gd.p[gd.n++]);
     gd.p[gd.n] = nn(ws + W.dp1, kMfbHidden, params + P.mfb_w1, D, dXacc[1], D, BN, D, kMfbHidden, 0);
     PM.attach(gd.p[gd.n++]);
     DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_GENERIC, prec));
+    GemmBatch gb{};   // dW0 = dp0^T . A_final, dW1 = dp1^T . M_final
+    gb.p[gb.n] = tn(ws + W.dp0, kMfbHidden, ms(L - 1, 0) + S.x, D, gp + P.mfb_w0, D, kMfbHidden, D, BN);
+    PM.attach(gb.p[gb.n++]);
+    gb.p[gb.n] = tn(ws + W.dp1, kMfbHidden, ms(L - 1, 1) + S.x, D, gp + P.mfb_w1, D, kMfbHidden, D, BN);
+    PM.attach(gb.p[gb.n++]);
+    DVGR_TRY(gemm_launch(hs, IC, IC, gb, TAG_GENERIC, prec));
     ColsumBatch cb{};
     cb.j[cb.n++] = ColsumJob{ws + W.dpo, nullptr, nullptr, nullptr, BN, 0, D, D, gp + P.mfb_bo};
     cb.j[cb.n++] = ColsumJob{ws + W.dp0, nullptr, nullptr, nullptr, BN, 0, kMfbHidden, kMfbHidden, gp + P.mfb_b0};
     cb.j[cb.n++] = ColsumJob{ws + W.dp1, nullptr, nullptr, nullptr, BN, 0, kMfbHidden, kMfbHidden, gp + P.mfb_b1};
     cb.chunks = 8;
-    DVGR_TRY(colsum(st, cb));
+    DVGR_TRY(colsum(hs, cb));
   }
   if (layer_done_events && layer_done_events[L]) {
-    const hipError_t e = hipEventRecord((hipEvent_t)layer_done_events[L], st);
+    const hipError_t e = hipEventRecord((hipEvent_t)layer_done_events[L], hs);
     if (e != hipSuccess) return (int)e;
   }
 
   // ---- layers, last to first -----------------------------------------------------------------------
+  hipEvent_t side_done[2] = {nullptr, nullptr};   // side stream finished the layer that used buffer set 0 / 1
   for (int l = L - 1; l >= 0; --l) {
+    const int set = l & 1;
     const Keys K = layer_keys(train, seed, l);
     const float* Xin[2] = {l == 0 ? io->A : ms(l - 1, 0) + S.x, l == 0 ? io->M : ms(l - 1, 1) + S.x};
     const float* outc[2] = {io->com_app + l * BND, io->com_mot + l * BND};
     const float* outs[2] = {io->aq_fusion + l * BND, io->mq_fusion + l * BND};
     ColsumBatch cb{};
+    if (side && side_done[set]) {      // layer l + 2 shared this buffer set
+      const hipError_t e = hipStreamWaitEvent(st, side_done[set], 0);
+      if (e != hipSuccess) return (int)e;
+    }
     // S5/S4 backward, row part
     {
       SfBwdArgs a{};
@@ -580,38 +639,39 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
         const float* gs = m == 0 ? g->g_aq_fusion : g->g_mq_fusion;
         a.g_z0[m] = gc ? gc + l * BND : nullptr;
         a.g_z1[m] = gs ? gs + l * BND : nullptr;
-        a.dw[m] = ws + W.dw[m]; a.dpre[m] = ws + W.dpre[m]; a.dz[m] = ws + W.dz[m];
-        a.dpre_p[m] = PM.out(ws + W.dpre[m], &plo);
+        a.dw[m] = ws + W.dw[set][m]; a.dpre[m] = ws + W.dpre[set][m]; a.dz[m] = ws + W.dz[m];
+        a.dpre_p[m] = PM.out(ws + W.dpre[set][m], &plo);
       }
       a.lo_off = plo;
       a.rows = BN; a.D = D;
       DVGR_TRY(sf_bwd(st, a));
+      DVGR_TRY(to_side());
     }
     for (int m = 0; m < 2; ++m) {
-      cb.j[cb.n++] = ColsumJob{ms(l, m) + S.tn, nullptr, ws + W.dw[m], nullptr, 2 * BN, 0, D, D, gmp(l, m) + P.sf_p2};
-      cb.j[cb.n++] = ColsumJob{ws + W.dpre[m], nullptr, nullptr, nullptr, 2 * BN, 0, D, D, gmp(l, m) + P.sf_bp};
+      cb.j[cb.n++] = ColsumJob{ms(l, m) + S.tn, nullptr, ws + W.dw[set][m], nullptr, 2 * BN, 0, D, D, gmp(l, m) + P.sf_p2};
+      cb.j[cb.n++] = ColsumJob{ws + W.dpre[set][m], nullptr, nullptr, nullptr, 2 * BN, 0, D, D, gmp(l, m) + P.sf_bp};
     }
     {
-      GemmBatch gb{};   // dP1 = sum_v dpre_v^T . z_v   (reduction over the two views = two row segments)
-      for (int m = 0; m < 2; ++m) {
-        GemmProblem p = tn(ws + W.dpre[m], D, outc[m], D, gmp(l, m) + P.sf_p1, D, D, D, 2 * BN);
-        p.kseg = BN;
-        p.A.p1 = ws + W.dpre[m] + BND;
-        p.B.p1 = outs[m];
-        PM.attach(p);
-        gb.p[gb.n++] = p;
-      }
-      DVGR_TRY(probe.begin(DVGR_PROBE_BWD_SF_DW, l));
-      DVGR_TRY(gemm_launch(st, IC, IC, gb, TAG_BWD_SF_DW, prec));
-      DVGR_TRY(probe.end(DVGR_PROBE_BWD_SF_DW, l));
       GemmBatch gd{};   // dz_v += dpre_v . P1
       for (int m = 0; m < 2; ++m) {
-        gd.p[gd.n] = nn(ws + W.dpre[m], D, mp(l, m) + P.sf_p1, D, ws + W.dz[m], D, 2 * BN, D, D, 1);
+        gd.p[gd.n] = nn(ws + W.dpre[set][m], D, mp(l, m) + P.sf_p1, D, ws + W.dz[m], D, 2 * BN, D, D, 1);
         PM.attach(gd.p[gd.n++]);
       }
       DVGR_TRY(probe.begin(DVGR_PROBE_BWD_SF_DX, l));
       DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_BWD_SF_DX, prec));
       DVGR_TRY(probe.end(DVGR_PROBE_BWD_SF_DX, l));
+      GemmBatch gb{};   // dP1 = sum_v dpre_v^T . z_v   (reduction over the two views = two row segments)
+      for (int m = 0; m < 2; ++m) {
+        GemmProblem p = tn(ws + W.dpre[set][m], D, outc[m], D, gmp(l, m) + P.sf_p1, D, D, D, 2 * BN);
+        p.kseg = BN;
+        p.A.p1 = ws + W.dpre[set][m] + BND;
+        p.B.p1 = outs[m];
+        PM.attach(p);
+        gb.p[gb.n++] = p;
+      }
+      DVGR_TRY(hprobe.begin(DVGR_PROBE_BWD_SF_DW, l));
+      DVGR_TRY(gemm_launch(hs, IC, IC, gb, TAG_BWD_SF_DW, prec));
+      DVGR_TRY(hprobe.end(DVGR_PROBE_BWD_SF_DW, l));
     }
     // S3 backward
     {
@@ -620,45 +680,30 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
         a.dz[m] = ws + W.dz[m]; a.out_c[m] = outc[m]; a.out_s[m] = outs[m];
         a.Wh[m] = ms(l, m) + S.wh; a.s[m] = ms(l, m) + S.s; a.u[m] = ms(l, m) + S.u; a.v[m] = ms(l, m) + S.v;
         a.gat_a[m] = mp(l, m) + P.gat_a; a.gat_c[m] = mp(l, m) + P.gat_c;
-        a.dWh[m] = ws + W.dWh[m]; a.ds_part[m] = ws + W.ds_part[m]; a.da_part[m] = ws + W.da_part[m];
-        a.dc_part[m] = ws + W.dc_part[m];
+        a.dWh[m] = ws + W.dWh[set][m]; a.ds_part[m] = ws + W.ds_part[set][m]; a.da_part[m] = ws + W.da_part[set][m];
+        a.dc_part[m] = ws + W.dc_part[set][m];
         for (int h = 0; h < 8; ++h) a.key_alpha[m][h] = K.alpha[m][h];
         for (int gi = 0; gi < 2; ++gi) a.key_out[m][gi] = K.out[m][gi];
-        a.dWh_p[m] = PM.out(ws + W.dWh[m], &plo);
+        a.dWh_p[m] = PM.out(ws + W.dWh[set][m], &plo);
       }
       a.lo_off = plo;
       a.B = B; a.N = N; a.D = D;
       DVGR_TRY(probe.begin(DVGR_PROBE_BWD_GAT_ATTN, l));
       DVGR_TRY(gat_attn_bwd(st, a));
       DVGR_TRY(probe.end(DVGR_PROBE_BWD_GAT_ATTN, l));
+      DVGR_TRY(to_side());
     }
     for (int m = 0; m < 2; ++m) {
-      cb.j[cb.n++] = ColsumJob{ws + W.da_part[m], nullptr, nullptr, nullptr, B, 0, kHeads * 2 * F, kHeads * 2 * F, gmp(l, m) + P.gat_a};
-      cb.j[cb.n++] = ColsumJob{ws + W.dc_part[m], nullptr, nullptr, nullptr, B, 0, kHeads, kHeads, gmp(l, m) + P.gat_c};
-      cb.j[cb.n++] = ColsumJob{ws + W.dWh[m], nullptr, nullptr, nullptr, BN, 0, HF, HF, gmp(l, m) + P.gat_b};
+      cb.j[cb.n++] = ColsumJob{ws + W.da_part[set][m], nullptr, nullptr, nullptr, B, 0, kHeads * 2 * F, kHeads * 2 * F, gmp(l, m) + P.gat_a};
+      cb.j[cb.n++] = ColsumJob{ws + W.dc_part[set][m], nullptr, nullptr, nullptr, B, 0, kHeads, kHeads, gmp(l, m) + P.gat_c};
+      cb.j[cb.n++] = ColsumJob{ws + W.dWh[set][m], nullptr, nullptr, nullptr, BN, 0, HF, HF, gmp(l, m) + P.gat_b};
     }
-    // S2 backward: dWcat = dWh^T . drop_x(X);  dX += drop_x(dWh . Wcat)
+    // S2 backward: dX += drop_x(dWh . Wcat) on the critical path;  dWcat = dWh^T . drop_x(X) on the side stream
     {
-      GemmBatch gb{};
-      for (int m = 0; m < 2; ++m) {
-        if (!train) {
-          gb.p[gb.n] = tn(ws + W.dWh[m], HF, Xin[m], D, gmp(l, m) + P.gat_w, D, HF, D, BN);
-          PM.attach(gb.p[gb.n++]);
-        } else {
-          for (int gi = 0; gi < 2; ++gi) {
-            gb.p[gb.n] = tn(ws + W.dWh[m] + gi * 4 * F, HF, ms(l, m) + S.xd + gi * BND, D,
-                            gmp(l, m) + P.gat_w + (int64_t)gi * 4 * F * D, D, 4 * F, D, BN);
-            PM.attach(gb.p[gb.n++]);
-          }
-        }
-      }
-      DVGR_TRY(probe.begin(DVGR_PROBE_BWD_GAT_DW, l));
-      DVGR_TRY(gemm_launch(st, IC, IC, gb, TAG_BWD_GAT_DW, prec));
-      DVGR_TRY(probe.end(DVGR_PROBE_BWD_GAT_DW, l));
       if (!train) {
         GemmBatch gd{};
         for (int m = 0; m < 2; ++m) {
-          gd.p[gd.n] = nn(ws + W.dWh[m], HF, mp(l, m) + P.gat_w, D, dXacc[m], D, BN, D, HF, 1);
+          gd.p[gd.n] = nn(ws + W.dWh[set][m], HF, mp(l, m) + P.gat_w, D, dXacc[m], D, BN, D, HF, 1);
           PM.attach(gd.p[gd.n++]);
         }
         DVGR_TRY(probe.begin(DVGR_PROBE_BWD_GAT_DX, l));
@@ -668,7 +713,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
         for (int gi = 0; gi < 2; ++gi) {   // the two GATs dropped x with different masks: two passes
           GemmBatch gd{};
           for (int m = 0; m < 2; ++m) {
-            gd.p[gd.n] = nn(ws + W.dWh[m] + gi * 4 * F, HF, mp(l, m) + P.gat_w + (int64_t)gi * 4 * F * D, D, dXacc[m], D,
+            gd.p[gd.n] = nn(ws + W.dWh[set][m] + gi * 4 * F, HF, mp(l, m) + P.gat_w + (int64_t)gi * 4 * F * D, D, dXacc[m], D,
                             BN, D, 4 * F, 1, K.x[m][gi]);
             PM.attach(gd.p[gd.n++]);
           }
@@ -677,36 +722,54 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
           if (gi == 1) DVGR_TRY(probe.end(DVGR_PROBE_BWD_GAT_DX, l));
         }
       }
+      GemmBatch gb{};
+      for (int m = 0; m < 2; ++m) {
+        if (!train) {
+          gb.p[gb.n] = tn(ws + W.dWh[set][m], HF, Xin[m], D, gmp(l, m) + P.gat_w, D, HF, D, BN);
+          PM.attach(gb.p[gb.n++]);
+        } else {
+          for (int gi = 0; gi < 2; ++gi) {
+            gb.p[gb.n] = tn(ws + W.dWh[set][m] + gi * 4 * F, HF, ms(l, m) + S.xd + gi * BND, D,
+                            gmp(l, m) + P.gat_w + (int64_t)gi * 4 * F * D, D, 4 * F, D, BN);
+            PM.attach(gb.p[gb.n++]);
+          }
+        }
+      }
+      DVGR_TRY(hprobe.begin(DVGR_PROBE_BWD_GAT_DW, l));
+      DVGR_TRY(gemm_launch(hs, IC, IC, gb, TAG_BWD_GAT_DW, prec));
+      DVGR_TRY(hprobe.end(DVGR_PROBE_BWD_GAT_DW, l));
     }
     // S1 backward
     {
       PunishBwdArgs a{};
       for (int m = 0; m < 2; ++m) {
-        a.ds_part[m] = ws + W.ds_part[m]; a.s[m] = ms(l, m) + S.s; a.p[m] = ms(l, m) + S.p;
+        a.ds_part[m] = ws + W.ds_part[set][m]; a.s[m] = ms(l, m) + S.s; a.p[m] = ms(l, m) + S.p;
         a.X[m] = Xin[m]; a.dX[m] = dXacc[m];
       }
-      a.dp_cat = ws + W.dp_cat; a.B = B; a.N = N; a.D = D;
+      a.dp_cat = ws + W.dp_cat[set]; a.B = B; a.N = N; a.D = D;
       DVGR_TRY(punish_bwd(st, a));
+      DVGR_TRY(to_side());
     }
+    // ---- everything below is off the critical path: query branch of this layer, bias gradients ----
     {
       GemmBatch gb{};   // dWq[m] = dp[m]^T . q
       for (int m = 0; m < 2; ++m)
-        gb.p[gb.n++] = tn(ws + W.dp_cat + m * D, 2 * D, ls(l) + S.qa_q, Wd, gmp(l, m) + P.wq, Wd, D, Wd, B);
-      DVGR_TRY(gemm_launch(st, IC, IC, gb, TAG_GENERIC, prec));
+        gb.p[gb.n++] = tn(ws + W.dp_cat[set] + m * D, 2 * D, ls(l) + S.qa_q, Wd, gmp(l, m) + P.wq, Wd, D, Wd, B);
+      DVGR_TRY(gemm_launch(hs, IC, IC, gb, TAG_GENERIC, prec));
       for (int m = 0; m < 2; ++m)
-        cb.j[cb.n++] = ColsumJob{ws + W.dp_cat + m * D, nullptr, nullptr, nullptr, B, 0, D, 2 * D, gmp(l, m) + P.bq};
+        cb.j[cb.n++] = ColsumJob{ws + W.dp_cat[set] + m * D, nullptr, nullptr, nullptr, B, 0, D, 2 * D, gmp(l, m) + P.bq};
       GemmBatch gd{};   // dqbar = [dp_app | dp_mot] . [Wq_app ; Wq_mot]
-      GemmProblem p = nn(ws + W.dp_cat, 2 * D, mp(l, 0) + P.wq, Wd, ws + W.dqbar, Wd, B, Wd, 2 * D, 0);
+      GemmProblem p = nn(ws + W.dp_cat[set], 2 * D, mp(l, 0) + P.wq, Wd, ws + W.dqbar, Wd, B, Wd, 2 * D, 0);
       p.kseg = D;
       p.B.p1 = mp(l, 1) + P.wq;
       p.atomic_ok = 1;                       // 3 output tiles x 48 K-tiles: split K, partials added atomically
       p.accumulate = 1;
       {
-        const hipError_t e = hipMemsetAsync(ws + W.dqbar, 0, (size_t)B * Wd * sizeof(float), st);
+        const hipError_t e = hipMemsetAsync(ws + W.dqbar, 0, (size_t)B * Wd * sizeof(float), hs);
         if (e != hipSuccess) return (int)e;
       }
       gd.p[gd.n++] = p;
-      DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_GENERIC, prec));
+      DVGR_TRY(gemm_launch(hs, KC, IC, gd, TAG_GENERIC, prec));
     }
     // S0 backward for this layer
     {
@@ -719,28 +782,34 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       a.first = (l == L - 1) ? 1 : 0;
       a.dy_p = PM.out(ws + W.dy, &plo);
       a.lo_off = plo;
-      DVGR_TRY(qa_bwd(st, a));
+      DVGR_TRY(qa_bwd(hs, a));
       GemmBatch gb{};   // dW1 = dy^T . dq
       gb.p[gb.n] = tn(ws + W.dy, D, io->dq, D, glp(l) + P.qa_w1, D, D, D, BT);
       PM.attach(gb.p[gb.n++]);
-      DVGR_TRY(gemm_launch(st, IC, IC, gb, TAG_GENERIC, prec));
+      DVGR_TRY(gemm_launch(hs, IC, IC, gb, TAG_GENERIC, prec));
       GemmBatch gd{};   // d(dq) (+)= dy . W1
       gd.p[gd.n] = nn(ws + W.dy, D, lp(l) + P.qa_w1, D, g->gdq, D, BT, D, D, 1);
       PM.attach(gd.p[gd.n++]);
       gd.p[0].atomic_ok = 1;
-      DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_GENERIC, prec));
+      DVGR_TRY(gemm_launch(hs, KC, IC, gd, TAG_GENERIC, prec));
       cb.j[cb.n++] = ColsumJob{ws + W.dy, nullptr, nullptr, nullptr, BT, 0, D, D, glp(l) + P.qa_b1};
       cb.j[cb.n++] = ColsumJob{ls(l) + S.qa_d, nullptr, ws + W.dr, nullptr, BT, 0, D, D, glp(l) + P.qa_w2};
       cb.j[cb.n++] = ColsumJob{ws + W.dr, nullptr, nullptr, nullptr, BT, 0, 1, 1, glp(l) + P.qa_b2};
     }
     cb.chunks = 8;
-    DVGR_TRY(colsum(st, cb));
+    DVGR_TRY(colsum(hs, cb));
     if (layer_done_events && layer_done_events[l]) {
-      const hipError_t e = hipEventRecord((hipEvent_t)layer_done_events[l], st);
+      const hipError_t e = hipEventRecord((hipEvent_t)layer_done_events[l], hs);
+      if (e != hipSuccess) return (int)e;
+    }
+    if (side) {
+      side_done[set] = side->next();
+      if (!side_done[set]) return (int)hipErrorOutOfMemory;
+      const hipError_t e = hipEventRecord(side_done[set], hs);
       if (e != hipSuccess) return (int)e;
     }
   }
-  return 0;
+  return to_main();      // the caller's stream sees every gradient
 }
 
 

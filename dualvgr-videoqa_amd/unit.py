@@ -19,6 +19,7 @@ graph_layers must be 1 (every reference config uses 1).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Tuple
 
 import torch
@@ -174,6 +175,7 @@ class _UnitFn(torch.autograd.Function):
                                        saved.numel(), ws.data_ptr(), ws.numel(), C.byref(opts), stream),
                  "dvgr_unit_forward")
         ctx.mod, ctx.dims, ctx.train, ctx.seed = mod, dims, train, seed
+        ctx.set_materialize_grads(False)     # outputs nobody differentiates arrive as None = NULL in dvgr_grads
         ctx.save_for_backward(A, M, dq, words, qlen, vis, aqe, mqe, *lists, saved, flat)
         mod.last_saved = saved if mod.keep_saved else None
         return (vis, aqe, mqe, *lists)
@@ -278,6 +280,7 @@ class DualVGRUnit_multiple(nn.Module):
         self.no_planes = False       # diagnostics: bf16 modes convert inside the contraction kernels instead
         self.forced_seed = None      # tests: fix the dropout seed of the next forward
         self.keep_saved = False      # tests: keep a handle on the saved-for-backward buffer
+        self.single_stream = bool(int(os.environ.get("DVGR_SINGLE_STREAM", "0")))   # DVGR_OPT_SINGLE_STREAM
         self.last_saved = None
         self.last_flat_grad = None
         self._grad_flat = None       # persistent flat gradient buffer (grad_mode='flat')
@@ -406,6 +409,8 @@ class DualVGRUnit_multiple(nn.Module):
     def make_opts(self, train: bool, seed: int, backward: bool) -> "L_.Opts":
         o = L_.Opts()
         o.train, o.seed = int(bool(train)), int(seed)
+        if self.single_stream:
+            o.flags |= L_.OPT_SINGLE_STREAM
         if self._probe is not None:
             site, layer, b, e = self._probe
             if (site >= L_.PROBE_BWD_SF_DW) == backward:

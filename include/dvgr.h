@@ -163,12 +163,18 @@ enum dvgr_probe_site {
   DVGR_PROBE_SITES
 };
 
+/* dvgr_opts.flags.  By default the backward enqueues the weight / bias gradients and the query branch on an
+ * internal lower-priority side stream (one per device, created on first use) so that they overlap the small
+ * kernels of the dX chain; the side stream forks from and joins back into `stream` inside the call, so the
+ * caller sees ordinary single-stream semantics.  DVGR_OPT_SINGLE_STREAM keeps every launch on `stream`. */
+#define DVGR_OPT_SINGLE_STREAM 1
+
 /* Per-call options of forward / backward (all fields may be zero). */
 typedef struct dvgr_opts {
   int32_t train;       /* != 0: the 24 dropout sites per layer are active (p = 0.15, F.dropout semantics) */
   int32_t probe_site;  /* enum dvgr_probe_site, bracketed at layer `probe_layer`                           */
   int32_t probe_layer;
-  int32_t reserved;
+  int32_t flags;       /* DVGR_OPT_* bits                                                                  */
   uint64_t seed;       /* key of the counter-based dropout RNG; masks are recomputed, never stored         */
   void *probe_begin;   /* hipEvent_t, recorded before the probed launch (nullable)                         */
   void *probe_end;     /* hipEvent_t, recorded after it                                                    */
