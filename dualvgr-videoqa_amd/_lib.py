@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdvgr_hip.so")
+LIB_PATH = os.environ.get("DVGR_LIB") or os.path.join(_HERE, "libdvgr_hip.so")   # DVGR_LIB: debug builds only
 
 DVGR_F32, DVGR_BF16, DVGR_BF16X3 = 0, 1, 2
 

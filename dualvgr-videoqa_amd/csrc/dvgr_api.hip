@@ -623,6 +623,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     const float* outc[2] = {io->com_app + l * BND, io->com_mot + l * BND};
     const float* outs[2] = {io->aq_fusion + l * BND, io->mq_fusion + l * BND};
     ColsumBatch cb{};
+    GemmBatch sf_dw{};
     if (side && side_done[set]) {      // layer l + 2 shared this buffer set
       const hipError_t e = hipStreamWaitEvent(st, side_done[set], 0);
       if (e != hipSuccess) return (int)e;
@@ -669,9 +670,12 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
         PM.attach(p);
         gb.p[gb.n++] = p;
       }
-      DVGR_TRY(hprobe.begin(DVGR_PROBE_BWD_SF_DW, l));
-      DVGR_TRY(gemm_launch(hs, IC, IC, gb, TAG_BWD_SF_DW, prec));
-      DVGR_TRY(hprobe.end(DVGR_PROBE_BWD_SF_DW, l));
+      sf_dw = gb;
+      if (l > 0) {
+        DVGR_TRY(hprobe.begin(DVGR_PROBE_BWD_SF_DW, l));
+        DVGR_TRY(gemm_launch(hs, IC, IC, sf_dw, TAG_BWD_SF_DW, prec));
+        DVGR_TRY(hprobe.end(DVGR_PROBE_BWD_SF_DW, l));
+      }
     }
     // S3 backward
     {
@@ -691,12 +695,22 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       DVGR_TRY(probe.begin(DVGR_PROBE_BWD_GAT_ATTN, l));
       DVGR_TRY(gat_attn_bwd(st, a));
       DVGR_TRY(probe.end(DVGR_PROBE_BWD_GAT_ATTN, l));
-      DVGR_TRY(to_side());
     }
     for (int m = 0; m < 2; ++m) {
       cb.j[cb.n++] = ColsumJob{ws + W.da_part[set][m], nullptr, nullptr, nullptr, B, 0, kHeads * 2 * F, kHeads * 2 * F, gmp(l, m) + P.gat_a};
       cb.j[cb.n++] = ColsumJob{ws + W.dc_part[set][m], nullptr, nullptr, nullptr, B, 0, kHeads, kHeads, gmp(l, m) + P.gat_c};
       cb.j[cb.n++] = ColsumJob{ws + W.dWh[set][m], nullptr, nullptr, nullptr, BN, 0, HF, HF, gmp(l, m) + P.gat_b};
+    }
+    // S1 backward (only adds into dX, so it can precede the S2 contraction: the query branch starts earlier)
+    {
+      PunishBwdArgs a{};
+      for (int m = 0; m < 2; ++m) {
+        a.ds_part[m] = ws + W.ds_part[set][m]; a.s[m] = ms(l, m) + S.s; a.p[m] = ms(l, m) + S.p;
+        a.X[m] = Xin[m]; a.dX[m] = dXacc[m];
+      }
+      a.dp_cat = ws + W.dp_cat[set]; a.B = B; a.N = N; a.D = D;
+      DVGR_TRY(punish_bwd(st, a));
+      DVGR_TRY(to_side());
     }
     // S2 backward: dX += drop_x(dWh . Wcat) on the critical path;  dWcat = dWh^T . drop_x(X) on the side stream
     {
@@ -735,20 +749,18 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
           }
         }
       }
-      DVGR_TRY(hprobe.begin(DVGR_PROBE_BWD_GAT_DW, l));
-      DVGR_TRY(gemm_launch(hs, IC, IC, gb, TAG_BWD_GAT_DW, prec));
-      DVGR_TRY(hprobe.end(DVGR_PROBE_BWD_GAT_DW, l));
-    }
-    // S1 backward
-    {
-      PunishBwdArgs a{};
-      for (int m = 0; m < 2; ++m) {
-        a.ds_part[m] = ws + W.ds_part[set][m]; a.s[m] = ms(l, m) + S.s; a.p[m] = ms(l, m) + S.p;
-        a.X[m] = Xin[m]; a.dX[m] = dXacc[m];
+      // the last layer processed has no successor to overlap with: its weight-gradient contractions follow the dX
+      // chain on the main stream while the side stream works through the query branch
+      const Probe& wp = l > 0 ? hprobe : probe;
+      hipStream_t wst = l > 0 ? hs : st;
+      if (l == 0) {
+        DVGR_TRY(wp.begin(DVGR_PROBE_BWD_SF_DW, l));
+        DVGR_TRY(gemm_launch(wst, IC, IC, sf_dw, TAG_BWD_SF_DW, prec));
+        DVGR_TRY(wp.end(DVGR_PROBE_BWD_SF_DW, l));
       }
-      a.dp_cat = ws + W.dp_cat[set]; a.B = B; a.N = N; a.D = D;
-      DVGR_TRY(punish_bwd(st, a));
-      DVGR_TRY(to_side());
+      DVGR_TRY(wp.begin(DVGR_PROBE_BWD_GAT_DW, l));
+      DVGR_TRY(gemm_launch(wst, IC, IC, gb, TAG_BWD_GAT_DW, prec));
+      DVGR_TRY(wp.end(DVGR_PROBE_BWD_GAT_DW, l));
     }
     // ---- everything below is off the critical path: query branch of this layer, bias gradients ----
     {
@@ -798,7 +810,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     }
     cb.chunks = 8;
     DVGR_TRY(colsum(hs, cb));
-    if (layer_done_events && layer_done_events[l]) {
+    if (l > 0 && layer_done_events && layer_done_events[l]) {
       const hipError_t e = hipEventRecord((hipEvent_t)layer_done_events[l], hs);
       if (e != hipSuccess) return (int)e;
     }
@@ -809,7 +821,12 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       if (e != hipSuccess) return (int)e;
     }
   }
-  return to_main();      // the caller's stream sees every gradient
+  DVGR_TRY(to_main());   // the caller's stream sees every gradient
+  if (layer_done_events && layer_done_events[0]) {   // layer 0's weight gradients were split over both streams
+    const hipError_t e = hipEventRecord((hipEvent_t)layer_done_events[0], st);
+    if (e != hipSuccess) return (int)e;
+  }
+  return 0;
 }
 
 

@@ -145,15 +145,31 @@ __device__ __forceinline__ float drop_factor(uint32_t key, uint32_t idx) {
 // ---------------------------------------------------------------------------------------------
 // Small device helpers
 // ---------------------------------------------------------------------------------------------
+// Wave-wide reductions on the DPP cross-lane path (VALU speed; the ds_bpermute butterfly that __shfl_xor compiles
+// to costs ~100 cycles per step).  Quads, then rows of 16, then row_bcast 15 / 31 carry the partials up to lane 63;
+// v_readlane broadcasts the result to every lane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float identity, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_move<0xb1, 0xf>(0.f, v);    // quad_perm [1,0,3,2]
+  v += dpp_move<0x4e, 0xf>(0.f, v);    // quad_perm [2,3,0,1]
+  v += dpp_move<0x114, 0xf>(0.f, v);   // row_shr 4
+  v += dpp_move<0x118, 0xf>(0.f, v);   // row_shr 8
+  v += dpp_move<0x142, 0xa>(0.f, v);   // row_bcast 15 -> rows 1, 3
+  v += dpp_move<0x143, 0xc>(0.f, v);   // row_bcast 31 -> rows 2, 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  const float ninf = -INFINITY;
+  v = fmaxf(v, dpp_move<0xb1, 0xf>(ninf, v));
+  v = fmaxf(v, dpp_move<0x4e, 0xf>(ninf, v));
+  v = fmaxf(v, dpp_move<0x114, 0xf>(ninf, v));
+  v = fmaxf(v, dpp_move<0x118, 0xf>(ninf, v));
+  v = fmaxf(v, dpp_move<0x142, 0xa>(ninf, v));
+  v = fmaxf(v, dpp_move<0x143, 0xc>(ninf, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float elu_f(float x) { return x > 0.0f ? x : expm1f(x); }
 // d ELU(P)/dP from the output value O = ELU(P)

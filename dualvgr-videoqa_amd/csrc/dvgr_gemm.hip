@@ -6,6 +6,8 @@
 //                   accumulate; TERMS = 1 (plain bf16) or 3 ("bf16x3": x = hi + lo with hi = bf16(x),
 //                   lo = bf16(x - hi); a.b ~ hi.hi + hi.lo + lo.hi, relative error ~2^-16 per product,
 //                   i.e. fp32-grade results at 3/16 of the fp32-MFMA cost).
+#include <stdlib.h>
+
 #include "dvgr_gemm.h"
 
 namespace dvgr {
@@ -775,7 +777,7 @@ __device__ __forceinline__ bf16x8 planes_frag(const uint16_t* tile, int idx16, i
   }
 }
 
-template <int LA, int LB, int TAG, int TERMS>
+template <int LA, int LB, int TAG, int TERMS, int NS = RS>
 __global__ __launch_bounds__(768) void gemm_planes_kernel(const GemmBatch batch) {
   const GemmProblem P = batch.p[blockIdx.z];
   int m0, n0;
@@ -784,7 +786,7 @@ __global__ __launch_bounds__(768) void gemm_planes_kernel(const GemmBatch batch)
   constexpr int kPlanes = (TERMS == 3) ? 2 : 1;
   constexpr int kSlot = 2 * kPlanes * kPlaneTile;              // A planes, then B planes
   constexpr int kEpi = 8 * 32 * (16 * 2 + 4) * 2;              // epilogue scratch (8 waves), in bf16-sized elements
-  constexpr int kLds = (RS * kSlot) > kEpi ? (RS * kSlot) : kEpi;
+  constexpr int kLds = (NS * kSlot) > kEpi ? (NS * kSlot) : kEpi;
   __shared__ __attribute__((aligned(16))) uint16_t smem[kLds];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave12 = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -804,14 +806,14 @@ __global__ __launch_bounds__(768) void gemm_planes_kernel(const GemmBatch batch)
     planes_prep<LA>(P.A, m0, P.M, wave, lane, offA);
     planes_prep<LB>(P.B, n0, P.N, wave, lane, offB);
 #pragma unroll
-    for (int s = 0; s < RS - 1; ++s)
+    for (int s = 0; s < NS - 1; ++s)
       if (s < nk) {
         planes_issue<LA, TERMS>(P.A, (kbeg + s) * BK, P.kseg, wave, lane, offA, smem + s * kSlot);
         planes_issue<LB, TERMS>(P.B, (kbeg + s) * BK, P.kseg, wave, lane, offB, smem + s * kSlot + kPlanes * kPlaneTile);
       }
     for (int kt = 0; kt < nk; ++kt) {
       // 4 * kPlanes DMA instructions per K-tile from this wave: keep the (up to two) younger tiles in flight
-      const int younger = nk - 1 - kt;
+      const int younger = (nk - 1 - kt) < NS - 2 ? (nk - 1 - kt) : NS - 2;
       if (TERMS == 3) {
         if (younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -822,10 +824,10 @@ __global__ __launch_bounds__(768) void gemm_planes_kernel(const GemmBatch batch)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_s_barrier();
-      if (kt + RS - 1 < nk) {
-        uint16_t* dst = smem + ((kt + RS - 1) % RS) * kSlot;
-        planes_issue<LA, TERMS>(P.A, (kbeg + kt + RS - 1) * BK, P.kseg, wave, lane, offA, dst);
-        planes_issue<LB, TERMS>(P.B, (kbeg + kt + RS - 1) * BK, P.kseg, wave, lane, offB, dst + kPlanes * kPlaneTile);
+      if (kt + NS - 1 < nk) {
+        uint16_t* dst = smem + ((kt + NS - 1) % NS) * kSlot;
+        planes_issue<LA, TERMS>(P.A, (kbeg + kt + NS - 1) * BK, P.kseg, wave, lane, offA, dst);
+        planes_issue<LB, TERMS>(P.B, (kbeg + kt + NS - 1) * BK, P.kseg, wave, lane, offB, dst + kPlanes * kPlaneTile);
       }
     }
     __builtin_amdgcn_s_barrier();
@@ -841,7 +843,7 @@ __global__ __launch_bounds__(768) void gemm_planes_kernel(const GemmBatch batch)
 
   for (int kt = 0; kt < nk; ++kt) {
     __builtin_amdgcn_s_barrier();
-    const uint16_t* curA = smem + (kt % RS) * kSlot;
+    const uint16_t* curA = smem + (kt % NS) * kSlot;
     const uint16_t* curB = curA + kPlanes * kPlaneTile;
     bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
 #pragma unroll
@@ -912,6 +914,7 @@ static int launch_ring(hipStream_t stream, const GemmBatch& b, int prec) {
   }
   const dim3 grid(8 * ((tiles + 7) / 8), split, b.n), block(768);
   if (prec != DVGR_F32 && planes_eligible(b, LA, LB)) {
+    // (2 ring slots = 64 KB would let two workgroups share a CU; measured slower alone and under the side stream)
     if (prec == DVGR_BF16X3) hipLaunchKernelGGL((gemm_planes_kernel<LA, LB, TAG, 3>), grid, block, 0, stream, b);
     else hipLaunchKernelGGL((gemm_planes_kernel<LA, LB, TAG, 1>), grid, block, 0, stream, b);
     return (int)hipGetLastError();

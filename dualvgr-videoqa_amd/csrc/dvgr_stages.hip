@@ -6,6 +6,19 @@ namespace dvgr {
 
 #define DVGR_LAUNCH_CHECK() return (int)hipGetLastError()
 
+// Phase clocks (debug builds only, `make clk`): thread 0 of every workgroup stamps the 100 MHz wall clock at phase
+// boundaries; tools/phase_clocks.py reads them back through dvgr_dbg_clocks.
+#ifdef DVGR_CLK
+__device__ long long g_clk[4096 * 8];
+#define CLK(k)                                                                                          \
+  do {                                                                                                  \
+    const int wg_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;                    \
+    if (threadIdx.x == 0 && wg_ < 4096) g_clk[wg_ * 8 + (k)] = wall_clock64();                         \
+  } while (0)
+#else
+#define CLK(k) do { } while (0)
+#endif
+
 // =================================================================================================
 // S0 rows forward.  grid (B, L), 256 threads.  model/utils.py:68-82
 // =================================================================================================
@@ -103,7 +116,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_fwd(const GatAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int b = blockIdx.x, h = blockIdx.y, mod = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int N = a.N, D = a.D, F = D / 4, FS = F + 1, HF = kHeads * F;
+  const int N = a.N, D = a.D, F = D / 4, FS = F + 4, HF = kHeads * F;   // FS: 16-byte aligned rows
   float* shZ = sm;                 // [N][FS]  Wh tile, later s_j * Wh_j
   float* shAT = shZ + ((N * FS + 3) & ~3);   // [N][NB] dropped attention, TRANSPOSED: shAT[j][i]
   float* shAl = shAT + N * NB;     // [F]
@@ -112,13 +125,34 @@ __global__ __launch_bounds__(256) void k_gat_attn_fwd(const GatAttnArgs a) {
   float* shU = shS + N;            // [N]
   float* shV = shU + N;            // [N]
   const float* Wh = a.Wh[mod] + (int64_t)b * N * HF + h * F;
+  CLK(0);
+  {                                                         // the tile as float4s, four independent loads in flight
+    const int F4 = F / 4, total = N * F4;
+    for (int base = 0; base < total; base += 1024) {
+      float4 v[4];
+      int dst[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int idx = base + r * 256 + tid;
+        dst[r] = -1;
+        if (idx < total) {
+          const int j = idx / F4, q = idx - j * F4;
+          v[r] = *reinterpret_cast<const float4*>(Wh + (int64_t)j * HF + 4 * q);
+          dst[r] = j * FS + 4 * q;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (dst[r] >= 0) *reinterpret_cast<float4*>(shZ + dst[r]) = v[r];
+    }
+  }
   for (int f = tid; f < F; f += 256) {
-    for (int j = 0; j < N; ++j) shZ[j * FS + f] = Wh[(int64_t)j * HF + f];
     shAl[f] = a.gat_a[mod][h * 2 * F + f];
     shAr[f] = a.gat_a[mod][h * 2 * F + F + f];
   }
   if (tid < N) shS[tid] = a.s[mod][b * N + tid];
   __syncthreads();
+  CLK(1);
   for (int i = wave; i < N; i += 4) {                       // u_i = a_l . Wh_i, v_i = a_r . Wh_i
     float pu = 0.f, pv = 0.f;
     for (int f = lane; f < F; f += 64) {
@@ -134,6 +168,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_fwd(const GatAttnArgs a) {
     }
   }
   __syncthreads();
+  CLK(2);
   {                                                         // softmax over j of LeakyReLU(u_i + v_j + c): one wave per row
     const float c = a.gat_c[mod][h];
     const uint32_t key = a.key_alpha[mod][h];
@@ -149,6 +184,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_fwd(const GatAttnArgs a) {
   for (int f = tid; f < F; f += 256)                        // punish AFTER the logits (GraphNN.py:102-104)
     for (int j = 0; j < N; ++j) shZ[j * FS + f] *= shS[j];
   __syncthreads();
+  CLK(3);
   const int g = h >> 2, hl = h & 3;
   float* out = (g ? a.out_s[mod] : a.out_c[mod]) + (int64_t)b * N * D + hl * F;
   const uint32_t ko = a.key_out[mod][g];
@@ -166,6 +202,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_fwd(const GatAttnArgs a) {
         acc[4 * i4 + 2] += a4.z * z; acc[4 * i4 + 3] += a4.w * z;
       }
     }
+    CLK(4);
 #pragma unroll
     for (int i = 0; i < NB; ++i)
       if (i < N) {
@@ -175,10 +212,11 @@ __global__ __launch_bounds__(256) void k_gat_attn_fwd(const GatAttnArgs a) {
         split_store1(zp, a.z_lo_off, (int64_t)b * N * D + hl * F + o, val);
       }
   }
+  CLK(5);
 }
 
 static size_t gat_fwd_lds(int N, int NB, int F) {
-  return sizeof(float) * ((((size_t)N * (F + 1) + 3) & ~(size_t)3) + (size_t)N * NB + 2 * F + 3 * N);
+  return sizeof(float) * ((((size_t)N * (F + 4) + 3) & ~(size_t)3) + (size_t)N * NB + 2 * F + 3 * N);
 }
 static int gat_nb(int N) { return N <= 8 ? 8 : N <= 16 ? 16 : N <= 24 ? 24 : N <= 32 ? 32 : 64; }
 
@@ -394,14 +432,40 @@ __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
   const float* outp = (g ? a.out_s[mod] : a.out_c[mod]) + (int64_t)b * N * D + hl * F;
   const uint32_t ko = a.key_out[mod][g];
   const uint32_t ka = a.key_alpha[mod][h];
-  for (int f = tid; f < F; f += 256) {
-    for (int i = 0; i < N; ++i) {
-      shW[i * FS + f] = Wh[(int64_t)i * HF + f];
-      const int64_t o = (int64_t)i * D + f;
-      const float kf = drop_factor(ko, (uint32_t)(((int64_t)b * N) * D + hl * F + o));
-      const float Oh = ko ? outp[o] * (1.0f - kDropP) : outp[o];   // un-dropped ELU output where kept
-      shP[i * FS + f] = dz[o] * kf * elu_grad_from_out(Oh);
+  CLK(0);
+  {                                                         // three tiles as float4s, independent loads in flight
+    const int F4 = F / 4, total = N * F4;
+    for (int base = 0; base < total; base += 512) {
+      float4 w[2], z[2], y[2];
+      int row[2], col[2];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int idx = base + r * 256 + tid;
+        row[r] = -1;
+        if (idx < total) {
+          const int i = idx / F4, q = idx - i * F4;
+          row[r] = i; col[r] = 4 * q;
+          w[r] = *reinterpret_cast<const float4*>(Wh + (int64_t)i * HF + 4 * q);
+          z[r] = *reinterpret_cast<const float4*>(dz + (int64_t)i * D + 4 * q);
+          y[r] = *reinterpret_cast<const float4*>(outp + (int64_t)i * D + 4 * q);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+        if (row[r] >= 0) {
+          *reinterpret_cast<float4*>(shW + row[r] * FS + col[r]) = w[r];
+          const uint32_t e0 = (uint32_t)(((int64_t)b * N + row[r]) * D + hl * F + col[r]);
+          const float sc = ko ? (1.0f - kDropP) : 1.0f;     // un-dropped ELU output where kept
+          float4 p;
+          p.x = z[r].x * drop_factor(ko, e0 + 0) * elu_grad_from_out(y[r].x * sc);
+          p.y = z[r].y * drop_factor(ko, e0 + 1) * elu_grad_from_out(y[r].y * sc);
+          p.z = z[r].z * drop_factor(ko, e0 + 2) * elu_grad_from_out(y[r].z * sc);
+          p.w = z[r].w * drop_factor(ko, e0 + 3) * elu_grad_from_out(y[r].w * sc);
+          *reinterpret_cast<float4*>(shP + row[r] * FS + col[r]) = p;
+        }
     }
+  }
+  for (int f = tid; f < F; f += 256) {
     shAl[f] = a.gat_a[mod][h * 2 * F + f];
     shAr[f] = a.gat_a[mod][h * 2 * F + F + f];
   }
@@ -411,6 +475,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
     shV[tid] = a.v[mod][((int64_t)b * kHeads + h) * N + tid];
   }
   __syncthreads();
+  CLK(1);
   const float c = a.gat_c[mod][h];
   for (int i = wave; i < N; i += 4) {                       // recompute alpha and alpha * keep: one wave per row
     float e = -INFINITY;
@@ -424,6 +489,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
       shAd[i * NB + lane] = al * drop_factor(ka, (uint32_t)((b * N + i) * N + lane));
     }
   }
+  CLK(2);
   for (int pr = tid; pr < N * N; pr += 256) {               // dalpha_ij = keep_ij * s_j * (dP_i . Wh_j)
     const int i = pr / N, j = pr - i * N;
     const float4* pi = reinterpret_cast<const float4*>(shP + i * FS);
@@ -436,6 +502,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
     shG[i * NB + j] = acc * shS[j] * drop_factor(ka, (uint32_t)((b * N + i) * N + j));
   }
   __syncthreads();
+  CLK(3);
   float dc_w = 0.f;
   for (int i = wave; i < N; i += 4) {                       // softmax and LeakyReLU backward, du_i: one wave per row
     const float al = lane < N ? shA[i * NB + lane] : 0.f;
@@ -457,6 +524,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
   }
   if (tid == 0) a.dc_part[mod][b * kHeads + h] = shRed[0] + shRed[1] + shRed[2] + shRed[3];
   __syncthreads();
+  CLK(4);
   float* dWh = a.dWh[mod] + (int64_t)b * N * HF + h * F;
   for (int f0 = 0; f0 < F; f0 += 256) {                     // uniform trip count: wave_sum needs all lanes
     const int f = f0 + tid;
@@ -475,6 +543,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
         }
       }
     }
+    CLK(5);
     float dal = 0.f, dar = 0.f;
     const float alf = act ? shAl[f] : 0.f, arf = act ? shAr[f] : 0.f;
 #pragma unroll
@@ -500,6 +569,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
     }
   }
   __syncthreads();
+  CLK(6);
   if (tid < N)
     a.ds_part[mod][((int64_t)b * kHeads + h) * N + tid] =
         shRed[4 + tid * 4] + shRed[4 + tid * 4 + 1] + shRed[4 + tid * 4 + 2] + shRed[4 + tid * 4 + 3];
@@ -744,3 +814,10 @@ int keep_mask_launch(hipStream_t st, uint32_t key, int64_t n, float* keep) {
   return (int)hipGetLastError();
 }
 }  // namespace dvgr
+
+#ifdef DVGR_CLK
+extern "C" int dvgr_dbg_clocks(long long* host_out, int n) {
+  if (n > 4096 * 8) n = 4096 * 8;
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dvgr::g_clk), sizeof(long long) * n, 0, hipMemcpyDeviceToHost);
+}
+#endif
