@@ -777,6 +777,25 @@ __device__ __forceinline__ bf16x8 planes_frag(const uint16_t* tile, int idx16, i
   }
 }
 
+// Phase clocks (debug builds only, `make clk`; read back by tools/gemm_clocks.py): where the first loader wave and the
+// first computing wave of every workgroup spend their time.
+#ifdef DVGR_CLK
+__device__ long long g_gemm_clk[4096 * 8];
+#define GCLK_DECL long long c_t0 = 0, c_acc[4] = {0, 0, 0, 0}
+#define GCLK_START() c_t0 = wall_clock64()
+#define GCLK_ADD(k) do { const long long n_ = wall_clock64(); c_acc[k] += n_ - c_t0; c_t0 = n_; } while (0)
+#define GCLK_FLUSH(base)                                                                                   \
+  do {                                                                                                     \
+    const int wg_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;                       \
+    if (lane == 0 && wg_ < 4096) for (int q_ = 0; q_ < 4; ++q_) g_gemm_clk[wg_ * 8 + (base) + q_] = c_acc[q_];  \
+  } while (0)
+#else
+#define GCLK_DECL
+#define GCLK_START() do { } while (0)
+#define GCLK_ADD(k) do { } while (0)
+#define GCLK_FLUSH(base) do { } while (0)
+#endif
+
 template <int LA, int LB, int TAG, int TERMS, int NS = RS>
 __global__ __launch_bounds__(768) void gemm_planes_kernel(const GemmBatch batch) {
   const GemmProblem P = batch.p[blockIdx.z];
@@ -811,9 +830,12 @@ __global__ __launch_bounds__(768) void gemm_planes_kernel(const GemmBatch batch)
         planes_issue<LA, TERMS>(P.A, (kbeg + s) * BK, P.kseg, wave, lane, offA, smem + s * kSlot);
         planes_issue<LB, TERMS>(P.B, (kbeg + s) * BK, P.kseg, wave, lane, offB, smem + s * kSlot + kPlanes * kPlaneTile);
       }
+    GCLK_DECL;
+    GCLK_START();
     for (int kt = 0; kt < nk; ++kt) {
       // 4 * kPlanes DMA instructions per K-tile from this wave: keep the (up to two) younger tiles in flight
       const int younger = (nk - 1 - kt) < NS - 2 ? (nk - 1 - kt) : NS - 2;
+      GCLK_ADD(2);                                 // DMA issue (back-pressure of the vector memory path)
       if (TERMS == 3) {
         if (younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -823,7 +845,9 @@ __global__ __launch_bounds__(768) void gemm_planes_kernel(const GemmBatch batch)
         else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
+      GCLK_ADD(0);                                 // waiting for the DMA of tile kt
       __builtin_amdgcn_s_barrier();
+      GCLK_ADD(1);                                 // waiting for the consumers at the barrier
       if (kt + NS - 1 < nk) {
         uint16_t* dst = smem + ((kt + NS - 1) % NS) * kSlot;
         planes_issue<LA, TERMS>(P.A, (kbeg + kt + NS - 1) * BK, P.kseg, wave, lane, offA, dst);
@@ -831,6 +855,7 @@ __global__ __launch_bounds__(768) void gemm_planes_kernel(const GemmBatch batch)
       }
     }
     __builtin_amdgcn_s_barrier();
+    if (wave == 0) GCLK_FLUSH(4);
     return;
   }
 
@@ -841,8 +866,12 @@ __global__ __launch_bounds__(768) void gemm_planes_kernel(const GemmBatch batch)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  GCLK_DECL;
+  GCLK_START();
   for (int kt = 0; kt < nk; ++kt) {
+    GCLK_ADD(1);                                   // fragment reads + MFMAs of the previous tile
     __builtin_amdgcn_s_barrier();
+    GCLK_ADD(0);                                   // waiting for tile kt
     const uint16_t* curA = smem + (kt % NS) * kSlot;
     const uint16_t* curB = curA + kPlanes * kPlaneTile;
     bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
@@ -868,9 +897,19 @@ __global__ __launch_bounds__(768) void gemm_planes_kernel(const GemmBatch batch)
       }
   }
   __builtin_amdgcn_s_barrier();
+  GCLK_ADD(1);
   if (P.dbg & 1) { if (acc[0][0][0] == 12345.678f) P.C[0] = 1.f; return; }
   epilogue_rows<MT, NT>(P, acc, m0 + wm, n0 + wn, lane, reinterpret_cast<float*>(smem) + wave * (32 * (16 * NT + 4)), gridDim.y > 1);
+  GCLK_ADD(2);
+  if (wave == 0) GCLK_FLUSH(0);
 }
+
+#ifdef DVGR_CLK
+extern "C" int dvgr_dbg_gemm_clocks(long long* host_out, int n) {
+  if (n > 4096 * 8) n = 4096 * 8;
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dvgr::g_gemm_clk), sizeof(long long) * n, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 static bool planes_eligible(const GemmBatch& b, int la, int lb) {
   for (int i = 0; i < b.n; ++i) {
