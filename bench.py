@@ -222,6 +222,10 @@ def main():
     achieved = probe_flops / (probe_ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[args.dtype]
     f_train = 3 * f_fwd(N, Lr, T)
+    # HBM bytes per launch of the probed kernel from PMC (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, separate
+    # passes; profiles/r01_v3_bf16x3_c2_pmc_hbm.txt): measured for this one configuration only
+    traffic = 90.0e6 if (args.config == "c2" and args.dtype == "bf16x3" and args.probe == "fwd_gat_gemm"
+                         and not args.eval_mode) else None
     out = {
         "metric": "QA-pairs/sec (forward+backward) per GPU, SVQA num_clips=20",
         "value": value, "unit": "QA-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -237,7 +241,7 @@ def main():
                    "unit_tflops": value / world * f_train / 1e12,
                    "unit_frac_of_mfma_peak": value / world * f_train / 1e12 / peak},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                     "traffic": None, "kernel": probe_name, "launch_ms": probe_ms,
+                     "traffic": traffic, "kernel": probe_name, "launch_ms": probe_ms,
                      "algorithmic_gflop_per_launch": probe_flops / 1e9},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
