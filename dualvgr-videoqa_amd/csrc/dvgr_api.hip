@@ -834,7 +834,7 @@ int dvgr_scope_u_loss(const dvgr_dims* dp, const dvgr_io* io, float alpha, float
                       float* loss3, float* g_vis, float* g_com_app, float* g_com_mot, float* g_aq_fusion,
                       float* g_mq_fusion, void* workspace, size_t workspace_bytes, void* stream) {
   if (!dp || !io || !loss3 || !workspace || !g_com_app || !g_com_mot || !g_aq_fusion || !g_mq_fusion) return DVGR_E_NULL;
-  if (!io->vis || !io->com_app || !io->com_mot || !io->aq_fusion || !io->mq_fusion) return DVGR_E_NULL;
+  if (!io->com_app || !io->com_mot || !io->aq_fusion || !io->mq_fusion) return DVGR_E_NULL;
   DVGR_TRY(dvgr_check_dims(dp));
   if (workspace_bytes < aux_ws_floats(*dp) * sizeof(float)) return DVGR_E_WORKSPACE;
   float* const g[4] = {g_com_app, g_com_mot, g_aq_fusion, g_mq_fusion};

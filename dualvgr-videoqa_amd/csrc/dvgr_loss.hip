@@ -66,7 +66,6 @@ __global__ __launch_bounds__(256) void k_aux_gram(const AuxArgs a) {
     for (int J = 0; J < NT; ++J) acc[I][J] = floatx4{0.f, 0.f, 0.f, 0.f};
   const int kw = D / 4;                               // D % 64 == 0: every wave owns a multiple of 16 columns
   const int nk = kw / 16;
-#pragma unroll 4
   for (int it = 0; it < nk; ++it) {
     const int k0 = wave * kw + it * 16;
     const float4 m = *reinterpret_cast<const float4*>(mu + k0 + 4 * kq);
@@ -314,7 +313,7 @@ int aux_losses(hipStream_t st, const dvgr_dims& d, const dvgr_io* io, float alph
   hipError_t e = hipMemsetAsync(loss3, 0, 3 * sizeof(float), st);
   if (e != hipSuccess) return (int)e;
   const int64_t nv = (int64_t)d.B * d.N * d.D;
-  hipLaunchKernelGGL(k_sum_and_ones, dim3(256), dim3(256), 0, st, io->vis, g_vis, nv, loss3);
+  if (io->vis) hipLaunchKernelGGL(k_sum_and_ones, dim3(256), dim3(256), 0, st, io->vis, g_vis, nv, loss3);
   DVGR_TRY_HIP(launch_gram(st, a));
   const size_t lds2 = sizeof(float) * (6 * NN + 6 * d.N + 8);
   if (lds2 > 48 * 1024)

@@ -59,38 +59,43 @@ def fused_scope_u_loss(raw, alpha: float = 1.0, beta: float = 1e-8, world_size: 
     (B,N,D) tensor that receives d loss / d vis (= 1)."""
     lib = L_.load()
     vis, _, _, ca, cm, aq, mq = raw
-    if not vis.is_cuda:
+    if not ca.is_cuda:
         raise RuntimeError("fused_scope_u_loss runs on a ROCm device only (no CPU fallback)")
-    vis, ca, cm, aq, mq = (t.detach().contiguous() for t in (vis, ca, cm, aq, mq))
+    ca, cm, aq, mq = (t.detach().contiguous() for t in (ca, cm, aq, mq))
+    vis = None if vis is None else vis.detach().contiguous()     # None: the auxiliary terms alone
     Lr, B, N, D = ca.shape
     dims = L_.make_dims(B, N, 1, D, 4, Lr, 1, L_.DVGR_F32)
     L_.check(lib.dvgr_check_dims(C.byref(dims)), "dvgr_check_dims")
-    dev = vis.device
+    dev = ca.device
     terms = torch.empty(3, device=dev, dtype=torch.float32)
-    if g_vis is None:
+    if g_vis is None and vis is not None:
         g_vis = torch.empty_like(vis)
     grads = [torch.empty_like(t) for t in (ca, cm, aq, mq)]
     ws = torch.empty(4 * (Lr * B * (4 * N * N + 4 * N * 64) + 128), device=dev, dtype=torch.uint8)
-    io = L_.IO(None, None, None, None, None, vis.data_ptr(), None, None, ca.data_ptr(), cm.data_ptr(), aq.data_ptr(),
-               mq.data_ptr())
+    io = L_.IO(None, None, None, None, None, None if vis is None else vis.data_ptr(), None, None, ca.data_ptr(),
+               cm.data_ptr(), aq.data_ptr(), mq.data_ptr())
     stream = torch.cuda.current_stream(dev).cuda_stream
     L_.check(lib.dvgr_scope_u_loss(C.byref(dims), C.byref(io), float(alpha), float(beta), float(world_size),
-                                   terms.data_ptr(), g_vis.data_ptr(), *[g.data_ptr() for g in grads], ws.data_ptr(),
+                                   terms.data_ptr(), None if vis is None else g_vis.data_ptr(),
+                                   *[g.data_ptr() for g in grads], ws.data_ptr(),
                                    ws.numel(), stream), "dvgr_scope_u_loss")
     return terms, [g_vis, None, None, *grads]
 
 
 class ScopeULoss(torch.autograd.Function):
     """scope_u_loss as one autograd node: forward runs the fused kernels and keeps the gradients they produce,
-    backward scales them by the incoming scalar."""
+    backward scales them by the incoming scalar.  `vis=None` gives alpha*common + beta*dependence alone (what
+    train.py:148-154 adds to the cross-entropy)."""
 
     @staticmethod
     def forward(ctx, alpha, beta, world_size, vis, ca, cm, aq, mq):
         terms, ups = fused_scope_u_loss((vis, None, None, ca, cm, aq, mq), alpha, beta, world_size)
-        ctx.save_for_backward(ups[0], *ups[3:])
+        ctx.has_vis = vis is not None
+        ctx.save_for_backward(*([ups[0]] if ctx.has_vis else []), *ups[3:])
         ctx.mark_non_differentiable(terms)
         return terms[0] + alpha * terms[1] + beta * world_size * terms[2], terms
 
     @staticmethod
     def backward(ctx, g, _):
-        return (None, None, None, *[g * t for t in ctx.saved_tensors])
+        grads = [g * t for t in ctx.saved_tensors]
+        return (None, None, None, *([] if ctx.has_vis else [None]), *grads)

@@ -214,7 +214,9 @@ int dvgr_param_layer_range(const dvgr_dims *d, int layer, int64_t *first, int64_
  * (there the first term is the cross-entropy of the classifier, which is outside the unit).
  * `loss3` (device, 3 floats) receives {sum(vis), mean_l common, mean_l dependence}.  The outputs g_vis (B,N,D;
  * may be NULL) and g_com_app / g_com_mot / g_aq_fusion / g_mq_fusion (L,B,N,D) receive d loss / d tensor and can be
- * handed to dvgr_unit_backward as the upstream gradients.  Only io->vis and the four list tensors are read.
+ * handed to dvgr_unit_backward as the upstream gradients.  Only io->vis and the four list tensors are read;
+ * io->vis == NULL drops the first term (loss3[0] = 0, g_vis untouched): the auxiliary terms alone, for a caller whose
+ * main loss is the classifier's cross-entropy.
  * `workspace` is the unit's workspace (dvgr_workspace_bytes). */
 int dvgr_scope_u_loss(const dvgr_dims *d, const dvgr_io *io, float alpha, float beta, float dep_scale,
                       float *loss3, float *g_vis, float *g_com_app, float *g_com_mot,

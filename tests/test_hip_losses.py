@@ -113,3 +113,16 @@ def test_autograd_node_end_to_end_equals_torch_losses():
             assert abs(float(a.ravel()[0]) - float(b.ravel()[0])) < 1e-5 * scale
         elif np.abs(a).max() > 1e-12:
             assert rel_err(b, a) < 5e-4
+
+
+def test_aux_terms_alone_without_vis():
+    """vis = None: alpha * common + beta * dependence only (the form train.py:148-154 adds to the cross-entropy)."""
+    lists, vis = random_lists(2, 3, 20, 128, seed=9)
+    ls = [t.clone().requires_grad_(True) for t in lists]
+    aux, terms = losses.ScopeULoss.apply(0.5, 2e-3, 1, None, *ls)
+    (3.0 * aux).backward()
+    want_t, want_g = oracle_terms_and_grads(lists, torch.zeros_like(vis), 0.5, 2e-3, 1.0)
+    assert float(terms[0]) == 0.0
+    assert abs(float(aux) - (0.5 * want_t[1] + 2e-3 * want_t[2])) <= TOL * abs(0.5 * want_t[1] + 2e-3 * want_t[2])
+    for t, w in zip(ls, want_g[1:]):
+        assert rel_err(t.grad.cpu().numpy(), 3.0 * w.numpy()) < TOL
