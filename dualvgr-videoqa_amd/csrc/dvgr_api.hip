@@ -17,11 +17,12 @@ namespace dvgr { size_t gat_lds_bytes_max(int N, int F); }
 
 namespace {
 
-struct FwdWs { int64_t Y, total; };
+struct FwdWs { int64_t Y, R, total; };
 FwdWs fwd_ws(const dvgr_dims& d) {
   FwdWs w{};
   int64_t o = 0;
   w.Y = o; o += round64((int64_t)d.L * d.B * d.T * d.D);
+  w.R = o; o += round64((int64_t)d.L * d.B * d.T);
   w.total = o;
   return w;
 }
@@ -358,7 +359,6 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
   const dvgr_opts& O = opts ? *opts : o0;
   const int train = O.train;
   const uint64_t seed = O.seed;
-  const Probe probe{O, st};
   const int prec = dp->dtype;
   const ParamLayout P = param_layout(d);
   const SavedLayout S = saved_layout(d);
@@ -385,42 +385,46 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
     DVGR_TRY(split_planes(st, sb));
   }
 
-  // ---- S0: query side of every layer (does not depend on A / M) ---------------------------------
+  // ---- S0: query side of every layer.  It does not depend on A / M and layer 0's Wh contraction does not depend on
+  // it, so it runs on the side stream and joins the main stream in front of layer 0's punish gate.
+  SideStream* side = (O.flags & DVGR_OPT_SINGLE_STREAM) ? nullptr : side_stream();
+  hipStream_t hs = side ? side->st : st;
+  const Probe hprobe{O, hs};
+  if (side) DVGR_TRY(side->order(st, hs));
   for (int l0 = 0; l0 < L; l0 += kMaxBatch) {
     GemmBatch gb{};
     for (int l = l0; l < L && l < l0 + kMaxBatch; ++l) {
       gb.p[gb.n] = nt(io->dq, D, lp(l) + P.qa_w1, D, ws + W.Y + (int64_t)l * BT * D, D, lp(l) + P.qa_b1, BT, D, D, ACT_NONE);
       PM.attach(gb.p[gb.n++]);
     }
-    DVGR_TRY(probe.begin(DVGR_PROBE_FWD_QA_GEMM, l0));
-    DVGR_TRY(gemm_launch(st, KC, KC, gb, TAG_GENERIC, prec));
-    DVGR_TRY(probe.end(DVGR_PROBE_FWD_QA_GEMM, l0));
+    DVGR_TRY(hprobe.begin(DVGR_PROBE_FWD_QA_GEMM, l0));
+    DVGR_TRY(gemm_launch(hs, KC, KC, gb, TAG_GENERIC, prec));
+    DVGR_TRY(hprobe.end(DVGR_PROBE_FWD_QA_GEMM, l0));
   }
   {
     QaRowsArgs a{};
-    a.Y = ws + W.Y; a.params = params; a.off_w2 = P.qa_w2; a.off_b2 = P.qa_b2; a.layer_stride = P.layer_stride;
+    a.Y = ws + W.Y; a.logit = ws + W.R; a.params = params; a.off_w2 = P.qa_w2; a.off_b2 = P.qa_b2; a.layer_stride = P.layer_stride;
     a.words = io->words; a.qlen = io->qlen; a.saved = saved; a.s_layer_stride = S.layer_stride;
     a.s_d = S.qa_d; a.s_nrm = S.qa_nrm; a.s_a = S.qa_a; a.s_ah = S.qa_ah; a.s_S = S.qa_s; a.s_q = S.qa_q;
     a.B = B; a.T = T; a.D = D; a.Wd = Wd; a.L = L;
-    DVGR_TRY(qa_rows_fwd(st, a));
+    DVGR_TRY(qa_rows_fwd(hs, a));
   }
   {
     GemmBatch gb{};
     for (int l = 0; l < L; ++l)
       for (int m = 0; m < 2; ++m) {
         gb.p[gb.n++] = nt(ls(l) + S.qa_q, Wd, mp(l, m) + P.wq, Wd, ms(l, m) + S.p, D, mp(l, m) + P.bq, B, D, Wd, ACT_NONE);
-        if (gb.n == kMaxBatch || (l == L - 1 && m == 1)) { DVGR_TRY(gemm_launch(st, KC, KC, gb, TAG_GENERIC, prec)); gb.n = 0; }
+        if (gb.n == kMaxBatch || (l == L - 1 && m == 1)) { DVGR_TRY(gemm_launch(hs, KC, KC, gb, TAG_GENERIC, prec)); gb.n = 0; }
       }
   }
 
+  const Probe fprobe{O, st};
   // ---- layers ---------------------------------------------------------------------------------------
   for (int l = 0; l < L; ++l) {
     const Keys K = layer_keys(train, seed, l);
     const float* Xin[2] = {l == 0 ? io->A : ms(l - 1, 0) + S.x, l == 0 ? io->M : ms(l - 1, 1) + S.x};
     float* outc[2] = {io->com_app + l * BND, io->com_mot + l * BND};
     float* outs[2] = {io->aq_fusion + l * BND, io->mq_fusion + l * BND};
-    // S1
-    DVGR_TRY(punish_fwd(st, Xin[0], Xin[1], ms(l, 0) + S.p, ms(l, 1) + S.p, ms(l, 0) + S.s, ms(l, 1) + S.s, B, N, D));
     // S2: Wh = drop_x(X) . Wcat^T + bcat.  Training: the two GATs of a modality see differently dropped
     // copies of X, materialised once (saved: the backward needs them for dWcat) so that the contraction
     // itself carries no mask and can run on the LDS-DMA ring kernel.
@@ -441,10 +445,13 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
           }
         }
       }
-      DVGR_TRY(probe.begin(DVGR_PROBE_FWD_GAT_GEMM, l));
+      DVGR_TRY(fprobe.begin(DVGR_PROBE_FWD_GAT_GEMM, l));
       DVGR_TRY(gemm_launch(st, KC, KC, gb, TAG_FWD_GAT, prec));
-      DVGR_TRY(probe.end(DVGR_PROBE_FWD_GAT_GEMM, l));
+      DVGR_TRY(fprobe.end(DVGR_PROBE_FWD_GAT_GEMM, l));
     }
+    // S1 (needs p from S0: the side stream joins here)
+    if (l == 0 && side) DVGR_TRY(side->order(hs, st));
+    DVGR_TRY(punish_fwd(st, Xin[0], Xin[1], ms(l, 0) + S.p, ms(l, 1) + S.p, ms(l, 0) + S.s, ms(l, 1) + S.s, B, N, D));
     // S3
     {
       GatAttnArgs a{};
@@ -460,9 +467,9 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
       }
       a.z_lo_off = plo;
       a.B = B; a.N = N; a.D = D;
-      DVGR_TRY(probe.begin(DVGR_PROBE_FWD_GAT_ATTN, l));
+      DVGR_TRY(fprobe.begin(DVGR_PROBE_FWD_GAT_ATTN, l));
       DVGR_TRY(gat_attn_fwd(st, a));
-      DVGR_TRY(probe.end(DVGR_PROBE_FWD_GAT_ATTN, l));
+      DVGR_TRY(fprobe.end(DVGR_PROBE_FWD_GAT_ATTN, l));
     }
     // S4: tn_v = tanh(z_v . P1^T + bP)
     {
@@ -473,9 +480,9 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
         gb.p[gb.n] = nt(outs[m], D, mp(l, m) + P.sf_p1, D, ms(l, m) + S.tn + BND, D, mp(l, m) + P.sf_bp, BN, D, D, ACT_TANH);
         PM.attach(gb.p[gb.n++]);
       }
-      DVGR_TRY(probe.begin(DVGR_PROBE_FWD_SF_GEMM, l));
+      DVGR_TRY(fprobe.begin(DVGR_PROBE_FWD_SF_GEMM, l));
       DVGR_TRY(gemm_launch(st, KC, KC, gb, TAG_FWD_SF, prec));
-      DVGR_TRY(probe.end(DVGR_PROBE_FWD_SF_GEMM, l));
+      DVGR_TRY(fprobe.end(DVGR_PROBE_FWD_SF_GEMM, l));
     }
     // S5
     {
@@ -499,9 +506,9 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
     PM.attach(gb.p[gb.n++]);
     gb.p[gb.n] = nt(ms(L - 1, 1) + S.x, D, params + P.mfb_w1, D, saved + S.mfb_x1, kMfbHidden, params + P.mfb_b1, BN, kMfbHidden, D, ACT_ELU);
     PM.attach(gb.p[gb.n++]);
-    DVGR_TRY(probe.begin(DVGR_PROBE_FWD_MFB_GEMM, 0));
+    DVGR_TRY(fprobe.begin(DVGR_PROBE_FWD_MFB_GEMM, 0));
     DVGR_TRY(gemm_launch(st, KC, KC, gb, TAG_GENERIC, prec));
-    DVGR_TRY(probe.end(DVGR_PROBE_FWD_MFB_GEMM, 0));
+    DVGR_TRY(fprobe.end(DVGR_PROBE_FWD_MFB_GEMM, 0));
     uint16_t* zfp = PM.out(saved + S.mfb_z, &plo);
     DVGR_TRY(mfb_pool_fwd(st, saved + S.mfb_x0, saved + S.mfb_x1, saved + S.mfb_z, BN, zfp, plo));
     GemmBatch go{};

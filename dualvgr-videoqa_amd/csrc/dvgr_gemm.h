@@ -48,7 +48,7 @@ struct GemmProblem {
                        // over several workgroups that add their partial tiles with float atomics
 };
 
-constexpr int kMaxBatch = 4;
+constexpr int kMaxBatch = 8;
 struct GemmBatch {
   GemmProblem p[kMaxBatch];
   int n;

@@ -10,6 +10,7 @@ namespace dvgr {
 // mask t < len; renormalise with +1e-5; q = sum_t ah_t words_t.   model/utils.py:68-82
 struct QaRowsArgs {
   const float* Y;        // [L][B*T][D]  feat_enhance output (workspace)
+  float* logit;          // [L][B*T]     scratch: fc logits between the two passes (workspace)
   const float* params;   // flat parameter buffer
   int64_t off_w2, off_b2, layer_stride;
   const float* words;    // (B, T, Wd)

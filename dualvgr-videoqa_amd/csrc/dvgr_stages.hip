@@ -22,32 +22,59 @@ __device__ long long g_clk[4096 * 8];
 // =================================================================================================
 // S0 rows forward.  grid (B, L), 256 threads.  model/utils.py:68-82
 // =================================================================================================
-__global__ __launch_bounds__(256) void k_qa_rows_fwd(const QaRowsArgs a) {
-  __shared__ float sh_r[256];
-  __shared__ float sh_ah[256];
-  const int b = blockIdx.x, l = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int T = a.T, D = a.D, Wd = a.Wd;
-  const float* w2 = a.params + (int64_t)l * a.layer_stride + a.off_w2;
+// pass 1: one wave per (layer, sample, word) row: L2-normalise, logit.  Every row is independent, so the grid is
+// L*B*T/4 workgroups instead of the L*B a per-sample kernel would have.
+__global__ __launch_bounds__(256) void k_qa_rows_norm(const QaRowsArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);        // (l * B + b) * T + t
+  const int T = a.T, D = a.D, D4 = D / 4;
+  if (row >= (int64_t)a.L * a.B * T) return;
+  const int l = (int)(row / ((int64_t)a.B * T));
+  const int bt = (int)(row - (int64_t)l * a.B * T);
+  const float4* w2 = reinterpret_cast<const float4*>(a.params + (int64_t)l * a.layer_stride + a.off_w2);
   const float b2 = a.params[(int64_t)l * a.layer_stride + a.off_b2];
   float* sav = a.saved + (int64_t)l * a.s_layer_stride;
-  const float* Y = a.Y + ((int64_t)l * a.B + b) * T * D;
-  float* dsv = sav + a.s_d + (int64_t)b * T * D;
-  for (int t = wave; t < T; t += 4) {
-    const float* y = Y + (int64_t)t * D;
-    float ss = 0.f;
-    for (int k = lane; k < D; k += 64) ss += y[k] * y[k];
-    ss = wave_sum(ss);
-    const float nrm = fmaxf(sqrtf(ss), 1e-12f);            // F.normalize eps
-    float rr = 0.f;
-    for (int k = lane; k < D; k += 64) {
-      const float dv = y[k] / nrm;
-      dsv[(int64_t)t * D + k] = dv;
-      rr += dv * w2[k];
-    }
-    rr = wave_sum(rr) + b2;
-    if (lane == 0) { sh_r[t] = rr; sav[a.s_nrm + b * T + t] = nrm; }
+  const float4* y = reinterpret_cast<const float4*>(a.Y + row * D);
+  float4* dsv = reinterpret_cast<float4*>(sav + a.s_d + (int64_t)bt * D);
+  float4 v[4];                                              // D <= 1024 in registers; larger D re-reads the row
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = lane + 64 * i;
+    v[i] = k < D4 ? y[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+    ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
   }
+  for (int k = lane + 256; k < D4; k += 64) { const float4 x = y[k]; ss += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w; }
+  ss = wave_sum(ss);
+  const float nrm = fmaxf(sqrtf(ss), 1e-12f);            // F.normalize eps
+  float rr = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = lane + 64 * i;
+    if (k < D4) {
+      const float4 d = make_float4(v[i].x / nrm, v[i].y / nrm, v[i].z / nrm, v[i].w / nrm), w = w2[k];
+      dsv[k] = d;
+      rr += d.x * w.x + d.y * w.y + d.z * w.z + d.w * w.w;
+    }
+  }
+  for (int k = lane + 256; k < D4; k += 64) {
+    const float4 x = y[k], w = w2[k];
+    const float4 d = make_float4(x.x / nrm, x.y / nrm, x.z / nrm, x.w / nrm);
+    dsv[k] = d;
+    rr += d.x * w.x + d.y * w.y + d.z * w.z + d.w * w.w;
+  }
+  rr = wave_sum(rr) + b2;
+  if (lane == 0) { a.logit[row] = rr; sav[a.s_nrm + bt] = nrm; }
+}
+
+// pass 2: per (sample, layer): softmax over ALL T, mask, renormalise, q = sum_t ah_t words_t
+__global__ __launch_bounds__(256) void k_qa_rows_attn(const QaRowsArgs a) {
+  __shared__ float sh_r[256];
+  __shared__ float sh_ah[256];
+  const int b = blockIdx.x, l = blockIdx.y, tid = threadIdx.x;
+  const int T = a.T, Wd = a.Wd;
+  float* sav = a.saved + (int64_t)l * a.s_layer_stride;
+  if (tid < T) sh_r[tid] = a.logit[((int64_t)l * a.B + b) * T + tid];
   __syncthreads();
   float mx = -INFINITY;
   for (int t = 0; t < T; ++t) mx = fmaxf(mx, sh_r[t]);
@@ -74,7 +101,9 @@ __global__ __launch_bounds__(256) void k_qa_rows_fwd(const QaRowsArgs a) {
 }
 
 int qa_rows_fwd(hipStream_t st, const QaRowsArgs& a) {
-  hipLaunchKernelGGL(k_qa_rows_fwd, dim3(a.B, a.L), dim3(256), 0, st, a);
+  const int64_t rows = (int64_t)a.L * a.B * a.T;
+  hipLaunchKernelGGL(k_qa_rows_norm, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_qa_rows_attn, dim3(a.B, a.L), dim3(256), 0, st, a);
   DVGR_LAUNCH_CHECK();
 }
 
