@@ -1,5 +1,6 @@
 // dvgr_api.hip -- C ABI (include/dvgr.h): layouts, argument checks and the stage schedules of the
 // forward and backward passes.  Host code only; all device work is enqueued on the caller's stream.
+#include <stdlib.h>
 #include <string.h>
 
 #include "dvgr_gemm.h"
@@ -30,7 +31,7 @@ FwdWs fwd_ws(const dvgr_dims& d) {
 // Buffers written by the critical path of layer l and read by the side stream (weight / bias gradients) exist
 // twice, indexed by l & 1: the critical path may run one layer ahead of the side stream.
 struct BwdWs {
-  int64_t dpo, dzf, dp0, dp1, dz[2];
+  int64_t dpo, dzf, dp0, dp1, dz[2], dxtmp[2];
   int64_t dw[2][2], dpre[2][2], dWh[2][2], ds_part[2][2], da_part[2][2], dc_part[2][2], dp_cat[2];   // [set][modality]
   int64_t dqbar, dr, dy, total;
 };
@@ -43,6 +44,7 @@ BwdWs bwd_ws(const dvgr_dims& d) {
   w.dp0 = o; o += round64(BN * kMfbHidden);
   w.dp1 = o; o += round64(BN * kMfbHidden);
   for (int m = 0; m < 2; ++m) { w.dz[m] = o; o += round64(2 * BN * D); }
+  for (int m = 0; m < 2; ++m) { w.dxtmp[m] = o; o += round64(BN * D); }
   for (int s = 0; s < 2; ++s) {
     for (int m = 0; m < 2; ++m) {
       w.dw[s][m] = o;      o += round64(2 * BN);
@@ -613,7 +615,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     cb.j[cb.n++] = ColsumJob{ws + W.dpo, nullptr, nullptr, nullptr, BN, 0, D, D, gp + P.mfb_bo};
     cb.j[cb.n++] = ColsumJob{ws + W.dp0, nullptr, nullptr, nullptr, BN, 0, kMfbHidden, kMfbHidden, gp + P.mfb_b0};
     cb.j[cb.n++] = ColsumJob{ws + W.dp1, nullptr, nullptr, nullptr, BN, 0, kMfbHidden, kMfbHidden, gp + P.mfb_b1};
-    cb.chunks = 8;
+    cb.chunks = 16;
     DVGR_TRY(colsum(hs, cb));
   }
   if (layer_done_events && layer_done_events[L]) {
@@ -631,6 +633,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     const float* outs[2] = {io->aq_fusion + l * BND, io->mq_fusion + l * BND};
     ColsumBatch cb{};
     GemmBatch sf_dw{};
+    bool sf_dw_main = false;
     if (side && side_done[set]) {      // layer l + 2 shared this buffer set
       const hipError_t e = hipStreamWaitEvent(st, side_done[set], 0);
       if (e != hipSuccess) return (int)e;
@@ -678,7 +681,8 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
         gb.p[gb.n++] = p;
       }
       sf_dw = gb;
-      if (l > 0) {
+      sf_dw_main = (l == 0);
+      if (!sf_dw_main) {
         DVGR_TRY(hprobe.begin(DVGR_PROBE_BWD_SF_DW, l));
         DVGR_TRY(gemm_launch(hs, IC, IC, sf_dw, TAG_BWD_SF_DW, prec));
         DVGR_TRY(hprobe.end(DVGR_PROBE_BWD_SF_DW, l));
@@ -703,21 +707,20 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       DVGR_TRY(gat_attn_bwd(st, a));
       DVGR_TRY(probe.end(DVGR_PROBE_BWD_GAT_ATTN, l));
     }
-    for (int m = 0; m < 2; ++m) {
-      cb.j[cb.n++] = ColsumJob{ws + W.da_part[set][m], nullptr, nullptr, nullptr, B, 0, kHeads * 2 * F, kHeads * 2 * F, gmp(l, m) + P.gat_a};
-      cb.j[cb.n++] = ColsumJob{ws + W.dc_part[set][m], nullptr, nullptr, nullptr, B, 0, kHeads, kHeads, gmp(l, m) + P.gat_c};
-      cb.j[cb.n++] = ColsumJob{ws + W.dWh[set][m], nullptr, nullptr, nullptr, BN, 0, HF, HF, gmp(l, m) + P.gat_b};
-    }
-    // S1 backward (only adds into dX, so it can precede the S2 contraction: the query branch starts earlier)
-    {
+    {                                      // S1 backward, dp part: everything the query branch needs
       PunishBwdArgs a{};
       for (int m = 0; m < 2; ++m) {
         a.ds_part[m] = ws + W.ds_part[set][m]; a.s[m] = ms(l, m) + S.s; a.p[m] = ms(l, m) + S.p;
         a.X[m] = Xin[m]; a.dX[m] = dXacc[m];
       }
-      a.dp_cat = ws + W.dp_cat[set]; a.B = B; a.N = N; a.D = D;
+      a.dp_cat = ws + W.dp_cat[set]; a.B = B; a.N = N; a.D = D; a.parts = 1;
       DVGR_TRY(punish_bwd(st, a));
-      DVGR_TRY(to_side());
+      DVGR_TRY(to_side());                 // dWh and dp are final: the side stream takes dWcat and the query branch
+    }
+    for (int m = 0; m < 2; ++m) {
+      cb.j[cb.n++] = ColsumJob{ws + W.da_part[set][m], nullptr, nullptr, nullptr, B, 0, kHeads * 2 * F, kHeads * 2 * F, gmp(l, m) + P.gat_a};
+      cb.j[cb.n++] = ColsumJob{ws + W.dc_part[set][m], nullptr, nullptr, nullptr, B, 0, kHeads, kHeads, gmp(l, m) + P.gat_c};
+      cb.j[cb.n++] = ColsumJob{ws + W.dWh[set][m], nullptr, nullptr, nullptr, BN, 0, HF, HF, gmp(l, m) + P.gat_b};
     }
     // S2 backward: dX += drop_x(dWh . Wcat) on the critical path;  dWcat = dWh^T . drop_x(X) on the side stream
     {
@@ -731,17 +734,19 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
         DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_BWD_GAT_DX, prec));
         DVGR_TRY(probe.end(DVGR_PROBE_BWD_GAT_DX, l));
       } else {
-        for (int gi = 0; gi < 2; ++gi) {   // the two GATs dropped x with different masks: two passes
-          GemmBatch gd{};
+        // the two GATs dropped x with different masks: the common GAT's partial accumulates into dX, the specific GAT's
+        // goes to a scratch tensor in the same launch (two tiles may not read-modify-write one output), and the punish
+        // backward, which rewrites every element of dX anyway, folds it in
+        GemmBatch gd{};
+        for (int gi = 0; gi < 2; ++gi)
           for (int m = 0; m < 2; ++m) {
-            gd.p[gd.n] = nn(ws + W.dWh[set][m] + gi * 4 * F, HF, mp(l, m) + P.gat_w + (int64_t)gi * 4 * F * D, D, dXacc[m], D,
-                            BN, D, 4 * F, 1, K.x[m][gi]);
+            gd.p[gd.n] = nn(ws + W.dWh[set][m] + gi * 4 * F, HF, mp(l, m) + P.gat_w + (int64_t)gi * 4 * F * D, D,
+                            gi == 0 ? dXacc[m] : ws + W.dxtmp[m], D, BN, D, 4 * F, gi == 0 ? 1 : 0, K.x[m][gi]);
             PM.attach(gd.p[gd.n++]);
           }
-          if (gi == 0) DVGR_TRY(probe.begin(DVGR_PROBE_BWD_GAT_DX, l));
-          DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_BWD_GAT_DX, prec));
-          if (gi == 1) DVGR_TRY(probe.end(DVGR_PROBE_BWD_GAT_DX, l));
-        }
+        DVGR_TRY(probe.begin(DVGR_PROBE_BWD_GAT_DX, l));
+        DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_BWD_GAT_DX, prec));
+        DVGR_TRY(probe.end(DVGR_PROBE_BWD_GAT_DX, l));
       }
       GemmBatch gb{};
       for (int m = 0; m < 2; ++m) {
@@ -756,18 +761,29 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
           }
         }
       }
-      // the last layer processed has no successor to overlap with: its weight-gradient contractions follow the dX
-      // chain on the main stream while the side stream works through the query branch
-      const Probe& wp = l > 0 ? hprobe : probe;
-      hipStream_t wst = l > 0 ? hs : st;
-      if (l == 0) {
-        DVGR_TRY(wp.begin(DVGR_PROBE_BWD_SF_DW, l));
-        DVGR_TRY(gemm_launch(wst, IC, IC, sf_dw, TAG_BWD_SF_DW, prec));
-        DVGR_TRY(wp.end(DVGR_PROBE_BWD_SF_DW, l));
+      // the last layer processed has no successor to overlap with: its dP1 contraction follows the dX chain on the main
+      // stream while the side stream works through the query branch
+      if (sf_dw_main) {
+        DVGR_TRY(probe.begin(DVGR_PROBE_BWD_SF_DW, l));
+        DVGR_TRY(gemm_launch(st, IC, IC, sf_dw, TAG_BWD_SF_DW, prec));
+        DVGR_TRY(probe.end(DVGR_PROBE_BWD_SF_DW, l));
       }
-      DVGR_TRY(wp.begin(DVGR_PROBE_BWD_GAT_DW, l));
-      DVGR_TRY(gemm_launch(wst, IC, IC, gb, TAG_BWD_GAT_DW, prec));
-      DVGR_TRY(wp.end(DVGR_PROBE_BWD_GAT_DW, l));
+      // dWcat stays on the main stream in every layer: with it the side stream (dP1, the query branch, all column sums)
+      // and the main stream carry about the same load (measured: +5 % over dWcat on the side stream)
+      DVGR_TRY(probe.begin(DVGR_PROBE_BWD_GAT_DW, l));
+      DVGR_TRY(gemm_launch(st, IC, IC, gb, TAG_BWD_GAT_DW, prec));
+      DVGR_TRY(probe.end(DVGR_PROBE_BWD_GAT_DW, l));
+    }
+    // S1 backward, dX part (folds the specific GAT's partial of the training-mode S2 backward in)
+    {
+      PunishBwdArgs a{};
+      for (int m = 0; m < 2; ++m) {
+        a.ds_part[m] = ws + W.ds_part[set][m]; a.s[m] = ms(l, m) + S.s; a.p[m] = ms(l, m) + S.p;
+        a.X[m] = Xin[m]; a.dX[m] = dXacc[m];
+        a.add[m] = train ? ws + W.dxtmp[m] : nullptr;
+      }
+      a.dp_cat = ws + W.dp_cat[set]; a.B = B; a.N = N; a.D = D; a.parts = 2;
+      DVGR_TRY(punish_bwd(st, a));
     }
     // ---- everything below is off the critical path: query branch of this layer, bias gradients ----
     {
@@ -815,7 +831,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       cb.j[cb.n++] = ColsumJob{ls(l) + S.qa_d, nullptr, ws + W.dr, nullptr, BT, 0, D, D, glp(l) + P.qa_w2};
       cb.j[cb.n++] = ColsumJob{ws + W.dr, nullptr, nullptr, nullptr, BT, 0, 1, 1, glp(l) + P.qa_b2};
     }
-    cb.chunks = 8;
+    cb.chunks = 16;
     DVGR_TRY(colsum(hs, cb));
     if (l > 0 && layer_done_events && layer_done_events[l]) {
       const hipError_t e = hipEventRecord((hipEvent_t)layer_done_events[l], hs);

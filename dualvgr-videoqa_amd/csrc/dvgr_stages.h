@@ -121,15 +121,17 @@ struct GatAttnBwdArgs {
 };
 int gat_attn_bwd(hipStream_t st, const GatAttnBwdArgs& a);
 
-// S1 backward: ds = sum_h ds_part; dtau = ds s (1-s); dX += dtau p; dp = sum_n dtau X.
+// S1 backward: ds = sum_h ds_part; dtau = ds s (1-s); dX += dtau p (+ add); dp = sum_n dtau X.
 struct PunishBwdArgs {
   const float* ds_part[2];
   const float* s[2];
   const float* p[2];
   const float* X[2];
   float* dX[2];            // accumulated in place
+  const float* add[2];     // nullable: a second partial of dX (B*N, D), folded in by the same read-modify-write
   float* dp_cat;           // (B, 2D): cols [mod*D, (mod+1)*D)
   int B, N, D;
+  int parts;               // bit 0: dp (needs only ds_part, s, X), bit 1: the dX update; 0 means both
 };
 int punish_bwd(hipStream_t st, const PunishBwdArgs& a);
 

@@ -645,13 +645,25 @@ __global__ __launch_bounds__(256) void k_punish_bwd(const PunishBwdArgs a) {
   if (d >= D) return;
   const float* X = a.X[mod] + (int64_t)b * N * D;
   float* dX = a.dX[mod] + (int64_t)b * N * D;
-  const float pd = a.p[mod][(int64_t)b * D + d];
-  float acc = 0.f;
-  for (int n = 0; n < N; ++n) {
-    acc += shT[n] * X[(int64_t)n * D + d];
-    dX[(int64_t)n * D + d] += shT[n] * pd;
+  const int parts = a.parts ? a.parts : 3;
+  if (parts == 1) {                                         // dp alone: the query branch can start before dX is final
+    float acc = 0.f;
+#pragma unroll 4
+    for (int n = 0; n < N; ++n) acc += shT[n] * X[(int64_t)n * D + d];
+    a.dp_cat[(int64_t)b * 2 * D + mod * D + d] = acc;
+    return;
   }
-  a.dp_cat[(int64_t)b * 2 * D + mod * D + d] = acc;
+  const float pd = a.p[mod][(int64_t)b * D + d];
+  const float* add = a.add[mod] ? a.add[mod] + (int64_t)b * N * D : nullptr;
+  float acc = 0.f;
+#pragma unroll 4
+  for (int n = 0; n < N; ++n) {
+    const float g = dX[(int64_t)n * D + d];
+    const float e = add ? add[(int64_t)n * D + d] : 0.f;
+    if (parts & 1) acc += shT[n] * X[(int64_t)n * D + d];
+    dX[(int64_t)n * D + d] = (g + e) + shT[n] * pd;
+  }
+  if (parts & 1) a.dp_cat[(int64_t)b * 2 * D + mod * D + d] = acc;
 }
 int punish_bwd(hipStream_t st, const PunishBwdArgs& a) {
   hipLaunchKernelGGL(k_punish_bwd, dim3(a.B, 2, (a.D + 255) / 256), dim3(256), 0, st, a);
@@ -731,31 +743,59 @@ int qa_bwd(hipStream_t st, const QaBwdArgs& a) {
 // =================================================================================================
 // Column sums: grid (ceil(cols / 64), jobs), 1024 threads = 16 waves; lane -> column, wave -> rows.
 // =================================================================================================
-__global__ __launch_bounds__(1024) void k_colsum(const ColsumBatch b) {
-  __shared__ float red[16][64];
+// 256 threads = 4 waves; a lane owns 4 adjacent columns (16-byte loads, 1 KB per row per wave), a workgroup 256 columns
+// of one row chunk; waves interleave rows, four loads in flight per lane.  Columns need not be a multiple of 4 (the
+// tail lanes fall back to scalar loads); ld and the base pointers are 16-byte aligned for every caller.
+__device__ __forceinline__ float4 colsum_load4(const float* row, int c, int cols) {
+  if (c + 4 <= cols && ((reinterpret_cast<uintptr_t>(row + c) & 15) == 0)) return *reinterpret_cast<const float4*>(row + c);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < cols) v.x = row[c];
+  if (c + 1 < cols) v.y = row[c + 1];
+  if (c + 2 < cols) v.z = row[c + 2];
+  if (c + 3 < cols) v.w = row[c + 3];
+  return v;
+}
+__device__ __forceinline__ void colsum_segment(const float* M, const float* w, int rows, int64_t ld, int cols, int c,
+                                               int ch, int nch, int wave, float4& acc) {
+  const int per = (rows + nch - 1) / nch;
+  const int b0 = ch * per, e0 = (b0 + per) < rows ? (b0 + per) : rows;
+  int r = b0 + wave;
+  for (; r + 12 < e0; r += 16) {
+    const float4 v0 = colsum_load4(M + (int64_t)r * ld, c, cols), v1 = colsum_load4(M + (int64_t)(r + 4) * ld, c, cols);
+    const float4 v2 = colsum_load4(M + (int64_t)(r + 8) * ld, c, cols), v3 = colsum_load4(M + (int64_t)(r + 12) * ld, c, cols);
+    const float w0 = w ? w[r] : 1.f, w1 = w ? w[r + 4] : 1.f, w2 = w ? w[r + 8] : 1.f, w3 = w ? w[r + 12] : 1.f;
+    acc.x += (w0 * v0.x + w1 * v1.x) + (w2 * v2.x + w3 * v3.x);
+    acc.y += (w0 * v0.y + w1 * v1.y) + (w2 * v2.y + w3 * v3.y);
+    acc.z += (w0 * v0.z + w1 * v1.z) + (w2 * v2.z + w3 * v3.z);
+    acc.w += (w0 * v0.w + w1 * v1.w) + (w2 * v2.w + w3 * v3.w);
+  }
+  for (; r < e0; r += 4) {
+    const float4 v = colsum_load4(M + (int64_t)r * ld, c, cols);
+    const float wr = w ? w[r] : 1.f;
+    acc.x += wr * v.x; acc.y += wr * v.y; acc.z += wr * v.z; acc.w += wr * v.w;
+  }
+}
+__global__ __launch_bounds__(256) void k_colsum(const ColsumBatch b) {
+  __shared__ float4 red[4][64];
   const ColsumJob& J = b.j[blockIdx.y];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
-  if (blockIdx.x * 64 >= J.cols) return;                    // uniform per workgroup
+  if (blockIdx.x * 256 >= J.cols) return;                   // uniform per workgroup
+  const int c = blockIdx.x * 256 + 4 * lane;
   const int nch = gridDim.z, ch = blockIdx.z;               // row chunk of this workgroup
-  float acc = 0.f;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < J.cols) {
-    const int per0 = (J.rows0 + nch - 1) / nch;
-    const int b0 = ch * per0, e0 = (b0 + per0) < J.rows0 ? (b0 + per0) : J.rows0;
-    for (int r = b0 + wave; r < e0; r += 16) acc += (J.w0 ? J.w0[r] : 1.f) * J.M0[(int64_t)r * J.ld + c];
-    if (J.M1) {
-      const int per1 = (J.rows1 + nch - 1) / nch;
-      const int b1 = ch * per1, e1 = (b1 + per1) < J.rows1 ? (b1 + per1) : J.rows1;
-      for (int r = b1 + wave; r < e1; r += 16) acc += (J.w1 ? J.w1[r] : 1.f) * J.M1[(int64_t)r * J.ld + c];
-    }
+    colsum_segment(J.M0, J.w0, J.rows0, J.ld, J.cols, c, ch, nch, wave, acc);
+    if (J.M1) colsum_segment(J.M1, J.w1, J.rows1, J.ld, J.cols, c, ch, nch, wave, acc);
   }
   red[wave][lane] = acc;
   __syncthreads();
   if (wave == 0 && c < J.cols) {
-    float s = 0.f;
+    const float4 a0 = red[0][lane], a1 = red[1][lane], a2 = red[2][lane], a3 = red[3][lane];
+    const float s[4] = {(a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z),
+                        (a0.w + a1.w) + (a2.w + a3.w)};
 #pragma unroll
-    for (int w = 0; w < 16; ++w) s += red[w][lane];
-    if (nch > 1) atomicAdd(J.out + c, s); else J.out[c] = s;
+    for (int q = 0; q < 4; ++q)
+      if (c + q < J.cols) { if (nch > 1) atomicAdd(J.out + c + q, s[q]); else J.out[c + q] = s[q]; }
   }
 }
 int colsum(hipStream_t st, const ColsumBatch& b) {
@@ -763,7 +803,7 @@ int colsum(hipStream_t st, const ColsumBatch& b) {
   int maxc = 0;
   for (int i = 0; i < b.n; ++i) maxc = b.j[i].cols > maxc ? b.j[i].cols : maxc;
   const int chunks = b.chunks > 1 ? b.chunks : 1;
-  hipLaunchKernelGGL(k_colsum, dim3((maxc + 63) / 64, b.n, chunks), dim3(1024), 0, st, b);
+  hipLaunchKernelGGL(k_colsum, dim3((maxc + 255) / 256, b.n, chunks), dim3(256), 0, st, b);
   DVGR_LAUNCH_CHECK();
 }
 
