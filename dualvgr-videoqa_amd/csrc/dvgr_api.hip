@@ -33,7 +33,7 @@ FwdWs fwd_ws(const dvgr_dims& d) {
 struct BwdWs {
   int64_t dpo, dzf, dp0, dp1, dz[2], dxtmp[2];
   int64_t dw[2][2], dpre[2][2], dWh[2][2], ds_part[2][2], da_part[2][2], dc_part[2][2], dp_cat[2];   // [set][modality]
-  int64_t dqbar, dr, dy, total;
+  int64_t dqbar, dr, dy, qdots, total;
 };
 BwdWs bwd_ws(const dvgr_dims& d) {
   BwdWs w{};
@@ -59,6 +59,7 @@ BwdWs bwd_ws(const dvgr_dims& d) {
   w.dqbar = o;  o += round64((int64_t)d.B * d.Wd);
   w.dr = o;     o += round64((int64_t)d.B * d.T);
   w.dy = o;     o += round64((int64_t)d.B * d.T * D);
+  w.qdots = o;  o += round64(2 * (int64_t)d.B * d.T);
   w.total = o;
   return w;
 }
@@ -812,7 +813,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       a.dqbar = ws + W.dqbar; a.words = io->words; a.qlen = io->qlen;
       a.params = lp(l); a.off_w2 = P.qa_w2; a.layer_stride = 0;
       a.saved = ls(l); a.s_layer_stride = 0; a.s_d = S.qa_d; a.s_nrm = S.qa_nrm; a.s_a = S.qa_a; a.s_ah = S.qa_ah; a.s_S = S.qa_s;
-      a.gwords = g->gwords; a.dr = ws + W.dr; a.dy = ws + W.dy;
+      a.gwords = g->gwords; a.dr = ws + W.dr; a.dy = ws + W.dy; a.rowdots = ws + W.qdots;
       a.B = B; a.T = T; a.D = D; a.Wd = Wd; a.L = 1;
       a.first = (l == L - 1) ? 1 : 0;
       a.dy_p = PM.out(ws + W.dy, &plo);

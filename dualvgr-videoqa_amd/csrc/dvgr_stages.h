@@ -145,6 +145,7 @@ struct QaBwdArgs {
   float* gwords;           // (B, T, Wd) fully written
   float* dr;               // [L][B*T]
   float* dy;               // [L][B*T][D]
+  float* rowdots;          // [2][L][B*T] scratch between the two passes
   int B, T, D, Wd, L;
   int first;               // 1: this launch initialises gwords, 0: it accumulates
   uint16_t* dy_p;          // bf16 planes of dy (nullable)

@@ -674,9 +674,36 @@ int punish_bwd(hipStream_t st, const PunishBwdArgs& a) {
 // S0 backward rows.  grid (B), loops over layers.  SURVEY.md Appendix A.1
 // =================================================================================================
 constexpr int kQaChunks = 4;   // workgroups per batch element: each redoes the (tiny) softmax part, then owns 1/4 of the rows
+// pass 1 of the S0 backward: one wave per (layer, sample, word) row: s1 = words_t . dqbar, s2 = d_t . w2
+__global__ __launch_bounds__(256) void k_qa_bwd_rows(const QaBwdArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);        // (l * B + b) * T + t
+  const int T = a.T, D = a.D, Wd = a.Wd;
+  if (row >= (int64_t)a.L * a.B * T) return;
+  const int l = (int)(row / ((int64_t)a.B * T));
+  const int bt = (int)(row - (int64_t)l * a.B * T), b = bt / T;
+  const float* sav = a.saved + (int64_t)l * a.s_layer_stride;
+  const float4* wrow = reinterpret_cast<const float4*>(a.words + (int64_t)bt * Wd);
+  const float4* dq4 = reinterpret_cast<const float4*>(a.dqbar + ((int64_t)l * a.B + b) * Wd);
+  const float4* drow = reinterpret_cast<const float4*>(sav + a.s_d + (int64_t)bt * D);
+  const float4* w24 = reinterpret_cast<const float4*>(a.params + (int64_t)l * a.layer_stride + a.off_w2);
+  float s1 = 0.f, s2 = 0.f;
+  for (int w = lane; w < Wd / 4; w += 64) {
+    const float4 x = wrow[w], y = dq4[w];
+    s1 += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+  }
+#pragma unroll 4
+  for (int k = lane; k < D / 4; k += 64) {
+    const float4 x = drow[k], y = w24[k];
+    s2 += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+  }
+  s1 = wave_sum(s1); s2 = wave_sum(s2);
+  if (lane == 0) { a.rowdots[row] = s1; a.rowdots[(int64_t)a.L * a.B * T + row] = s2; }
+}
+
 __global__ __launch_bounds__(256) void k_qa_bwd(const QaBwdArgs a) {
   __shared__ float sh_dah[256], sh_c[256], sh_ah[256], sh_a[256], sh_da[256], sh_dr[256];
-  const int b = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
   const int T = a.T, D = a.D, Wd = a.Wd;
   const int len = (int)a.qlen[b];
   for (int l = 0; l < a.L; ++l) {
@@ -684,22 +711,9 @@ __global__ __launch_bounds__(256) void k_qa_bwd(const QaBwdArgs a) {
     const float* w2 = a.params + (int64_t)l * a.layer_stride + a.off_w2;
     const float* dqb = a.dqbar + ((int64_t)l * a.B + b) * Wd;
     const float* dsv = sav + a.s_d + (int64_t)b * T * D;
-    for (int t = wave; t < T; t += 4) {
-      float s1 = 0.f, s2 = 0.f;
-      const float4* wrow = reinterpret_cast<const float4*>(a.words + ((int64_t)b * T + t) * Wd);
-      const float4* dq4 = reinterpret_cast<const float4*>(dqb);
-      for (int w = lane; w < Wd / 4; w += 64) {
-        const float4 x = wrow[w], y = dq4[w];
-        s1 += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
-      }
-      const float4* drow = reinterpret_cast<const float4*>(dsv + (int64_t)t * D);
-      const float4* w24 = reinterpret_cast<const float4*>(w2);
-      for (int k = lane; k < D / 4; k += 64) {
-        const float4 x = drow[k], y = w24[k];
-        s2 += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
-      }
-      s1 = wave_sum(s1); s2 = wave_sum(s2);
-      if (lane == 0) { sh_dah[t] = s1; sh_c[t] = s2; }
+    if (tid < T) {                                          // row dots from k_qa_bwd_rows
+      sh_dah[tid] = a.rowdots[((int64_t)l * a.B + b) * T + tid];
+      sh_c[tid] = a.rowdots[((int64_t)(a.L + l) * a.B + b) * T + tid];
     }
     if (tid < T) { sh_ah[tid] = sav[a.s_ah + b * T + tid]; sh_a[tid] = sav[a.s_a + b * T + tid]; }
     __syncthreads();
@@ -726,16 +740,21 @@ __global__ __launch_bounds__(256) void k_qa_bwd(const QaBwdArgs a) {
         gw[w] = (a.first && l == 0) ? val : (gw[w] + val);
       }
       const float nrm = sav[a.s_nrm + b * T + t], drt = sh_dr[t], ct = sh_c[t];
-      for (int k = tid; k < D; k += 256) {                  // dy = (dd - d (d.dd)) / nrm, dd = dr * w2
-        const float dyv = drt * (w2[k] - dsv[(int64_t)t * D + k] * ct) / nrm;
-        dy[(int64_t)t * D + k] = dyv;
-        split_store1(a.dy_p, a.lo_off, (((int64_t)l * a.B + b) * T + t) * D + k, dyv);
+      const float sc = drt / nrm;
+      for (int k = tid; k < D / 4; k += 256) {              // dy = (dd - d (d.dd)) / nrm, dd = dr * w2
+        const float4 w = reinterpret_cast<const float4*>(w2)[k];
+        const float4 dv = reinterpret_cast<const float4*>(dsv + (int64_t)t * D)[k];
+        const float4 o = make_float4(sc * (w.x - dv.x * ct), sc * (w.y - dv.y * ct), sc * (w.z - dv.z * ct), sc * (w.w - dv.w * ct));
+        reinterpret_cast<float4*>(dy + (int64_t)t * D)[k] = o;
+        split_store4(a.dy_p, a.lo_off, (((int64_t)l * a.B + b) * T + t) * D + 4 * k, o);
       }
     }
     __syncthreads();
   }
 }
 int qa_bwd(hipStream_t st, const QaBwdArgs& a) {
+  const int64_t rows = (int64_t)a.L * a.B * a.T;
+  hipLaunchKernelGGL(k_qa_bwd_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a);
   hipLaunchKernelGGL(k_qa_bwd, dim3(a.B, kQaChunks), dim3(256), 0, st, a);
   DVGR_LAUNCH_CHECK();
 }
