@@ -115,7 +115,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--probe", default="fwd_gat_gemm")
-    ap.add_argument("--loss", default="fused", choices=["fused", "precomputed"],
+    ap.add_argument("--loss", default="fused", choices=["fused", "fused-after", "precomputed"],
                     help="fused: the scope-U loss and its gradients are computed inside every timed step by "
                          "dvgr_scope_u_loss; precomputed: fixed upstream gradients (unit kernels only)")
     args = ap.parse_args()
@@ -149,6 +149,8 @@ def main():
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
     m = m.to(dev)
     m.train(not args.eval_mode)
+    if args.loss == "fused":
+        m.loss_in_forward = (1.0, 1e-8, float(world))
     inp = synth.unit_inputs(B, N, T, D, WD, seed=666 + rank)  # each rank owns its own QA pairs (weak scaling)
     t = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
     for k in ("A", "M", "dq", "words"):
@@ -190,7 +192,11 @@ def main():
             t[k].grad = None
         raw = m.forward_raw(t["A"], t["M"], t["dq"], t["words"], t["qlen"])
         if args.loss == "fused":
-            # loss value + its gradients w.r.t. all outputs by the fused kernels (csrc/dvgr_loss.hip), every step
+            # loss value + its gradients w.r.t. all outputs by the fused kernels (csrc/dvgr_loss.hip), every step;
+            # enqueued by the forward itself (dvgr_opts.loss) so that they run under its last contractions
+            _, g = m.last_loss
+            torch.autograd.backward([raw[0], *raw[3:]], [g[0], *g[3:]])
+        elif args.loss == "fused-after":
             _, g = losses.fused_scope_u_loss(raw, 1.0, 1e-8, world)
             torch.autograd.backward([raw[0], *raw[3:]], [g[0], *g[3:]])
         else:
@@ -235,7 +241,7 @@ def main():
                                f"T={T}, {'eval' if args.eval_mode else 'training (dropout 0.15 on)'}",
                    "global_batch": world * B, "parallelism": f"dp{world}",
                    "loss": ("sum(vis)+common+1e-8*HSIC evaluated with its gradients inside every timed step "
-                            "(fused HIP kernels, dvgr_scope_u_loss)") if args.loss == "fused" else
+                            "(fused HIP kernels, dvgr_opts.loss / dvgr_scope_u_loss)") if args.loss.startswith("fused") else
                            "upstream gradients of sum(vis)+common+1e-8*HSIC for all 3+4L outputs, precomputed once",
                    "algorithmic_gflop_per_qa_train": f_train / 1e9,
                    "unit_tflops": value / world * f_train / 1e12,

@@ -39,10 +39,16 @@ class Grads(C.Structure):
                                           "g_aq_fusion", "g_mq_fusion", "gA", "gM", "gdq", "gwords", "gparams")]
 
 
+class LossSpec(C.Structure):
+    _fields_ = [("alpha", C.c_float), ("beta", C.c_float), ("dep_scale", C.c_float), ("loss3", C.c_void_p),
+                ("g_vis", C.c_void_p), ("g_com_app", C.c_void_p), ("g_com_mot", C.c_void_p), ("g_aq_fusion", C.c_void_p),
+                ("g_mq_fusion", C.c_void_p)]
+
+
 class Opts(C.Structure):
     _fields_ = [("train", C.c_int32), ("probe_site", C.c_int32), ("probe_layer", C.c_int32), ("flags", C.c_int32),
                 ("seed", C.c_uint64), ("probe_begin", C.c_void_p), ("probe_end", C.c_void_p),
-                ("layer_done_events", C.POINTER(C.c_void_p))]
+                ("layer_done_events", C.POINTER(C.c_void_p)), ("loss", C.POINTER(LossSpec))]
 
 
 OPT_SINGLE_STREAM = 1

@@ -8,7 +8,13 @@
 
 using namespace dvgr;
 
-namespace dvgr { size_t gat_lds_bytes_max(int N, int F); }
+namespace dvgr {
+size_t gat_lds_bytes_max(int N, int F);
+size_t aux_ws_floats(const dvgr_dims& d);
+int aux_losses(hipStream_t st, const dvgr_dims& d, const dvgr_io* io, float alpha, float beta, float dep_scale,
+               float* loss3, float* g_vis, float* const g[4], float* ws);
+int sum_and_ones(hipStream_t st, const float* x, float* g_ones, int64_t n, float* out);
+}
 
 #define DVGR_TRY(expr)                 \
   do {                                 \
@@ -65,7 +71,7 @@ BwdWs bwd_ws(const dvgr_dims& d) {
 }
 
 int64_t ws_floats(const dvgr_dims& d) {
-  const int64_t f = fwd_ws(d).total, b = bwd_ws(d).total;
+  const int64_t f = fwd_ws(d).total + round64((int64_t)aux_ws_floats(d)), b = bwd_ws(d).total;   // forward may carry the loss
   return f > b ? f : b;
 }
 
@@ -232,12 +238,6 @@ int check_common(const dvgr_dims* d, const void* params, const dvgr_io* io, cons
 }
 
 }  // namespace
-
-namespace dvgr {
-size_t aux_ws_floats(const dvgr_dims& d);
-int aux_losses(hipStream_t st, const dvgr_dims& d, const dvgr_io* io, float alpha, float beta, float dep_scale,
-               float* loss3, float* g_vis, float* const g[4], float* ws);
-}
 
 extern "C" {
 
@@ -474,6 +474,17 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
       DVGR_TRY(gat_attn_fwd(st, a));
       DVGR_TRY(fprobe.end(DVGR_PROBE_FWD_GAT_ATTN, l));
     }
+    // every list output exists now: the auxiliary losses and their gradients (VALU / HBM work) go under the
+    // contractions that are still to come (S4 of this layer, MFB)
+    if (l == L - 1 && O.loss) {
+      const dvgr_loss_spec& Q = *O.loss;
+      if (!Q.loss3 || !Q.g_com_app || !Q.g_com_mot || !Q.g_aq_fusion || !Q.g_mq_fusion) return DVGR_E_NULL;
+      if (side) DVGR_TRY(side->order(st, hs));
+      dvgr_io lio = *io;
+      lio.vis = nullptr;                   // sum(vis) follows at the very end
+      float* const gl[4] = {Q.g_com_app, Q.g_com_mot, Q.g_aq_fusion, Q.g_mq_fusion};
+      DVGR_TRY(aux_losses(hs, d, &lio, Q.alpha, Q.beta, Q.dep_scale, Q.loss3, nullptr, gl, ws + fwd_ws(d).total));
+    }
     // S4: tn_v = tanh(z_v . P1^T + bP)
     {
       GemmBatch gb{};
@@ -518,6 +529,10 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
     go.p[go.n] = nt(saved + S.mfb_z, kMfbPooled, params + P.mfb_wo, kMfbPooled, io->vis, D, params + P.mfb_bo, BN, D, kMfbPooled, ACT_ELU);
     PM.attach(go.p[go.n++]);
     DVGR_TRY(gemm_launch(st, KC, KC, go, TAG_GENERIC, prec));
+  }
+  if (O.loss) {
+    if (side) DVGR_TRY(side->order(hs, st));
+    if (O.loss->g_vis) DVGR_TRY(sum_and_ones(st, io->vis, O.loss->g_vis, BND, O.loss->loss3));
   }
   return 0;
 }

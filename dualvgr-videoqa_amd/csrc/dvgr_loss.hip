@@ -274,6 +274,11 @@ static int launch_gram(hipStream_t st, const AuxArgs& a) {
   }
 }
 
+int sum_and_ones(hipStream_t st, const float* x, float* g_ones, int64_t n, float* out) {
+  hipLaunchKernelGGL(k_sum_and_ones, dim3(256), dim3(256), 0, st, x, g_ones, n, out);
+  return (int)hipGetLastError();
+}
+
 static int nb_of(int N) { return N <= 8 ? 8 : N <= 16 ? 16 : N <= 24 ? 24 : N <= 32 ? 32 : 64; }
 
 template <int NB, int CPT>

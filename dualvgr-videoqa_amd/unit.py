@@ -171,6 +171,17 @@ class _UnitFn(torch.autograd.Function):
                    lists[3].data_ptr())
         stream = torch.cuda.current_stream(dev).cuda_stream
         opts = mod.make_opts(train, seed, backward=False)
+        mod.last_loss = None
+        if mod.loss_in_forward is not None:
+            # scope-U loss and its gradients by the forward itself (dvgr_opts.loss): under the last contractions
+            alpha, beta, scale = mod.loss_in_forward
+            terms = torch.empty(3, device=dev, dtype=torch.float32)
+            g_vis = torch.empty_like(vis)
+            g_lists = [torch.empty_like(t) for t in lists]
+            spec = L_.LossSpec(float(alpha), float(beta), float(scale), terms.data_ptr(), g_vis.data_ptr(),
+                               *[g.data_ptr() for g in g_lists])
+            opts.loss = C.pointer(spec)
+            mod.last_loss = (terms, [g_vis, None, None, *g_lists])
         L_.check(lib.dvgr_unit_forward(C.byref(dims), flat.data_ptr(), mod.lowp_ptr(), C.byref(io), saved.data_ptr(),
                                        saved.numel(), ws.data_ptr(), ws.numel(), C.byref(opts), stream),
                  "dvgr_unit_forward")
@@ -281,6 +292,11 @@ class DualVGRUnit_multiple(nn.Module):
         self.forced_seed = None      # tests: fix the dropout seed of the next forward
         self.keep_saved = False      # tests: keep a handle on the saved-for-backward buffer
         self.single_stream = bool(int(os.environ.get("DVGR_SINGLE_STREAM", "0")))   # DVGR_OPT_SINGLE_STREAM
+        # (alpha, beta, dep_scale) or None: when set, forward_raw() also evaluates the scope-U loss
+        # sum(vis) + alpha*common + beta*dep_scale*dependence with its gradients w.r.t. the outputs (dvgr_opts.loss)
+        # and leaves (terms, upstream_grads) in `last_loss`, ready for torch.autograd.backward(raw, upstream_grads)
+        self.loss_in_forward = None
+        self.last_loss = None
         self.last_saved = None
         self.last_flat_grad = None
         self._grad_flat = None       # persistent flat gradient buffer (grad_mode='flat')

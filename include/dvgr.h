@@ -169,6 +169,16 @@ enum dvgr_probe_site {
  * caller sees ordinary single-stream semantics.  DVGR_OPT_SINGLE_STREAM keeps every launch on `stream`. */
 #define DVGR_OPT_SINGLE_STREAM 1
 
+/* Scope-U loss evaluated by the forward itself (dvgr_opts.loss): the same arithmetic and outputs as
+ * dvgr_scope_u_loss below, but the kernels are enqueued as soon as the last layer's list outputs exist and run on the
+ * side stream under the forward's remaining contractions (last S4, MFB) instead of after them. */
+typedef struct dvgr_loss_spec {
+  float alpha, beta, dep_scale;
+  float *loss3;                 /* device, 3 floats: {sum(vis), mean_l common, mean_l dependence}           */
+  float *g_vis;                 /* (B, N, D), nullable: d loss / d vis (= 1); NULL also drops the sum(vis) term */
+  float *g_com_app, *g_com_mot, *g_aq_fusion, *g_mq_fusion;   /* (L, B, N, D): d loss / d list tensor     */
+} dvgr_loss_spec;
+
 /* Per-call options of forward / backward (all fields may be zero). */
 typedef struct dvgr_opts {
   int32_t train;       /* != 0: the 24 dropout sites per layer are active (p = 0.15, F.dropout semantics) */
@@ -182,6 +192,7 @@ typedef struct dvgr_opts {
                           MFB parameter gradients are final, event[l] when layer l's are, so a data-parallel
                           caller can start the RCCL all-reduce of that slice of `gparams` while the earlier
                           layers are still running */
+  const dvgr_loss_spec *loss;     /* forward only, nullable: also evaluate the scope-U loss and its gradients */
 } dvgr_opts;
 
 /* Forward of the whole stacked unit: replaces DualVGRUnit_multiple.forward (model/models.py:

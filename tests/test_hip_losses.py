@@ -126,3 +126,24 @@ def test_aux_terms_alone_without_vis():
     assert abs(float(aux) - (0.5 * want_t[1] + 2e-3 * want_t[2])) <= TOL * abs(0.5 * want_t[1] + 2e-3 * want_t[2])
     for t, w in zip(ls, want_g[1:]):
         assert rel_err(t.grad.cpu().numpy(), 3.0 * w.numpy()) < TOL
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_loss_evaluated_by_the_forward_equals_the_separate_call(train):
+    """dvgr_opts.loss (kernels enqueued by the forward, on the side stream) == dvgr_scope_u_loss afterwards."""
+    case = GoldenCase("g_real_n20_l3")
+    m = dv.DualVGRUnit_multiple(word_dim=case.Wd, module_dim=case.D, num_of_nodes=case.N, unit_layers=case.L)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in case.sd_np.items()}, strict=True)
+    m = m.cuda().train(train)
+    m.forced_seed = 77
+    m.loss_in_forward = (0.7, 3e-3, 2.0)
+    t = case.torch_inputs(device="cuda")
+    raw = m.forward_raw(t["A"], t["M"], t["dq"], t["words"], t["qlen"])
+    terms, ups = m.last_loss
+    terms2, ups2 = losses.fused_scope_u_loss(raw, 0.7, 3e-3, 2)
+    torch.cuda.synchronize()
+    assert torch.allclose(terms, terms2, rtol=1e-6, atol=0)
+    for a, b in zip(ups, ups2):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a, b)
