@@ -180,13 +180,15 @@ def main():
                    "bwd_gat_dw": (L_.PROBE_BWD_GAT_DW, 8 * B * N * D * D, "gemm_kernel<IC,IC,*,*,TAG_BWD_GAT_DW=3>"),
                    "bwd_gat_dx": (L_.PROBE_BWD_GAT_DX, 8 * B * N * D * D, "gemm_kernel<KC,IC,*,*,TAG_BWD_GAT_DX=4>")}
     site, probe_flops, probe_name = probe_sites[args.probe]
+    # layer 0's Wh contraction shares the chip with the query-side chain on the side stream; layer 1's runs alone
+    probe_layer = min(1, Lr - 1)
     pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     for ev in [e for pr in pairs for e in pr] + (events or []):
         ev.record()          # torch creates the hipEvent lazily at the first record; the C ABI needs the handle
 
     def step(i=None):
         if i is not None:
-            m.set_probe(site, 0, pairs[i][0], pairs[i][1])
+            m.set_probe(site, probe_layer, pairs[i][0], pairs[i][1])
         m.zero_grad_flat()
         for k in ("A", "M", "dq", "words"):
             t[k].grad = None
