@@ -837,12 +837,15 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       GemmBatch gb{};   // dW1 = dy^T . dq
       gb.p[gb.n] = tn(ws + W.dy, D, io->dq, D, glp(l) + P.qa_w1, D, D, D, BT);
       PM.attach(gb.p[gb.n++]);
-      DVGR_TRY(gemm_launch(hs, IC, IC, gb, TAG_GENERIC, prec));
       GemmBatch gd{};   // d(dq) (+)= dy . W1
       gd.p[gd.n] = nn(ws + W.dy, D, lp(l) + P.qa_w1, D, g->gdq, D, BT, D, D, 1);
       PM.attach(gd.p[gd.n++]);
       gd.p[0].atomic_ok = 1;
-      DVGR_TRY(gemm_launch(hs, KC, IC, gd, TAG_GENERIC, prec));
+      // last layer processed: the main stream is idle by now and takes this contraction while the side stream does dW1
+      hipStream_t qs = hs;
+      if (l == 0 && side) { DVGR_TRY(side->order(hs, st)); qs = st; }
+      DVGR_TRY(gemm_launch(qs, KC, IC, gd, TAG_GENERIC, prec));
+      DVGR_TRY(gemm_launch(hs, IC, IC, gb, TAG_GENERIC, prec));
       cb.j[cb.n++] = ColsumJob{ws + W.dy, nullptr, nullptr, nullptr, BT, 0, D, D, glp(l) + P.qa_b1};
       cb.j[cb.n++] = ColsumJob{ls(l) + S.qa_d, nullptr, ws + W.dr, nullptr, BT, 0, D, D, glp(l) + P.qa_w2};
       cb.j[cb.n++] = ColsumJob{ws + W.dr, nullptr, nullptr, nullptr, BT, 0, 1, 1, glp(l) + P.qa_b2};
