@@ -377,3 +377,39 @@ def test_other_graph_sizes_against_oracle(N, D, Lr, B, T, dtype):
     # gradients by up to 1e-2, while plain bf16 moves them by O(1)).  Exact fp32 keeps the tight gradient bound.
     gtol = GTOL if dtype == "fp32" else 2e-2
     assert max(errs) < TOL and max(gerrs) < gtol and werr < gtol
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_side_stream_schedule_equals_single_stream(train):
+    """The two-stream schedules (forward: query chain + loss on the side stream; backward: weight gradients and the query
+    branch) against DVGR_OPT_SINGLE_STREAM on the full-size problem, several times in a row: any missing dependency edge
+    shows up as a mismatch.  Tolerance covers only the order of float atomics in split-K / column-sum accumulation."""
+    B, N, Lr, T, D, Wd = 64, 20, 3, 15, 768, 300
+    shapes = O.param_shapes(Wd, D, Lr, 1)
+    sd = synth.xavier_state_dict(shapes, seed=5, bias_range=0.1)
+    inp = synth.unit_inputs(B, N, T, D, Wd, seed=5)
+    results = []
+    for single in (True, False, False, False):
+        m = dv.DualVGRUnit_multiple(word_dim=Wd, module_dim=D, num_of_nodes=N, unit_layers=Lr, dtype="bf16x3")
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+        m = m.cuda().train(train)
+        m.forced_seed = 4242
+        m.single_stream = single
+        m.loss_in_forward = (1.0, 1e-3, 1.0)
+        t = {k: torch.from_numpy(v.copy()).cuda() for k, v in inp.items()}
+        for k in ("A", "M", "dq", "words"):
+            t[k].requires_grad_(True)
+        for _ in range(3):                      # back-to-back steps: the schedules also have to be safe across calls
+            m.zero_grad_flat()
+            for k in ("A", "M", "dq", "words"):
+                t[k].grad = None
+            raw = m.forward_raw(t["A"], t["M"], t["dq"], t["words"], t["qlen"])
+            terms, g = m.last_loss
+            torch.autograd.backward([raw[0], *raw[3:]], [g[0], *g[3:]])
+        torch.cuda.synchronize()
+        results.append(([r.detach().cpu().numpy() for r in raw] + [terms.cpu().numpy()] +
+                        [t[k].grad.cpu().numpy() for k in ("A", "M", "dq", "words")] + [m.last_flat_grad.cpu().numpy()]))
+    ref = results[0]
+    for other in results[1:]:
+        for a, b in zip(ref, other):
+            assert rel_err(b, a) < 2e-6
