@@ -341,11 +341,13 @@ def test_bf16_operands_stated_tolerance():
     assert max(errs.values()) < 3e-2 and max(gerrs.values()) < 1e-1
 
 
-@pytest.mark.parametrize("N,D,Lr,B,T", [(64, 128, 2, 3, 7), (16, 256, 6, 4, 5), (8, 768, 3, 5, 12), (33, 64, 1, 2, 3)])
+@pytest.mark.parametrize("N,D,Lr,B,T", [(64, 128, 2, 3, 7), (16, 256, 6, 4, 5), (8, 768, 3, 5, 12), (33, 64, 1, 2, 3),
+                                        (20, 768, 1, 1, 1), (64, 768, 1, 2, 40), (2, 64, 2, 130, 2)])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16x3"])
 def test_other_graph_sizes_against_oracle(N, D, Lr, B, T, dtype):
-    """Clip counts / depths of the other BASELINE.json configs (N = 8, 16, 64; L up to 6) and an odd N,
-    forward + backward against the factorised oracle on the same seeded inputs."""
+    """Clip counts / depths of the other BASELINE.json configs (N = 8, 16, 64; L up to 6), an odd N, and the corners
+    (one sample with a one-word question; the largest graph at full width with a long question; a batch wider than
+    one 128-row tile of two-clip graphs), forward + backward against the factorised oracle on the same seeded inputs."""
     Wd = 300 if D == 768 else 32
     sd_np = synth.xavier_state_dict(O.param_shapes(Wd, D, Lr), seed=11, bias_range=0.1)
     inp = synth.unit_inputs(B, N, T, D, Wd, seed=11)
