@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared_symbols():
     names = set()
-    for h in ("dvgr.h", "dvgr_debug.h"):
+    for h in ("dvgr.h", "dvgr_debug.h", "dvgr_head.h"):
         text = open(os.path.join(ROOT, "include", h)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         names |= set(re.findall(r"\b(dvgr_[a-z_0-9]+)\s*\(", text))
@@ -30,7 +30,9 @@ def test_library_exports_every_declared_symbol():
     lib = L.load()
     declared = _declared_symbols()
     assert len(declared) >= 15
-    bound = {n for n, _, _ in L.SYMBOLS}
+    from dualvgr_videoqa_amd import head as HD
+    HD.load()
+    bound = {n for n, _, _ in L.SYMBOLS} | {n for n, _, _ in HD.HEAD_SYMBOLS}
     assert declared == bound, declared ^ bound
     for name in declared:
         assert getattr(lib, name) is not None
@@ -158,3 +160,24 @@ def test_dropout_replica_statistics_and_site_keys():
     assert abs(np.mean(m[0::2] * m[1::2]) - 0.85 ** 2) < 2e-3
     masks = dropout.site_masks(seed, 2, 5, 64, 2)
     assert set(masks) == set(O.dropout_site_shapes(2, 5, 64, 2))
+
+
+def test_head_layout_and_argument_checks():
+    """Answer head (include/dvgr_head.h): dims checks, parameter table = the reference's state_dict surface, refusals."""
+    from dualvgr_videoqa_amd import head as HD
+    from oracle import head_torch as H
+    lib = HD.load()
+    ok = HD.HeadDims(4, 20, 768, 1000, 0)
+    assert lib.dvgr_head_check_dims(C.byref(ok)) == 0
+    for bad in (HD.HeadDims(0, 20, 768, 1000, 0), HD.HeadDims(4, 65, 768, 1000, 0), HD.HeadDims(4, 20, 100, 1000, 0),
+                HD.HeadDims(4, 20, 768, 1001, 0), HD.HeadDims(4, 20, 768, 1000, 9)):
+        assert lib.dvgr_head_check_dims(C.byref(bad)) == -1
+    m = dv.AnswerHead(module_dim=64, num_answers=10)
+    want = dict(H.param_shapes(64, 10))
+    got = {k: tuple(v.shape) for k, v in m.named_parameters()}
+    assert got == want
+    offs = sorted(m._table)
+    assert all(o % 64 == 0 for o in offs) and len(set(offs)) == len(offs)
+    io = HD.HeadIO()
+    assert lib.dvgr_head_forward(C.byref(ok), None, C.byref(io), None, 0, None, 0, 0, 0, None) == -2
+    assert lib.dvgr_head_saved_bytes(C.byref(ok)) > 0 and lib.dvgr_head_workspace_bytes(C.byref(ok)) > 0
