@@ -115,6 +115,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--probe", default="fwd_gat_gemm")
+    ap.add_argument("--head", action="store_true",
+                    help="row f2: also run the clip read-out + classifier (AnswerHead, 1000 answers) and a cross-entropy "
+                         "loss on its logits inside every step; the unit then gets d CE / d vis instead of ones")
     ap.add_argument("--loss", default="fused", choices=["fused", "fused-after", "precomputed"],
                     help="fused: the scope-U loss and its gradients are computed inside every timed step by "
                          "dvgr_scope_u_loss; precomputed: fixed upstream gradients (unit kernels only)")
@@ -150,7 +153,16 @@ def main():
     m = m.to(dev)
     m.train(not args.eval_mode)
     if args.loss == "fused":
-        m.loss_in_forward = (1.0, 1e-8, float(world))
+        m.loss_in_forward = (1.0, 1e-8, float(world), not args.head)
+    head = None
+    if args.head:
+        if args.loss != "fused":
+            raise SystemExit("--head needs --loss fused")
+        torch.manual_seed(666)
+        head = dv.AnswerHead(module_dim=D, num_answers=1000, dtype=args.dtype).to(dev)
+        head.train(not args.eval_mode)
+        qe = torch.from_numpy(synth.normal("bench_qe", (B, D), 0.5, 666 + rank)).to(dev).requires_grad_(True)
+        answers = torch.from_numpy((synth.uniform("bench_ans", (B,), 0.0, 1000.0, 666 + rank)).astype(np.int64)).to(dev)
     inp = synth.unit_inputs(B, N, T, D, WD, seed=666 + rank)  # each rank owns its own QA pairs (weak scaling)
     t = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
     for k in ("A", "M", "dq", "words"):
@@ -197,7 +209,13 @@ def main():
             # loss value + its gradients w.r.t. all outputs by the fused kernels (csrc/dvgr_loss.hip), every step;
             # enqueued by the forward itself (dvgr_opts.loss) so that they run under its last contractions
             _, g = m.last_loss
-            torch.autograd.backward([raw[0], *raw[3:]], [g[0], *g[3:]])
+            if head is not None:
+                head.zero_grad(set_to_none=True)
+                qe.grad = None
+                ce = torch.nn.functional.cross_entropy(head(qe, raw[0]), answers)     # train.py:147
+                torch.autograd.backward([ce, *raw[3:]], [None, *g[3:]])
+            else:
+                torch.autograd.backward([raw[0], *raw[3:]], [g[0], *g[3:]])
         elif args.loss == "fused-after":
             _, g = losses.fused_scope_u_loss(raw, 1.0, 1e-8, world)
             torch.autograd.backward([raw[0], *raw[3:]], [g[0], *g[3:]])
@@ -242,6 +260,7 @@ def main():
         "config": {"workload": f"{cfg['name']}: DualVGR unit forward+backward, per-GPU batch {B}, D={D}, word_dim={WD}, "
                                f"T={T}, {'eval' if args.eval_mode else 'training (dropout 0.15 on)'}",
                    "global_batch": world * B, "parallelism": f"dp{world}",
+                   "head": "AnswerHead (read-out + classifier, 1000 answers) + cross-entropy inside the step" if args.head else None,
                    "loss": ("sum(vis)+common+1e-8*HSIC evaluated with its gradients inside every timed step "
                             "(fused HIP kernels, dvgr_opts.loss / dvgr_scope_u_loss)") if args.loss.startswith("fused") else
                            "upstream gradients of sum(vis)+common+1e-8*HSIC for all 3+4L outputs, precomputed once",

@@ -1004,6 +1004,9 @@ static int launch_layout(hipStream_t stream, const GemmBatch& b, int prec) {
   return launch_cfg<LA, LB, 64, 64, TAG>(stream, b, prec);
 }
 
+bool small_eligible(const GemmBatch& b, int la, int lb);
+int small_launch(hipStream_t st, int la, int lb, const GemmBatch& b);
+
 int gemm_launch(hipStream_t stream, int la, int lb, const GemmBatch& b, int tag, int prec) {
   if (b.n < 1 || b.n > kMaxBatch) return DVGR_E_DIMS;
   for (int i = 0; i < b.n; ++i) {
@@ -1015,6 +1018,7 @@ int gemm_launch(hipStream_t stream, int la, int lb, const GemmBatch& b, int tag,
     if (lb == KC && (p.K & 3)) return DVGR_E_DIMS;
     if (lb == IC && (p.N & 3)) return DVGR_E_DIMS;
   }
+  if (small_eligible(b, la, lb)) return small_launch(stream, la, lb, b);     // batch-sized problems: dvgr_small.hip
   if (la == KC && lb == KC) {
     if (tag == TAG_FWD_GAT) return launch_layout<KC, KC, TAG_FWD_GAT>(stream, b, prec);
     if (tag == TAG_FWD_SF) return launch_layout<KC, KC, TAG_FWD_SF>(stream, b, prec);

@@ -147,17 +147,19 @@ __global__ __launch_bounds__(256) void k_readout_fwd(const float* e, const float
 }
 
 // ---- BatchNorm1d + dropout: one thread per feature ------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_bn_fwd(const float* he, const float* gamma, const float* beta, float* run_mean,
+__global__ __launch_bounds__(64) void k_bn_fwd(const float* he, const float* gamma, const float* beta, float* run_mean,
                                                 float* run_var, float* s_mean, float* s_istd, float* yd, uint32_t key, int B,
                                                 int D, int train) {
-  const int d = blockIdx.x * 256 + threadIdx.x;
+  const int d = blockIdx.x * 64 + threadIdx.x;
   if (d >= D) return;
   float mean, var;
   if (train) {
     float s = 0.f;
+#pragma unroll 8
     for (int b = 0; b < B; ++b) s += he[(int64_t)b * D + d];
     mean = s / (float)B;
     float q = 0.f;
+#pragma unroll 8
     for (int b = 0; b < B; ++b) { const float c = he[(int64_t)b * D + d] - mean; q += c * c; }
     var = q / (float)B;                                     // biased: what the normalisation uses
     run_mean[d] = (1.f - kBnMomentum) * run_mean[d] + kBnMomentum * mean;
@@ -170,6 +172,7 @@ __global__ __launch_bounds__(256) void k_bn_fwd(const float* he, const float* ga
   s_mean[d] = mean;
   s_istd[d] = istd;
   const float g = gamma[d], bt = beta[d];
+#pragma unroll 8
   for (int b = 0; b < B; ++b) {
     const int64_t i = (int64_t)b * D + d;
     yd[i] = (g * (he[i] - mean) * istd + bt) * drop_factor(key, (uint32_t)i);
@@ -177,13 +180,14 @@ __global__ __launch_bounds__(256) void k_bn_fwd(const float* he, const float* ga
 }
 
 // dyd -> (dgamma, dbeta, dpre1 = dhe * ELU'(he))
-__global__ __launch_bounds__(256) void k_bn_bwd(const float* dyd, const float* he, const float* gamma, const float* s_mean,
+__global__ __launch_bounds__(64) void k_bn_bwd(const float* dyd, const float* he, const float* gamma, const float* s_mean,
                                                 const float* s_istd, float* dgamma, float* dbeta, float* dpre1, uint32_t key,
                                                 int B, int D, int train) {
-  const int d = blockIdx.x * 256 + threadIdx.x;
+  const int d = blockIdx.x * 64 + threadIdx.x;
   if (d >= D) return;
   const float mean = s_mean[d], istd = s_istd[d], g = gamma[d];
   float sb = 0.f, sg = 0.f;
+#pragma unroll 8
   for (int b = 0; b < B; ++b) {
     const int64_t i = (int64_t)b * D + d;
     const float dy = dyd[i] * drop_factor(key, (uint32_t)i);
@@ -192,6 +196,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd(const float* dyd, const float* h
   }
   dgamma[d] = sg;
   dbeta[d] = sb;
+#pragma unroll 8
   for (int b = 0; b < B; ++b) {
     const int64_t i = (int64_t)b * D + d;
     const float dy = dyd[i] * drop_factor(key, (uint32_t)i);
@@ -303,7 +308,7 @@ int dvgr_head_forward(const dvgr_head_dims* dp, const float* params, const dvgr_
   HEAD_TRY(launch1(st, KC, KC, nt(io->qe, D, params + P.wq, D, sv + S.cat + D, 2 * D, params + P.bq, B, D, D, ACT_NONE), prec));
   if (train) HEAD_TRY(head_drop(st, sv + S.cat, sv + S.cat, head_key(1, seed, 1), B, 2 * D, 2 * D));
   HEAD_TRY(launch1(st, KC, KC, nt(sv + S.cat, 2 * D, params + P.w1, 2 * D, sv + S.he, D, params + P.b1, B, D, 2 * D, ACT_ELU), prec));
-  hipLaunchKernelGGL(k_bn_fwd, dim3((D + 255) / 256), dim3(256), 0, st, sv + S.he, params + P.gamma, params + P.beta, io->run_mean,
+  hipLaunchKernelGGL(k_bn_fwd, dim3((D + 63) / 64), dim3(64), 0, st, sv + S.he, params + P.gamma, params + P.beta, io->run_mean,
                      io->run_var, sv + S.mean, sv + S.istd, sv + S.yd, head_key(train, seed, 2), B, D, train);
   HEAD_LAUNCH_OK();
   HEAD_TRY(launch1(st, KC, KC, nt(sv + S.yd, D, params + P.w2, D, io->logits, C, params + P.b2, B, C, D, ACT_NONE), prec));
@@ -338,7 +343,7 @@ int dvgr_head_backward(const dvgr_head_dims* dp, const float* params, const dvgr
   cb.j[cb.n++] = ColsumJob{g->g_logits, nullptr, nullptr, nullptr, B, 0, C, C, gp + P.b2};
   HEAD_TRY(launch1(st, KC, IC, nn(g->g_logits, C, params + P.w2, D, ws + W.dyd, D, B, D, C, 0), prec));
   // dropout 2, BatchNorm1d, ELU
-  hipLaunchKernelGGL(k_bn_bwd, dim3((D + 255) / 256), dim3(256), 0, st, ws + W.dyd, sv + S.he, params + P.gamma, sv + S.mean,
+  hipLaunchKernelGGL(k_bn_bwd, dim3((D + 63) / 64), dim3(64), 0, st, ws + W.dyd, sv + S.he, params + P.gamma, sv + S.mean,
                      sv + S.istd, gp + P.gamma, gp + P.beta, ws + W.dpre1, head_key(train, seed, 2), B, D, train);
   HEAD_LAUNCH_OK();
   // he = ELU(cat W1^T + b1)

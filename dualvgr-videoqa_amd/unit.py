@@ -174,12 +174,13 @@ class _UnitFn(torch.autograd.Function):
         mod.last_loss = None
         if mod.loss_in_forward is not None:
             # scope-U loss and its gradients by the forward itself (dvgr_opts.loss): under the last contractions
-            alpha, beta, scale = mod.loss_in_forward
+            alpha, beta, scale = mod.loss_in_forward[:3]
+            with_vis = len(mod.loss_in_forward) < 4 or bool(mod.loss_in_forward[3])   # False: auxiliary terms alone
             terms = torch.empty(3, device=dev, dtype=torch.float32)
-            g_vis = torch.empty_like(vis)
+            g_vis = torch.empty_like(vis) if with_vis else None
             g_lists = [torch.empty_like(t) for t in lists]
-            spec = L_.LossSpec(float(alpha), float(beta), float(scale), terms.data_ptr(), g_vis.data_ptr(),
-                               *[g.data_ptr() for g in g_lists])
+            spec = L_.LossSpec(float(alpha), float(beta), float(scale), terms.data_ptr(),
+                               g_vis.data_ptr() if with_vis else None, *[g.data_ptr() for g in g_lists])
             opts.loss = C.pointer(spec)
             mod.last_loss = (terms, [g_vis, None, None, *g_lists])
         L_.check(lib.dvgr_unit_forward(C.byref(dims), flat.data_ptr(), mod.lowp_ptr(), C.byref(io), saved.data_ptr(),
@@ -292,7 +293,7 @@ class DualVGRUnit_multiple(nn.Module):
         self.forced_seed = None      # tests: fix the dropout seed of the next forward
         self.keep_saved = False      # tests: keep a handle on the saved-for-backward buffer
         self.single_stream = bool(int(os.environ.get("DVGR_SINGLE_STREAM", "0")))   # DVGR_OPT_SINGLE_STREAM
-        # (alpha, beta, dep_scale) or None: when set, forward_raw() also evaluates the scope-U loss
+        # (alpha, beta, dep_scale[, with_sum_vis = True]) or None: when set, forward_raw() also evaluates the scope-U loss
         # sum(vis) + alpha*common + beta*dep_scale*dependence with its gradients w.r.t. the outputs (dvgr_opts.loss)
         # and leaves (terms, upstream_grads) in `last_loss`, ready for torch.autograd.backward(raw, upstream_grads)
         self.loss_in_forward = None

@@ -5,7 +5,8 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-idx = [i for i, r in enumerate(rows) if 'k_sum_and_ones' in r['Kernel_Name']]
+marker = 'k_sum_and_ones' if any('k_sum_and_ones' in r['Kernel_Name'] for r in rows) else 'k_split_planes'
+idx = [i for i, r in enumerate(rows) if marker in r['Kernel_Name']]
 a, b = idx[-back], idx[-back + 1]
 t0 = int(rows[a]['Start_Timestamp'])
 qs = sorted({r['Queue_Id'] for r in rows[a:b]})
