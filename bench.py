@@ -212,8 +212,9 @@ def main():
             if head is not None:
                 head.zero_grad(set_to_none=True)
                 qe.grad = None
-                ce = torch.nn.functional.cross_entropy(head(qe, raw[0]), answers)     # train.py:147
-                torch.autograd.backward([ce, *raw[3:]], [None, *g[3:]])
+                logits = head(qe, raw[0])
+                _, g_logits = head.cross_entropy(logits, answers)                     # train.py:147, fused value + gradient
+                torch.autograd.backward([logits, *raw[3:]], [g_logits, *g[3:]])
             else:
                 torch.autograd.backward([raw[0], *raw[3:]], [g[0], *g[3:]])
         elif args.loss == "fused-after":

@@ -243,6 +243,25 @@ __global__ __launch_bounds__(256) void k_readout_bwd(const float* dcat, const fl
   }
 }
 
+// ---- cross-entropy, value + gradient: one wave per sample --------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cross_entropy(const float* logits, const int64_t* target, float* loss, float* g, int B,
+                                                       int C, int Cv, float scale) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const float* row = logits + (int64_t)b * C;
+  float mx = -INFINITY;
+  for (int c = lane; c < Cv; c += 64) mx = fmaxf(mx, row[c]);
+  mx = wave_max(mx);
+  float se = 0.f;
+  for (int c = lane; c < Cv; c += 64) se += expf(row[c] - mx);
+  se = wave_sum(se);
+  const int t = (int)target[b];
+  const float inv = scale / (float)B;
+  for (int c = lane; c < C; c += 64)
+    g[(int64_t)b * C + c] = c < Cv ? (expf(row[c] - mx) / se - (c == t ? 1.f : 0.f)) * inv : 0.f;
+  if (lane == 0) atomicAdd(loss, (logf(se) + mx - row[t]) / (float)B);
+}
+
 int check_head(const dvgr_head_dims* d) {
   if (!d) return DVGR_E_NULL;
   if (d->B < 1 || d->N < 1 || d->N > 64 || d->D < 64 || (d->D % 64) || d->C < 4 || (d->C % 4)) return DVGR_E_DIMS;
@@ -367,6 +386,18 @@ int dvgr_head_backward(const dvgr_head_dims* dp, const float* params, const dvgr
   cb.chunks = 8;
   HEAD_TRY(colsum(st, cb));
   return 0;
+}
+
+int dvgr_head_cross_entropy(const dvgr_head_dims* dp, int C_valid, const float* logits, const int64_t* target, float scale,
+                            float* loss, float* g_logits, void* stream) {
+  HEAD_TRY(check_head(dp));
+  if (!logits || !target || !loss || !g_logits) return DVGR_E_NULL;
+  if (C_valid < 1 || C_valid > dp->C) return DVGR_E_DIMS;
+  hipStream_t st = (hipStream_t)stream;
+  const hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(k_cross_entropy, dim3((dp->B + 3) / 4), dim3(256), 0, st, logits, target, loss, g_logits, dp->B, dp->C, C_valid, scale);
+  return (int)hipGetLastError();
 }
 
 int dvgr_head_dbg_keep_mask(uint64_t seed, int site, int64_t n, float* keep, void* stream) {

@@ -43,6 +43,8 @@ HEAD_SYMBOLS = [
                                     C.c_size_t, C.c_int, C.c_uint64, C.c_void_p]),
     ("dvgr_head_backward", C.c_int, [C.POINTER(HeadDims), C.c_void_p, C.POINTER(HeadIO), C.POINTER(HeadGrads), C.c_void_p,
                                      C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_uint64, C.c_void_p]),
+    ("dvgr_head_cross_entropy", C.c_int, [C.POINTER(HeadDims), C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]),
     ("dvgr_head_dbg_keep_mask", C.c_int, [C.c_uint64, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
 ]
 _bound = False
@@ -117,6 +119,7 @@ class _HeadFn(torch.autograd.Function):
             bn.num_batches_tracked += 1
         ctx.mod, ctx.dims, ctx.train, ctx.seed = mod, dims, train, seed
         ctx.save_for_backward(vis, qe, saved, flat)
+        mod.last_logits_padded = logits
         return logits[:, :mod.num_answers]
 
     @staticmethod
@@ -125,8 +128,12 @@ class _HeadFn(torch.autograd.Function):
         mod, dims = ctx.mod, ctx.dims
         vis, qe, saved, flat = ctx.saved_tensors
         dev = vis.device
-        gl = torch.zeros((dims.B, mod.c_pad), device=dev, dtype=torch.float32)
-        gl[:, :mod.num_answers] = g_logits
+        if (g_logits.dim() == 2 and g_logits.shape[1] == mod.num_answers and g_logits.stride(0) == mod.c_pad
+                and g_logits.stride(1) == 1 and g_logits.storage_offset() == 0 and g_logits.dtype == torch.float32):
+            gl = g_logits                       # already a view of a (B, c_pad) buffer (cross_entropy() below): no copy
+        else:
+            gl = torch.zeros((dims.B, mod.c_pad), device=dev, dtype=torch.float32)
+            gl[:, :mod.num_answers] = g_logits
         g_vis, g_qe, gflat = torch.empty_like(vis), torch.empty_like(qe), torch.empty_like(flat)
         ws = torch.empty(lib.dvgr_head_workspace_bytes(C.byref(dims)), device=dev, dtype=torch.uint8)
         bn = mod.output_unit.classifier[3]
@@ -154,6 +161,7 @@ class AnswerHead(nn.Module):
         self.feature_aggregation = _Readout(D)
         self.output_unit = _Classifier(D, self.num_answers)
         self.forced_seed = None
+        self.last_logits_padded = None
         cl = self.output_unit.classifier
         self._plist = [self.feature_aggregation.v_proj.weight, self.feature_aggregation.attn.weight,
                        self.feature_aggregation.attn.bias, self.output_unit.question_proj.weight,
@@ -218,6 +226,22 @@ class AnswerHead(nn.Module):
         if self._flat is None or tuple(p.data_ptr() for p in self._plist) != self._ptrs:
             self._flatten()
         return self._flat
+
+    def cross_entropy(self, logits, target, scale: float = 1.0):
+        """nn.CrossEntropyLoss()(logits, target) of train.py:147 on the logits this module just produced: returns
+        (loss (1-element tensor), g_logits) from one fused launch; feed `g_logits` to
+        `torch.autograd.backward([logits, ...], [g_logits, ...])`."""
+        lib = load()
+        lp = self.last_logits_padded
+        B = lp.shape[0]
+        dims = HeadDims(B, 1, self.module_dim, self.c_pad, self.dtype_code)
+        loss = torch.empty(1, device=lp.device, dtype=torch.float32)
+        g = torch.empty_like(lp)
+        L_.check(lib.dvgr_head_cross_entropy(C.byref(dims), self.num_answers, lp.data_ptr(),
+                                             target.to(torch.int64).contiguous().data_ptr(), float(scale), loss.data_ptr(),
+                                             g.data_ptr(), torch.cuda.current_stream(lp.device).cuda_stream),
+                 "dvgr_head_cross_entropy")
+        return loss, g[:, :self.num_answers]
 
     def forward(self, question_embedding, visual_feature):
         """(B, D) question embedding, (B, N, D) visual_feature of the unit -> logits (B, num_answers)."""

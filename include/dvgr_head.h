@@ -67,6 +67,13 @@ int dvgr_head_backward(const dvgr_head_dims *d, const float *params, const dvgr_
                        const dvgr_head_grads *g, const void *saved, size_t saved_bytes, void *workspace,
                        size_t workspace_bytes, int train, uint64_t seed, void *stream);
 
+/* Cross-entropy of the logits against the answer indices (`nn.CrossEntropyLoss()` of train.py:93, :147; mean over the
+ * batch), value and gradient in one launch: loss[0] = mean_b (logsumexp(logits_b) - logits_b[target_b]),
+ * g_logits = (softmax(logits) - onehot(target)) * scale / B (the padding columns C_valid..C-1 get 0 and are ignored).
+ * `target` holds int64 class indices < C_valid; `scale` multiplies the gradient (loss weights, 1 / world size). */
+int dvgr_head_cross_entropy(const dvgr_head_dims *d, int C_valid, const float *logits, const int64_t *target, float scale,
+                            float *loss, float *g_logits, void *stream);
+
 /* test hook: element keep-mask (1 / 0) of dropout site 0 (read-out input), 1 (concatenation), 2 (after BatchNorm) */
 int dvgr_head_dbg_keep_mask(uint64_t seed, int site, int64_t n, float *keep, void *stream);
 

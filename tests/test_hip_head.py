@@ -107,3 +107,18 @@ def test_head_num_answers_not_a_multiple_of_four_and_state_dict_names():
     assert rel_err(logits.detach().cpu().numpy(), want.numpy()) < TOL
     logits.sum().backward()
     assert m.output_unit.classifier[5].weight.grad.shape == (10, 64)
+
+
+@pytest.mark.parametrize("Cn", [10, 1000])
+def test_fused_cross_entropy_matches_torch(Cn):
+    m = dv.AnswerHead(module_dim=64, num_answers=Cn).cuda().eval()
+    vis = torch.randn(5, 7, 64, device="cuda")
+    qe = torch.randn(5, 64, device="cuda")
+    logits = m(qe, vis)
+    target = torch.randint(0, Cn, (5,), device="cuda")
+    loss, g = m.cross_entropy(logits, target, scale=0.5)
+    ref_logits = logits.detach().clone().requires_grad_(True)
+    want = torch.nn.functional.cross_entropy(ref_logits, target)
+    (0.5 * want).backward()
+    assert abs(float(loss) - float(want)) <= 1e-5 * abs(float(want))
+    assert rel_err(g.cpu().numpy(), ref_logits.grad.cpu().numpy()) < 1e-5
