@@ -139,16 +139,24 @@ int punish_fwd(hipStream_t st, const float* X0, const float* X1, const float* p0
 // =================================================================================================
 // S3 forward: one workgroup per (b, head, modality).  model/GraphNN.py:97-111 in factorised form.
 // =================================================================================================
-// NB = N rounded up to a compile-time bound: the per-thread accumulators over the N nodes live in registers.
-template <int NB>
+// The aggregation alpha . (s * Wh) runs on the fp32 MFMA (v_mfma_f32_16x16x4_f32: exact fp32 products): A = the dropped
+// attention matrix (rows i, reduction j), B = the punished projections (reduction j, columns f).  NT = ceil(N / 16).
+// LDS images are padded with zeros up to 16 NT rows / 4 S reduction steps so that fragments need no bounds checks:
+//   shZ [4 S][F + 16]   row stride = 16 banks mod 64: the B fragment (4 rows x 16 columns per wave read) is conflict free
+//   shA [16 NT][4 S + 1] odd row stride: the A fragment (16 rows x 4 columns) is conflict free
+// The result tile goes back through LDS so that the ELU / dropout / planes epilogue stores whole 16-byte vectors.
+typedef float gat_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NT>
 __global__ __launch_bounds__(256) void k_gat_attn_fwd(const GatAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int b = blockIdx.x, h = blockIdx.y, mod = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int N = a.N, D = a.D, F = D / 4, FS = F + 4, HF = kHeads * F;   // FS: 16-byte aligned rows
-  float* shZ = sm;                 // [N][FS]  Wh tile, later s_j * Wh_j
-  float* shAT = shZ + ((N * FS + 3) & ~3);   // [N][NB] dropped attention, TRANSPOSED: shAT[j][i]
-  float* shAl = shAT + N * NB;     // [F]
+  const int N = a.N, D = a.D, F = D / 4, FS = F + 16, HF = kHeads * F;
+  const int S = (N + 3) / 4, NP = 4 * S + 1, ZR = 4 * S;    // reduction steps, shA row stride, rows of shZ
+  float* shZ = sm;                 // [ZR][FS]   Wh tile, later s_j * Wh_j, finally the output tile
+  float* shA = shZ + ZR * FS;      // [16 NT][NP] dropped attention alpha_d[i][j]
+  float* shAl = shA + 16 * NT * NP;  // [F]
   float* shAr = shAl + F;          // [F]
   float* shS = shAr + F;           // [N]
   float* shU = shS + N;            // [N]
@@ -156,7 +164,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_fwd(const GatAttnArgs a) {
   const float* Wh = a.Wh[mod] + (int64_t)b * N * HF + h * F;
   CLK(0);
   {                                                         // the tile as float4s, four independent loads in flight
-    const int F4 = F / 4, total = N * F4;
+    const int F4 = F / 4, total = ZR * F4;                  // rows N .. ZR-1 are zero padding
     for (int base = 0; base < total; base += 1024) {
       float4 v[4];
       int dst[4];
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_fwd(const GatAttnArgs a) {
         dst[r] = -1;
         if (idx < total) {
           const int j = idx / F4, q = idx - j * F4;
-          v[r] = *reinterpret_cast<const float4*>(Wh + (int64_t)j * HF + 4 * q);
+          v[r] = j < N ? *reinterpret_cast<const float4*>(Wh + (int64_t)j * HF + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
           dst[r] = j * FS + 4 * q;
         }
       }
@@ -175,6 +183,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_fwd(const GatAttnArgs a) {
         if (dst[r] >= 0) *reinterpret_cast<float4*>(shZ + dst[r]) = v[r];
     }
   }
+  for (int e = tid; e < 16 * NT * NP; e += 256) shA[e] = 0.f;
   for (int f = tid; f < F; f += 256) {
     shAl[f] = a.gat_a[mod][h * 2 * F + f];
     shAr[f] = a.gat_a[mod][h * 2 * F + F + f];
@@ -207,63 +216,91 @@ __global__ __launch_bounds__(256) void k_gat_attn_fwd(const GatAttnArgs a) {
       const float mx = wave_max(e);
       const float pe = lane < N ? expf(e - mx) : 0.f;
       const float sum = wave_sum(pe);
-      if (lane < N) shAT[lane * NB + i] = pe / sum * drop_factor(key, (uint32_t)((b * N + i) * N + lane));
+      if (lane < N) shA[i * NP + lane] = pe / sum * drop_factor(key, (uint32_t)((b * N + i) * N + lane));
     }
   }
-  for (int f = tid; f < F; f += 256)                        // punish AFTER the logits (GraphNN.py:102-104)
-    for (int j = 0; j < N; ++j) shZ[j * FS + f] *= shS[j];
+  for (int e = tid; e < N * (F / 4); e += 256) {            // punish AFTER the logits (GraphNN.py:102-104)
+    const int j = e / (F / 4), q = e - j * (F / 4);
+    float4* p = reinterpret_cast<float4*>(shZ + j * FS + 4 * q);
+    const float sj = shS[j];
+    float4 v = *p;
+    v.x *= sj; v.y *= sj; v.z *= sj; v.w *= sj;
+    *p = v;
+  }
   __syncthreads();
   CLK(3);
+  // ---- aggregation on the MFMA: wave w owns the column tiles J = w, w + 4, ... of the F / 16.  Only the owner of a
+  // column tile ever reads those 16 columns of shZ, so it overwrites them with its result tile without a barrier. ----
+  const int r16 = lane & 15, kq = lane >> 4, JT = F / 16;
+  float af[NT][4 * NT];                                     // this lane's A fragments of every (row tile, k-step)
+#pragma unroll
+  for (int I = 0; I < NT; ++I)
+#pragma unroll
+    for (int s4 = 0; s4 < 4 * NT; ++s4) af[I][s4] = s4 < S ? shA[(16 * I + r16) * NP + 4 * s4 + kq] : 0.f;
+  for (int J = wave; J < JT; J += 4) {
+    gat_f32x4 acc[NT];
+#pragma unroll
+    for (int I = 0; I < NT; ++I) acc[I] = gat_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s4 = 0; s4 < 4 * NT; ++s4) {
+      if (s4 < S) {
+        const float bf = shZ[(4 * s4 + kq) * FS + 16 * J + r16];
+#pragma unroll
+        for (int I = 0; I < NT; ++I) acc[I] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[I][s4], bf, acc[I], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * I + 4 * kq + r;
+        if (row < N) shZ[row * FS + 16 * J + r16] = acc[I][r];
+      }
+  }
+  __syncthreads();
+  CLK(4);
   const int g = h >> 2, hl = h & 3;
   float* out = (g ? a.out_s[mod] : a.out_c[mod]) + (int64_t)b * N * D + hl * F;
   const uint32_t ko = a.key_out[mod][g];
   uint16_t* zp = g ? a.zp_s[mod] : a.zp_c[mod];
-  for (int f = tid; f < F; f += 256) {
-    float acc[NB];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) acc[i] = 0.f;
-    for (int j = 0; j < N; ++j) {
-      const float z = shZ[j * FS + f];
-#pragma unroll
-      for (int i4 = 0; i4 < NB / 4; ++i4) {                 // one broadcast b128 read serves four nodes i
-        const float4 a4 = *reinterpret_cast<const float4*>(shAT + j * NB + 4 * i4);
-        acc[4 * i4 + 0] += a4.x * z; acc[4 * i4 + 1] += a4.y * z;
-        acc[4 * i4 + 2] += a4.z * z; acc[4 * i4 + 3] += a4.w * z;
-      }
-    }
-    CLK(4);
-#pragma unroll
-    for (int i = 0; i < NB; ++i)
-      if (i < N) {
-        const int64_t o = (int64_t)i * D + f;
-        const float val = elu_f(acc[i]) * drop_factor(ko, (uint32_t)(((int64_t)b * N) * D + hl * F + o));
-        out[o] = val;
-        split_store1(zp, a.z_lo_off, (int64_t)b * N * D + hl * F + o, val);
-      }
+  for (int e = tid; e < N * (F / 4); e += 256) {            // ELU, dropout, fp32 + planes, 16 bytes per lane
+    const int i = e / (F / 4), q = e - i * (F / 4);
+    const float4 v = *reinterpret_cast<const float4*>(shZ + i * FS + 4 * q);
+    const int64_t o = (int64_t)i * D + 4 * q;
+    const uint32_t e0 = (uint32_t)(((int64_t)b * N) * D + hl * F + o);
+    float4 y;
+    y.x = elu_f(v.x) * drop_factor(ko, e0 + 0);
+    y.y = elu_f(v.y) * drop_factor(ko, e0 + 1);
+    y.z = elu_f(v.z) * drop_factor(ko, e0 + 2);
+    y.w = elu_f(v.w) * drop_factor(ko, e0 + 3);
+    *reinterpret_cast<float4*>(out + o) = y;
+    split_store4(zp, a.z_lo_off, (int64_t)b * N * D + hl * F + o, y);
   }
   CLK(5);
 }
 
-static size_t gat_fwd_lds(int N, int NB, int F) {
-  return sizeof(float) * ((((size_t)N * (F + 4) + 3) & ~(size_t)3) + (size_t)N * NB + 2 * F + 3 * N);
+static int gat_nt(int N) { return (N + 15) / 16; }
+static size_t gat_fwd_lds(int N, int F) {
+  const size_t S = (N + 3) / 4, NT = gat_nt(N);
+  return sizeof(float) * (4 * S * (F + 16) + 16 * NT * (4 * S + 1) + 2 * F + 3 * N + 16);
 }
 static int gat_nb(int N) { return N <= 8 ? 8 : N <= 16 ? 16 : N <= 24 ? 24 : N <= 32 ? 32 : 64; }
 
-template <int NB>
-static int gat_attn_fwd_nb(hipStream_t st, const GatAttnArgs& a) {
-  const size_t lds = gat_fwd_lds(a.N, NB, a.D / 4);
+template <int NT>
+static int gat_attn_fwd_nt(hipStream_t st, const GatAttnArgs& a) {
+  const size_t lds = gat_fwd_lds(a.N, a.D / 4);
   if (lds > 48 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gat_attn_fwd<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_gat_attn_fwd<NB>, dim3(a.B, kHeads, 2), dim3(256), lds, st, a);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gat_attn_fwd<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_gat_attn_fwd<NT>, dim3(a.B, kHeads, 2), dim3(256), lds, st, a);
   DVGR_LAUNCH_CHECK();
 }
+
 int gat_attn_fwd(hipStream_t st, const GatAttnArgs& a) {
-  switch (gat_nb(a.N)) {
-    case 8: return gat_attn_fwd_nb<8>(st, a);
-    case 16: return gat_attn_fwd_nb<16>(st, a);
-    case 24: return gat_attn_fwd_nb<24>(st, a);
-    case 32: return gat_attn_fwd_nb<32>(st, a);
-    default: return gat_attn_fwd_nb<64>(st, a);
+  switch (gat_nt(a.N)) {
+    case 1: return gat_attn_fwd_nt<1>(st, a);
+    case 2: return gat_attn_fwd_nt<2>(st, a);
+    case 3: return gat_attn_fwd_nt<3>(st, a);
+    default: return gat_attn_fwd_nt<4>(st, a);
   }
 }
 
@@ -607,7 +644,10 @@ __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
 static size_t gat_bwd_lds(int N, int NB, int F) {
   return sizeof(float) * (2 * (size_t)N * (F + 4) + 3 * (size_t)N * NB + 2 * F + 5 * N + 4 + 4 * NB);
 }
-size_t gat_lds_bytes_max(int N, int F) { return gat_bwd_lds(N, gat_nb(N), F); }
+size_t gat_lds_bytes_max(int N, int F) {
+  const size_t f = gat_fwd_lds(N, F), b = gat_bwd_lds(N, gat_nb(N), F);
+  return f > b ? f : b;
+}
 
 template <int NB>
 static int gat_attn_bwd_nb(hipStream_t st, const GatAttnBwdArgs& a) {
