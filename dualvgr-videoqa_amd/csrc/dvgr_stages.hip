@@ -473,26 +473,33 @@ int sf_bwd(hipStream_t st, const SfBwdArgs& a) {
 // =================================================================================================
 // S3 backward: one workgroup per (b, head, modality).  SURVEY.md Appendix A.3
 // =================================================================================================
-template <int NB>
+// Both contractions run on the fp32 MFMA (exact fp32 products), NT = ceil(N / 16), S = ceil(N / 4):
+//   dalpha_raw[i][j] = dP_i . Wh_j       A = dP rows, B = Wh rows, reduction over F in float4 slots (as k_aux_gram)
+//   dZ[j][f] = sum_i alpha_d[i][j] dP[i][f]   A = alpha_d^T (registers), B = dP; a wave owns whole 16-column strips of f,
+//              so it overwrites its strip of shP with dZ without a barrier (only the owner reads those columns)
+// LDS images are zero padded to 16 NT rows (shW, shP) / 4 S rows and 16 NT columns (shAd) so fragments need no guards.
+template <int NT>
 __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int b = blockIdx.x, h = blockIdx.y, mod = blockIdx.z;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int N = a.N, D = a.D, F = D / 4, FS = F + 4, HF = kHeads * F;   // FS: 16-byte aligned rows (b128 reads)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, kq = lane >> 4;
+  const int N = a.N, D = a.D, F = D / 4, FS = F + 4, HF = kHeads * F, F4 = F / 4;   // FS: 16-byte aligned rows
+  const int S = (N + 3) / 4, NP = N + 1;                    // k-steps over the nodes; row stride of the N x N images
+  // Fragment rows / columns beyond N are redirected to one all-zero row (index N) / column (index N) instead of padding
+  // every image to 16 NT rows: at N = 20 that is 39 KB of LDS per workgroup (4 per CU) instead of 62 KB (2 per CU).
+  const int WR = ((N + 1) * FS > 8 * F) ? (N + 1) * FS : 8 * F;   // shW doubles as the d a_l / d a_r partial buffer at the end
   const int g = h >> 2, hl = h & 3;
-  float* shW = sm;                 // [N][FS] Wh (unscaled)
-  float* shP = shW + N * FS;       // [N][FS] dP
-  float* shA = shP + N * FS;       // [N][NB] alpha
-  float* shAd = shA + N * NB;      // [N][NB] alpha * keep
-  float* shG = shAd + N * NB;      // [N][NB] dalpha, then dpre
-  float* shAl = shG + N * NB;      // [F]
-  float* shAr = shAl + F;          // [F]
-  float* shS = shAr + F;           // [N]
+  float* shW = sm;                 // [N + 1][FS] Wh (unscaled); row N = 0
+  float* shP = shW + WR;           // [N + 1][FS] dP, later dZ; row N = 0
+  float* shA = shP + (N + 1) * FS; // [N][NP]     alpha
+  float* shAd = shA + N * NP;      // [N + 1][NP] alpha * keep; row N and column N = 0
+  float* shG = shAd + (N + 1) * NP;  // [N][NP]   dalpha, then dpre
+  float* shS = shG + N * NP;       // [N]
   float* shU = shS + N;            // [N]
   float* shV = shU + N;            // [N]
   float* shDu = shV + N;           // [N]
   float* shDv = shDu + N;          // [N]
-  float* shRed = shDv + N;         // [NB][4] per-wave partials of ds_j
+  float* shRed = shDv + N;         // [4]
   const float* Wh = a.Wh[mod] + (int64_t)b * N * HF + h * F;
   const float* dz = a.dz[mod] + (int64_t)g * a.B * N * D + (int64_t)b * N * D + hl * F;   // view g of (2, B*N, D)
   const float* outp = (g ? a.out_s[mod] : a.out_c[mod]) + (int64_t)b * N * D + hl * F;
@@ -500,7 +507,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
   const uint32_t ka = a.key_alpha[mod][h];
   CLK(0);
   {                                                         // three tiles as float4s, independent loads in flight
-    const int F4 = F / 4, total = N * F4;
+    const int total = (N + 1) * F4;                         // row N is the zero row
     for (int base = 0; base < total; base += 512) {
       float4 w[2], z[2], y[2];
       int row[2], col[2];
@@ -511,30 +518,32 @@ __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
         if (idx < total) {
           const int i = idx / F4, q = idx - i * F4;
           row[r] = i; col[r] = 4 * q;
-          w[r] = *reinterpret_cast<const float4*>(Wh + (int64_t)i * HF + 4 * q);
-          z[r] = *reinterpret_cast<const float4*>(dz + (int64_t)i * D + 4 * q);
-          y[r] = *reinterpret_cast<const float4*>(outp + (int64_t)i * D + 4 * q);
+          if (i < N) {
+            w[r] = *reinterpret_cast<const float4*>(Wh + (int64_t)i * HF + 4 * q);
+            z[r] = *reinterpret_cast<const float4*>(dz + (int64_t)i * D + 4 * q);
+            y[r] = *reinterpret_cast<const float4*>(outp + (int64_t)i * D + 4 * q);
+          }
         }
       }
 #pragma unroll
       for (int r = 0; r < 2; ++r)
         if (row[r] >= 0) {
-          *reinterpret_cast<float4*>(shW + row[r] * FS + col[r]) = w[r];
-          const uint32_t e0 = (uint32_t)(((int64_t)b * N + row[r]) * D + hl * F + col[r]);
-          const float sc = ko ? (1.0f - kDropP) : 1.0f;     // un-dropped ELU output where kept
-          float4 p;
-          p.x = z[r].x * drop_factor(ko, e0 + 0) * elu_grad_from_out(y[r].x * sc);
-          p.y = z[r].y * drop_factor(ko, e0 + 1) * elu_grad_from_out(y[r].y * sc);
-          p.z = z[r].z * drop_factor(ko, e0 + 2) * elu_grad_from_out(y[r].z * sc);
-          p.w = z[r].w * drop_factor(ko, e0 + 3) * elu_grad_from_out(y[r].w * sc);
+          float4 p = make_float4(0.f, 0.f, 0.f, 0.f), wv = p;
+          if (row[r] < N) {
+            wv = w[r];
+            const uint32_t e0 = (uint32_t)(((int64_t)b * N + row[r]) * D + hl * F + col[r]);
+            const float sc = ko ? (1.0f - kDropP) : 1.0f;   // un-dropped ELU output where kept
+            p.x = z[r].x * drop_factor(ko, e0 + 0) * elu_grad_from_out(y[r].x * sc);
+            p.y = z[r].y * drop_factor(ko, e0 + 1) * elu_grad_from_out(y[r].y * sc);
+            p.z = z[r].z * drop_factor(ko, e0 + 2) * elu_grad_from_out(y[r].z * sc);
+            p.w = z[r].w * drop_factor(ko, e0 + 3) * elu_grad_from_out(y[r].w * sc);
+          }
+          *reinterpret_cast<float4*>(shW + row[r] * FS + col[r]) = wv;
           *reinterpret_cast<float4*>(shP + row[r] * FS + col[r]) = p;
         }
     }
   }
-  for (int f = tid; f < F; f += 256) {
-    shAl[f] = a.gat_a[mod][h * 2 * F + f];
-    shAr[f] = a.gat_a[mod][h * 2 * F + F + f];
-  }
+  for (int e = tid; e < (N + 1) * NP; e += 256) shAd[e] = 0.f;
   if (tid < N) {
     shS[tid] = a.s[mod][b * N + tid];
     shU[tid] = a.u[mod][((int64_t)b * kHeads + h) * N + tid];
@@ -551,32 +560,43 @@ __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
     const float sum = wave_sum(pe);
     if (lane < N) {
       const float al = pe / sum;
-      shA[i * NB + lane] = al;
-      shAd[i * NB + lane] = al * drop_factor(ka, (uint32_t)((b * N + i) * N + lane));
+      shA[i * NP + lane] = al;
+      shAd[i * NP + lane] = al * drop_factor(ka, (uint32_t)((b * N + i) * N + lane));
     }
   }
   CLK(2);
-  for (int pr = tid; pr < N * N; pr += 256) {               // dalpha_ij = keep_ij * s_j * (dP_i . Wh_j)
-    const int i = pr / N, j = pr - i * N;
-    const float4* pi = reinterpret_cast<const float4*>(shP + i * FS);
-    const float4* wj = reinterpret_cast<const float4*>(shW + j * FS);
-    float acc = 0.f;
-    for (int f4 = 0; f4 < F / 4; ++f4) {
-      const float4 x = pi[f4], y = wj[f4];
-      acc += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+  // ---- dalpha_ij = keep_ij * s_j * (dP_i . Wh_j): NT x NT tiles dealt round-robin to the waves ----
+  for (int tile = wave; tile < NT * NT; tile += 4) {
+    const int I = tile / NT, J = tile - I * NT;
+    gat_f32x4 acc = gat_f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ra = 16 * I + r16, rb = 16 * J + r16;
+    const float* pa = shP + (ra < N ? ra : N) * FS + 4 * kq;
+    const float* pb = shW + (rb < N ? rb : N) * FS + 4 * kq;
+#pragma unroll 4
+    for (int t = 0; t < F / 16; ++t) {
+      const float4 x = *reinterpret_cast<const float4*>(pa + 16 * t), y = *reinterpret_cast<const float4*>(pb + 16 * t);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, y.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, y.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, y.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, y.w, acc, 0, 0, 0);
     }
-    shG[i * NB + j] = acc * shS[j] * drop_factor(ka, (uint32_t)((b * N + i) * N + j));
+    const int j = 16 * J + r16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * I + 4 * kq + r;
+      if (i < N && j < N) shG[i * NP + j] = acc[r] * shS[j] * drop_factor(ka, (uint32_t)((b * N + i) * N + j));
+    }
   }
   __syncthreads();
   CLK(3);
   float dc_w = 0.f;
   for (int i = wave; i < N; i += 4) {                       // softmax and LeakyReLU backward, du_i: one wave per row
-    const float al = lane < N ? shA[i * NB + lane] : 0.f;
-    const float da = lane < N ? shG[i * NB + lane] : 0.f;
+    const float al = lane < N ? shA[i * NP + lane] : 0.f;
+    const float da = lane < N ? shG[i * NP + lane] : 0.f;
     const float rowdot = wave_sum(al * da);
     const float pre = lane < N ? shU[i] + shV[lane] + c : 0.f;
     const float dpre = al * (da - rowdot) * (pre > 0.f ? 1.f : kSlope);
-    if (lane < N) shG[i * NB + lane] = dpre;
+    if (lane < N) shG[i * NP + lane] = dpre;
     const float du = wave_sum(lane < N ? dpre : 0.f);
     if (lane == 0) shDu[i] = du;
     dc_w += du;
@@ -585,85 +605,121 @@ __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
   __syncthreads();
   if (tid < N) {                                            // dv_j
     float dv = 0.f;
-    for (int i = 0; i < N; ++i) dv += shG[i * NB + tid];
+    for (int i = 0; i < N; ++i) dv += shG[i * NP + tid];
     shDv[tid] = dv;
   }
   if (tid == 0) a.dc_part[mod][b * kHeads + h] = shRed[0] + shRed[1] + shRed[2] + shRed[3];
-  __syncthreads();
   CLK(4);
-  float* dWh = a.dWh[mod] + (int64_t)b * N * HF + h * F;
-  for (int f0 = 0; f0 < F; f0 += 256) {                     // uniform trip count: wave_sum needs all lanes
-    const int f = f0 + tid;
-    const bool act = f < F;
-    float dZ[NB];
+  // ---- dZ = alpha_d^T . dP: wave w owns the column strips Ft = w, w + 4, ... and overwrites them in shP ----
+  {
+    float af[NT][4 * NT];                                   // A fragments: alpha_d[4 s + kq][16 Jt + r16]
 #pragma unroll
-    for (int j = 0; j < NB; ++j) dZ[j] = 0.f;
-    if (act) {
-      for (int i = 0; i < N; ++i) {                         // dZ_j = sum_i alpha_d[i][j] dP[i][f]
-        const float pv = shP[i * FS + f];
+    for (int Jt = 0; Jt < NT; ++Jt)
 #pragma unroll
-        for (int j4 = 0; j4 < NB / 4; ++j4) {
-          const float4 a4 = *reinterpret_cast<const float4*>(shAd + i * NB + 4 * j4);
-          dZ[4 * j4 + 0] += a4.x * pv; dZ[4 * j4 + 1] += a4.y * pv;
-          dZ[4 * j4 + 2] += a4.z * pv; dZ[4 * j4 + 3] += a4.w * pv;
+      for (int s4 = 0; s4 < 4 * NT; ++s4) {
+        const int i = 4 * s4 + kq, j = 16 * Jt + r16;
+        af[Jt][s4] = s4 < S ? shAd[(i < N ? i : N) * NP + (j < N ? j : N)] : 0.f;
+      }
+    for (int Ft = wave; Ft < F / 16; Ft += 4) {
+      gat_f32x4 acc[NT];
+#pragma unroll
+      for (int Jt = 0; Jt < NT; ++Jt) acc[Jt] = gat_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s4 = 0; s4 < 4 * NT; ++s4) {
+        if (s4 < S) {
+          const int i = 4 * s4 + kq;
+          const float bf = shP[(i < N ? i : N) * FS + 16 * Ft + r16];
+#pragma unroll
+          for (int Jt = 0; Jt < NT; ++Jt) acc[Jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[Jt][s4], bf, acc[Jt], 0, 0, 0);
         }
       }
-    }
-    CLK(5);
-    float dal = 0.f, dar = 0.f;
-    const float alf = act ? shAl[f] : 0.f, arf = act ? shAr[f] : 0.f;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      if (j < N) {                                          // N is uniform: no divergence
-        const float w = act ? shW[j * FS + f] : 0.f;
-        if (act) {
-          const float dwv = shS[j] * dZ[j] + shDu[j] * alf + shDv[j] * arf;
-          dWh[(int64_t)j * HF + f] = dwv;
-          split_store1(a.dWh_p[mod], a.lo_off, (int64_t)b * N * HF + h * F + (int64_t)j * HF + f, dwv);
-          dal += shDu[j] * w;
-          dar += shDv[j] * w;
+      for (int Jt = 0; Jt < NT; ++Jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = 16 * Jt + 4 * kq + r;
+          if (j < N) shP[j * FS + 16 * Ft + r16] = acc[Jt][r];
         }
-        const float part = wave_sum(act ? dZ[j] * w : 0.f); // ds_j partial of this wave
-        if (lane == 0) {
-          if (f0 == 0) shRed[4 + j * 4 + wave] = part; else shRed[4 + j * 4 + wave] += part;
-        }
-      }
-    }
-    if (act) {
-      a.da_part[mod][((int64_t)b * kHeads + h) * 2 * F + f] = dal;
-      a.da_part[mod][((int64_t)b * kHeads + h) * 2 * F + F + f] = dar;
     }
   }
   __syncthreads();
+  CLK(5);
+  // ---- epilogue, one wave per row j: dWh_j = s_j dZ_j + du_j a_l + dv_j a_r (fp32 + planes), ds_j = dZ_j . Wh_j,
+  //      d a_l += du_j Wh_j, d a_r += dv_j Wh_j (per-wave partials in registers, then summed through LDS) ----
+  float* dWh = a.dWh[mod] + (int64_t)b * N * HF + h * F;
+  float4 pal[2], par[2], gal[2], gar[2];                    // this lane's columns 4 (lane + 64 t) .. + 3, t < 2 (F <= 512)
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    pal[t] = make_float4(0.f, 0.f, 0.f, 0.f); par[t] = pal[t]; gal[t] = pal[t]; gar[t] = pal[t];
+    const int q = lane + 64 * t;
+    if (q < F4) {
+      gal[t] = *reinterpret_cast<const float4*>(a.gat_a[mod] + h * 2 * F + 4 * q);
+      gar[t] = *reinterpret_cast<const float4*>(a.gat_a[mod] + h * 2 * F + F + 4 * q);
+    }
+  }
+  for (int j = wave; j < N; j += 4) {
+    const float sj = shS[j], duj = shDu[j], dvj = shDv[j];
+    float dsp = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int q = lane + 64 * t;
+      if (q < F4) {
+        const float4 z = *reinterpret_cast<const float4*>(shP + j * FS + 4 * q), w = *reinterpret_cast<const float4*>(shW + j * FS + 4 * q);
+        const float4 al = gal[t], ar = gar[t];
+        const float4 o = make_float4(sj * z.x + duj * al.x + dvj * ar.x, sj * z.y + duj * al.y + dvj * ar.y,
+                                     sj * z.z + duj * al.z + dvj * ar.z, sj * z.w + duj * al.w + dvj * ar.w);
+        *reinterpret_cast<float4*>(dWh + (int64_t)j * HF + 4 * q) = o;
+        split_store4(a.dWh_p[mod], a.lo_off, (int64_t)b * N * HF + h * F + (int64_t)j * HF + 4 * q, o);
+        dsp += z.x * w.x + z.y * w.y + z.z * w.z + z.w * w.w;
+        pal[t].x += duj * w.x; pal[t].y += duj * w.y; pal[t].z += duj * w.z; pal[t].w += duj * w.w;
+        par[t].x += dvj * w.x; par[t].y += dvj * w.y; par[t].z += dvj * w.z; par[t].w += dvj * w.w;
+      }
+    }
+    dsp = wave_sum(dsp);
+    if (lane == 0) a.ds_part[mod][((int64_t)b * kHeads + h) * N + j] = dsp;
+  }
+  __syncthreads();                                          // every wave is done with shW: it now holds the partials
+  float* shDa = shW;                                        // [4][2 F]
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int q = lane + 64 * t;
+    if (q < F4) {
+      *reinterpret_cast<float4*>(shDa + wave * 2 * F + 4 * q) = pal[t];
+      *reinterpret_cast<float4*>(shDa + wave * 2 * F + F + 4 * q) = par[t];
+    }
+  }
+  __syncthreads();
+  for (int f = tid; f < 2 * F; f += 256)
+    a.da_part[mod][((int64_t)b * kHeads + h) * 2 * F + f] = (shDa[f] + shDa[2 * F + f]) + (shDa[4 * F + f] + shDa[6 * F + f]);
   CLK(6);
-  if (tid < N)
-    a.ds_part[mod][((int64_t)b * kHeads + h) * N + tid] =
-        shRed[4 + tid * 4] + shRed[4 + tid * 4 + 1] + shRed[4 + tid * 4 + 2] + shRed[4 + tid * 4 + 3];
 }
 
-static size_t gat_bwd_lds(int N, int NB, int F) {
-  return sizeof(float) * (2 * (size_t)N * (F + 4) + 3 * (size_t)N * NB + 2 * F + 5 * N + 4 + 4 * NB);
+static size_t gat_bwd_lds(int N, int F) {
+  const size_t NP = N + 1, FS = F + 4;
+  const size_t WR = ((N + 1) * FS > 8 * (size_t)F) ? (N + 1) * FS : 8 * (size_t)F;
+  return sizeof(float) * (WR + (N + 1) * FS + (3 * (size_t)N + 1) * NP + 5 * N + 8);
 }
 size_t gat_lds_bytes_max(int N, int F) {
-  const size_t f = gat_fwd_lds(N, F), b = gat_bwd_lds(N, gat_nb(N), F);
+  const size_t f = gat_fwd_lds(N, F), b = gat_bwd_lds(N, F);
   return f > b ? f : b;
 }
 
-template <int NB>
-static int gat_attn_bwd_nb(hipStream_t st, const GatAttnBwdArgs& a) {
-  const size_t lds = gat_bwd_lds(a.N, NB, a.D / 4);
+template <int NT>
+static int gat_attn_bwd_nt(hipStream_t st, const GatAttnBwdArgs& a) {
+  const size_t lds = gat_bwd_lds(a.N, a.D / 4);
   if (lds > 48 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gat_attn_bwd<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_gat_attn_bwd<NB>, dim3(a.B, kHeads, 2), dim3(256), lds, st, a);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gat_attn_bwd<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_gat_attn_bwd<NT>, dim3(a.B, kHeads, 2), dim3(256), lds, st, a);
   DVGR_LAUNCH_CHECK();
 }
+
 int gat_attn_bwd(hipStream_t st, const GatAttnBwdArgs& a) {
-  switch (gat_nb(a.N)) {
-    case 8: return gat_attn_bwd_nb<8>(st, a);
-    case 16: return gat_attn_bwd_nb<16>(st, a);
-    case 24: return gat_attn_bwd_nb<24>(st, a);
-    case 32: return gat_attn_bwd_nb<32>(st, a);
-    default: return gat_attn_bwd_nb<64>(st, a);
+  if (a.D / 4 > 512) return DVGR_E_DIMS;                    // the epilogue keeps two float4 column slots per lane
+  switch (gat_nt(a.N)) {
+    case 1: return gat_attn_bwd_nt<1>(st, a);
+    case 2: return gat_attn_bwd_nt<2>(st, a);
+    case 3: return gat_attn_bwd_nt<3>(st, a);
+    default: return gat_attn_bwd_nt<4>(st, a);
   }
 }
 
