@@ -1,5 +1,6 @@
 // dvgr_api.hip -- C ABI (include/dvgr.h): layouts, argument checks and the stage schedules of the
-// forward and backward passes.  Host code only; all device work is enqueued on the caller's stream.
+// forward and backward passes.  Host code only; device work is enqueued on the caller's stream and, for what is off
+// the critical path, on an internal side stream that forks from and joins back into it inside each call.
 #include <stdlib.h>
 #include <string.h>
 
@@ -590,29 +591,29 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
   const Probe hprobe{O, hs};
   auto to_side = [&]() -> int { return side ? side->order(st, hs) : 0; };     // hs continues after st's work so far
   auto to_main = [&]() -> int { return side ? side->order(hs, st) : 0; };     // st continues after hs's work so far
-  DVGR_TRY(to_side());
+  // (every fork costs the main stream a ~6 us bubble -- the event's barrier packet -- so there is one per layer, not one
+  // per dependency: the side stream's work of a layer is enqueued behind the layer's last producer it needs)
 
   // ---- S6 backward ------------------------------------------------------------------------------------
   {
     uint16_t* dpop = PM.out(ws + W.dpo, &plo);
     DVGR_TRY(elu_bwd(st, g->g_vis, io->vis, ws + W.dpo, BND, dpop, plo));
-    DVGR_TRY(to_side());
   }
   {
     GemmBatch gd{};   // dz = dpo . Wo
     gd.p[gd.n] = nn(ws + W.dpo, D, params + P.mfb_wo, kMfbPooled, ws + W.dzf, kMfbPooled, BN, kMfbPooled, D, 0);
     PM.attach(gd.p[gd.n++]);
     DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_GENERIC, prec));
-    GemmBatch gb{};   // dWo = dpo^T . z
-    gb.p[gb.n] = tn(ws + W.dpo, D, saved + S.mfb_z, kMfbPooled, gp + P.mfb_wo, kMfbPooled, D, kMfbPooled, BN);
-    PM.attach(gb.p[gb.n++]);
-    DVGR_TRY(gemm_launch(hs, IC, IC, gb, TAG_GENERIC, prec));
   }
   {
     uint16_t* q0 = PM.out(ws + W.dp0, &plo);
     uint16_t* q1 = PM.out(ws + W.dp1, &plo);
     DVGR_TRY(mfb_pool_bwd(st, ws + W.dzf, saved + S.mfb_x0, saved + S.mfb_x1, ws + W.dp0, ws + W.dp1, BN, q0, q1, plo));
     DVGR_TRY(to_side());
+    GemmBatch gb{};   // dWo = dpo^T . z
+    gb.p[gb.n] = tn(ws + W.dpo, D, saved + S.mfb_z, kMfbPooled, gp + P.mfb_wo, kMfbPooled, D, kMfbPooled, BN);
+    PM.attach(gb.p[gb.n++]);
+    DVGR_TRY(gemm_launch(hs, IC, IC, gb, TAG_GENERIC, prec));
   }
   {
     GemmBatch gd{};   // dA = dp0 . W0, dM = dp1 . W1
@@ -672,7 +673,6 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       a.lo_off = plo;
       a.rows = BN; a.D = D;
       DVGR_TRY(sf_bwd(st, a));
-      DVGR_TRY(to_side());
     }
     for (int m = 0; m < 2; ++m) {
       cb.j[cb.n++] = ColsumJob{ms(l, m) + S.tn, nullptr, ws + W.dw[set][m], nullptr, 2 * BN, 0, D, D, gmp(l, m) + P.sf_p2};
@@ -698,11 +698,6 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       }
       sf_dw = gb;
       sf_dw_main = (l == 0);
-      if (!sf_dw_main) {
-        DVGR_TRY(hprobe.begin(DVGR_PROBE_BWD_SF_DW, l));
-        DVGR_TRY(gemm_launch(hs, IC, IC, sf_dw, TAG_BWD_SF_DW, prec));
-        DVGR_TRY(hprobe.end(DVGR_PROBE_BWD_SF_DW, l));
-      }
     }
     // S3 backward
     {
@@ -731,7 +726,12 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       }
       a.dp_cat = ws + W.dp_cat[set]; a.B = B; a.N = N; a.D = D; a.parts = 1;
       DVGR_TRY(punish_bwd(st, a));
-      DVGR_TRY(to_side());                 // dWh and dp are final: the side stream takes dWcat and the query branch
+      DVGR_TRY(to_side());                 // dpre, dWh and dp are final: the side stream takes dP1 and the query branch
+      if (!sf_dw_main) {
+        DVGR_TRY(hprobe.begin(DVGR_PROBE_BWD_SF_DW, l));
+        DVGR_TRY(gemm_launch(hs, IC, IC, sf_dw, TAG_BWD_SF_DW, prec));
+        DVGR_TRY(hprobe.end(DVGR_PROBE_BWD_SF_DW, l));
+      }
     }
     for (int m = 0; m < 2; ++m) {
       cb.j[cb.n++] = ColsumJob{ws + W.da_part[set][m], nullptr, nullptr, nullptr, B, 0, kHeads * 2 * F, kHeads * 2 * F, gmp(l, m) + P.gat_a};

@@ -163,10 +163,11 @@ enum dvgr_probe_site {
   DVGR_PROBE_SITES
 };
 
-/* dvgr_opts.flags.  By default the backward enqueues the weight / bias gradients and the query branch on an
- * internal lower-priority side stream (one per device, created on first use) so that they overlap the small
- * kernels of the dX chain; the side stream forks from and joins back into `stream` inside the call, so the
- * caller sees ordinary single-stream semantics.  DVGR_OPT_SINGLE_STREAM keeps every launch on `stream`. */
+/* dvgr_opts.flags.  By default forward and backward enqueue what is off their critical path (forward: the query-side
+ * chain S0 and, with dvgr_opts.loss, the loss kernels; backward: dP1, the query branch, every column sum) on an internal
+ * lower-priority side stream (one per device and calling thread, created on first use) so that it overlaps the
+ * latency-bound kernels of the critical path; the side stream forks from and joins back into `stream` inside the call,
+ * so the caller sees ordinary single-stream semantics.  DVGR_OPT_SINGLE_STREAM keeps every launch on `stream`. */
 #define DVGR_OPT_SINGLE_STREAM 1
 
 /* Scope-U loss evaluated by the forward itself (dvgr_opts.loss): the same arithmetic and outputs as
