@@ -572,7 +572,6 @@ __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
     const int ra = 16 * I + r16, rb = 16 * J + r16;
     const float* pa = shP + (ra < N ? ra : N) * FS + 4 * kq;
     const float* pb = shW + (rb < N ? rb : N) * FS + 4 * kq;
-#pragma unroll 4
     for (int t = 0; t < F / 16; ++t) {
       const float4 x = *reinterpret_cast<const float4*>(pa + 16 * t), y = *reinterpret_cast<const float4*>(pb + 16 * t);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, y.x, acc, 0, 0, 0);
