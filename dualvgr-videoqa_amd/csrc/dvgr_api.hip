@@ -40,7 +40,7 @@ FwdWs fwd_ws(const dvgr_dims& d) {
 struct BwdWs {
   int64_t dpo, dzf, dp0, dp1, dz[2], dxtmp[2];
   int64_t dw[2][2], dpre[2][2], dWh[2][2], ds_part[2][2], da_part[2][2], dc_part[2][2], dp_cat[2];   // [set][modality]
-  int64_t dqbar, dr, dy, qdots, total;
+  int64_t dqbar[2], dr, dy, qdots, total;
 };
 BwdWs bwd_ws(const dvgr_dims& d) {
   BwdWs w{};
@@ -63,7 +63,7 @@ BwdWs bwd_ws(const dvgr_dims& d) {
     }
     w.dp_cat[s] = o; o += round64((int64_t)d.B * 2 * D);
   }
-  w.dqbar = o;  o += round64((int64_t)d.B * d.Wd);
+  for (int s = 0; s < 2; ++s) { w.dqbar[s] = o; o += round64((int64_t)d.B * d.Wd); }
   w.dr = o;     o += round64((int64_t)d.B * d.T);
   w.dy = o;     o += round64((int64_t)d.B * d.T * D);
   w.qdots = o;  o += round64(2 * (int64_t)d.B * d.T);
@@ -725,6 +725,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
         a.X[m] = Xin[m]; a.dX[m] = dXacc[m];
       }
       a.dp_cat = ws + W.dp_cat[set]; a.B = B; a.N = N; a.D = D; a.parts = 1;
+      a.zero = ws + W.dqbar[set]; a.zero_cols = Wd;          // dq-bar accumulates split-K partials: cleared here
       DVGR_TRY(punish_bwd(st, a));
       DVGR_TRY(to_side());                 // dpre, dWh and dp are final: the side stream takes dP1 and the query branch
       if (!sf_dw_main) {
@@ -810,22 +811,18 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       for (int m = 0; m < 2; ++m)
         cb.j[cb.n++] = ColsumJob{ws + W.dp_cat[set] + m * D, nullptr, nullptr, nullptr, B, 0, D, 2 * D, gmp(l, m) + P.bq};
       GemmBatch gd{};   // dqbar = [dp_app | dp_mot] . [Wq_app ; Wq_mot]
-      GemmProblem p = nn(ws + W.dp_cat[set], 2 * D, mp(l, 0) + P.wq, Wd, ws + W.dqbar, Wd, B, Wd, 2 * D, 0);
+      GemmProblem p = nn(ws + W.dp_cat[set], 2 * D, mp(l, 0) + P.wq, Wd, ws + W.dqbar[set], Wd, B, Wd, 2 * D, 0);
       p.kseg = D;
       p.B.p1 = mp(l, 1) + P.wq;
       p.atomic_ok = 1;                       // 3 output tiles x 48 K-tiles: split K, partials added atomically
       p.accumulate = 1;
-      {
-        const hipError_t e = hipMemsetAsync(ws + W.dqbar, 0, (size_t)B * Wd * sizeof(float), hs);
-        if (e != hipSuccess) return (int)e;
-      }
       gd.p[gd.n++] = p;
       DVGR_TRY(gemm_launch(hs, KC, IC, gd, TAG_GENERIC, prec));
     }
     // S0 backward for this layer
     {
       QaBwdArgs a{};
-      a.dqbar = ws + W.dqbar; a.words = io->words; a.qlen = io->qlen;
+      a.dqbar = ws + W.dqbar[set]; a.words = io->words; a.qlen = io->qlen;
       a.params = lp(l); a.off_w2 = P.qa_w2; a.layer_stride = 0;
       a.saved = ls(l); a.s_layer_stride = 0; a.s_d = S.qa_d; a.s_nrm = S.qa_nrm; a.s_a = S.qa_a; a.s_ah = S.qa_ah; a.s_S = S.qa_s;
       a.gwords = g->gwords; a.dr = ws + W.dr; a.dy = ws + W.dy; a.rowdots = ws + W.qdots;

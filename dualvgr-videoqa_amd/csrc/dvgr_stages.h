@@ -132,6 +132,8 @@ struct PunishBwdArgs {
   float* dp_cat;           // (B, 2D): cols [mod*D, (mod+1)*D)
   int B, N, D;
   int parts;               // bit 0: dp (needs only ds_part, s, X), bit 1: the dX update; 0 means both
+  float* zero;             // nullable: a (B, zero_cols) buffer the dp part clears on its way (saves a memset launch)
+  int zero_cols;
 };
 int punish_bwd(hipStream_t st, const PunishBwdArgs& a);
 

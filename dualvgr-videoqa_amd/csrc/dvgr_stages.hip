@@ -741,6 +741,8 @@ __global__ __launch_bounds__(256) void k_punish_bwd(const PunishBwdArgs a) {
   const float* X = a.X[mod] + (int64_t)b * N * D;
   float* dX = a.dX[mod] + (int64_t)b * N * D;
   const int parts = a.parts ? a.parts : 3;
+  if (a.zero && (parts & 1) && mod == 0 && blockIdx.z == 0)
+    for (int w = tid; w < a.zero_cols; w += 256) a.zero[(int64_t)b * a.zero_cols + w] = 0.f;
   if (parts == 1) {                                         // dp alone: the query branch can start before dX is final
     float acc = 0.f;
 #pragma unroll 4

@@ -163,7 +163,7 @@ class _UnitFn(torch.autograd.Function):
         saved = torch.empty(lib.dvgr_saved_bytes(C.byref(dims)), device=dev, dtype=torch.uint8)
         ws = mod.workspace(lib.dvgr_workspace_bytes(C.byref(dims)), dev)
         train = bool(mod.training)
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if train else 0
+        seed = mod._next_seed() if train else 0
         if mod.forced_seed is not None:
             seed = int(mod.forced_seed)
         io = L_.IO(A.data_ptr(), M.data_ptr(), dq.data_ptr(), words.data_ptr(), qlen.data_ptr(), vis.data_ptr(),
@@ -298,6 +298,7 @@ class DualVGRUnit_multiple(nn.Module):
         # and leaves (terms, upstream_grads) in `last_loss`, ready for torch.autograd.backward(raw, upstream_grads)
         self.loss_in_forward = None
         self.last_loss = None
+        self._seed_pool = []
         self.last_saved = None
         self.last_flat_grad = None
         self._grad_flat = None       # persistent flat gradient buffer (grad_mode='flat')
@@ -401,6 +402,13 @@ class DualVGRUnit_multiple(nn.Module):
                                                  torch.cuda.current_stream(flat.device).cuda_stream), "dvgr_pack_weights")
             self._lowp_version = ver
         return self._lowp.data_ptr()
+
+    def _next_seed(self) -> int:
+        """Dropout seed of one forward, drawn from torch's CPU generator (so torch.manual_seed reproduces a run) in
+        batches of 256: one small tensor op per 256 steps instead of one per step on the launch path."""
+        if not self._seed_pool:
+            self._seed_pool = torch.randint(0, 2 ** 62, (256,)).tolist()
+        return self._seed_pool.pop()
 
     def workspace(self, nbytes: int, dev) -> torch.Tensor:
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
