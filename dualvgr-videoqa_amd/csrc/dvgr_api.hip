@@ -434,7 +434,7 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
     // itself carries no mask and can run on the LDS-DMA ring kernel.
     {
       GemmBatch gb{};
-      if (train)
+      if (train && l == 0)                 // layers > 0: the previous layer's S5 kernel wrote the dropped copies
         DVGR_TRY(drop_x(st, Xin[0], Xin[1], ms(l, 0) + S.xd, ms(l, 1) + S.xd, K.x, BND, PM.out(ms(l, 0) + S.xd, &plo),
                         PM.out(ms(l, 1) + S.xd, &plo), plo));
       for (int m = 0; m < 2; ++m) {
@@ -455,7 +455,8 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
     }
     // S1 (needs p from S0: the side stream joins here)
     if (l == 0 && side) DVGR_TRY(side->order(hs, st));
-    DVGR_TRY(punish_fwd(st, Xin[0], Xin[1], ms(l, 0) + S.p, ms(l, 1) + S.p, ms(l, 0) + S.s, ms(l, 1) + S.s, B, N, D));
+    if (l == 0)                            // layers > 0: gate computed by the previous layer's S5 kernel
+      DVGR_TRY(punish_fwd(st, Xin[0], Xin[1], ms(l, 0) + S.p, ms(l, 1) + S.p, ms(l, 0) + S.s, ms(l, 1) + S.s, B, N, D));
     // S3
     {
       GatAttnArgs a{};
@@ -509,7 +510,17 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
         a.xp[m] = PM.out(ms(l, m) + S.x, &plo);
       }
       a.x_lo_off = plo;
-      a.rows = BN; a.D = D;
+      a.rows = BN; a.D = D; a.N = N;
+      if (l + 1 < L) {                     // S1 and the x-site dropout of layer l + 1, on the row while it is in registers
+        const Keys Kn = layer_keys(train, seed, l + 1);
+        for (int m = 0; m < 2; ++m) {
+          a.next_p[m] = ms(l + 1, m) + S.p; a.next_s[m] = ms(l + 1, m) + S.s;
+          a.next_xd[m] = train ? ms(l + 1, m) + S.xd : nullptr;
+          a.next_xd_p[m] = train ? PM.out(ms(l + 1, m) + S.xd, &plo) : nullptr;
+          for (int gi = 0; gi < 2; ++gi) a.next_key[m][gi] = Kn.x[m][gi];
+        }
+        a.next_xd_lo_off = plo;
+      }
       DVGR_TRY(sf_combine_fwd(st, a));
     }
   }

@@ -67,6 +67,15 @@ struct SfCombineArgs {
   uint16_t* xp[2];       // bf16 planes of X' (nullable)
   int64_t x_lo_off;
   int rows, D;
+  // Optional: the next layer's S1 and x-site dropout on the row while it is still in registers (saves two launches and
+  // two re-reads of X' per layer).  next_p == nullptr: off.
+  const float* next_p[2];   // (B, D) punish vectors of the next layer
+  float* next_s[2];         // (B*N)  gates of the next layer
+  float* next_xd[2];        // (2, B*N, D) dropped copies for the next layer's two GATs (training), nullable
+  uint16_t* next_xd_p[2];   // their bf16 planes (nullable)
+  int64_t next_xd_lo_off;
+  uint32_t next_key[2][2];  // [mod][gat] x-site dropout keys of the next layer
+  int N;                    // clips per sample (row / N = sample), needed with next_p
 };
 int sf_combine_fwd(hipStream_t st, const SfCombineArgs& a);
 

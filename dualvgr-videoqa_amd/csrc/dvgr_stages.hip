@@ -331,6 +331,10 @@ __global__ __launch_bounds__(256) void k_sf_combine_fwd(const SfCombineArgs a) {
   const float4* x = reinterpret_cast<const float4*>(a.X[mod] + (int64_t)row * a.D);
   float4* xo = reinterpret_cast<float4*>(a.Xout[mod] + (int64_t)row * a.D);
   float4* oo = a.o[mod] ? reinterpret_cast<float4*>(a.o[mod] + (int64_t)row * a.D) : nullptr;
+  const float4* np = a.next_p[mod] ? reinterpret_cast<const float4*>(a.next_p[mod] + (int64_t)(row / a.N) * a.D) : nullptr;
+  float* nxd = a.next_xd[mod];
+  const int64_t n4 = (int64_t)a.rows * D4;                  // float4s of one (B*N, D) tensor
+  float gate = 0.f;
   for (int k = lane; k < D4; k += 64) {
     const float4 u = z0[k], v = z1[k], xx = x[k];
     const float4 o = make_float4(b0 * u.x + b1 * v.x, b0 * u.y + b1 * v.y, b0 * u.z + b1 * v.z, b0 * u.w + b1 * v.w);
@@ -338,6 +342,31 @@ __global__ __launch_bounds__(256) void k_sf_combine_fwd(const SfCombineArgs a) {
     const float4 xn = make_float4(xx.x + o.x, xx.y + o.y, xx.z + o.z, xx.w + o.w);
     xo[k] = xn;
     split_store4(a.xp[mod], a.x_lo_off, (int64_t)row * a.D + 4 * k, xn);
+    if (np) {                                               // next layer: gate logit and the two dropped copies of X'
+      const float4 pv = np[k];
+      gate += xn.x * pv.x + xn.y * pv.y + xn.z * pv.z + xn.w * pv.w;
+      if (nxd) {
+        const int64_t i = (int64_t)row * D4 + k;            // float4 index, as k_drop_x
+        const uint32_t e = (uint32_t)(i * 4);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const uint32_t key = a.next_key[mod][g];
+          const uint32_t h0 = mix32(((e >> 1) * 0x9E3779B1u) ^ key);
+          const uint32_t h1 = mix32((((e >> 1) + 1u) * 0x9E3779B1u) ^ key);
+          float4 y;
+          y.x = xn.x * (((h0 & 0xFFFFu) >= kDropThresh16) ? kKeepScale : 0.f);
+          y.y = xn.y * (((h0 >> 16) >= kDropThresh16) ? kKeepScale : 0.f);
+          y.z = xn.z * (((h1 & 0xFFFFu) >= kDropThresh16) ? kKeepScale : 0.f);
+          y.w = xn.w * (((h1 >> 16) >= kDropThresh16) ? kKeepScale : 0.f);
+          reinterpret_cast<float4*>(nxd)[(int64_t)g * n4 + i] = y;
+          split_store4(a.next_xd_p[mod], a.next_xd_lo_off, ((int64_t)g * n4 + i) * 4, y);
+        }
+      }
+    }
+  }
+  if (np) {
+    gate = wave_sum(gate);
+    if (lane == 0) a.next_s[mod][row] = sigmoid_f(gate);
   }
 }
 
