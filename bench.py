@@ -250,7 +250,7 @@ def main():
     peak = PEAK_TFLOPS[args.dtype]
     f_train = 3 * f_fwd(N, Lr, T)
     # HBM bytes per launch of the probed kernel from PMC (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, separate
-    # passes; profiles/r01_v7_bf16x3_c2_pmc_hbm.txt): measured for this one configuration only
+    # passes; profiles/r01_v8_bf16x3_c2_pmc_hbm.txt): measured for this one configuration only
     traffic = 90.0e6 if (args.config == "c2" and args.dtype == "bf16x3" and args.probe == "fwd_gat_gemm"
                          and not args.eval_mode) else None
     out = {
