@@ -6,6 +6,7 @@
 // Contractions go through the unit's engine (dvgr_gemm.h); the rest are the small kernels below.
 #include "../../include/dvgr_head.h"
 #include "dvgr_gemm.h"
+#include "dvgr_side.h"
 #include "dvgr_stages.h"
 
 using namespace dvgr;
@@ -356,35 +357,42 @@ int dvgr_head_backward(const dvgr_head_dims* dp, const float* params, const dvgr
     const hipError_t e = hipMemsetAsync(gp, 0, (size_t)P.total * sizeof(float), st);
     if (e != hipSuccess) return (int)e;
   }
+  // Two streams, as the unit's backward: the chain of input gradients stays on `st`, the weight gradients and column
+  // sums follow on the side stream behind two forks (each fork costs `st` a ~6 us bubble, so not one per dependency).
+  SideStream* side = side_stream();
+  hipStream_t hs = side ? side->st : st;
   ColsumBatch cb{};
   // logits = yd W2^T + b2
-  HEAD_TRY(launch1(st, IC, IC, tn(g->g_logits, C, sv + S.yd, D, gp + P.w2, D, C, D, B), prec));
   cb.j[cb.n++] = ColsumJob{g->g_logits, nullptr, nullptr, nullptr, B, 0, C, C, gp + P.b2};
   HEAD_TRY(launch1(st, KC, IC, nn(g->g_logits, C, params + P.w2, D, ws + W.dyd, D, B, D, C, 0), prec));
   // dropout 2, BatchNorm1d, ELU
   hipLaunchKernelGGL(k_bn_bwd, dim3((D + 63) / 64), dim3(64), 0, st, ws + W.dyd, sv + S.he, params + P.gamma, sv + S.mean,
                      sv + S.istd, gp + P.gamma, gp + P.beta, ws + W.dpre1, head_key(train, seed, 2), B, D, train);
   HEAD_LAUNCH_OK();
-  // he = ELU(cat W1^T + b1)
-  HEAD_TRY(launch1(st, IC, IC, tn(ws + W.dpre1, D, sv + S.cat, 2 * D, gp + P.w1, 2 * D, D, 2 * D, B), prec));
+  if (side) HEAD_TRY(side->order(st, hs));                  // fork 1: gparams is zeroed, dpre1 final
+  HEAD_TRY(launch1(hs, IC, IC, tn(g->g_logits, C, sv + S.yd, D, gp + P.w2, D, C, D, B), prec));
+  HEAD_TRY(launch1(hs, IC, IC, tn(ws + W.dpre1, D, sv + S.cat, 2 * D, gp + P.w1, 2 * D, D, 2 * D, B), prec));
   cb.j[cb.n++] = ColsumJob{ws + W.dpre1, nullptr, nullptr, nullptr, B, 0, D, D, gp + P.b1};
+  // he = ELU(cat W1^T + b1)
   HEAD_TRY(launch1(st, KC, IC, nn(ws + W.dpre1, D, params + P.w1, 2 * D, ws + W.dcat, 2 * D, B, 2 * D, D, 0), prec));
   if (train) HEAD_TRY(head_drop(st, ws + W.dcat, ws + W.dcat, head_key(1, seed, 1), B, 2 * D, 2 * D));
   // question_proj: right half of dcat
-  HEAD_TRY(launch1(st, IC, IC, tn(ws + W.dcat + D, 2 * D, io->qe, D, gp + P.wq, D, D, D, B), prec));
   cb.j[cb.n++] = ColsumJob{ws + W.dcat + D, nullptr, nullptr, nullptr, B, 0, D, 2 * D, gp + P.bq};
   HEAD_TRY(launch1(st, KC, IC, nn(ws + W.dcat + D, 2 * D, params + P.wq, D, g->g_qe, D, B, D, D, 0), prec));
   // read-out
   hipLaunchKernelGGL(k_readout_bwd, dim3(B), dim3(256), 0, st, ws + W.dcat, xd, sv + S.e, sv + S.attn, params + P.wa, ws + W.dl,
                      g->g_vis, ws + W.dvp, N, D);
   HEAD_LAUNCH_OK();
+  if (side) HEAD_TRY(side->order(st, hs));                  // fork 2: dcat, dl, dvp final
+  HEAD_TRY(launch1(hs, IC, IC, tn(ws + W.dcat + D, 2 * D, io->qe, D, gp + P.wq, D, D, D, B), prec));
+  HEAD_TRY(launch1(hs, IC, IC, tn(ws + W.dvp, D, xd, D, gp + P.wv, D, D, D, BN), prec));
   cb.j[cb.n++] = ColsumJob{sv + S.e, nullptr, ws + W.dl, nullptr, BN, 0, D, D, gp + P.wa};
   cb.j[cb.n++] = ColsumJob{ws + W.dl, nullptr, nullptr, nullptr, BN, 0, 1, 1, gp + P.ba};
-  HEAD_TRY(launch1(st, IC, IC, tn(ws + W.dvp, D, xd, D, gp + P.wv, D, D, D, BN), prec));
+  cb.chunks = 8;
+  HEAD_TRY(colsum(hs, cb));
   HEAD_TRY(launch1(st, KC, IC, nn(ws + W.dvp, D, params + P.wv, D, g->g_vis, D, BN, D, D, 1), prec));
   if (train) HEAD_TRY(head_drop(st, g->g_vis, g->g_vis, head_key(1, seed, 0), (int64_t)BN, D, D));
-  cb.chunks = 8;
-  HEAD_TRY(colsum(st, cb));
+  if (side) HEAD_TRY(side->order(hs, st));                  // join
   return 0;
 }
 

@@ -59,7 +59,9 @@ typedef struct dvgr_head_grads {
 } dvgr_head_grads;
 
 /* train != 0: the three nn.Dropout(0.15) sites are active (counter-hash RNG of the unit, keyed by `seed`) and
- * BatchNorm1d uses batch statistics and updates the running ones (momentum 0.1, eps 1e-5). */
+ * BatchNorm1d uses batch statistics and updates the running ones (momentum 0.1, eps 1e-5).
+ * The backward enqueues the weight gradients and column sums on the library's internal side stream (see
+ * DVGR_OPT_SINGLE_STREAM in dvgr.h); it forks from and joins back into `stream` inside the call. */
 int dvgr_head_forward(const dvgr_head_dims *d, const float *params, const dvgr_head_io *io, void *saved,
                       size_t saved_bytes, void *workspace, size_t workspace_bytes, int train, uint64_t seed,
                       void *stream);
