@@ -342,7 +342,10 @@ def test_bf16_operands_stated_tolerance():
 
 
 @pytest.mark.parametrize("N,D,Lr,B,T", [(64, 128, 2, 3, 7), (16, 256, 6, 4, 5), (8, 768, 3, 5, 12), (33, 64, 1, 2, 3),
-                                        (20, 768, 1, 1, 1), (64, 768, 1, 2, 40), (2, 64, 2, 130, 2)])
+                                        (20, 768, 1, 1, 1), (64, 768, 1, 2, 40), (2, 64, 2, 130, 2),
+                                        # every fragment-edge case of the MFMA attention kernels (16-row tiles, 4-wide k-steps)
+                                        (3, 64, 1, 2, 3), (15, 64, 1, 2, 3), (17, 64, 2, 2, 3), (31, 64, 1, 2, 3), (32, 64, 1, 2, 3),
+                                        (47, 64, 1, 2, 3), (48, 64, 2, 2, 3), (49, 64, 1, 2, 3), (63, 128, 1, 2, 3)])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16x3"])
 def test_other_graph_sizes_against_oracle(N, D, Lr, B, T, dtype):
     """Clip counts / depths of the other BASELINE.json configs (N = 8, 16, 64; L up to 6), an odd N, and the corners
