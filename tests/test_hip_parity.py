@@ -418,3 +418,38 @@ def test_side_stream_schedule_equals_single_stream(train):
     for other in results[1:]:
         for a, b in zip(ref, other):
             assert rel_err(b, a) < 2e-6
+
+
+@pytest.mark.parametrize("N,D,Lr,B,T", [(20, 128, 3, 3, 6), (33, 64, 2, 2, 4), (64, 64, 1, 2, 3), (16, 256, 2, 70, 5)])
+def test_train_mode_mask_injected_other_sizes(N, D, Lr, B, T):
+    """Training mode beyond the small golden case: all dropout sites, the S5 kernel that also prepares the next layer's
+    gate and dropped copies, the one-launch S2 dX with its scratch partial -- against the oracle fed with the same masks."""
+    Wd = 32
+    sd_np = synth.xavier_state_dict(O.param_shapes(Wd, D, Lr), seed=21, bias_range=0.1)
+    inp = synth.unit_inputs(B, N, T, D, Wd, seed=21)
+    m = dv.DualVGRUnit_multiple(word_dim=Wd, module_dim=D, num_of_nodes=N, unit_layers=Lr, dtype="fp32")
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
+    m = m.cuda().train()
+    seed = 987654321
+    m.forced_seed = seed
+    t = {k: torch.from_numpy(v.copy()).cuda() for k, v in inp.items()}
+    for k in ("A", "M", "dq", "words"):
+        t[k].requires_grad_(True)
+    outs = m(t["A"], t["M"], t["dq"], t["words"], t["qlen"])
+    Rv = torch.from_numpy(synth.normal("Rv", (B, N, D), 1.0, 21)).cuda()
+    (outs[0] * Rv).sum().add(sum((x * Rv).sum() for x in outs[3] + outs[4] + outs[5] + outs[6])).backward()
+    torch.cuda.synchronize()
+    masks = {k: torch.from_numpy(v) for k, v in dropout.site_masks(seed, B, N, D, Lr).items()}
+    sd = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in sd_np.items()}
+    ti = {k: torch.from_numpy(v.copy()) for k, v in inp.items()}
+    for k in ("A", "M", "dq", "words"):
+        ti[k].requires_grad_(True)
+    oo = O.unit_forward(sd, ti["A"], ti["M"], ti["dq"], ti["words"], ti["qlen"], Lr, 1, masks=masks, naive=False)
+    (oo[0] * Rv.cpu()).sum().add(sum((x * Rv.cpu()).sum() for x in oo[3] + oo[4] + oo[5] + oo[6])).backward()
+    flat_h = [outs[0], outs[1], outs[2]] + outs[3] + outs[4] + outs[5] + outs[6]
+    flat_o = [oo[0], oo[1], oo[2]] + oo[3] + oo[4] + oo[5] + oo[6]
+    assert max(rel_err(h.detach().cpu(), o.detach()) for h, o in zip(flat_h, flat_o)) < TOL
+    assert max(rel_err(t[k].grad.cpu(), ti[k].grad) for k in ("A", "M", "dq", "words")) < GTOL
+    werr = max(float((p.grad.cpu() - sd[k].grad).abs().max()) / max(float(sd[k].grad.abs().max()), 1e-3)
+               for k, p in m.named_parameters() if not k.endswith(".fc.bias") and not k.endswith(".a.bias"))
+    assert werr < GTOL, werr
