@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void k_aux_gram(const AuxArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int N = a.N, D = a.D;
   float* mu = sm;                                     // [D]
-  float* red = sm + D;                                // [4][NT*NT][256]
+  float* red = sm + D;                                // [NT (NT + 1) / 2][256]
   const float* E = a.t[t] + ((int64_t)l * a.B + b) * N * D;
   for (int d4 = tid; d4 < D / 4; d4 += 256) {           // column means, 4 rows in flight per thread
     const float4* col = reinterpret_cast<const float4*>(E) + d4;
@@ -66,46 +66,70 @@ __global__ __launch_bounds__(256) void k_aux_gram(const AuxArgs a) {
     for (int J = 0; J < NT; ++J) acc[I][J] = floatx4{0.f, 0.f, 0.f, 0.f};
   const int kw = D / 4;                               // D % 64 == 0: every wave owns a multiple of 16 columns
   const int nk = kw / 16;
-  for (int it = 0; it < nk; ++it) {
+  // two operand sets: the loads of step it + 1 are in flight while the MFMAs of step it issue
+  auto load = [&](int it, float (&f)[NT][4]) {
     const int k0 = wave * kw + it * 16;
-    const float4 m = *reinterpret_cast<const float4*>(mu + k0 + 4 * kq);
-    float f[NT][4];
+    const bool in = it < nk;
+    const float4 m = in ? *reinterpret_cast<const float4*>(mu + k0 + 4 * kq) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int I = 0; I < NT; ++I) {
       const int row = 16 * I + r16;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < N) {
+      if (in && row < N) {
         v = *reinterpret_cast<const float4*>(E + (int64_t)row * D + k0 + 4 * kq);
         v.x -= m.x; v.y -= m.y; v.z -= m.z; v.w -= m.w;
       }
       f[I][0] = v.x; f[I][1] = v.y; f[I][2] = v.z; f[I][3] = v.w;
     }
+  };
+  auto mma = [&](const float (&f)[NT][4]) {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
       for (int I = 0; I < NT; ++I)
 #pragma unroll
         for (int J = I; J < NT; ++J) acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[I][e], f[J][e], acc[I][J], 0, 0, 0);
+  };
+  float f0[NT][4], f1[NT][4];
+  load(0, f0);
+  for (int it = 0; it < nk; it += 2) {
+    load(it + 1, f1);
+    mma(f0);
+    load(it + 2, f0);
+    mma(f1);
   }
+  // the four waves add their partial tiles into one LDS image in a fixed order (deterministic; 1/4 of the LDS of four
+  // separate images, which matters for occupancy at N = 64)
+  constexpr int NTP = NT * (NT + 1) / 2;
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+      int tix = 0;
 #pragma unroll
-  for (int I = 0; I < NT; ++I)
+      for (int I = 0; I < NT; ++I)
 #pragma unroll
-    for (int J = I; J < NT; ++J)
+        for (int J = I; J < NT; ++J, ++tix)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[((wave * NT + I) * NT + J) * 256 + r * 64 + lane] = acc[I][J][r];
-  __syncthreads();
+          for (int r = 0; r < 4; ++r) {
+            float* p = red + tix * 256 + r * 64 + lane;
+            *p = (w == 0) ? acc[I][J][r] : *p + acc[I][J][r];
+          }
+    }
+    __syncthreads();
+  }
   float* G = a.gram + (((int64_t)l * a.B + b) * 4 + t) * N * N;
   const int r = tid >> 6;
+  {
+    int tix = 0;
 #pragma unroll
-  for (int I = 0; I < NT; ++I)
+    for (int I = 0; I < NT; ++I)
 #pragma unroll
-    for (int J = I; J < NT; ++J) {
-      float v = 0.f;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) v += red[((w * NT + I) * NT + J) * 256 + tid];
-      const int row = 16 * I + 4 * (lane >> 4) + r, col = 16 * J + (lane & 15);
-      if (row < N && col < N) { G[row * N + col] = v; G[col * N + row] = v; }
-    }
+      for (int J = I; J < NT; ++J, ++tix) {
+        const float v = red[tix * 256 + tid];
+        const int row = 16 * I + 4 * (lane >> 4) + r, col = 16 * J + (lane & 15);
+        if (row < N && col < N) { G[row * N + col] = v; G[col * N + row] = v; }
+      }
+  }
+  (void)NTP;
 }
 
 // ---- pass 2: N x N algebra of one (b, l) ------------------------------------------------------------------------
@@ -259,7 +283,7 @@ __global__ __launch_bounds__(256) void k_sum_and_ones(const float* x, float* g_o
 
 template <int NT>
 static int launch_gram_nt(hipStream_t st, const AuxArgs& a) {
-  const size_t lds = sizeof(float) * ((size_t)a.D + 4 * NT * NT * 256);
+  const size_t lds = sizeof(float) * ((size_t)a.D + (NT * (NT + 1) / 2) * 256);
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_aux_gram<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k_aux_gram<NT>, dim3(a.B, a.L * 4), dim3(256), lds, st, a);
