@@ -270,7 +270,11 @@ def main():
                    "unit_frac_of_mfma_peak": value / world * f_train / 1e12 / peak},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                      "traffic": traffic, "kernel": probe_name, "launch_ms": probe_ms,
-                     "algorithmic_gflop_per_launch": probe_flops / 1e9},
+                     "algorithmic_gflop_per_launch": probe_flops / 1e9,
+                     # SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GRBM_GUI_ACTIVE per XCD of this kernel, collected with
+                     # rocprofv3 --pmc at C2; not re-measured by this run
+                     "mfma_pipe_busy_pmc": ({"bf16x3": 0.20, "fp32": 0.55}.get(args.dtype)
+                                            if args.config == "c2" and args.probe == "fwd_gat_gemm" else None)},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
