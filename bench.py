@@ -118,6 +118,10 @@ def main():
     ap.add_argument("--head", action="store_true",
                     help="row f2: also run the clip read-out + classifier (AnswerHead, 1000 answers) and a cross-entropy "
                          "loss on its logits inside every step; the unit then gets d CE / d vis instead of ones")
+    ap.add_argument("--model", action="store_true",
+                    help="row f3 (first stage): the whole DualVGR model -- question / appearance BiLSTMs and the motion Linear on "
+                         "stock PyTorch-ROCm (MIOpen, hipBLASLt), unit + answer head on HIP -- on raw (B, N, 16, 2048) / "
+                         "(B, N, 2048) features, cross-entropy + auxiliary losses, forward + backward")
     ap.add_argument("--loss", default="fused", choices=["fused", "fused-after", "precomputed"],
                     help="fused: the scope-U loss and its gradients are computed inside every timed step by "
                          "dvgr_scope_u_loss; precomputed: fixed upstream gradients (unit kernels only)")
@@ -146,6 +150,8 @@ def main():
 
     cfg = CONFIGS[args.config]
     B, N, Lr, T = cfg["B"], cfg["N"], cfg["L"], cfg["T"]
+    if args.model:
+        return bench_model(args, dev, rank, world, cfg)
     shapes = {n: s for n, s, _ in dv.param_table(L_.make_dims(1, N, 1, D, WD, Lr))}
     sd_np = synth.xavier_state_dict(shapes, seed=666)          # same weights on every rank (as after a broadcast)
     m = dv.DualVGRUnit_multiple(word_dim=WD, module_dim=D, num_of_nodes=N, unit_layers=Lr, dtype=args.dtype)
@@ -282,6 +288,53 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def bench_model(args, dev, rank, world, cfg):
+    """Scope M: the whole model at the DualVGR.forward boundary (synthetic inputs as listed there)."""
+    import dualvgr_videoqa_amd as dv
+    from dualvgr_videoqa_amd import synth
+    B, N, Lr, T = cfg["B"], cfg["N"], cfg["L"], cfg["T"]
+    V, FR, VQ, VA = 2048, 16, 4000, 1000
+    vocab = {"question_token_to_idx": {str(i): i for i in range(VQ)}, "answer_token_to_idx": {str(i): i for i in range(VA)}}
+    torch.manual_seed(666)
+    m = dv.DualVGR(vision_dim=V, module_dim=D, word_dim=WD, vocab=vocab, num_of_nodes=N, graph_module="GAT", graph_layers=1,
+                   unit_layers=Lr, dtype=args.dtype).to(dev)
+    m.train(not args.eval_mode)
+    unit, head = m.visual_input_unit, m._head
+    unit.loss_in_forward = (1.0, 1e-8, float(world), False)
+    app = torch.from_numpy(np.abs(synth.normal("b_app", (B, N, FR, V), 0.5, 666 + rank))).to(dev)
+    mot = torch.from_numpy(np.abs(synth.normal("b_mot", (B, N, V), 0.5, 666 + rank))).to(dev)
+    qlen = torch.from_numpy((3 + (synth.uniform("b_ql", (B,), 0.0, 1.0, 666 + rank) * (T - 2)).astype(np.int64)).clip(1, T)).to(dev)
+    qlen[0] = T
+    q = torch.from_numpy((2 + (synth.uniform("b_q", (B, T), 0.0, 1.0, 666 + rank) * (VQ - 2)).astype(np.int64)).clip(2, VQ - 1)).to(dev)
+    q = q * (torch.arange(T, device=dev)[None, :] < qlen[:, None])
+    answers = torch.from_numpy((synth.uniform("b_ans", (B,), 0.0, float(VA), 666 + rank)).astype(np.int64)).to(dev)
+
+    def step():
+        m.zero_grad(set_to_none=True)
+        logits, _, _, ca, cm, aq, mq = m(app, mot, q, qlen)
+        _, g_logits = head.cross_entropy(logits, answers, scale=1.0)
+        _, g = unit.last_loss
+        torch.autograd.backward([logits, *ca, *cm, *aq, *mq],
+                                [g_logits, *g[3].unbind(0), *g[4].unbind(0), *g[5].unbind(0), *g[6].unbind(0)])
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"metric": "QA-pairs/sec (forward+backward) per GPU, whole model (scope M), SVQA num_clips=20",
+           "value": world * B * args.steps / dt, "unit": "QA-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": f"{cfg['name']}: whole DualVGR model forward+backward, per-GPU batch {B}, raw features "
+                                  f"(B,{N},{FR},{V}) + (B,{N},{V}), T={T}, vocab {VQ}/{VA}; encoders on MIOpen / hipBLASLt, unit + head on HIP"}}
+    if rank == 0:
+        print(json.dumps(out))
 
 
 if __name__ == "__main__":
