@@ -131,11 +131,13 @@ inline uint32_t site_key(uint64_t seed, uint32_t site) {
 inline uint32_t drop_site(int layer, int mod, int gat, int which) {
   return (uint32_t)(((layer * 2 + mod) * 2 + gat) * 6 + which);
 }
-__device__ __forceinline__ bool drop_keep(uint32_t key, uint32_t idx) {
+// keep iff the element's 16-bit field >= thresh (= floor(p * 65536))
+__device__ __forceinline__ bool drop_keep_t(uint32_t key, uint32_t idx, uint32_t thresh) {
   const uint32_t r = mix32(((idx >> 1) * 0x9E3779B1u) ^ key);
   const uint32_t f = (idx & 1u) ? (r >> 16) : (r & 0xFFFFu);
-  return f >= kDropThresh16;
+  return f >= thresh;
 }
+__device__ __forceinline__ bool drop_keep(uint32_t key, uint32_t idx) { return drop_keep_t(key, idx, kDropThresh16); }
 // scaled keep factor: 1/(1-p) or 0; key == 0 -> 1 (eval mode)
 __device__ __forceinline__ float drop_factor(uint32_t key, uint32_t idx) {
   if (key == 0u) return 1.0f;

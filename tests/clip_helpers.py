@@ -1,0 +1,41 @@
+"""Golden-case loader of the appearance-encoder tests (tests/golden/g_clip_*.npz, written by make_golden_clip.py)."""
+import os
+
+import numpy as np
+import torch
+
+from dualvgr_videoqa_amd import synth
+from oracle import clip_torch as CT
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CLIP_CASES = ["g_clip_small_eval", "g_clip_small_train", "g_clip_t1_eval", "g_clip_real_train"]
+
+
+class ClipCase:
+    """Weights and inputs are regenerated from the (seed, name) generator exactly as make_golden_clip.py built them."""
+
+    def __init__(self, name):
+        self.z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.V, self.D, self.B, self.N, self.T, train, self.seed, self.stride = [int(v) for v in self.z["meta"]]
+        self.train = bool(train)
+        self.sd_np = synth.xavier_state_dict(CT.param_shapes(self.V, self.D), seed=self.seed, bias_range=0.1)
+        self.x = np.abs(synth.normal("clip_x", (self.B, self.N, self.T, self.V), 0.8, self.seed)).astype(np.float32)
+        self.R = synth.normal("clip_R", (self.B, self.N, self.D), 1.0, self.seed)
+
+    def masks(self):
+        if not self.train:
+            return None
+        shapes = {"in": (self.B, self.N, self.T, self.V), "out": (self.B * self.N, self.D)}
+        out = {}
+        for nm, shape in shapes.items():
+            bits = np.unpackbits(self.z["mask_" + nm])[: int(np.prod(shape))]
+            out[nm] = torch.from_numpy(bits.reshape(shape).astype(np.float32))
+        return out
+
+    def check_param_grads(self, grads, tol, rel_err):
+        """grads: {state_dict key: ndarray}; the golden file holds every `stride`-th row / column of the matrices."""
+        for k in self.sd_np:
+            ref = self.z["g_" + k]
+            g = grads[k]
+            g = g[::self.stride, ::self.stride] if g.ndim == 2 else g
+            assert rel_err(g, ref) < tol, (k, rel_err(g, ref))

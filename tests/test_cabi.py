@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared_symbols():
     names = set()
-    for h in ("dvgr.h", "dvgr_debug.h", "dvgr_head.h"):
+    for h in ("dvgr.h", "dvgr_debug.h", "dvgr_head.h", "dvgr_clip.h"):
         text = open(os.path.join(ROOT, "include", h)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         names |= set(re.findall(r"\b(dvgr_[a-z_0-9]+)\s*\(", text))
@@ -31,8 +31,10 @@ def test_library_exports_every_declared_symbol():
     declared = _declared_symbols()
     assert len(declared) >= 15
     from dualvgr_videoqa_amd import head as HD
+    from dualvgr_videoqa_amd import clip as CL
     HD.load()
-    bound = {n for n, _, _ in L.SYMBOLS} | {n for n, _, _ in HD.HEAD_SYMBOLS}
+    CL.load()
+    bound = {n for n, _, _ in L.SYMBOLS} | {n for n, _, _ in HD.HEAD_SYMBOLS} | {n for n, _, _ in CL.CLIP_SYMBOLS}
     assert declared == bound, declared ^ bound
     for name in declared:
         assert getattr(lib, name) is not None
@@ -181,3 +183,25 @@ def test_head_layout_and_argument_checks():
     io = HD.HeadIO()
     assert lib.dvgr_head_forward(C.byref(ok), None, C.byref(io), None, 0, None, 0, 0, 0, None) == -2
     assert lib.dvgr_head_saved_bytes(C.byref(ok)) > 0 and lib.dvgr_head_workspace_bytes(C.byref(ok)) > 0
+
+
+def test_clip_layout_and_argument_checks():
+    """Appearance encoder (include/dvgr_clip.h): dims checks, parameter table = torch.nn.LSTM's state_dict surface, refusals."""
+    from dualvgr_videoqa_amd import clip as CL
+    from oracle import clip_torch as CT
+    lib = CL.load()
+    ok = CL.ClipDims(64 * 20, 16, 2048, 384, 0)
+    assert lib.dvgr_clip_check_dims(C.byref(ok)) == 0
+    for bad in (CL.ClipDims(0, 16, 2048, 384, 0), CL.ClipDims(8, 0, 2048, 384, 0), CL.ClipDims(8, 65, 2048, 384, 0),
+                CL.ClipDims(8, 16, 2000, 384, 0), CL.ClipDims(8, 16, 2048, 100, 0), CL.ClipDims(8, 16, 2048, 384, 5),
+                CL.ClipDims(1 << 20, 64, 2048, 384, 0)):
+        assert lib.dvgr_clip_check_dims(C.byref(bad)) == -1
+    m = dv.ClipEncoder(appearance_dim=64, module_dim=64)
+    want = dict(CT.param_shapes(64, 64))
+    got = {k: tuple(v.shape) for k, v in m.named_parameters()}
+    assert got == want
+    ref = torch.nn.LSTM(64, 32, bidirectional=True)
+    assert list(m.encoder.state_dict().keys()) == list(ref.state_dict().keys())
+    assert len(set(m._table)) == 8 and m._total == sum(p.numel() for p in ref.parameters())
+    assert lib.dvgr_clip_forward(C.byref(ok), None, None, None, None, 0, None, 0, 0, 0, None) == -2
+    assert lib.dvgr_clip_saved_bytes(C.byref(ok)) > 0 and lib.dvgr_clip_workspace_bytes(C.byref(ok)) > 0
