@@ -119,9 +119,11 @@ def main():
                     help="row f2: also run the clip read-out + classifier (AnswerHead, 1000 answers) and a cross-entropy "
                          "loss on its logits inside every step; the unit then gets d CE / d vis instead of ones")
     ap.add_argument("--model", action="store_true",
-                    help="row f3 (first stage): the whole DualVGR model -- question / appearance BiLSTMs and the motion Linear on "
-                         "stock PyTorch-ROCm (MIOpen, hipBLASLt), unit + answer head on HIP -- on raw (B, N, 16, 2048) / "
+                    help="row f3: the whole DualVGR model -- appearance BiLSTM, unit and answer head on HIP, question BiLSTMs "
+                         "and the motion Linear on stock PyTorch-ROCm (MIOpen, hipBLASLt) -- on raw (B, N, 16, 2048) / "
                          "(B, N, 2048) features, cross-entropy + auxiliary losses, forward + backward")
+    ap.add_argument("--appearance-encoder", default="hip", choices=["hip", "miopen"],
+                    help="with --model: the appearance BiLSTM on this package's HIP path (default) or on nn.LSTM / MIOpen")
     ap.add_argument("--loss", default="fused", choices=["fused", "fused-after", "precomputed"],
                     help="fused: the scope-U loss and its gradients are computed inside every timed step by "
                          "dvgr_scope_u_loss; precomputed: fixed upstream gradients (unit kernels only)")
@@ -299,7 +301,7 @@ def bench_model(args, dev, rank, world, cfg):
     vocab = {"question_token_to_idx": {str(i): i for i in range(VQ)}, "answer_token_to_idx": {str(i): i for i in range(VA)}}
     torch.manual_seed(666)
     m = dv.DualVGR(vision_dim=V, module_dim=D, word_dim=WD, vocab=vocab, num_of_nodes=N, graph_module="GAT", graph_layers=1,
-                   unit_layers=Lr, dtype=args.dtype).to(dev)
+                   unit_layers=Lr, dtype=args.dtype, appearance_encoder=args.appearance_encoder).to(dev)
     m.train(not args.eval_mode)
     unit, head = m.visual_input_unit, m._head
     unit.loss_in_forward = (1.0, 1e-8, float(world), False)
@@ -332,7 +334,7 @@ def bench_model(args, dev, rank, world, cfg):
            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": f"{cfg['name']}: whole DualVGR model forward+backward, per-GPU batch {B}, raw features "
-                                  f"(B,{N},{FR},{V}) + (B,{N},{V}), T={T}, vocab {VQ}/{VA}; encoders on MIOpen / hipBLASLt, unit + head on HIP"}}
+                                  f"(B,{N},{FR},{V}) + (B,{N},{V}), T={T}, vocab {VQ}/{VA}; appearance encoder on {args.appearance_encoder}, question encoder on MIOpen, unit + head on HIP"}}
     if rank == 0:
         print(json.dumps(out))
 

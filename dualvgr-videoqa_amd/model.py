@@ -1,11 +1,12 @@
-"""Whole-model wrapper (first stage): `DualVGR` with the reference's constructor,
-`forward()` and state_dict surface (model/models.py:34-83).
+"""Whole-model wrapper: `DualVGR` with the reference's constructor, `forward()` and
+state_dict surface (model/models.py:34-83).
 
-The reasoning unit and the answer head are this package's HIP paths (`DualVGRUnit_multiple`, `AnswerHead`).  The input
-encoders around them -- question embedding + two BiLSTMs, the appearance BiLSTM over the frames of a clip, the motion
-Linear (model/Preprocessing.py:7-45, :89-127, :191-234; model/models.py:46) -- are restated here on stock PyTorch-ROCm
-modules (MIOpen LSTM, hipBLASLt Linear), exactly as SURVEY.md ranks them: "start with MIOpen via nn.LSTM".  They are
-harness around the hot path, not part of it.
+The reasoning unit, the answer head and the appearance encoder (the BiLSTM over the frames of every clip, 90 % of the
+encoders' time) are this package's HIP paths (`DualVGRUnit_multiple`, `AnswerHead`, `ClipEncoder`).  The small encoders
+left -- question embedding + two BiLSTMs over <= T words of B questions, the motion Linear (model/Preprocessing.py:7-45,
+:89-127; model/models.py:46) -- are restated here on stock PyTorch-ROCm modules (MIOpen LSTM, hipBLASLt Linear), as
+SURVEY.md ranks them: "start with MIOpen via nn.LSTM".  `appearance_encoder="miopen"` puts the appearance encoder on
+nn.LSTM as well (the first stage of this row, kept for A/B timing).
 """
 from __future__ import annotations
 
@@ -13,6 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .clip import ClipEncoder
 from .head import AnswerHead
 from .unit import DualVGRUnit_multiple
 
@@ -81,12 +83,17 @@ class DualVGR(nn.Module):
     signature and 7-tuple, same state_dict keys (a reference checkpoint loads with strict=True)."""
 
     def __init__(self, vision_dim=2048, module_dim=768, word_dim=300, vocab=None, num_of_nodes=8, graph_module="GAT",
-                 graph_layers=1, unit_layers=2, dtype="fp32"):
+                 graph_layers=1, unit_layers=2, dtype="fp32", appearance_encoder="hip"):
         super().__init__()
         n_q = len(vocab["question_token_to_idx"])
         self.num_classes = len(vocab["answer_token_to_idx"])
         self.linguistic_input_unit = InputUnitLinguisticDynamic(vocab_size=n_q, wordvec_dim=word_dim, rnn_dim=module_dim)
-        self.visual_appearance_input_unit = VisualAppearanceEncoder(appearance_dim=vision_dim, module_dim=module_dim)
+        if appearance_encoder == "hip":
+            self.visual_appearance_input_unit = ClipEncoder(appearance_dim=vision_dim, module_dim=module_dim, dtype=dtype)
+        elif appearance_encoder == "miopen":
+            self.visual_appearance_input_unit = VisualAppearanceEncoder(appearance_dim=vision_dim, module_dim=module_dim)
+        else:
+            raise ValueError("appearance_encoder must be 'hip' or 'miopen'")
         self.visual_motion_input_unit = nn.Linear(vision_dim, module_dim)
         self.visual_input_unit = DualVGRUnit_multiple(word_dim=word_dim, module_dim=module_dim, num_of_nodes=num_of_nodes,
                                                       appearance_graph_layers=graph_layers, motion_graph_layers=graph_layers,
@@ -98,7 +105,7 @@ class DualVGR(nn.Module):
         self.output_unit = head.output_unit
         object.__setattr__(self, "_head", head)
         for m in self.modules():                    # model/utils.py:8-33 init_modules(w_init="xavier_uniform")
-            if isinstance(m, (nn.Linear, nn.LSTM)):
+            if isinstance(m, (nn.Linear, nn.LSTM)) or type(m).__name__ == "_LSTMParams":
                 for name, p in m.named_parameters(recurse=False):
                     if "bias" in name:
                         nn.init.zeros_(p)
