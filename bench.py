@@ -122,6 +122,8 @@ def main():
                     help="row f3: the whole DualVGR model -- appearance BiLSTM, unit and answer head on HIP, question BiLSTMs "
                          "and the motion Linear on stock PyTorch-ROCm (MIOpen, hipBLASLt) -- on raw (B, N, 16, 2048) / "
                          "(B, N, 2048) features, cross-entropy + auxiliary losses, forward + backward")
+    ap.add_argument("--question-encoder", default="hip", choices=["hip", "miopen"],
+                    help="with --model: the two packed question BiLSTMs on this package's HIP path (default) or on nn.LSTM / MIOpen")
     ap.add_argument("--appearance-encoder", default="hip", choices=["hip", "miopen"],
                     help="with --model: the appearance BiLSTM on this package's HIP path (default) or on nn.LSTM / MIOpen")
     ap.add_argument("--loss", default="fused", choices=["fused", "fused-after", "precomputed"],
@@ -301,7 +303,8 @@ def bench_model(args, dev, rank, world, cfg):
     vocab = {"question_token_to_idx": {str(i): i for i in range(VQ)}, "answer_token_to_idx": {str(i): i for i in range(VA)}}
     torch.manual_seed(666)
     m = dv.DualVGR(vision_dim=V, module_dim=D, word_dim=WD, vocab=vocab, num_of_nodes=N, graph_module="GAT", graph_layers=1,
-                   unit_layers=Lr, dtype=args.dtype, appearance_encoder=args.appearance_encoder).to(dev)
+                   unit_layers=Lr, dtype=args.dtype, appearance_encoder=args.appearance_encoder,
+                   question_encoder=args.question_encoder).to(dev)
     m.train(not args.eval_mode)
     unit, head = m.visual_input_unit, m._head
     unit.loss_in_forward = (1.0, 1e-8, float(world), False)
@@ -334,7 +337,7 @@ def bench_model(args, dev, rank, world, cfg):
            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": f"{cfg['name']}: whole DualVGR model forward+backward, per-GPU batch {B}, raw features "
-                                  f"(B,{N},{FR},{V}) + (B,{N},{V}), T={T}, vocab {VQ}/{VA}; appearance encoder on {args.appearance_encoder}, question encoder on MIOpen, unit + head on HIP"}}
+                                  f"(B,{N},{FR},{V}) + (B,{N},{V}), T={T}, vocab {VQ}/{VA}; appearance encoder on {args.appearance_encoder}, question encoder on {args.question_encoder}, unit + head on hip"}}
     if rank == 0:
         print(json.dumps(out))
 

@@ -1,6 +1,8 @@
-"""The appearance encoder in front of the unit on libdvgr_hip.so.
+"""The recurrent encoders in front of the unit on libdvgr_hip.so.
 
-`ClipEncoder` holds the parameters of the reference's `VisualAppearanceEncoder` (model/Preprocessing.py:191-234) under
+`BiLSTM` is a one-layer bidirectional LSTM over padded, optionally variable-length sequences with torch.nn.LSTM's parameter
+names, shapes and registration order; `QuestionEncoder` uses two of them to restate `InputUnitLinguisticDynamic`
+(model/Preprocessing.py:89-127, with `DynamicRNN` :7-45).  `ClipEncoder` holds the parameters of the reference's `VisualAppearanceEncoder` (model/Preprocessing.py:191-234) under
 the same names and shapes (`encoder.weight_ih_l0`, ... `encoder.bias_hh_l0_reverse`), so that slice of a reference
 checkpoint loads with strict=True, and computes dropout -> tanh -> BiLSTM over the frames of every clip -> final states
 -> dropout through the C ABI of include/dvgr_clip.h -- forward and backward.  No CPU / eager fallback.
@@ -21,6 +23,17 @@ LSTM_ORDER = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weigh
               "bias_ih_l0_reverse", "bias_hh_l0_reverse"]
 
 
+LSTM_EMBED_INPUT, LSTM_DROP_FINAL = 1, 2
+
+
+class LstmIO(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("x", "lens", "out_final", "out_seq")]
+
+
+class LstmGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("g_final", "g_seq", "g_x", "gparams")]
+
+
 class ClipDims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("S", "T", "V", "H", "dtype")]
 
@@ -36,6 +49,10 @@ CLIP_SYMBOLS = [
                                     C.c_size_t, C.c_int, C.c_uint64, C.c_void_p]),
     ("dvgr_clip_backward", C.c_int, [C.POINTER(ClipDims), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                      C.c_size_t, C.c_int, C.c_uint64, C.c_void_p]),
+    ("dvgr_lstm_forward", C.c_int, [C.POINTER(ClipDims), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
+                                    C.c_size_t, C.c_int, C.c_uint64, C.c_void_p]),
+    ("dvgr_lstm_backward", C.c_int, [C.POINTER(ClipDims), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
+                                     C.c_void_p, C.c_size_t, C.c_int, C.c_uint64, C.c_void_p]),
     ("dvgr_clip_dbg_keep_mask", C.c_int, [C.c_uint64, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
 ]
 _bound = False
@@ -52,89 +69,101 @@ def load():
     return lib
 
 
-class _LSTMParams(nn.Module):
-    """Parameter container with torch.nn.LSTM(bidirectional=True)'s names, shapes and registration order."""
+class _LstmFn(torch.autograd.Function):
+    """(x (S, T, V), lens or None) -> (final (S, 2H), seq (S, T, 2H)); `want` selects which of the two are computed."""
 
-    def __init__(self, V, H):
-        super().__init__()
-        for name in LSTM_ORDER:
-            shape = (4 * H, V) if "weight_ih" in name else (4 * H, H) if "weight_hh" in name else (4 * H,)
-            setattr(self, name, nn.Parameter(torch.zeros(shape)))
-
-    def flatten_parameters(self):          # model/Preprocessing.py:220 calls it; the flat buffer is always contiguous
-        return None
-
-
-class _ClipFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mod: "ClipEncoder", x, *params):
+    def forward(ctx, mod: "BiLSTM", x, lens, flags, want_final, want_seq, *params):
         lib = load()
         if not x.is_cuda:
-            raise RuntimeError("ClipEncoder runs on a ROCm device only (no CPU fallback)")
+            raise RuntimeError("BiLSTM runs on a ROCm device only (no CPU fallback)")
         x = x.contiguous().float()
-        bs, n_clips, n_frames, feat = x.shape
-        if feat != mod.appearance_dim:
-            raise RuntimeError("inconsistent input shape for ClipEncoder.forward")
-        dims = ClipDims(bs * n_clips, n_frames, feat, mod.module_dim // 2, mod.dtype_code)
+        S, T, V = x.shape
+        if V != mod.input_size:
+            raise RuntimeError("inconsistent input shape for BiLSTM.forward")
+        H = mod.hidden_size
+        dims = ClipDims(S, T, V, H, mod.dtype_code)
         L_.check(lib.dvgr_clip_check_dims(C.byref(dims)), "dvgr_clip_check_dims")
         dev = x.device
+        if lens is not None:
+            lens = lens.to(device=dev, dtype=torch.int64).contiguous()
         flat = mod.flat_params()
-        out = torch.empty((bs, n_clips, mod.module_dim), device=dev, dtype=torch.float32)
+        final = torch.empty((S, 2 * H), device=dev, dtype=torch.float32) if want_final else None
+        seq = torch.empty((S, T, 2 * H), device=dev, dtype=torch.float32) if want_seq else None
         saved = torch.empty(lib.dvgr_clip_saved_bytes(C.byref(dims)), device=dev, dtype=torch.uint8)
         ws = mod.workspace(lib.dvgr_clip_workspace_bytes(C.byref(dims)), dev)
         train = bool(mod.training)
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if train else 0
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if train and flags else 0
         if mod.forced_seed is not None:
             seed = int(mod.forced_seed)
+        io = LstmIO(x.data_ptr(), lens.data_ptr() if lens is not None else None, final.data_ptr() if want_final else None,
+                    seq.data_ptr() if want_seq else None)
         stream = torch.cuda.current_stream(dev).cuda_stream
-        L_.check(lib.dvgr_clip_forward(C.byref(dims), flat.data_ptr(), x.data_ptr(), out.data_ptr(), saved.data_ptr(), saved.numel(),
-                                       ws.data_ptr(), ws.numel(), int(train), seed, stream), "dvgr_clip_forward")
-        ctx.mod, ctx.dims, ctx.train, ctx.seed = mod, dims, train, seed
+        L_.check(lib.dvgr_lstm_forward(C.byref(dims), flat.data_ptr(), C.byref(io), int(flags), saved.data_ptr(), saved.numel(),
+                                       ws.data_ptr(), ws.numel(), int(train), seed, stream), "dvgr_lstm_forward")
+        ctx.mod, ctx.dims, ctx.train, ctx.seed, ctx.flags = mod, dims, train, seed, int(flags)
+        ctx.lens = lens
+        ctx.want = (want_final, want_seq)
+        ctx.need_gx = ctx.needs_input_grad[1]
         ctx.save_for_backward(saved, flat)
+        ctx.set_materialize_grads(False)
         mod.last_seed = seed
-        return out
+        outs = (final if want_final else x.new_zeros(0), seq if want_seq else x.new_zeros(0))
+        ctx.mark_non_differentiable(*[o for o, w in zip(outs, ctx.want) if not w])
+        return outs
 
     @staticmethod
-    def backward(ctx, g_out):
+    def backward(ctx, g_final, g_seq):
         lib = load()
         mod, dims = ctx.mod, ctx.dims
         saved, flat = ctx.saved_tensors
         dev = saved.device
-        g = g_out.contiguous().float()
+        S, T, V, H = dims.S, dims.T, dims.V, dims.H
+        g_final = g_final.contiguous().float() if (g_final is not None and ctx.want[0]) else None
+        g_seq = g_seq.contiguous().float() if (g_seq is not None and ctx.want[1]) else None
+        if g_final is None and g_seq is None:
+            return (None,) * (6 + len(mod._plist))
         gflat = torch.empty_like(flat)
+        g_x = torch.empty((S, T, V), device=dev, dtype=torch.float32) if ctx.need_gx else None
         ws = mod.workspace(lib.dvgr_clip_workspace_bytes(C.byref(dims)), dev)
+        io = LstmIO(None, ctx.lens.data_ptr() if ctx.lens is not None else None, None, None)
+        gr = LstmGrads(g_final.data_ptr() if g_final is not None else None, g_seq.data_ptr() if g_seq is not None else None,
+                       g_x.data_ptr() if g_x is not None else None, gflat.data_ptr())
         stream = torch.cuda.current_stream(dev).cuda_stream
-        L_.check(lib.dvgr_clip_backward(C.byref(dims), flat.data_ptr(), g.data_ptr(), gflat.data_ptr(), saved.data_ptr(),
+        L_.check(lib.dvgr_lstm_backward(C.byref(dims), flat.data_ptr(), C.byref(io), C.byref(gr), ctx.flags, saved.data_ptr(),
                                         saved.numel(), ws.data_ptr(), ws.numel(), int(ctx.train), ctx.seed, stream),
-                 "dvgr_clip_backward")
+                 "dvgr_lstm_backward")
         pgrads = [gflat[o:o + p.numel()].view(p.shape) for p, o in zip(mod._plist, mod._table)]
-        return (None, None, *pgrads)
+        return (None, g_x, None, None, None, None, *pgrads)
 
 
-class ClipEncoder(nn.Module):
-    """Drop-in for the reference's VisualAppearanceEncoder(appearance_dim, module_dim): (B, N, frames, feat) -> (B, N, D)."""
+class BiLSTM(nn.Module):
+    """One-layer bidirectional LSTM; parameters named, shaped and ordered as torch.nn.LSTM(bidirectional=True)'s, so the
+    matching slice of a reference checkpoint loads with strict=True.  `run()` is the batch-first call."""
 
-    def __init__(self, appearance_dim: int = 2048, module_dim: int = 512, dtype: str = "fp32"):
+    def __init__(self, input_size: int, hidden_size: int, dtype: str = "fp32"):
         super().__init__()
-        self.appearance_dim, self.module_dim = int(appearance_dim), int(module_dim)
+        self.input_size, self.hidden_size = int(input_size), int(hidden_size)
         self.dtype_code = {"fp32": L_.DVGR_F32, "bf16": L_.DVGR_BF16, "bf16x3": L_.DVGR_BF16X3}[dtype]
-        H = self.module_dim // 2
-        self.encoder = _LSTMParams(self.appearance_dim, H)
+        V, H = self.input_size, self.hidden_size
+        k = 1.0 / (H ** 0.5)                      # torch.nn.LSTM.reset_parameters: U(-1/sqrt(H), 1/sqrt(H))
+        for name in LSTM_ORDER:
+            shape = (4 * H, V) if "weight_ih" in name else (4 * H, H) if "weight_hh" in name else (4 * H,)
+            setattr(self, name, nn.Parameter(torch.empty(shape).uniform_(-k, k)))
         self.forced_seed = None
         self.last_seed = 0
-        self._plist = [getattr(self.encoder, n) for n in CP_NAMES]
+        self._plist = [getattr(self, n) for n in CP_NAMES]
         self._table = None
         self._flat = None
         self._ptrs = None
         self._ws = None
-        k = 1.0 / (H ** 0.5)                      # torch.nn.LSTM.reset_parameters: U(-1/sqrt(H), 1/sqrt(H))
-        with torch.no_grad():
-            for p in self._plist:
-                p.uniform_(-k, k)
         self._build_table()
 
+    def flatten_parameters(self):          # model/Preprocessing.py:118, :220 call it; the flat buffer is always contiguous
+        return None
+
     def _build_table(self):
-        dims = ClipDims(1, 1, self.appearance_dim, self.module_dim // 2, self.dtype_code)
+        dims = ClipDims(1, 1, self.input_size, self.hidden_size, self.dtype_code)
         try:
             lib = load()
         except RuntimeError:
@@ -178,5 +207,65 @@ class ClipEncoder(nn.Module):
             self._ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
         return self._ws
 
+    def run(self, x, lens=None, flags: int = 0, want_final: bool = True, want_seq: bool = False):
+        """x (S, T, V) -> (final (S, 2H) or None, seq (S, T, 2H) or None)."""
+        final, seq = _LstmFn.apply(self, x, lens, int(flags), bool(want_final), bool(want_seq), *self._plist)
+        return (final if want_final else None), (seq if want_seq else None)
+
+
+class ClipEncoder(nn.Module):
+    """Drop-in for the reference's VisualAppearanceEncoder(appearance_dim, module_dim): (B, N, frames, feat) -> (B, N, D)."""
+
+    def __init__(self, appearance_dim: int = 2048, module_dim: int = 512, dtype: str = "fp32"):
+        super().__init__()
+        self.appearance_dim, self.module_dim = int(appearance_dim), int(module_dim)
+        self.encoder = BiLSTM(self.appearance_dim, self.module_dim // 2, dtype=dtype)
+
+    @property
+    def forced_seed(self):
+        return self.encoder.forced_seed
+
+    @forced_seed.setter
+    def forced_seed(self, v):
+        self.encoder.forced_seed = v
+
     def forward(self, appearance_clips):
-        return _ClipFn.apply(self, appearance_clips, *self._plist)
+        bs, n_clips, n_frames, feat = appearance_clips.shape
+        if feat != self.appearance_dim:
+            raise RuntimeError("inconsistent input shape for ClipEncoder.forward")
+        x = appearance_clips.reshape(bs * n_clips, n_frames, feat)
+        final, _ = self.encoder.run(x, None, LSTM_EMBED_INPUT | LSTM_DROP_FINAL)
+        return final.view(bs, n_clips, self.module_dim)
+
+
+class _PackedRNN(nn.Module):
+    """`DynamicRNN` (model/Preprocessing.py:7-45): the per-step outputs of a packed BiLSTM, zero past each length."""
+
+    def __init__(self, input_size, hidden_size, dtype):
+        super().__init__()
+        self.rnn = BiLSTM(input_size, hidden_size, dtype=dtype)
+
+    def forward(self, x, seq_len, max_len):
+        _, seq = self.rnn.run(x, seq_len, 0, want_final=False, want_seq=True)
+        return seq
+
+
+class QuestionEncoder(nn.Module):
+    """Drop-in for the reference's InputUnitLinguisticDynamic (model/Preprocessing.py:89-127): embedding -> dropout -> tanh =
+    word features; one BiLSTM gives the per-word dynamic embedding (zero past the question length), a second one the
+    question embedding (final states -> dropout 0.18).  The two LSTMs run on HIP; the embedding lookup, its dropout and
+    tanh stay torch element-wise ops (their gradient is a scatter into the embedding table)."""
+
+    def __init__(self, vocab_size, wordvec_dim=300, rnn_dim=512, dtype: str = "fp32"):
+        super().__init__()
+        self.encoder_embed = nn.Embedding(vocab_size, wordvec_dim)
+        self.concatRNN = _PackedRNN(wordvec_dim, rnn_dim // 2, dtype)
+        self.encoder = BiLSTM(wordvec_dim, rnn_dim // 2, dtype=dtype)
+        self.embedding_dropout = nn.Dropout(p=0.15)
+
+    def forward(self, questions, question_len):
+        max_len = questions.size(1)
+        words = torch.tanh(self.embedding_dropout(self.encoder_embed(questions)))
+        output_embedding = self.concatRNN(words, question_len, max_len)
+        question_embedding, _ = self.encoder.run(words, question_len, LSTM_DROP_FINAL)
+        return question_embedding, words, output_embedding

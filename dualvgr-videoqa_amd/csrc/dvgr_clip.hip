@@ -58,7 +58,7 @@ ClipSaved clip_saved(const dvgr_clip_dims& d) {
   return s;
 }
 
-struct ClipWs { int64_t w_p, bias, g_p, dh, dc, total; };
+struct ClipWs { int64_t w_p, bias, g_p, dh, dc, carry, de, total; };
 ClipWs clip_ws(const dvgr_clip_dims& d) {
   ClipWs w{};
   const int64_t TS = (int64_t)d.T * d.S, H = d.H, V = d.V, S = d.S;
@@ -68,13 +68,15 @@ ClipWs clip_ws(const dvgr_clip_dims& d) {
   w.g_p = o; o += TS * 8 * H;              // planes of the step gradients
   w.dh = o; o += round64(S * 2 * H);
   w.dc = o; o += round64(S * 2 * H);
+  w.carry = o; o += round64(S * 2 * H);    // dh of steps a sequence sat out (variable lengths), waiting for its last active step
+  w.de = o; o += TS * V;                   // gradient of the embedded input, time-major (only when g_x is wanted)
   w.total = o;
   return w;
 }
 
 int check_clip(const dvgr_clip_dims* d) {
   if (!d) return DVGR_E_NULL;
-  if (d->S < 1 || d->T < 1 || d->T > 64 || d->V < 32 || (d->V % 32) || d->H < 32 || (d->H % 32)) return DVGR_E_DIMS;
+  if (d->S < 1 || d->T < 1 || d->T > 64 || d->V < 4 || (d->V % 4) || d->H < 32 || (d->H % 32)) return DVGR_E_DIMS;
   if (d->dtype != DVGR_F32 && d->dtype != DVGR_BF16 && d->dtype != DVGR_BF16X3) return DVGR_E_DIMS;
   const int64_t TS = (int64_t)d->T * d->S, wide = d->V > 8 * d->H ? d->V : 8 * d->H;
   if (TS * wide >= (1ll << 31)) return DVGR_E_DIMS;      // 32-bit element offsets inside the engine / dropout counters
@@ -91,7 +93,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 
 // ---- e[t*S + s][:] = tanh(drop(x[s][t][:])), fp32 + planes -------------------------------------------------------
 __global__ __launch_bounds__(256) void k_clip_embed(const float* __restrict__ x, float* __restrict__ e, uint16_t* e_p, int64_t lo_off,
-                                                    uint32_t key, int S, int T, int V) {
+                                                    uint32_t key, int S, int T, int V, int embed) {
   const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t n4 = (int64_t)S * T * V / 4;
   if (i4 >= n4) return;
@@ -101,10 +103,12 @@ __global__ __launch_bounds__(256) void k_clip_embed(const float* __restrict__ x,
   const int t = (int)(st % T);
   const int64_t s = st / T;
   float4 a = reinterpret_cast<const float4*>(x)[i4];
+  if (embed) {
   a.x = tanhf(a.x * keep_scaled(key, (uint32_t)idx, kThreshIn, kScaleIn));
   a.y = tanhf(a.y * keep_scaled(key, (uint32_t)idx + 1, kThreshIn, kScaleIn));
   a.z = tanhf(a.z * keep_scaled(key, (uint32_t)idx + 2, kThreshIn, kScaleIn));
   a.w = tanhf(a.w * keep_scaled(key, (uint32_t)idx + 3, kThreshIn, kScaleIn));
+  }
   const int64_t dst = ((int64_t)t * S + s) * V + v;
   *reinterpret_cast<float4*>(e + dst) = a;
   split_store4(e_p, lo_off, dst, a);
@@ -118,7 +122,8 @@ __global__ __launch_bounds__(256) void k_clip_bias(const float* bih, const float
 // ---- one step of both directions: gates -> (c, h) ---------------------------------------------------------------
 // thread = 4 consecutive hidden units of one (clip, direction); row of direction d = t[d] * S + s
 __global__ __launch_bounds__(256) void k_clip_cell_fwd(float* __restrict__ G, float* __restrict__ Cs, float* __restrict__ Hs,
-                                                       uint16_t* h_p, int64_t lo_off, int S, int H, int t0, int t1, int has_prev) {
+                                                       uint16_t* h_p, int64_t lo_off, int S, int H, int t0, int t1, int has_prev,
+                                                       const int64_t* __restrict__ lens, float* __restrict__ out_seq, int T) {
   const int per_row = 2 * H / 4;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (int64_t)S * per_row) return;
@@ -130,6 +135,16 @@ __global__ __launch_bounds__(256) void k_clip_cell_fwd(float* __restrict__ G, fl
                gg = *reinterpret_cast<const float4*>(g + 2 * H), go = *reinterpret_cast<const float4*>(g + 3 * H);
   float4 cp = make_float4(0.f, 0.f, 0.f, 0.f);
   if (has_prev) cp = *reinterpret_cast<const float4*>(Cs + ((int64_t)tp * S + s) * 2 * H + c4);
+  const int64_t o = ((int64_t)t * S + s) * 2 * H + c4;
+  if (lens && t >= (int)lens[s]) {        // inactive step: the state passes through, the step emits zeros
+    float4 hp = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (has_prev) hp = *reinterpret_cast<const float4*>(Hs + ((int64_t)tp * S + s) * 2 * H + c4);
+    *reinterpret_cast<float4*>(Cs + o) = cp;
+    *reinterpret_cast<float4*>(Hs + o) = hp;
+    split_store4(h_p, lo_off, o, hp);
+    if (out_seq) *reinterpret_cast<float4*>(out_seq + ((int64_t)s * T + t) * 2 * H + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
   const float pi[4] = {gi.x, gi.y, gi.z, gi.w}, pf[4] = {gf.x, gf.y, gf.z, gf.w}, pg[4] = {gg.x, gg.y, gg.z, gg.w},
               po[4] = {go.x, go.y, go.z, go.w}, pc[4] = {cp.x, cp.y, cp.z, cp.w};
   float ai[4], af[4], ag[4], ao[4], c[4], h[4];
@@ -143,22 +158,23 @@ __global__ __launch_bounds__(256) void k_clip_cell_fwd(float* __restrict__ G, fl
   *reinterpret_cast<float4*>(g + H) = make_float4(af[0], af[1], af[2], af[3]);
   *reinterpret_cast<float4*>(g + 2 * H) = make_float4(ag[0], ag[1], ag[2], ag[3]);
   *reinterpret_cast<float4*>(g + 3 * H) = make_float4(ao[0], ao[1], ao[2], ao[3]);
-  const int64_t o = ((int64_t)t * S + s) * 2 * H + c4;
   *reinterpret_cast<float4*>(Cs + o) = make_float4(c[0], c[1], c[2], c[3]);
   const float4 hv = make_float4(h[0], h[1], h[2], h[3]);
   *reinterpret_cast<float4*>(Hs + o) = hv;
   split_store4(h_p, lo_off, o, hv);
+  if (out_seq) *reinterpret_cast<float4*>(out_seq + ((int64_t)s * T + t) * 2 * H + c4) = hv;
 }
 
 // ---- out = drop([h_f(T-1) | h_r(0)]);  the same kernel turns g_out into the initial dh (mask applied, dc = 0) -------
 __global__ __launch_bounds__(256) void k_clip_out(const float* __restrict__ src_f, const float* __restrict__ src_r, float* __restrict__ out,
-                                                  float* zero, uint32_t key, int S, int H) {
+                                                  float* zero, float* zero2, uint32_t key, int S, int H) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (int64_t)S * 2 * H) return;
   const int c = (int)(i % (2 * H));
-  const float v = (c < H ? src_f : src_r)[i];
+  const float v = src_f ? (c < H ? src_f : src_r)[i] : 0.f;
   out[i] = v * keep_scaled(key, (uint32_t)i, kThreshOut, kScaleOut);
   if (zero) zero[i] = 0.f;
+  if (zero2) zero2[i] = 0.f;
 }
 
 // ---- one step of the backward of both directions ------------------------------------------------------------------
@@ -166,7 +182,8 @@ __global__ __launch_bounds__(256) void k_clip_out(const float* __restrict__ src_
 // the activations (fp32 + planes), dc for the previous step.
 __global__ __launch_bounds__(256) void k_clip_cell_bwd(float* __restrict__ G, uint16_t* g_p, int64_t lo_off, const float* __restrict__ Cs,
                                                        const float* __restrict__ dh, float* __restrict__ dc, int S, int H, int t0,
-                                                       int t1, int has_prev) {
+                                                       int t1, int has_prev, const int64_t* __restrict__ lens,
+                                                       float* __restrict__ carry, const float* __restrict__ g_seq, int T) {
   const int per_row = 2 * H / 4;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (int64_t)S * per_row) return;
@@ -181,7 +198,26 @@ __global__ __launch_bounds__(256) void k_clip_cell_bwd(float* __restrict__ G, ui
   float4 vp = make_float4(0.f, 0.f, 0.f, 0.f);
   if (has_prev) vp = *reinterpret_cast<const float4*>(Cs + ((int64_t)tp * S + s) * 2 * H + c4);
   const int64_t so = (int64_t)s * 2 * H + c4;
-  const float4 vdh = *reinterpret_cast<const float4*>(dh + so), vdc = *reinterpret_cast<const float4*>(dc + so);
+  float4 vdh = *reinterpret_cast<const float4*>(dh + so);
+  const float4 vdc = *reinterpret_cast<const float4*>(dc + so);
+  if (lens) {                              // variable lengths: add what the steps this sequence sat out passed down
+    const float4 cr = *reinterpret_cast<const float4*>(carry + so);
+    vdh.x += cr.x; vdh.y += cr.y; vdh.z += cr.z; vdh.w += cr.w;
+    if (t >= (int)lens[s]) {               // inactive step: no gate gradients, (dh, dc) pass through unchanged
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(g) = z; *reinterpret_cast<float4*>(g + H) = z;
+      *reinterpret_cast<float4*>(g + 2 * H) = z; *reinterpret_cast<float4*>(g + 3 * H) = z;
+      split_store4(g_p, lo_off, go_, z); split_store4(g_p, lo_off, go_ + H, z);
+      split_store4(g_p, lo_off, go_ + 2 * H, z); split_store4(g_p, lo_off, go_ + 3 * H, z);
+      *reinterpret_cast<float4*>(carry + so) = vdh;
+      return;
+    }
+    *reinterpret_cast<float4*>(carry + so) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (g_seq) {
+    const float4 gs = *reinterpret_cast<const float4*>(g_seq + ((int64_t)s * T + t) * 2 * H + c4);
+    vdh.x += gs.x; vdh.y += gs.y; vdh.z += gs.z; vdh.w += gs.w;
+  }
   const float ai[4] = {vi.x, vi.y, vi.z, vi.w}, af[4] = {vf.x, vf.y, vf.z, vf.w}, ag[4] = {vg.x, vg.y, vg.z, vg.w},
               ao[4] = {vo.x, vo.y, vo.z, vo.w}, c[4] = {vc.x, vc.y, vc.z, vc.w}, cp[4] = {vp.x, vp.y, vp.z, vp.w},
               gh[4] = {vdh.x, vdh.y, vdh.z, vdh.w}, gc[4] = {vdc.x, vdc.y, vdc.z, vdc.w};
@@ -207,6 +243,28 @@ __global__ __launch_bounds__(256) void k_clip_cell_bwd(float* __restrict__ G, ui
   split_store4(g_p, lo_off, go_ + 2 * H, wg);
   split_store4(g_p, lo_off, go_ + 3 * H, wo);
   *reinterpret_cast<float4*>(dc + so) = make_float4(dcp[0], dcp[1], dcp[2], dcp[3]);
+}
+
+// ---- g_x[s][t][:] = dE[t*S + s][:] (through tanh and the input dropout when the prologue ran here) ---------------
+__global__ __launch_bounds__(256) void k_clip_gx(const float* __restrict__ de, const float* __restrict__ e, float* __restrict__ gx,
+                                                 uint32_t key, int S, int T, int V, int embed) {
+  const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i4 >= (int64_t)S * T * V / 4) return;
+  const int64_t idx = 4 * i4;
+  const int v = (int)(idx % V);
+  const int64_t st = idx / V;
+  const int t = (int)(st % T);
+  const int64_t s = st / T;
+  const int64_t src = ((int64_t)t * S + s) * V + v;
+  float4 g = *reinterpret_cast<const float4*>(de + src);
+  if (embed) {
+    const float4 a = *reinterpret_cast<const float4*>(e + src);
+    g.x *= (1.f - a.x * a.x) * keep_scaled(key, (uint32_t)idx, kThreshIn, kScaleIn);
+    g.y *= (1.f - a.y * a.y) * keep_scaled(key, (uint32_t)idx + 1, kThreshIn, kScaleIn);
+    g.z *= (1.f - a.z * a.z) * keep_scaled(key, (uint32_t)idx + 2, kThreshIn, kScaleIn);
+    g.w *= (1.f - a.w * a.w) * keep_scaled(key, (uint32_t)idx + 3, kThreshIn, kScaleIn);
+  }
+  reinterpret_cast<float4*>(gx)[i4] = g;
 }
 
 __global__ __launch_bounds__(256) void k_clip_keep_mask(uint32_t key, int64_t n, float* keep, uint32_t thresh) {
@@ -262,12 +320,12 @@ int dvgr_clip_param_offset(const dvgr_clip_dims* d, int kind, int64_t* offset, i
 size_t dvgr_clip_saved_bytes(const dvgr_clip_dims* d) { return (d && !check_clip(d)) ? (size_t)clip_saved(*d).total * 4 : 0; }
 size_t dvgr_clip_workspace_bytes(const dvgr_clip_dims* d) { return (d && !check_clip(d)) ? (size_t)clip_ws(*d).total * 4 : 0; }
 
-int dvgr_clip_forward(const dvgr_clip_dims* dp, const float* params, const float* x, float* out, void* saved_v, size_t saved_bytes,
-                      void* ws_v, size_t ws_bytes, int train, uint64_t seed, void* stream) {
+int dvgr_lstm_forward(const dvgr_clip_dims* dp, const float* params, const dvgr_lstm_io* io, int flags, void* saved_v,
+                      size_t saved_bytes, void* ws_v, size_t ws_bytes, int train, uint64_t seed, void* stream) {
   CLIP_TRY(check_clip(dp));
-  if (!params || !x || !out || !saved_v || !ws_v) return DVGR_E_NULL;
+  if (!params || !io || !io->x || (!io->out_final && !io->out_seq) || !saved_v || !ws_v) return DVGR_E_NULL;
   if (saved_bytes < dvgr_clip_saved_bytes(dp) || ws_bytes < dvgr_clip_workspace_bytes(dp)) return DVGR_E_WORKSPACE;
-  if (!al16(params) || !al16(x) || !al16(out) || !al16(saved_v) || !al16(ws_v)) return DVGR_E_ALIGN;
+  if (!al16(params) || !al16(io->x) || !al16(io->out_final) || !al16(io->out_seq) || !al16(saved_v) || !al16(ws_v)) return DVGR_E_ALIGN;
   const dvgr_clip_dims d = *dp;
   hipStream_t st = (hipStream_t)stream;
   const ClipParams P = clip_params(d);
@@ -282,13 +340,15 @@ int dvgr_clip_forward(const dvgr_clip_dims* dp, const float* params, const float
   uint16_t* e_p = (uint16_t*)(sv + SV.e_p);
   uint16_t* h_p = (uint16_t*)(sv + SV.h_p);
   const int64_t e_lo = TS * V, h_lo = TS * 2 * H;
+  const int embed = (flags & DVGR_LSTM_EMBED_INPUT) ? 1 : 0;
 
   CLIP_TRY(split_weights(st, params, P, w_p, nW));
   hipLaunchKernelGGL(k_clip_bias, dim3(blocks_for(8 * H)), dim3(256), 0, st, params + P.bih, params + P.bhh, ws + W.bias, 8 * H);
   CLIP_LAUNCH_OK();
-  hipLaunchKernelGGL(k_clip_embed, dim3(blocks_for(TS * V / 4)), dim3(256), 0, st, x, sv + SV.e, e_p, e_lo, clip_key(train, seed, 0), S, T, V);
+  hipLaunchKernelGGL(k_clip_embed, dim3(blocks_for(TS * V / 4)), dim3(256), 0, st, io->x, sv + SV.e, e_p, e_lo,
+                     clip_key(train && embed, seed, 0), S, T, V, embed);
   CLIP_LAUNCH_OK();
-  {  // input contraction of every frame and both directions
+  {  // input contraction of every step and both directions
     GemmBatch b{};
     b.p[b.n++] = problem(opnd(sv + SV.e, V, e_p, e_lo), opnd(params + P.wih, V, w_p, nW), sv + SV.g, 8 * H, ws + W.bias,
                          (int)TS, 8 * H, V, 0);
@@ -307,21 +367,25 @@ int dvgr_clip_forward(const dvgr_clip_dims* dp, const float* params, const float
       CLIP_TRY(gemm_launch(st, KC, KC, b, TAG_GENERIC, prec));
     }
     hipLaunchKernelGGL(k_clip_cell_fwd, dim3(blocks_for((int64_t)S * 2 * H / 4)), dim3(256), 0, st, sv + SV.g, sv + SV.c, sv + SV.h,
-                       h_p, h_lo, S, H, t[0], t[1], k > 0 ? 1 : 0);
+                       h_p, h_lo, S, H, t[0], t[1], k > 0 ? 1 : 0, io->lens, io->out_seq, T);
     CLIP_LAUNCH_OK();
   }
-  hipLaunchKernelGGL(k_clip_out, dim3(blocks_for((int64_t)S * 2 * H)), dim3(256), 0, st, sv + SV.h + (int64_t)(T - 1) * S * 2 * H, sv + SV.h,
-                     out, (float*)nullptr, clip_key(train, seed, 1), S, H);
-  CLIP_LAUNCH_OK();
+  if (io->out_final) {
+    hipLaunchKernelGGL(k_clip_out, dim3(blocks_for((int64_t)S * 2 * H)), dim3(256), 0, st, (const float*)(sv + SV.h + (int64_t)(T - 1) * S * 2 * H),
+                       (const float*)(sv + SV.h), io->out_final, (float*)nullptr, (float*)nullptr,
+                       clip_key(train && (flags & DVGR_LSTM_DROP_FINAL), seed, 1), S, H);
+    CLIP_LAUNCH_OK();
+  }
   return 0;
 }
 
-int dvgr_clip_backward(const dvgr_clip_dims* dp, const float* params, const float* g_out, float* gparams, void* saved_v,
-                       size_t saved_bytes, void* ws_v, size_t ws_bytes, int train, uint64_t seed, void* stream) {
+int dvgr_lstm_backward(const dvgr_clip_dims* dp, const float* params, const dvgr_lstm_io* io, const dvgr_lstm_grads* gr, int flags,
+                       void* saved_v, size_t saved_bytes, void* ws_v, size_t ws_bytes, int train, uint64_t seed, void* stream) {
   CLIP_TRY(check_clip(dp));
-  if (!params || !g_out || !gparams || !saved_v || !ws_v) return DVGR_E_NULL;
+  if (!params || !io || !gr || !gr->gparams || (!gr->g_final && !gr->g_seq) || !saved_v || !ws_v) return DVGR_E_NULL;
   if (saved_bytes < dvgr_clip_saved_bytes(dp) || ws_bytes < dvgr_clip_workspace_bytes(dp)) return DVGR_E_WORKSPACE;
-  if (!al16(params) || !al16(g_out) || !al16(gparams) || !al16(saved_v) || !al16(ws_v)) return DVGR_E_ALIGN;
+  if (!al16(params) || !al16(gr->g_final) || !al16(gr->g_seq) || !al16(gr->g_x) || !al16(gr->gparams) || !al16(saved_v) || !al16(ws_v))
+    return DVGR_E_ALIGN;
   const dvgr_clip_dims d = *dp;
   hipStream_t st = (hipStream_t)stream;
   const ClipParams P = clip_params(d);
@@ -329,6 +393,7 @@ int dvgr_clip_backward(const dvgr_clip_dims* dp, const float* params, const floa
   const ClipWs W = clip_ws(d);
   float* sv = (float*)saved_v;
   float* ws = (float*)ws_v;
+  float* gparams = gr->gparams;
   const int S = d.S, T = d.T, V = d.V, H = d.H, prec = d.dtype;
   const int64_t TS = (int64_t)T * S;
   const int64_t nW = 8ll * H * V + 8ll * H * H;
@@ -337,18 +402,19 @@ int dvgr_clip_backward(const dvgr_clip_dims* dp, const float* params, const floa
   uint16_t* h_p = (uint16_t*)(sv + SV.h_p);
   uint16_t* g_p = (uint16_t*)(ws + W.g_p);
   const int64_t e_lo = TS * V, h_lo = TS * 2 * H, g_lo = TS * 8 * H;
+  const int embed = (flags & DVGR_LSTM_EMBED_INPUT) ? 1 : 0;
 
   if (hipMemsetAsync(gparams, 0, (size_t)P.total * 4, st) != hipSuccess) return (int)hipGetLastError();
   CLIP_TRY(split_weights(st, params, P, w_p, nW));
-  // dh of the last step = g_out through the output dropout (both halves: the forward direction's last step is frame
-  // T-1, the reverse direction's is frame 0, and both are step T-1); dc = 0
-  hipLaunchKernelGGL(k_clip_out, dim3(blocks_for((int64_t)S * 2 * H)), dim3(256), 0, st, g_out, g_out, ws + W.dh, ws + W.dc,
-                     clip_key(train, seed, 1), S, H);
+  // dh of the last step = g_final through the output dropout (both halves: the forward direction's last step is frame
+  // T-1, the reverse direction's is frame 0, and both are step T-1); dc = 0; nothing carried yet
+  hipLaunchKernelGGL(k_clip_out, dim3(blocks_for((int64_t)S * 2 * H)), dim3(256), 0, st, gr->g_final, gr->g_final, ws + W.dh, ws + W.dc,
+                     io->lens ? ws + W.carry : (float*)nullptr, clip_key(train && (flags & DVGR_LSTM_DROP_FINAL), seed, 1), S, H);
   CLIP_LAUNCH_OK();
   for (int k = T - 1; k >= 0; --k) {
     const int t[2] = {k, T - 1 - k};
     hipLaunchKernelGGL(k_clip_cell_bwd, dim3(blocks_for((int64_t)S * 2 * H / 4)), dim3(256), 0, st, sv + SV.g, g_p, g_lo, sv + SV.c,
-                       ws + W.dh, ws + W.dc, S, H, t[0], t[1], k > 0 ? 1 : 0);
+                       ws + W.dh, ws + W.dc, S, H, t[0], t[1], k > 0 ? 1 : 0, io->lens, ws + W.carry, gr->g_seq, T);
     CLIP_LAUNCH_OK();
     if (k > 0) {     // dh of the previous step = dG[t] Whh
       GemmBatch b{};
@@ -388,7 +454,34 @@ int dvgr_clip_backward(const dvgr_clip_dims* dp, const float* params, const floa
     if (hipMemcpyAsync(gparams + P.bhh, gparams + P.bih, (size_t)8 * H * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
       return (int)hipGetLastError();
   }
+  if (gr->g_x) {  // gradient of the input: dE = dG [Wih_f; Wih_r], back to batch-first (and through the prologue)
+    GemmBatch b{};
+    b.p[b.n++] = problem(opnd(sv + SV.g, 8 * H, g_p, g_lo), opnd(params + P.wih, V, w_p, nW), ws + W.de, V, nullptr, (int)TS, V, 8 * H, 0);
+    CLIP_TRY(gemm_launch(st, KC, IC, b, TAG_GENERIC, prec));
+    hipLaunchKernelGGL(k_clip_gx, dim3(blocks_for(TS * V / 4)), dim3(256), 0, st, (const float*)(ws + W.de), (const float*)(sv + SV.e), gr->g_x,
+                       clip_key(train && embed, seed, 0), S, T, V, embed);
+    CLIP_LAUNCH_OK();
+  }
   return 0;
+}
+
+int dvgr_clip_forward(const dvgr_clip_dims* dp, const float* params, const float* x, float* out, void* saved_v, size_t saved_bytes,
+                      void* ws_v, size_t ws_bytes, int train, uint64_t seed, void* stream) {
+  if (!x || !out) return DVGR_E_NULL;
+  dvgr_lstm_io io{};
+  io.x = x; io.out_final = out;
+  return dvgr_lstm_forward(dp, params, &io, DVGR_LSTM_EMBED_INPUT | DVGR_LSTM_DROP_FINAL, saved_v, saved_bytes, ws_v, ws_bytes, train, seed,
+                           stream);
+}
+
+int dvgr_clip_backward(const dvgr_clip_dims* dp, const float* params, const float* g_out, float* gparams, void* saved_v,
+                       size_t saved_bytes, void* ws_v, size_t ws_bytes, int train, uint64_t seed, void* stream) {
+  if (!g_out || !gparams) return DVGR_E_NULL;
+  dvgr_lstm_io io{};
+  dvgr_lstm_grads gr{};
+  gr.g_final = g_out; gr.gparams = gparams;
+  return dvgr_lstm_backward(dp, params, &io, &gr, DVGR_LSTM_EMBED_INPUT | DVGR_LSTM_DROP_FINAL, saved_v, saved_bytes, ws_v, ws_bytes, train,
+                            seed, stream);
 }
 
 int dvgr_clip_dbg_keep_mask(uint64_t seed, int site, int64_t n, float* keep, void* stream) {

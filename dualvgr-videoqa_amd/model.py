@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .clip import ClipEncoder
+from .clip import ClipEncoder, QuestionEncoder
 from .head import AnswerHead
 from .unit import DualVGRUnit_multiple
 
@@ -83,11 +83,17 @@ class DualVGR(nn.Module):
     signature and 7-tuple, same state_dict keys (a reference checkpoint loads with strict=True)."""
 
     def __init__(self, vision_dim=2048, module_dim=768, word_dim=300, vocab=None, num_of_nodes=8, graph_module="GAT",
-                 graph_layers=1, unit_layers=2, dtype="fp32", appearance_encoder="hip"):
+                 graph_layers=1, unit_layers=2, dtype="fp32", appearance_encoder="hip",
+                 question_encoder="hip"):
         super().__init__()
         n_q = len(vocab["question_token_to_idx"])
         self.num_classes = len(vocab["answer_token_to_idx"])
-        self.linguistic_input_unit = InputUnitLinguisticDynamic(vocab_size=n_q, wordvec_dim=word_dim, rnn_dim=module_dim)
+        if question_encoder == "hip":
+            self.linguistic_input_unit = QuestionEncoder(vocab_size=n_q, wordvec_dim=word_dim, rnn_dim=module_dim, dtype=dtype)
+        elif question_encoder == "miopen":
+            self.linguistic_input_unit = InputUnitLinguisticDynamic(vocab_size=n_q, wordvec_dim=word_dim, rnn_dim=module_dim)
+        else:
+            raise ValueError("question_encoder must be 'hip' or 'miopen'")
         if appearance_encoder == "hip":
             self.visual_appearance_input_unit = ClipEncoder(appearance_dim=vision_dim, module_dim=module_dim, dtype=dtype)
         elif appearance_encoder == "miopen":
@@ -105,7 +111,7 @@ class DualVGR(nn.Module):
         self.output_unit = head.output_unit
         object.__setattr__(self, "_head", head)
         for m in self.modules():                    # model/utils.py:8-33 init_modules(w_init="xavier_uniform")
-            if isinstance(m, (nn.Linear, nn.LSTM)) or type(m).__name__ == "_LSTMParams":
+            if isinstance(m, (nn.Linear, nn.LSTM)) or type(m).__name__ == "BiLSTM":
                 for name, p in m.named_parameters(recurse=False):
                     if "bias" in name:
                         nn.init.zeros_(p)

@@ -19,7 +19,7 @@ extern "C" {
 typedef struct dvgr_clip_dims {
   int32_t S;      /* clips = B * N (the LSTM's batch)                                 */
   int32_t T;      /* frames per clip (the LSTM's sequence length), 1..64             */
-  int32_t V;      /* frame feature size (2048), multiple of 32                       */
+  int32_t V;      /* input feature size (2048 frames / 300 words), multiple of 4     */
   int32_t H;      /* hidden size per direction = module_dim / 2, multiple of 32      */
   int32_t dtype;  /* DVGR_F32 / DVGR_BF16 / DVGR_BF16X3: operand format of the contractions */
 } dvgr_clip_dims;
@@ -57,6 +57,36 @@ int dvgr_clip_forward(const dvgr_clip_dims *d, const float *params, const float 
  * matching forward filled (it is consumed: the step gradients overwrite the gate activations); `train`/`seed` as there. */
 int dvgr_clip_backward(const dvgr_clip_dims *d, const float *params, const float *g_out, float *gparams, void *saved,
                        size_t saved_bytes, void *workspace, size_t workspace_bytes, int train, uint64_t seed, void *stream);
+
+/* ---- the same engine as a general one-layer bidirectional LSTM over padded, variable-length sequences ----------------
+ * Replaces `DynamicRNN.forward` (model/Preprocessing.py:17-45: sort, pack_padded_sequence, nn.LSTM, pad_packed_sequence,
+ * un-sort) and the packed `self.encoder` call of `InputUnitLinguisticDynamic.forward` (model/Preprocessing.py:116-121).
+ * Packing semantics without packing: sequence s is active at step t iff t < lens[s]; an inactive step leaves (h, c) as
+ * they were and emits zeros, so the forward direction's final state is the one at lens[s]-1 and the reverse direction
+ * starts at lens[s]-1 from zeros -- exactly what pack_padded_sequence gives.  `d->V` only has to be a multiple of 4 here
+ * (word vectors are 300 wide). */
+#define DVGR_LSTM_EMBED_INPUT 1 /* x is raw: apply dropout(0.15) then tanh first (the appearance encoder's prologue) */
+#define DVGR_LSTM_DROP_FINAL  2 /* dropout(0.18) on out_final                                                      */
+
+typedef struct dvgr_lstm_io {
+  const float *x;        /* (S, T, V) batch-first input                                          */
+  const int64_t *lens;   /* (S) lengths in 1..T, or NULL: every sequence has T steps             */
+  float *out_final;      /* (S, 2H) [h_forward(last) | h_reverse(first)], or NULL               */
+  float *out_seq;        /* (S, T, 2H) hidden states of every step, zeros past lens[s], or NULL */
+} dvgr_lstm_io;
+
+typedef struct dvgr_lstm_grads {
+  const float *g_final;  /* (S, 2H) or NULL (= zeros)                                  */
+  const float *g_seq;    /* (S, T, 2H) or NULL (= zeros)                               */
+  float *g_x;            /* (S, T, V) fully written, or NULL: not wanted               */
+  float *gparams;        /* flat buffer like `params`, fully written                   */
+} dvgr_lstm_grads;
+
+int dvgr_lstm_forward(const dvgr_clip_dims *d, const float *params, const dvgr_lstm_io *io, int flags, void *saved,
+                      size_t saved_bytes, void *workspace, size_t workspace_bytes, int train, uint64_t seed, void *stream);
+int dvgr_lstm_backward(const dvgr_clip_dims *d, const float *params, const dvgr_lstm_io *io, const dvgr_lstm_grads *grads,
+                       int flags, void *saved, size_t saved_bytes, void *workspace, size_t workspace_bytes, int train,
+                       uint64_t seed, void *stream);
 
 /* Test aid: 0/1 keep flags of dropout site `site` (0: input, p = 0.15, n = S*T*V; 1: output, p = 0.18, n = S*2H). */
 int dvgr_clip_dbg_keep_mask(uint64_t seed, int site, int64_t n, float *keep, void *stream);

@@ -39,3 +39,36 @@ class ClipCase:
             g = grads[k]
             g = g[::self.stride, ::self.stride] if g.ndim == 2 else g
             assert rel_err(g, ref) < tol, (k, rel_err(g, ref))
+
+
+QUESTION_CASES = ["g_question_small_eval", "g_question_small_train", "g_question_wd300_eval"]
+
+
+class QuestionCase:
+    """As make_golden_question.py::case_tensors."""
+
+    def __init__(self, name):
+        self.z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.VQ, self.Wd, self.D, self.B, self.T, train, self.seed = [int(v) for v in self.z["meta"]]
+        self.train = bool(train)
+        VQ, Wd, D, B, T, seed = self.VQ, self.Wd, self.D, self.B, self.T, self.seed
+        self.sd_np = synth.xavier_state_dict(CT.question_param_shapes(VQ, Wd, D), seed=seed, bias_range=0.1)
+        qlen = (1 + (synth.uniform("q_len", (B,), 0.0, 1.0, seed) * T).astype(np.int64)).clip(1, T)
+        qlen[0] = T
+        if B > 2:
+            qlen[1] = 1
+        q = (2 + (synth.uniform("q_tok", (B, T), 0.0, 1.0, seed) * (VQ - 2)).astype(np.int64)).clip(2, VQ - 1)
+        self.q = (q * (np.arange(T)[None, :] < qlen[:, None])).astype(np.int64)
+        self.qlen = qlen.astype(np.int64)
+        self.R = {"qe": synth.normal("q_Rqe", (B, D), 1.0, seed), "words": synth.normal("q_Rw", (B, T, Wd), 1.0, seed),
+                  "seq": synth.normal("q_Rs", (B, T, D), 1.0, seed)}
+
+    def masks(self):
+        if not self.train:
+            return None
+        shapes = {"emb": (self.B, self.T, self.Wd), "final": (self.B, self.D)}
+        out = {}
+        for nm, shape in shapes.items():
+            bits = np.unpackbits(self.z["mask_" + nm])[: int(np.prod(shape))]
+            out[nm] = torch.from_numpy(bits.reshape(shape).astype(np.float32))
+        return out

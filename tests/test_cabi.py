@@ -193,7 +193,7 @@ def test_clip_layout_and_argument_checks():
     ok = CL.ClipDims(64 * 20, 16, 2048, 384, 0)
     assert lib.dvgr_clip_check_dims(C.byref(ok)) == 0
     for bad in (CL.ClipDims(0, 16, 2048, 384, 0), CL.ClipDims(8, 0, 2048, 384, 0), CL.ClipDims(8, 65, 2048, 384, 0),
-                CL.ClipDims(8, 16, 2000, 384, 0), CL.ClipDims(8, 16, 2048, 100, 0), CL.ClipDims(8, 16, 2048, 384, 5),
+                CL.ClipDims(8, 16, 2002, 384, 0), CL.ClipDims(8, 16, 2048, 100, 0), CL.ClipDims(8, 16, 2048, 384, 5),
                 CL.ClipDims(1 << 20, 64, 2048, 384, 0)):
         assert lib.dvgr_clip_check_dims(C.byref(bad)) == -1
     m = dv.ClipEncoder(appearance_dim=64, module_dim=64)
@@ -202,6 +202,10 @@ def test_clip_layout_and_argument_checks():
     assert got == want
     ref = torch.nn.LSTM(64, 32, bidirectional=True)
     assert list(m.encoder.state_dict().keys()) == list(ref.state_dict().keys())
-    assert len(set(m._table)) == 8 and m._total == sum(p.numel() for p in ref.parameters())
+    assert len(set(m.encoder._table)) == 8 and m.encoder._total == sum(p.numel() for p in ref.parameters())
+    q = CL.QuestionEncoder(50, 300, 64)
+    assert {k: tuple(v.shape) for k, v in q.state_dict().items()} == CT.question_param_shapes(50, 300, 64)
+    io = CL.LstmIO()
+    assert lib.dvgr_lstm_forward(C.byref(ok), None, C.byref(io), 0, None, 0, None, 0, 0, 0, None) == -2
     assert lib.dvgr_clip_forward(C.byref(ok), None, None, None, None, 0, None, 0, 0, 0, None) == -2
     assert lib.dvgr_clip_saved_bytes(C.byref(ok)) > 0 and lib.dvgr_clip_workspace_bytes(C.byref(ok)) > 0

@@ -9,7 +9,7 @@ import torch
 
 import dualvgr_videoqa_amd as dv
 from dualvgr_videoqa_amd import clip as CL
-from clip_helpers import CLIP_CASES, ClipCase
+from clip_helpers import CLIP_CASES, QUESTION_CASES, ClipCase, QuestionCase
 from helpers import rel_err
 from oracle import clip_torch as CT
 
@@ -105,3 +105,78 @@ def test_clip_eval_is_deterministic_and_training_draws_new_masks():
     assert not torch.equal(c, d)
     with pytest.raises(RuntimeError):
         m(x.cpu())
+
+
+# ---- question encoder: two packed BiLSTMs over the words (model/Preprocessing.py:89-127, :7-45) ---------------------------
+@pytest.mark.parametrize("name", [n for n in QUESTION_CASES if n.endswith("eval")])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x3"])
+def test_question_encoder_eval_matches_reference_golden(name, dtype):
+    case = QuestionCase(name)
+    m = CL.QuestionEncoder(case.VQ, case.Wd, case.D, dtype=dtype)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in case.sd_np.items()}, strict=True)
+    m = m.cuda().eval()
+    qe, words, seq = m(torch.from_numpy(case.q).cuda(), torch.from_numpy(case.qlen).cuda())
+    R = {k: torch.from_numpy(v).cuda() for k, v in case.R.items()}
+    ((qe * R["qe"]).sum() + (words * R["words"]).sum() + (seq * R["seq"]).sum()).backward()
+    torch.cuda.synchronize()
+    assert rel_err(qe.detach().cpu().numpy(), case.z["qe"]) < TOL
+    assert rel_err(words.detach().cpu().numpy(), case.z["words"]) < 1e-6
+    assert rel_err(seq.detach().cpu().numpy(), case.z["seq"]) < TOL
+    qlen = torch.from_numpy(case.qlen)
+    for t in range(case.T):
+        assert float(seq.detach().cpu()[qlen <= t, t].abs().sum()) == 0.0
+    gtol = GTOL if dtype == "fp32" else 2e-3
+    for k, p in m.named_parameters():                 # includes the embedding table (through g_x of both LSTMs)
+        assert rel_err(p.grad.cpu().numpy(), case.z["g_" + k]) < gtol, k
+
+
+@pytest.mark.parametrize("shape", [(4, 6, 20, 32), (64, 15, 300, 384), (7, 1, 8, 32), (130, 9, 64, 64)])
+@pytest.mark.parametrize("train", [False, True])
+def test_packed_bilstm_matches_oracle(shape, train):
+    """(S, T, V, H): BiLSTM.run with lengths, both outputs and the input gradient; training mode adds the 0.18 dropout on
+    the final states with the device's own mask injected into the oracle."""
+    from dualvgr_videoqa_amd import synth
+    S, T, V, H = shape
+    sd_np = synth.xavier_state_dict(CT.lstm_shapes("", V, H), seed=31, bias_range=0.1)
+    x_np = synth.normal("bl_x", (S, T, V), 0.6, 31)
+    lens_np = (1 + (synth.uniform("bl_len", (S,), 0.0, 1.0, 31) * T).astype(np.int64)).clip(1, T)
+    lens_np[0] = T
+    Rf, Rs = synth.normal("bl_Rf", (S, 2 * H), 1.0, 31), synth.normal("bl_Rs", (S, T, 2 * H), 1.0, 31)
+    m = CL.BiLSTM(V, H, dtype="fp32")
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()}, strict=True)
+    m = m.cuda().train(train)
+    m.forced_seed = 424242
+    x = torch.from_numpy(x_np.copy()).cuda().requires_grad_(True)
+    final, seq = m.run(x, torch.from_numpy(lens_np).cuda(), CL.LSTM_DROP_FINAL, want_final=True, want_seq=True)
+    ((final * torch.from_numpy(Rf).cuda()).sum() + (seq * torch.from_numpy(Rs).cuda()).sum()).backward()
+    torch.cuda.synchronize()
+    sd = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in sd_np.items()}
+    xo = torch.from_numpy(x_np.copy()).requires_grad_(True)
+    of, os_ = CT.packed_bilstm(sd, "", xo, torch.from_numpy(lens_np))
+    if train:
+        keep = torch.empty(S * 2 * H, device="cuda")
+        assert CL.load().dvgr_clip_dbg_keep_mask(m.forced_seed, 1, keep.numel(), keep.data_ptr(),
+                                                 torch.cuda.current_stream().cuda_stream) == 0
+        of = of * keep.view(S, 2 * H).cpu() / (1.0 - CT.DROP_OUT)
+    ((of * torch.from_numpy(Rf)).sum() + (os_ * torch.from_numpy(Rs)).sum()).backward()
+    assert rel_err(final.detach().cpu().numpy(), of.detach().numpy()) < TOL
+    assert rel_err(seq.detach().cpu().numpy(), os_.detach().numpy()) < TOL
+    assert rel_err(x.grad.cpu().numpy(), xo.grad.numpy()) < GTOL
+    for k, p in m.named_parameters():
+        assert rel_err(p.grad.cpu().numpy(), sd[k].grad.numpy()) < GTOL, k
+
+
+def test_bilstm_single_output_variants():
+    """Only the final states / only the per-step states requested: same values, gradients flow through the one asked for."""
+    from dualvgr_videoqa_amd import synth
+    S, T, V, H = 6, 5, 16, 32
+    m = CL.BiLSTM(V, H).cuda().eval()
+    x = torch.from_numpy(synth.normal("bl_x", (S, T, V), 0.6, 5)).cuda()
+    lens = torch.tensor([5, 1, 3, 2, 5, 4], device="cuda")
+    f_both, s_both = m.run(x, lens, 0, True, True)
+    f_only, none1 = m.run(x, lens, 0, True, False)
+    none2, s_only = m.run(x, lens, 0, False, True)
+    assert none1 is None and none2 is None
+    assert torch.equal(f_both, f_only) and torch.equal(s_both, s_only)
+    s_only.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
