@@ -306,6 +306,7 @@ def bench_model(args, dev, rank, world, cfg):
                    unit_layers=Lr, dtype=args.dtype, appearance_encoder=args.appearance_encoder,
                    question_encoder=args.question_encoder).to(dev)
     m.train(not args.eval_mode)
+    m.overlap_encoders = os.environ.get("DVGR_NO_ENCODER_OVERLAP", "0") != "1"
     unit, head = m.visual_input_unit, m._head
     unit.loss_in_forward = (1.0, 1e-8, float(world), False)
     app = torch.from_numpy(np.abs(synth.normal("b_app", (B, N, FR, V), 0.5, 666 + rank))).to(dev)

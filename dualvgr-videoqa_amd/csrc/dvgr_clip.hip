@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void k_clip_out(const float* __restrict__ src_
 // in: activations (i, f, g, o) in G[t], c[t], c[t_prev], dh (this step), dc (carried);  out: pre-activation gradients over
 // the activations (fp32 + planes), dc for the previous step.
 __global__ __launch_bounds__(256) void k_clip_cell_bwd(float* __restrict__ G, uint16_t* g_p, int64_t lo_off, const float* __restrict__ Cs,
-                                                       const float* __restrict__ dh, float* __restrict__ dc, int S, int H, int t0,
+                                                       float* __restrict__ dh, float* __restrict__ dc, int S, int H, int t0,
                                                        int t1, int has_prev, const int64_t* __restrict__ lens,
                                                        float* __restrict__ carry, const float* __restrict__ g_seq, int T) {
   const int per_row = 2 * H / 4;
@@ -199,6 +199,7 @@ __global__ __launch_bounds__(256) void k_clip_cell_bwd(float* __restrict__ G, ui
   if (has_prev) vp = *reinterpret_cast<const float4*>(Cs + ((int64_t)tp * S + s) * 2 * H + c4);
   const int64_t so = (int64_t)s * 2 * H + c4;
   float4 vdh = *reinterpret_cast<const float4*>(dh + so);
+  *reinterpret_cast<float4*>(dh + so) = make_float4(0.f, 0.f, 0.f, 0.f);   // the next contraction ADDS dG Whh (it may split K)
   const float4 vdc = *reinterpret_cast<const float4*>(dc + so);
   if (lens) {                              // variable lengths: add what the steps this sequence sat out passed down
     const float4 cr = *reinterpret_cast<const float4*>(carry + so);
@@ -421,8 +422,9 @@ int dvgr_lstm_backward(const dvgr_clip_dims* dp, const float* params, const dvgr
       for (int dir = 0; dir < 2; ++dir) {
         const int64_t go = (int64_t)t[dir] * S * 8 * H + dir * 4 * H;
         const int64_t wo = 8ll * H * V + (int64_t)dir * 4 * H * H;
-        b.p[b.n++] = problem(opnd(sv + SV.g + go, 8 * H, g_p + go, g_lo), opnd(params + P.wih + wo, H, w_p + wo, nW),
-                             ws + W.dh + dir * H, 2 * H, nullptr, S, H, 4 * H, 0);
+        b.p[b.n] = problem(opnd(sv + SV.g + go, 8 * H, g_p + go, g_lo), opnd(params + P.wih + wo, H, w_p + wo, nW),
+                           ws + W.dh + dir * H, 2 * H, nullptr, S, H, 4 * H, 1);
+        b.p[b.n++].atomic_ok = 1;          // dh was cleared by the cell kernel above
       }
       CLIP_TRY(gemm_launch(st, KC, IC, b, TAG_GENERIC, prec));
     }
@@ -455,8 +457,10 @@ int dvgr_lstm_backward(const dvgr_clip_dims* dp, const float* params, const dvgr
       return (int)hipGetLastError();
   }
   if (gr->g_x) {  // gradient of the input: dE = dG [Wih_f; Wih_r], back to batch-first (and through the prologue)
+    if (hipMemsetAsync(ws + W.de, 0, (size_t)TS * V * 4, st) != hipSuccess) return (int)hipGetLastError();
     GemmBatch b{};
-    b.p[b.n++] = problem(opnd(sv + SV.g, 8 * H, g_p, g_lo), opnd(params + P.wih, V, w_p, nW), ws + W.de, V, nullptr, (int)TS, V, 8 * H, 0);
+    b.p[b.n] = problem(opnd(sv + SV.g, 8 * H, g_p, g_lo), opnd(params + P.wih, V, w_p, nW), ws + W.de, V, nullptr, (int)TS, V, 8 * H, 1);
+    b.p[b.n++].atomic_ok = 1;
     CLIP_TRY(gemm_launch(st, KC, IC, b, TAG_GENERIC, prec));
     hipLaunchKernelGGL(k_clip_gx, dim3(blocks_for(TS * V / 4)), dim3(256), 0, st, (const float*)(ws + W.de), (const float*)(sv + SV.e), gr->g_x,
                        clip_key(train && embed, seed, 0), S, T, V, embed);

@@ -110,6 +110,8 @@ class DualVGR(nn.Module):
         self.feature_aggregation = head.feature_aggregation
         self.output_unit = head.output_unit
         object.__setattr__(self, "_head", head)
+        self.overlap_encoders = True
+        object.__setattr__(self, "_enc_streams", {})
         for m in self.modules():                    # model/utils.py:8-33 init_modules(w_init="xavier_uniform")
             if isinstance(m, (nn.Linear, nn.LSTM)) or type(m).__name__ == "BiLSTM":
                 for name, p in m.named_parameters(recurse=False):
@@ -119,15 +121,37 @@ class DualVGR(nn.Module):
                         nn.init.xavier_uniform_(p)
         nn.init.uniform_(self.linguistic_input_unit.encoder_embed.weight, -1.0, 1.0)
 
+    def _encoder_stream(self, dev):
+        key = (dev.type, dev.index)
+        if key not in self._enc_streams:
+            self._enc_streams[key] = torch.cuda.Stream(device=dev)
+        return self._enc_streams[key]
+
     def train(self, mode: bool = True):
         super().train(mode)
         self._head.train(mode)
         return self
 
     def forward(self, video_appearance_feat, video_motion_feat, question, question_len):
-        question_embedding, word_embedding, dynamic_question_embedding = self.linguistic_input_unit(question, question_len)
-        app = self.visual_appearance_input_unit(video_appearance_feat)
-        mot = self.visual_motion_input_unit(video_motion_feat)
+        # The question encoder (chains of small launches over <= T words of B questions) and the visual encoders are
+        # independent: run the former on a second stream so its kernels fill the gaps of the latter.  autograd replays
+        # each node's backward on the stream of its forward, so the backward overlaps the same way.
+        dev = video_appearance_feat.device
+        if dev.type == "cuda" and self.overlap_encoders:
+            cur = torch.cuda.current_stream(dev)
+            side = self._encoder_stream(dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                question_embedding, word_embedding, dynamic_question_embedding = self.linguistic_input_unit(question, question_len)
+            app = self.visual_appearance_input_unit(video_appearance_feat)
+            mot = self.visual_motion_input_unit(video_motion_feat)
+            cur.wait_stream(side)
+            for t in (question_embedding, word_embedding, dynamic_question_embedding):
+                t.record_stream(cur)
+        else:
+            question_embedding, word_embedding, dynamic_question_embedding = self.linguistic_input_unit(question, question_len)
+            app = self.visual_appearance_input_unit(video_appearance_feat)
+            mot = self.visual_motion_input_unit(video_motion_feat)
         visual_embedding, aq_embed, mq_embed, com_app, com_motion, aq_fusion, mq_fusion = self.visual_input_unit(
             app, mot, dynamic_question_embedding, word_embedding, question_len)
         out = self._head(question_embedding, visual_embedding)
