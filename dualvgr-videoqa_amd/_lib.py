@@ -60,6 +60,7 @@ OPT_SINGLE_STREAM = 1
 # every symbol include/dvgr.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("dvgr_version", C.c_char_p, []),
+    ("dvgr_streams_init", C.c_int, []),
     ("dvgr_check_dims", C.c_int, [C.POINTER(Dims)]),
     ("dvgr_param_count", C.c_int64, [C.POINTER(Dims)]),
     ("dvgr_param_offset", C.c_int, [C.POINTER(Dims), C.c_int, C.c_int, C.c_int,
@@ -111,6 +112,33 @@ def load():
         fn.argtypes = argtypes
     _lib = lib
     return lib
+
+
+_streams = {}
+STREAM_ORDER = os.environ.get("DVGR_STREAM_ORDER", "encoder,side,copy").split(",")
+
+
+def streams(dev):
+    """Every stream this package uses on `dev` besides the caller's, created ONCE and in a fixed order, whichever
+    component asks first: {'encoder': torch stream of DualVGR's question encoder, 'copy': torch stream of the loader's
+    host-to-device copies}; the library's internal side stream is created in between (dvgr_streams_init).  The HIP
+    runtime maps streams to hardware queues in creation order; with the loader's copy stream created before the
+    model's streams the whole-model step cost 10.7 ms instead of 5.3 ms."""
+    import torch
+    dev = torch.device(dev)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    key = dev.index
+    if key not in _streams:
+        made = {}
+        with torch.cuda.device(dev):
+            for name in STREAM_ORDER:
+                if name == "side":
+                    check(load().dvgr_streams_init(), "dvgr_streams_init")
+                else:
+                    made[name] = torch.cuda.Stream(device=dev)
+        _streams[key] = made
+    return _streams[key]
 
 
 def check(code: int, what: str):

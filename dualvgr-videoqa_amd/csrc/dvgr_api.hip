@@ -207,6 +207,13 @@ int check_common(const dvgr_dims* d, const void* params, const dvgr_io* io, cons
 extern "C" {
 
 const char* dvgr_version(void) { return "dvgr-hip 0.1.0 gfx950"; }
+int dvgr_streams_init(void) {
+  int dev = 0;
+  const hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  if (dev < 0 || dev >= 16) return DVGR_E_DIMS;
+  return shared_side_stream(dev) ? 0 : (int)hipErrorOutOfMemory;
+}
 
 int dvgr_check_dims(const dvgr_dims* d) {
   if (!d) return DVGR_E_NULL;

@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib
 from .clip import ClipEncoder, QuestionEncoder
 from .head import AnswerHead
 from .unit import DualVGRUnit_multiple
@@ -111,7 +112,6 @@ class DualVGR(nn.Module):
         self.output_unit = head.output_unit
         object.__setattr__(self, "_head", head)
         self.overlap_encoders = True
-        object.__setattr__(self, "_enc_streams", {})
         for m in self.modules():                    # model/utils.py:8-33 init_modules(w_init="xavier_uniform")
             if isinstance(m, (nn.Linear, nn.LSTM)) or type(m).__name__ == "BiLSTM":
                 for name, p in m.named_parameters(recurse=False):
@@ -122,10 +122,7 @@ class DualVGR(nn.Module):
         nn.init.uniform_(self.linguistic_input_unit.encoder_embed.weight, -1.0, 1.0)
 
     def _encoder_stream(self, dev):
-        key = (dev.type, dev.index)
-        if key not in self._enc_streams:
-            self._enc_streams[key] = torch.cuda.Stream(device=dev)
-        return self._enc_streams[key]
+        return _lib.streams(dev)["encoder"]
 
     def train(self, mode: bool = True):
         super().train(mode)

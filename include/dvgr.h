@@ -119,6 +119,11 @@ typedef struct dvgr_grads {
 
 /* Library version string "dvgr-hip <semver> gfx950". */
 const char *dvgr_version(void);
+/* Creates, for the calling thread's current device, the internal lower-priority side stream the two-stream schedules
+ * use (otherwise created by the first forward / backward).  The HIP runtime maps streams onto its hardware queues in
+ * creation order and the mapping decides what cross-stream dependencies cost, so a host program that creates streams of
+ * its own (copy streams, encoder streams) calls this at a fixed place in that order (see _lib.py: streams()). */
+int dvgr_streams_init(void);
 
 /* 0 when `d` is supported: B,N,T,L >= 1, G == 1, D % 64 == 0, Wd % 4 == 0, N <= 64, T <= 256. */
 int dvgr_check_dims(const dvgr_dims *d);

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared_symbols():
     names = set()
-    for h in ("dvgr.h", "dvgr_debug.h", "dvgr_head.h", "dvgr_clip.h"):
+    for h in ("dvgr.h", "dvgr_debug.h", "dvgr_head.h", "dvgr_clip.h", "dvgr_store.h"):
         text = open(os.path.join(ROOT, "include", h)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         names |= set(re.findall(r"\b(dvgr_[a-z_0-9]+)\s*\(", text))
@@ -32,9 +32,12 @@ def test_library_exports_every_declared_symbol():
     assert len(declared) >= 15
     from dualvgr_videoqa_amd import head as HD
     from dualvgr_videoqa_amd import clip as CL
+    from dualvgr_videoqa_amd import store as ST
     HD.load()
     CL.load()
-    bound = {n for n, _, _ in L.SYMBOLS} | {n for n, _, _ in HD.HEAD_SYMBOLS} | {n for n, _, _ in CL.CLIP_SYMBOLS}
+    ST.load()
+    bound = ({n for n, _, _ in L.SYMBOLS} | {n for n, _, _ in HD.HEAD_SYMBOLS} | {n for n, _, _ in CL.CLIP_SYMBOLS}
+             | {n for n, _, _ in ST.STORE_SYMBOLS})
     assert declared == bound, declared ^ bound
     for name in declared:
         assert getattr(lib, name) is not None
