@@ -431,8 +431,9 @@ int dvgr_lstm_backward(const dvgr_clip_dims* dp, const float* params, const dvgr
   }
   {  // dWih[both directions] = dG^T e, reduction over all T * S rows
     GemmBatch b{};
-    b.p[b.n++] = problem(opnd(sv + SV.g, 8 * H, g_p, g_lo), opnd(sv + SV.e, V, e_p, e_lo), gparams + P.wih, V, nullptr, 8 * H, V,
-                         (int)TS, 0);
+    b.p[b.n] = problem(opnd(sv + SV.g, 8 * H, g_p, g_lo), opnd(sv + SV.e, V, e_p, e_lo), gparams + P.wih, V, nullptr, 8 * H, V,
+                       (int)TS, 1);
+    b.p[b.n++].atomic_ok = 1;            // gparams was cleared above: the launcher may split the T * S reduction
     CLIP_TRY(gemm_launch(st, IC, IC, b, TAG_GENERIC, prec));
   }
   if (T > 1) {  // dWhh[dir] = sum over steps of dG[t]^T h_prev: forward pairs frame t with t-1, reverse pairs t with t+1
@@ -440,8 +441,9 @@ int dvgr_lstm_backward(const dvgr_clip_dims* dp, const float* params, const dvgr
     for (int dir = 0; dir < 2; ++dir) {
       const int64_t go = (dir == 0 ? (int64_t)S * 8 * H : 0) + dir * 4 * H;
       const int64_t ho = (dir == 0 ? 0 : (int64_t)S * 2 * H) + dir * H;
-      b.p[b.n++] = problem(opnd(sv + SV.g + go, 8 * H, g_p + go, g_lo), opnd(sv + SV.h + ho, 2 * H, h_p + ho, h_lo),
-                           gparams + P.whh + (int64_t)dir * 4 * H * H, H, nullptr, 4 * H, H, (int)((int64_t)(T - 1) * S), 0);
+      b.p[b.n] = problem(opnd(sv + SV.g + go, 8 * H, g_p + go, g_lo), opnd(sv + SV.h + ho, 2 * H, h_p + ho, h_lo),
+                         gparams + P.whh + (int64_t)dir * 4 * H * H, H, nullptr, 4 * H, H, (int)((int64_t)(T - 1) * S), 1);
+      b.p[b.n++].atomic_ok = 1;
     }
     CLIP_TRY(gemm_launch(st, IC, IC, b, TAG_GENERIC, prec));
   }

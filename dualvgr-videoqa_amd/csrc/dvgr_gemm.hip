@@ -950,6 +950,16 @@ static int launch_ring(hipStream_t stream, const GemmBatch& b, int prec) {
     if (split > nk_min / 16) split = nk_min / 16;
     if (split < 1) split = 1;
     if (split > 8) split = 8;
+  } else if (atomic_ok && nk_min >= 128) {
+    // more tiles than CUs and a very long reduction (the LSTM's weight gradients, K = T * S): what matters is the
+    // last, partly filled round of workgroups.  Cost model in K-tile units: rounds * (K-tiles per workgroup + epilogue),
+    // epilogue ~3 plain, ~18 with atomics.
+    long best = ((total + 255) / 256) * (long)(nk_min + 3);
+    for (int s = 2; s <= 4; ++s) {
+      if (nk_min / s < 64) break;
+      const long cost = ((total * s + 255) / 256) * (long)(nk_min / s + 18);
+      if (cost < best) { best = cost; split = s; }
+    }
   }
   const dim3 grid(8 * ((tiles + 7) / 8), split, b.n), block(768);
   if (prec != DVGR_F32 && planes_eligible(b, LA, LB)) {
