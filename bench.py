@@ -155,7 +155,10 @@ def main():
     cfg = CONFIGS[args.config]
     B, N, Lr, T = cfg["B"], cfg["N"], cfg["L"], cfg["T"]
     if args.model:
-        return bench_model(args, dev, rank, world, cfg)
+        bench_model(args, dev, rank, world, cfg)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     shapes = {n: s for n, s, _ in dv.param_table(L_.make_dims(1, N, 1, D, WD, Lr))}
     sd_np = synth.xavier_state_dict(shapes, seed=666)          # same weights on every rank (as after a broadcast)
     m = dv.DualVGRUnit_multiple(word_dim=WD, module_dim=D, num_of_nodes=N, unit_layers=Lr, dtype=args.dtype)
@@ -320,19 +323,33 @@ def bench_model(args, dev, rank, world, cfg):
     def step():
         m.zero_grad(set_to_none=True)
         logits, _, _, ca, cm, aq, mq = m(app, mot, q, qlen)
-        _, g_logits = head.cross_entropy(logits, answers, scale=1.0)
+        _, g_logits = head.cross_entropy(logits, answers, scale=1.0 / world)
         _, g = unit.last_loss
         torch.autograd.backward([logits, *ca, *cm, *aq, *mq],
                                 [g_logits, *g[3].unbind(0), *g[4].unbind(0), *g[5].unbind(0), *g[6].unbind(0)])
+        if world > 1:      # data parallel: one flattened all-reduce of every gradient (losses are already scaled by 1/world)
+            grads = [p.grad for p in m.parameters() if p.grad is not None]
+            flat = torch._utils._flatten_dense_tensors(grads)
+            dist.all_reduce(flat)
+            for gr, red in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
+                gr.copy_(red)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
     out = {"metric": "QA-pairs/sec (forward+backward) per GPU, whole model (scope M), SVQA num_clips=20",
            "value": world * B * args.steps / dt, "unit": "QA-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
