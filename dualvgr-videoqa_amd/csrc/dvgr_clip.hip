@@ -2,7 +2,7 @@
 // Restates model/Preprocessing.py:191-234 (checked against oracle/clip_torch.py = torch.nn.LSTM on the CPU):
 //   e = tanh(drop_in(x));  G = e [Wih_f; Wih_r]^T + (b_ih + b_hh)            one contraction over all T * S rows
 //   step k = 0..T-1 (forward direction at frame k, reverse direction at frame T-1-k, both in the same launches):
-//     G[t] += h_prev Whh^T;  i, f, o = sigmoid, g = tanh;  c = f c_prev + i g;  h = o tanh(c)
+//     G[t] += h_prev Whh^T;  i, f, o = sigmoid(.), g = tanh(.) of it;  c = f c_prev + i g;  h = o tanh(c)
 //   out = drop_out([h_f(T-1) | h_r(0)])
 // Backward: the steps in reverse (cell kernel + dh_prev = dG[t] Whh per step), then the weight gradients as three
 // contractions with the whole T * S extent as the reduction (dWih = dG^T e, dWhh = dG^T h_prev) and one column sum.
@@ -50,7 +50,7 @@ ClipSaved clip_saved(const dvgr_clip_dims& d) {
   int64_t o = 0;
   s.e = o; o += TS * V;
   s.e_p = o; o += TS * V;
-  s.g = o; o += TS * 8 * H;        // pre-activations, then activations (forward), then pre-activation gradients (backward)
+  s.g = o; o += TS * 8 * H;        // gate pre-activations (forward), then their gradients (backward)
   s.c = o; o += TS * 2 * H;
   s.h = o; o += TS * 2 * H;
   s.h_p = o; o += TS * 2 * H;
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void k_clip_bias(const float* bih, const float
 
 // ---- one step of both directions: gates -> (c, h) ---------------------------------------------------------------
 // thread = 4 consecutive hidden units of one (clip, direction); row of direction d = t[d] * S + s
-__global__ __launch_bounds__(256) void k_clip_cell_fwd(float* __restrict__ G, float* __restrict__ Cs, float* __restrict__ Hs,
+__global__ __launch_bounds__(256) void k_clip_cell_fwd(const float* __restrict__ G, float* __restrict__ Cs, float* __restrict__ Hs,
                                                        uint16_t* h_p, int64_t lo_off, int S, int H, int t0, int t1, int has_prev,
                                                        const int64_t* __restrict__ lens, float* __restrict__ out_seq, int T) {
   const int per_row = 2 * H / 4;
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void k_clip_cell_fwd(float* __restrict__ G, fl
   const int s = (int)(i / per_row), c4 = 4 * (int)(i % per_row);
   const int d = c4 / H, j = c4 - d * H;
   const int t = d ? t1 : t0, tp = d ? t1 + 1 : t0 - 1;
-  float* g = G + ((int64_t)t * S + s) * 8 * H + d * 4 * H + j;
+  const float* g = G + ((int64_t)t * S + s) * 8 * H + d * 4 * H + j;
   const float4 gi = *reinterpret_cast<const float4*>(g), gf = *reinterpret_cast<const float4*>(g + H),
                gg = *reinterpret_cast<const float4*>(g + 2 * H), go = *reinterpret_cast<const float4*>(g + 3 * H);
   float4 cp = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -154,10 +154,7 @@ __global__ __launch_bounds__(256) void k_clip_cell_fwd(float* __restrict__ G, fl
     c[q] = af[q] * pc[q] + ai[q] * ag[q];
     h[q] = ao[q] * tanhf(c[q]);
   }
-  *reinterpret_cast<float4*>(g) = make_float4(ai[0], ai[1], ai[2], ai[3]);
-  *reinterpret_cast<float4*>(g + H) = make_float4(af[0], af[1], af[2], af[3]);
-  *reinterpret_cast<float4*>(g + 2 * H) = make_float4(ag[0], ag[1], ag[2], ag[3]);
-  *reinterpret_cast<float4*>(g + 3 * H) = make_float4(ao[0], ao[1], ao[2], ao[3]);
+  // the pre-activations stay in G: the backward re-applies the four cheap activations instead of this kernel writing them
   *reinterpret_cast<float4*>(Cs + o) = make_float4(c[0], c[1], c[2], c[3]);
   const float4 hv = make_float4(h[0], h[1], h[2], h[3]);
   *reinterpret_cast<float4*>(Hs + o) = hv;
@@ -178,8 +175,8 @@ __global__ __launch_bounds__(256) void k_clip_out(const float* __restrict__ src_
 }
 
 // ---- one step of the backward of both directions ------------------------------------------------------------------
-// in: activations (i, f, g, o) in G[t], c[t], c[t_prev], dh (this step), dc (carried);  out: pre-activation gradients over
-// the activations (fp32 + planes), dc for the previous step.
+// in: pre-activations of (i, f, g, o) in G[t], c[t], c[t_prev], dh (this step), dc (carried);  out: pre-activation gradients
+// over them (fp32 + planes), dc for the previous step.
 __global__ __launch_bounds__(256) void k_clip_cell_bwd(float* __restrict__ G, uint16_t* g_p, int64_t lo_off, const float* __restrict__ Cs,
                                                        float* __restrict__ dh, float* __restrict__ dc, int S, int H, int t0,
                                                        int t1, int has_prev, const int64_t* __restrict__ lens,
@@ -219,9 +216,11 @@ __global__ __launch_bounds__(256) void k_clip_cell_bwd(float* __restrict__ G, ui
     const float4 gs = *reinterpret_cast<const float4*>(g_seq + ((int64_t)s * T + t) * 2 * H + c4);
     vdh.x += gs.x; vdh.y += gs.y; vdh.z += gs.z; vdh.w += gs.w;
   }
-  const float ai[4] = {vi.x, vi.y, vi.z, vi.w}, af[4] = {vf.x, vf.y, vf.z, vf.w}, ag[4] = {vg.x, vg.y, vg.z, vg.w},
-              ao[4] = {vo.x, vo.y, vo.z, vo.w}, c[4] = {vc.x, vc.y, vc.z, vc.w}, cp[4] = {vp.x, vp.y, vp.z, vp.w},
-              gh[4] = {vdh.x, vdh.y, vdh.z, vdh.w}, gc[4] = {vdc.x, vdc.y, vdc.z, vdc.w};
+  const float ai[4] = {sigmoidf_(vi.x), sigmoidf_(vi.y), sigmoidf_(vi.z), sigmoidf_(vi.w)},
+              af[4] = {sigmoidf_(vf.x), sigmoidf_(vf.y), sigmoidf_(vf.z), sigmoidf_(vf.w)},
+              ag[4] = {tanhf(vg.x), tanhf(vg.y), tanhf(vg.z), tanhf(vg.w)},
+              ao[4] = {sigmoidf_(vo.x), sigmoidf_(vo.y), sigmoidf_(vo.z), sigmoidf_(vo.w)}, c[4] = {vc.x, vc.y, vc.z, vc.w},
+              cp[4] = {vp.x, vp.y, vp.z, vp.w}, gh[4] = {vdh.x, vdh.y, vdh.z, vdh.w}, gc[4] = {vdc.x, vdc.y, vdc.z, vdc.w};
   float di[4], df[4], dg[4], dgo[4], dcp[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {

@@ -45,14 +45,15 @@ def model_inputs(B, N, Fr, V, T, vocab_q, seed):
     return app.astype(np.float32), mot.astype(np.float32), q.astype(np.int64), qlen.astype(np.int64)
 
 
-@pytest.mark.parametrize("appearance_encoder,question_encoder", [("hip", "hip"), ("miopen", "miopen"), ("hip", "miopen")])
-def test_whole_model_matches_reference_golden_and_trains(appearance_encoder, question_encoder):
+@pytest.mark.parametrize("appearance_encoder,question_encoder,dtype", [("hip", "hip", "fp32"), ("hip", "hip", "bf16x3"),
+                                                                       ("miopen", "miopen", "fp32"), ("hip", "miopen", "fp32")])
+def test_whole_model_matches_reference_golden_and_trains(appearance_encoder, question_encoder, dtype):
     z = np.load(GOLDEN)
     V, D, Wd, N, Fr, L, B, T, vq, va, seed = [int(v) for v in z["meta"]]
     vocab = {"question_token_to_idx": {str(i): i for i in range(vq)}, "answer_token_to_idx": {str(i): i for i in range(va)}}
     m = dv.DualVGR(vision_dim=V, module_dim=D, word_dim=Wd, vocab=vocab, num_of_nodes=N, graph_module="GAT", graph_layers=1,
                    unit_layers=L, appearance_encoder=appearance_encoder,
-                   question_encoder=question_encoder)
+                   question_encoder=question_encoder, dtype=dtype)
     keys = [str(k) for k in z["keys"]]
     assert sorted(m.state_dict().keys()) == keys                      # the reference's state_dict surface, key for key
     m.load_state_dict(seeded_state(keys, [str(s) for s in z["shapes"]], seed), strict=True)
