@@ -25,6 +25,8 @@ inline hipStream_t shared_side_stream(int dev) {
   }
   return st[dev];
 }
+// The events only order streams of ONE device: no system-scope fence (host / peer visibility) at the record.
+constexpr unsigned kEventFlags = hipEventDisableTiming | hipEventDisableSystemFence;
 struct SideStream {
   hipStream_t st = nullptr;
   hipEvent_t ev[256] = {};
@@ -36,7 +38,7 @@ struct SideStream {
   }
   hipEvent_t next() {
     if (used >= 256) used = 0;
-    if (!ev[used] && hipEventCreateWithFlags(&ev[used], hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (!ev[used] && hipEventCreateWithFlags(&ev[used], kEventFlags) != hipSuccess) return nullptr;
     return ev[used++];
   }
   // everything enqueued on `from` so far happens before whatever is enqueued on `to` from now on
