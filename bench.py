@@ -141,8 +141,14 @@ def main():
     local = min(local, torch.cuda.device_count() - 1)          # (testing aid: several ranks may share one GPU with gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # DVGR_DDP_SELFTEST=1: run the data-parallel plumbing (process group, per-layer buckets gated by the library's events,
+    # communication stream) with a single rank, to check it on a one-GPU box
+    ddp = world > 1 or os.environ.get("DVGR_DDP_SELFTEST", "0") == "1"
+    if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -156,7 +162,7 @@ def main():
     B, N, Lr, T = cfg["B"], cfg["N"], cfg["L"], cfg["T"]
     if args.model:
         bench_model(args, dev, rank, world, cfg)
-        if world > 1:
+        if ddp:
             dist.destroy_process_group()
         return
     shapes = {n: s for n, s, _ in dv.param_table(L_.make_dims(1, N, 1, D, WD, Lr))}
@@ -194,10 +200,11 @@ def main():
 
     events = None
     reducer = None
-    if world > 1:
+    if ddp:
         events = [torch.cuda.Event() for _ in range(Lr + 1)]
         m.set_layer_events(events)
         reducer = parallel.LayerBucketReducer(parallel.layer_buckets(m), device=dev)
+        reducer.force = world == 1          # self-test: run the collectives even with one rank
         ev_order = [events[Lr]] + [events[l] for l in range(Lr - 1, -1, -1)]
 
     probe_sites = {"fwd_gat_gemm": (L_.PROBE_FWD_GAT_GEMM, 8 * B * N * D * D, "gemm_planes_kernel<KC,KC,TAG_FWD_GAT=1,TERMS> / gemm_ring_kernel<KC,KC,1,F32> (Wh = X.Wcat^T, both modalities)"),
@@ -240,17 +247,17 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if ddp:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if ddp:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if ddp:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -293,7 +300,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if ddp:
         dist.destroy_process_group()
 
 

@@ -39,7 +39,7 @@ class LayerBucketReducer:
     def reduce(self, flat_grad: torch.Tensor, events: Optional[Sequence] = None) -> None:
         """In-place average of `flat_grad`.  `events[i]` (torch.cuda.Event or None) gates bucket i
         on the communication stream; with no events every bucket waits for the current stream."""
-        if self.world == 1:
+        if self.world == 1 and not getattr(self, "force", False):
             return
         if flat_grad.is_cuda and self.stream is not None:
             cur = torch.cuda.current_stream(flat_grad.device)
