@@ -904,6 +904,107 @@ __global__ __launch_bounds__(768) void gemm_planes_kernel(const GemmBatch batch)
   if (wave == 0) GCLK_FLUSH(0);
 }
 
+// -------------------------------------------------------------------------------------------------
+// Wide variant for contractions with thousands of tiles (the LSTM's input contraction and weight gradients):
+// 128 x 256 output tile, each computing wave owns 64 x 64 of it (4 x 4 MFMA blocks), so one K-tile of LDS traffic
+// (A tile + two B tiles through the DMA, 8 + 8 fragment reads per wave) feeds 48 MFMAs per wave instead of 24:
+// a quarter less DMA and a third fewer LDS-read bytes per MFMA.  3 ring slots of 48 KB.
+// -------------------------------------------------------------------------------------------------
+template <int LA, int LB, int TERMS>
+__global__ __launch_bounds__(768) void gemm_planes_wide_kernel(const GemmBatch batch) {
+  const GemmProblem P = batch.p[blockIdx.z];
+  int m0, n0;
+  if (!tile_coords(P.M, P.N, RT, 2 * RT, &m0, &n0)) return;
+
+  constexpr int NSW = 3;
+  constexpr int kPlanes = (TERMS == 3) ? 2 : 1;
+  constexpr int kOp = kPlanes * kPlaneTile;                    // one operand tile (hi [, lo])
+  constexpr int kSlot = 3 * kOp;                               // A, B columns 0..127, B columns 128..255
+  constexpr int kEpi = 8 * 32 * (16 * 4 + 4) * 2;              // epilogue scratch (8 waves), in bf16-sized elements
+  constexpr int kLds = (NSW * kSlot) > kEpi ? (NSW * kSlot) : kEpi;
+  __shared__ __attribute__((aligned(16))) uint16_t smem[kLds];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave12 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave12 >= 8;
+  const int wave = loader ? wave12 - 8 : wave12;
+  constexpr int MT = 4, NT = 4;
+
+  const int nk_all = P.K / BK;
+  const int per = (nk_all + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int kbeg = (int)blockIdx.y * per;
+  const int nk = (nk_all - kbeg) < per ? (nk_all - kbeg) : per;
+  if (nk <= 0) return;
+
+  if (loader) {
+    uint32_t offA[2], offB0[2], offB1[2];
+    planes_prep<LA>(P.A, m0, P.M, wave, lane, offA);
+    planes_prep<LB>(P.B, n0, P.N, wave, lane, offB0);
+    planes_prep<LB>(P.B, n0 + RT, P.N, wave, lane, offB1);
+#pragma unroll
+    for (int s = 0; s < NSW - 1; ++s)
+      if (s < nk) {
+        planes_issue<LA, TERMS>(P.A, (kbeg + s) * BK, P.kseg, wave, lane, offA, smem + s * kSlot);
+        planes_issue<LB, TERMS>(P.B, (kbeg + s) * BK, P.kseg, wave, lane, offB0, smem + s * kSlot + kOp);
+        planes_issue<LB, TERMS>(P.B, (kbeg + s) * BK, P.kseg, wave, lane, offB1, smem + s * kSlot + 2 * kOp);
+      }
+    for (int kt = 0; kt < nk; ++kt) {
+      // 6 * kPlanes DMA instructions per K-tile from this wave; at most one younger tile is in flight
+      if (kt + 1 < nk) {
+        if (TERMS == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      if (kt + NSW - 1 < nk) {
+        uint16_t* dst = smem + ((kt + NSW - 1) % NSW) * kSlot;
+        planes_issue<LA, TERMS>(P.A, (kbeg + kt + NSW - 1) * BK, P.kseg, wave, lane, offA, dst);
+        planes_issue<LB, TERMS>(P.B, (kbeg + kt + NSW - 1) * BK, P.kseg, wave, lane, offB0, dst + kOp);
+        planes_issue<LB, TERMS>(P.B, (kbeg + kt + NSW - 1) * BK, P.kseg, wave, lane, offB1, dst + 2 * kOp);
+      }
+    }
+    __builtin_amdgcn_s_barrier();
+    return;
+  }
+
+  const int wm = (wave >> 2) * 64, wn = (wave & 3) * 64;
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int kt = 0; kt < nk; ++kt) {
+    __builtin_amdgcn_s_barrier();
+    const uint16_t* curA = smem + (kt % NSW) * kSlot;
+    const uint16_t* curB = curA + kOp + (wn >> 7) * kOp;       // this wave's 64 columns lie in one of the two B tiles
+    const int bn = wn & 127;
+    bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      ah[i] = planes_frag<LA>(curA, wm + i * 16, lane);
+      if (TERMS == 3) al[i] = planes_frag<LA>(curA + kPlaneTile, wm + i * 16, lane);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      bh[j] = planes_frag<LB>(curB, bn + j * 16, lane);
+      if (TERMS == 3) bl[j] = planes_frag<LB>(curB + kPlaneTile, bn + j * 16, lane);
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if (TERMS == 3) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        }
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      }
+  }
+  __builtin_amdgcn_s_barrier();
+  epilogue_rows<MT, NT>(P, acc, m0 + wm, n0 + wn, lane, reinterpret_cast<float*>(smem) + wave * (32 * (16 * NT + 4)), gridDim.y > 1);
+}
+
 #ifdef DVGR_CLK
 extern "C" int dvgr_dbg_gemm_clocks(long long* host_out, int n) {
   if (n > 4096 * 8) n = 4096 * 8;
@@ -922,6 +1023,11 @@ static bool planes_eligible(const GemmBatch& b, int la, int lb) {
     if (lb == IC && ((p.N & 7) || p.N < 8)) return false;
   }
   return true;
+}
+
+static bool dbg_any(const GemmBatch& b) {
+  for (int i = 0; i < b.n; ++i) if (b.p[i].dbg) return true;
+  return false;
 }
 
 template <int LA, int LB, int TAG>
@@ -959,6 +1065,32 @@ static int launch_ring(hipStream_t stream, const GemmBatch& b, int prec) {
       if (nk_min / s < 64) break;
       const long cost = ((total * s + 255) / 256) * (long)(nk_min / s + 18);
       if (cost < best) { best = cost; split = s; }
+    }
+  }
+  if (prec != DVGR_F32 && planes_eligible(b, LA, LB) && !dbg_any(b)) {
+    // thousands of tiles: the 128 x 256 variant (a third fewer LDS bytes per MFMA)
+    int tiles_w = 0;
+    long total_w = 0;
+    for (int i = 0; i < b.n; ++i) {
+      const int t = ((b.p[i].M + RT - 1) / RT) * ((b.p[i].N + 2 * RT - 1) / (2 * RT));
+      tiles_w = t > tiles_w ? t : tiles_w;
+      total_w += t;
+    }
+    const bool long_k = atomic_ok && nk_min >= 256;
+    if (total_w >= 480 || (long_k && total_w >= 128)) {
+      int split_w = 1;
+      if (long_k) {
+        long best = ((total_w + 255) / 256) * (long)(2 * nk_min + 6);
+        for (int sp = 2; sp <= 8; ++sp) {
+          if (nk_min / sp < 64) break;
+          const long cost = ((total_w * sp + 255) / 256) * (long)(2 * (nk_min / sp) + 36);
+          if (cost < best) { best = cost; split_w = sp; }
+        }
+      }
+      const dim3 grid_w(8 * ((tiles_w + 7) / 8), split_w, b.n);
+      if (prec == DVGR_BF16X3) hipLaunchKernelGGL((gemm_planes_wide_kernel<LA, LB, 3>), grid_w, dim3(768), 0, stream, b);
+      else hipLaunchKernelGGL((gemm_planes_wide_kernel<LA, LB, 1>), grid_w, dim3(768), 0, stream, b);
+      return (int)hipGetLastError();
     }
   }
   const dim3 grid(8 * ((tiles + 7) / 8), split, b.n), block(768);

@@ -286,3 +286,34 @@ def test_gemm_planes_kernel(mode, M, N, K):
     scale = float(want.abs().max())
     assert float((_gemm_planes(mode, A, B, M, N, K, 2).double() - want).abs().max()) / scale < 2e-5
     assert float((_gemm_planes(mode, A, B, M, N, K, 1).double() - want).abs().max()) / scale < 2e-2
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(2560, 6144, 64), (2568, 6024, 96)])
+def test_gemm_planes_wide_kernel(mode, M, N, K):
+    """>= 480 tiles of 128 x 256: the launcher takes gemm_planes_wide_kernel (64 x 64 per wave).  Exact on small integers
+    in both bf16 modes, ragged edges included (the last tile's second B half holds 8 valid columns), fp32-grade on random
+    operands in bf16x3."""
+    shapes = {0: ((M, K), (N, K)), 1: ((M, K), (K, N)), 2: ((K, M), (K, N))}[mode]
+    A, B = _ints(shapes[0], seed=51), _ints(shapes[1], seed=52)
+    ref = lambda a, b: (a.double() @ b.double().T) if mode == 0 else (a.double() @ b.double()) if mode == 1 else (a.double().T @ b.double())
+    want = ref(A, B)
+    for prec in (1, 2):
+        got = _gemm_planes(mode, A, B, M, N, K, prec)
+        assert torch.equal(got, want.float()), (prec, float((got - want.float()).abs().max()))
+    torch.manual_seed(7)
+    A, B = torch.randn(shapes[0], device="cuda"), torch.randn(shapes[1], device="cuda") * 0.05
+    want = ref(A, B)
+    assert float((_gemm_planes(mode, A, B, M, N, K, 2).double() - want).abs().max()) / float(want.abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("mode,M,N,K", [(2, 1024, 4096, 8192), (2, 3072, 2048, 8192), (0, 1024, 4096, 8192)])
+def test_gemm_planes_wide_splitk(mode, M, N, K):
+    """Long reductions into an accumulating output (the LSTM's weight gradients): the wide kernel with K split over
+    workgroups that add their partial tiles with float atomics -- exact on small integers, on top of a non-zero C."""
+    shapes = {0: ((M, K), (N, K)), 2: ((K, M), (K, N))}[mode]
+    A, B = _ints(shapes[0], seed=61), _ints(shapes[1], seed=62)
+    want = (A.double() @ B.double().T) if mode == 0 else (A.double().T @ B.double())
+    C0 = _ints((M, N), seed=63)
+    got = _gemm_planes(mode, A, B, M, N, K, 2, accumulate=True, C0=C0)
+    assert torch.equal(got, (C0.double() + want).float()), float((got.double() - C0.double() - want).abs().max())
