@@ -51,9 +51,9 @@ class LayerBucketReducer:
                     else:
                         self.stream.wait_stream(cur)
                     works.append(dist.all_reduce(flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-                for w in works:
+                for w, (a, b) in zip(works, self.buckets):     # scale bucket i while bucket i+1 is still on the wire
                     w.wait()
-                flat_grad.mul_(1.0 / self.world)
+                    flat_grad[a:b].mul_(1.0 / self.world)
             cur.wait_stream(self.stream)
         else:
             for (a, b) in self.buckets:
