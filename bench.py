@@ -214,8 +214,9 @@ def main():
     site, probe_flops, probe_name = probe_sites[args.probe]
     # layer 0's Wh contraction shares the chip with the query-side chain on the side stream; layer 1's runs alone
     probe_layer = min(1, Lr - 1)
-    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    for ev in [e for pr in pairs for e in pr] + (events or []):
+    # timing events without the system-scope fence at their record (their documented use): closer to the kernel's own duration
+    pairs = [(L_.ProbeEvent(), L_.ProbeEvent()) for _ in range(args.steps)]
+    for ev in (events or []):
         ev.record()          # torch creates the hipEvent lazily at the first record; the C ABI needs the handle
 
     def step(i=None):

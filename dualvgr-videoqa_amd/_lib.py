@@ -91,6 +91,9 @@ SYMBOLS += [
     ("dvgr_dbg_colsum", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
     ("dvgr_dbg_keep_mask", C.c_int, [C.c_uint32, C.c_int64, C.c_void_p, C.c_void_p]),
     ("dvgr_dbg_site_key", C.c_uint32, [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("dvgr_dbg_event_create", C.c_int, [C.POINTER(C.c_void_p)]),
+    ("dvgr_dbg_event_elapsed_ms", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
+    ("dvgr_dbg_event_destroy", C.c_int, [C.c_void_p]),
 ]
 
 _lib = None
@@ -112,6 +115,31 @@ def load():
         fn.argtypes = argtypes
     _lib = lib
     return lib
+
+
+class ProbeEvent:
+    """A timing hipEvent without the system-scope fence at its record (dvgr_dbg_event_create); quacks like the
+    torch.cuda.Event the probe hooks take (`cuda_event`, `elapsed_time`)."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        check(load().dvgr_dbg_event_create(C.byref(h)), "dvgr_dbg_event_create")
+        self.cuda_event = h.value
+
+    def record(self):                 # recorded by the library around the probed launch
+        return None
+
+    def elapsed_time(self, end: "ProbeEvent") -> float:
+        ms = C.c_float()
+        check(load().dvgr_dbg_event_elapsed_ms(self.cuda_event, end.cuda_event, C.byref(ms)), "dvgr_dbg_event_elapsed_ms")
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            if self.cuda_event:
+                load().dvgr_dbg_event_destroy(self.cuda_event)
+        except Exception:
+            pass
 
 
 _streams = {}

@@ -929,6 +929,21 @@ int dvgr_dbg_keep_mask(uint32_t key, int64_t n, float* keep, void* stream) {
   return keep_mask_launch((hipStream_t)stream, key, n, keep);
 }
 
+int dvgr_dbg_event_create(void** event) {
+  if (!event) return DVGR_E_NULL;
+  hipEvent_t e = nullptr;
+  const hipError_t r = hipEventCreateWithFlags(&e, hipEventDisableSystemFence);
+  *event = (void*)e;
+  return (int)r;
+}
+int dvgr_dbg_event_elapsed_ms(void* begin, void* end, float* ms) {
+  if (!begin || !end || !ms) return DVGR_E_NULL;
+  hipError_t r = hipEventSynchronize((hipEvent_t)end);
+  if (r == hipSuccess) r = hipEventElapsedTime(ms, (hipEvent_t)begin, (hipEvent_t)end);
+  return (int)r;
+}
+int dvgr_dbg_event_destroy(void* event) { return event ? (int)hipEventDestroy((hipEvent_t)event) : 0; }
+
 uint32_t dvgr_dbg_site_key(uint64_t seed, int layer, int mod, int gat, int which) {
   return site_key(seed, drop_site(layer, mod, gat, which));
 }

@@ -41,6 +41,13 @@ int dvgr_dbg_keep_mask(uint32_t key, int64_t n, float *keep, void *stream);
 /* site key of (seed, layer, mod, gat, which) exactly as the forward derives it. */
 uint32_t dvgr_dbg_site_key(uint64_t seed, int layer, int mod, int gat, int which);
 
+/* Timing events for dvgr_opts.probe_begin / probe_end, created with hipEventDisableSystemFence: the record then costs no
+ * cache writeback / invalidate of its own, which is what the flag is documented for (more accurate timings of the commands
+ * between two events).  bench.py times the dominant launch with them. */
+int dvgr_dbg_event_create(void **event);
+int dvgr_dbg_event_elapsed_ms(void *begin, void *end, float *ms);   /* synchronises on `end` first */
+int dvgr_dbg_event_destroy(void *event);
+
 #ifdef __cplusplus
 }
 #endif
