@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""End-to-end check of the whole pipeline under a real optimizer: a small synthetic VideoQA set (answer = a fixed random
+function of the video and the first question token) written in the on-disk layout, read by VideoQAFlatLoader, trained with
+the reference's objective (train.py:147-154: cross-entropy + alpha * common + beta * dependence) and Adam for a few
+epochs.  The training loss has to fall and the training accuracy to rise well above chance -- every gradient path
+(encoders, unit, head, auxiliary losses) takes part.  usage: python tools/train_synthetic.py [epochs]"""
+import json
+import os
+import pickle
+import sys
+import tempfile
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import dualvgr_videoqa_amd as dv
+from dualvgr_videoqa_amd import losses
+
+epochs = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+V, N, FR, FEAT, Q, T, VQ, VA, B = 48, 8, 16, 2048, 768, 10, 200, 12, 32
+rng = np.random.default_rng(3)
+root = tempfile.mkdtemp(prefix="dvgr_train_")
+ids = np.arange(1000, 1000 + V)
+dv.write_flat(os.path.join(root, "a.dvgrf"), ids, np.abs(rng.standard_normal((V, N, FR, FEAT), dtype=np.float32)) * 0.5)
+dv.write_flat(os.path.join(root, "m.dvgrf"), ids, np.abs(rng.standard_normal((V, N, FEAT), dtype=np.float32)) * 0.5)
+vid = rng.integers(0, V, Q)
+qlen = rng.integers(3, T + 1, Q)
+q = rng.integers(2, VQ, (Q, T)) * (np.arange(T)[None] < qlen[:, None])
+table = rng.integers(0, VA, (V, VQ))
+ans = table[vid, q[:, 0]]
+pickle.dump({"questions": q.astype(np.int32), "questions_len": qlen.astype(np.int32), "question_id": list(range(Q)),
+             "video_ids": ids[vid], "answers": list(ans), "glove": np.zeros((VQ, 300), np.float32)}, open(os.path.join(root, "q.pt"), "wb"))
+vocab = {"question_token_to_idx": {str(i): i for i in range(VQ)}, "answer_token_to_idx": {str(i): i for i in range(VA)},
+         "question_answer_token_to_idx": {}}
+json.dump(vocab, open(os.path.join(root, "v.json"), "w"))
+
+torch.manual_seed(0)
+loader = dv.VideoQAFlatLoader(vocab_json=os.path.join(root, "v.json"), question_pt=os.path.join(root, "q.pt"),
+                              appearance_feat=os.path.join(root, "a.dvgrf"), motion_feat=os.path.join(root, "m.dvgrf"),
+                              batch_size=B, shuffle=True, seed=0)
+model = dv.DualVGR(vision_dim=FEAT, module_dim=768, word_dim=300, vocab=vocab, num_of_nodes=N, graph_module="GAT", graph_layers=1,
+                   unit_layers=2, dtype="bf16x3").cuda().train()
+opt = torch.optim.Adam(model.parameters(), lr=2e-4)
+alpha, beta = 1.0, 1e-8
+first = last = None
+for ep in range(epochs):
+    t0, tot, correct, n = time.perf_counter(), 0.0, 0, 0
+    for _, _, answers, app, mot, question, question_len in loader:
+        opt.zero_grad(set_to_none=True)
+        logits, aq, mq, com_app, com_mot, aq_fusion, mq_fusion = model(app, mot, question, question_len)
+        ce = torch.nn.functional.cross_entropy(logits, answers)                                            # train.py:147
+        aux = losses.ScopeULoss.apply(alpha, beta, 1, None, torch.stack(com_app), torch.stack(com_mot), torch.stack(aq_fusion),
+                                      torch.stack(mq_fusion))[0]                                           # train.py:148-154, fused
+        (ce + aux).backward()
+        opt.step()
+        tot += float(ce.detach()) * len(answers)
+        correct += int((logits.argmax(1) == answers).sum())
+        n += len(answers)
+    torch.cuda.synchronize()
+    print(f"epoch {ep}: cross-entropy {tot / n:.4f}  accuracy {correct / n:.3f}  ({n / (time.perf_counter() - t0):.0f} QA/s incl. optimizer and .item() syncs)")
+    first = tot / n if first is None else first
+    last, acc = tot / n, correct / n
+assert last < 0.8 * first and acc > 3.0 / VA, (first, last, acc)
+print("training check ok")
