@@ -19,6 +19,9 @@
  * which is mapped read-only; a batch is assembled by copying its rows into a pinned staging buffer with a few host threads
  * and ONE host-to-device copy per feature kind (the per-item opens and per-item H2D copies of the reference's default
  * collate + `.to(device)` are gone).  0 / DVGR_E_* / -errno style negative / hipError_t return codes.
+ * Threading: open / lookup / gather_host are safe from any number of threads on one store; gather_device and a
+ * prefetcher's next() keep per-object staging state and belong to ONE consumer thread each (several prefetchers may
+ * share a store).
  */
 #ifndef DVGR_STORE_H
 #define DVGR_STORE_H
