@@ -180,3 +180,52 @@ def test_bilstm_single_output_variants():
     assert torch.equal(f_both, f_only) and torch.equal(s_both, s_only)
     s_only.sum().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def test_packed_bilstm_random_shape_sweep():
+    """20 seeded random (S, T, V, H, lengths, which outputs) draws against the oracle: odd row counts, V not a multiple of
+    8 (no planes), T = 1, S = 1, every contraction path of the engine (batch-sized, generic, ring, split-K)."""
+    from dualvgr_videoqa_amd import synth
+    rng = np.random.default_rng(2024)
+    for case in range(20):
+        S, T = int(rng.integers(1, 90)), int(rng.integers(1, 13))
+        V, H = 4 * int(rng.integers(1, 40)), 32 * int(rng.integers(1, 4))
+        with_lens = bool(rng.integers(0, 2))
+        want_final, want_seq = [(True, True), (True, False), (False, True)][int(rng.integers(0, 3))]
+        sd_np = synth.xavier_state_dict(CT.lstm_shapes("", V, H), seed=100 + case, bias_range=0.1)
+        x_np = synth.normal("sw_x", (S, T, V), 0.7, 100 + case)
+        lens_np = rng.integers(1, T + 1, S).astype(np.int64)
+        m = CL.BiLSTM(V, H, dtype="fp32")
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()}, strict=True)
+        m = m.cuda().eval()
+        x = torch.from_numpy(x_np.copy()).cuda().requires_grad_(True)
+        lens = torch.from_numpy(lens_np).cuda() if with_lens else None
+        final, seq = m.run(x, lens, 0, want_final=want_final, want_seq=want_seq)
+        Rf, Rs = synth.normal("sw_Rf", (S, 2 * H), 1.0, case), synth.normal("sw_Rs", (S, T, 2 * H), 1.0, case)
+        loss = 0.0
+        if want_final:
+            loss = loss + (final * torch.from_numpy(Rf).cuda()).sum()
+        if want_seq:
+            loss = loss + (seq * torch.from_numpy(Rs).cuda()).sum()
+        loss.backward()
+        sd = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in sd_np.items()}
+        xo = torch.from_numpy(x_np.copy()).requires_grad_(True)
+        of, os_ = CT.packed_bilstm(sd, "", xo, torch.from_numpy(lens_np) if with_lens else None)
+        lo = 0.0
+        if want_final:
+            lo = lo + (of * torch.from_numpy(Rf)).sum()
+        if want_seq:
+            lo = lo + (os_ * torch.from_numpy(Rs)).sum()
+        lo.backward()
+        tag = (case, S, T, V, H, with_lens, want_final, want_seq)
+        if want_final:
+            assert rel_err(final.detach().cpu().numpy(), of.detach().numpy()) < TOL, tag
+        if want_seq:
+            assert rel_err(seq.detach().cpu().numpy(), os_.detach().numpy()) < TOL, tag
+        assert rel_err(x.grad.cpu().numpy(), xo.grad.numpy()) < GTOL, tag
+        for k, p in m.named_parameters():
+            ref = sd[k].grad.numpy()
+            if np.abs(ref).max() == 0.0:
+                assert float(p.grad.abs().max()) == 0.0, (tag, k)
+            else:
+                assert rel_err(p.grad.cpu().numpy(), ref) < GTOL, (tag, k)
