@@ -150,7 +150,8 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)   # RCCL's own stream on a queue of its own as well
+            dist.init_process_group("nccl", device_id=dev, pg_options=opts)
         else:
             dist.init_process_group(args.backend)
 
@@ -205,6 +206,8 @@ def main():
         m.set_layer_events(events)
         reducer = parallel.LayerBucketReducer(parallel.layer_buckets(m), device=dev)
         reducer.force = world == 1          # self-test: run the collectives even with one rank
+        # each bucket's all-reduce is enqueued from inside the backward call, right after its event (dvgr_opts.layer_done_cb)
+        m.set_layer_callback(lambda idx, g: reducer.launch(idx, g, events[idx]))
         ev_order = [events[Lr]] + [events[l] for l in range(Lr - 1, -1, -1)]
 
     probe_sites = {"fwd_gat_gemm": (L_.PROBE_FWD_GAT_GEMM, 8 * B * N * D * D, "gemm_planes_kernel<KC,KC,TAG_FWD_GAT=1,TERMS> / gemm_ring_kernel<KC,KC,1,F32> (Wh = X.Wcat^T, both modalities)"),
@@ -223,6 +226,8 @@ def main():
         if i is not None:
             m.set_probe(site, probe_layer, pairs[i][0], pairs[i][1])
         m.zero_grad_flat()
+        if reducer is not None:
+            reducer.start(Lr)
         for k in ("A", "M", "dq", "words"):
             t[k].grad = None
         raw = m.forward_raw(t["A"], t["M"], t["dq"], t["words"], t["qlen"])
@@ -244,7 +249,7 @@ def main():
         else:
             torch.autograd.backward(raw, ups)
         if reducer is not None:
-            reducer.reduce(m.last_flat_grad, ev_order)
+            reducer.finish()
 
     for _ in range(args.warmup):
         step()

@@ -48,7 +48,11 @@ class LossSpec(C.Structure):
 class Opts(C.Structure):
     _fields_ = [("train", C.c_int32), ("probe_site", C.c_int32), ("probe_layer", C.c_int32), ("flags", C.c_int32),
                 ("seed", C.c_uint64), ("probe_begin", C.c_void_p), ("probe_end", C.c_void_p),
-                ("layer_done_events", C.POINTER(C.c_void_p)), ("loss", C.POINTER(LossSpec))]
+                ("layer_done_events", C.POINTER(C.c_void_p)), ("loss", C.POINTER(LossSpec)),
+                ("layer_done_cb", C.c_void_p), ("layer_done_user", C.c_void_p)]
+
+
+LAYER_DONE_CB = C.CFUNCTYPE(None, C.c_int32, C.c_void_p)
 
 
 OPT_SINGLE_STREAM = 1

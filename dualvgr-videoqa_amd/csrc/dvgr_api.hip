@@ -620,6 +620,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
   if (layer_done_events && layer_done_events[L]) {
     const hipError_t e = hipEventRecord((hipEvent_t)layer_done_events[L], hs);
     if (e != hipSuccess) return (int)e;
+    if (O.layer_done_cb) O.layer_done_cb(L, O.layer_done_user);
   }
 
   // ---- layers, last to first -----------------------------------------------------------------------
@@ -834,6 +835,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     if (l > 0 && layer_done_events && layer_done_events[l]) {
       const hipError_t e = hipEventRecord((hipEvent_t)layer_done_events[l], hs);
       if (e != hipSuccess) return (int)e;
+      if (O.layer_done_cb) O.layer_done_cb(l, O.layer_done_user);
     }
     if (side) {
       side_done[set] = side->next();
@@ -846,6 +848,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
   if (layer_done_events && layer_done_events[0]) {   // layer 0's weight gradients were split over both streams
     const hipError_t e = hipEventRecord((hipEvent_t)layer_done_events[0], st);
     if (e != hipSuccess) return (int)e;
+    if (O.layer_done_cb) O.layer_done_cb(0, O.layer_done_user);
   }
   return 0;
 }

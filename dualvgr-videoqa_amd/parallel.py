@@ -34,7 +34,9 @@ class LayerBucketReducer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.stream = None
         if device is not None and device.type == "cuda":
-            self.stream = torch.cuda.Stream(device=device)
+            # high priority: the runtime gives such a stream a hardware queue of its own; a normal-priority one was seen
+            # sharing the caller's queue, where its event waits sit in front of the backward's later launches
+            self.stream = torch.cuda.Stream(device=device, priority=-1)
 
     def reduce(self, flat_grad: torch.Tensor, events: Optional[Sequence] = None) -> None:
         """In-place average of `flat_grad`.  `events[i]` (torch.cuda.Event or None) gates bucket i
@@ -59,6 +61,76 @@ class LayerBucketReducer:
             for (a, b) in self.buckets:
                 dist.all_reduce(flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group)
             flat_grad.mul_(1.0 / self.world)
+
+
+    # ---- the same reduction, launched bucket by bucket from the backward's host callback --------------------------------
+    # (dvgr_opts.layer_done_cb / DualVGRUnit_multiple.set_layer_callback): the collective of a bucket enters the
+    # communication stream the moment its event has been enqueued, not after the whole backward has been launched.
+    def start(self, num_layers: int, threaded: bool = True) -> None:
+        """Begin one step.  threaded: the collectives are enqueued by a helper thread, so that their host cost (tens of
+        microseconds each) does not sit in the backward's launch path -- the callback only posts the bucket."""
+        self._works = []
+        self._bucket_of_layer = {layer: i for i, layer in enumerate([num_layers] + list(range(num_layers - 1, -1, -1)))}
+        self._error = None
+        if threaded and self.stream is not None and getattr(self, "_q", None) is None:
+            import queue
+            import threading
+            self._q = queue.Queue()
+            dev = self.stream.device
+
+            def worker():
+                torch.cuda.set_device(dev)
+                while True:
+                    item = self._q.get()
+                    try:
+                        if item is None:
+                            return
+                        self._launch_now(*item)
+                    except BaseException as e:      # surfaced by finish()
+                        self._error = e
+                    finally:
+                        self._q.task_done()
+
+            self._thread = threading.Thread(target=worker, daemon=True)
+            self._thread.start()
+        self._threaded = bool(threaded) and getattr(self, "_q", None) is not None
+
+    def _launch_now(self, layer_index: int, flat_grad: torch.Tensor, event=None) -> None:
+        a, b = self.buckets[self._bucket_of_layer[layer_index]]
+        if flat_grad.is_cuda and self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                if event is not None:
+                    self.stream.wait_event(event)
+                else:
+                    self.stream.wait_stream(torch.cuda.current_stream(flat_grad.device))
+                w = dist.all_reduce(flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                w.wait()                                   # stream-ordered, no host block
+                flat_grad[a:b].mul_(1.0 / self.world)
+            self._works.append((w, a, b, flat_grad))
+        else:
+            dist.all_reduce(flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group)
+            flat_grad[a:b].mul_(1.0 / self.world)
+
+    def launch(self, layer_index: int, flat_grad: torch.Tensor, event=None) -> None:
+        if self.world == 1 and not getattr(self, "force", False):
+            return
+        if getattr(self, "_threaded", False) and flat_grad.is_cuda:
+            self._q.put((layer_index, flat_grad, event))
+        else:
+            self._launch_now(layer_index, flat_grad, event)
+
+    def finish(self) -> None:
+        """After the backward call: scale every launched bucket and make the current stream wait for all of them."""
+        if getattr(self, "_threaded", False):
+            self._q.join()
+        if getattr(self, "_error", None) is not None:
+            err, self._error = self._error, None
+            raise err
+        works = getattr(self, "_works", [])
+        if not works:
+            return
+        torch.cuda.current_stream(works[0][3].device).wait_stream(self.stream)
+        self._works = []
 
 
 def shard_batch(n_items: int, rank: int, world: int) -> Tuple[int, int]:

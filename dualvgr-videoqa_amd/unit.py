@@ -212,9 +212,13 @@ class _UnitFn(torch.autograd.Function):
                       gA.data_ptr(), gM.data_ptr(), gdq.data_ptr(), gwords.data_ptr(), gflat.data_ptr())
         stream = torch.cuda.current_stream(dev).cuda_stream
         opts = mod.make_opts(ctx.train, ctx.seed, backward=True)
+        mod._backward_gflat = gflat
         L_.check(lib.dvgr_unit_backward(C.byref(dims), flat.data_ptr(), mod.lowp_ptr(), C.byref(io), C.byref(gr),
                                         saved.data_ptr(), saved.numel(), ws.data_ptr(), ws.numel(), C.byref(opts),
                                         stream), "dvgr_unit_backward")
+        if getattr(mod, "_layer_cb_error", None) is not None:
+            err, mod._layer_cb_error = mod._layer_cb_error, None
+            raise err
         if flat_mode:
             mod._deposit_grad(gflat, deposit)
             return (None, gA, gM, gdq, gwords, None, None)
@@ -289,6 +293,10 @@ class DualVGRUnit_multiple(nn.Module):
         self._events = None
         self._events_arr = None
         self._probe = None
+        self._layer_cb = None
+        self._layer_cb_c = None
+        self._layer_cb_error = None
+        self._backward_gflat = None
         self.no_planes = False       # diagnostics: bf16 modes convert inside the contraction kernels instead
         self.forced_seed = None      # tests: fix the dropout seed of the next forward
         self.keep_saved = False      # tests: keep a handle on the saved-for-backward buffer
@@ -423,6 +431,24 @@ class DualVGRUnit_multiple(nn.Module):
                 ev.record()          # torch creates the hipEvent lazily at the first record
         self._events = events
 
+    def set_layer_callback(self, fn):
+        """fn(layer_index, flat_grad) is called on the host, from inside the backward call, right after the event of
+        `layer_index` (set_layer_events; index L = the MFB block) has been enqueued: the place to launch that slice's
+        all-reduce (parallel.LayerBucketReducer.launch).  None disables."""
+        self._layer_cb = fn
+        self._layer_cb_error = None
+        if fn is None:
+            self._layer_cb_c = None
+            return
+
+        def _thunk(index, _user):
+            try:
+                fn(int(index), self._backward_gflat)
+            except BaseException as e:          # cannot propagate through the C frame: re-raised after the call
+                self._layer_cb_error = e
+
+        self._layer_cb_c = L_.LAYER_DONE_CB(_thunk)
+
     def set_probe(self, site: int, layer: int = 0, begin=None, end=None):
         """Bracket one launch site (enum dvgr_probe_site) of the following calls with two
         torch.cuda.Event(enable_timing=True); site 0 disables.  Used by bench.py."""
@@ -447,6 +473,8 @@ class DualVGRUnit_multiple(nn.Module):
                 arr[i] = ev.cuda_event
             self._events_arr = arr               # keep alive for the duration of the call
             o.layer_done_events = C.cast(arr, C.POINTER(C.c_void_p))
+            if getattr(self, "_layer_cb_c", None) is not None:
+                o.layer_done_cb = C.cast(self._layer_cb_c, C.c_void_p)
         return o
 
     def layer_param_range(self, layer: int) -> Tuple[int, int]:

@@ -199,6 +199,11 @@ typedef struct dvgr_opts {
                           caller can start the RCCL all-reduce of that slice of `gparams` while the earlier
                           layers are still running */
   const dvgr_loss_spec *loss;     /* forward only, nullable: also evaluate the scope-U loss and its gradients */
+  void (*layer_done_cb)(int32_t index, void *user); /* backward only, nullable: called ON THE HOST, in the calling thread,
+                          right after layer_done_events[index] has been enqueued -- the place to enqueue that slice's
+                          all-reduce, so that the collectives enter their stream while the rest of the backward is still
+                          being launched (after the call returns the device has usually finished the backward already) */
+  void *layer_done_user;
 } dvgr_opts;
 
 /* Forward of the whole stacked unit: replaces DualVGRUnit_multiple.forward (model/models.py:

@@ -56,7 +56,15 @@ def _worker(rank, world, port, q):
         buckets = parallel.layer_buckets(m)
         assert buckets[0] == m.layer_param_range(LR) and buckets[-1] == m.layer_param_range(0)
         assert sorted(buckets)[0][0] == 0 and sorted(buckets)[-1][1] == flat.numel()
+        flat2 = flat.clone()
         parallel.LayerBucketReducer(buckets).reduce(flat)
+        # the same reduction driven bucket by bucket, in the order the backward's host callback fires (L, L-1, .., 0)
+        red = parallel.LayerBucketReducer(buckets)
+        red.start(LR)
+        for layer in [LR] + list(range(LR - 1, -1, -1)):
+            red.launch(layer, flat2)
+        red.finish()
+        assert torch.equal(flat, flat2)
         if rank == 0:
             q.put(flat.numpy())
     finally:
