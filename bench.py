@@ -208,7 +208,6 @@ def main():
         reducer.force = world == 1          # self-test: run the collectives even with one rank
         # each bucket's all-reduce is enqueued from inside the backward call, right after its event (dvgr_opts.layer_done_cb)
         m.set_layer_callback(lambda idx, g: reducer.launch(idx, g, events[idx]))
-        ev_order = [events[Lr]] + [events[l] for l in range(Lr - 1, -1, -1)]
 
     probe_sites = {"fwd_gat_gemm": (L_.PROBE_FWD_GAT_GEMM, 8 * B * N * D * D, "gemm_planes_kernel<KC,KC,TAG_FWD_GAT=1,TERMS> / gemm_ring_kernel<KC,KC,1,F32> (Wh = X.Wcat^T, both modalities)"),
                    "fwd_sf_gemm": (L_.PROBE_FWD_SF_GEMM, 8 * B * N * D * D, "gemm_kernel<KC,KC,*,*,TAG_FWD_SF=2>"),
@@ -319,8 +318,10 @@ def bench_model(args, dev, rank, world, cfg):
     vocab = {"question_token_to_idx": {str(i): i for i in range(VQ)}, "answer_token_to_idx": {str(i): i for i in range(VA)}}
     torch.manual_seed(666)
     m = dv.DualVGR(vision_dim=V, module_dim=D, word_dim=WD, vocab=vocab, num_of_nodes=N, graph_module="GAT", graph_layers=1,
-                   unit_layers=Lr, dtype=args.dtype, appearance_encoder=args.appearance_encoder,
-                   question_encoder=args.question_encoder).to(dev)
+                   unit_layers=Lr, dtype=args.dtype).to(dev)
+    if "miopen" in (args.appearance_encoder, args.question_encoder):      # A/B timing against MIOpen's nn.LSTM (tools/)
+        from tools.stock_encoders import use_stock_encoders
+        use_stock_encoders(m, appearance=args.appearance_encoder == "miopen", question=args.question_encoder == "miopen")
     m.train(not args.eval_mode)
     m.overlap_encoders = os.environ.get("DVGR_NO_ENCODER_OVERLAP", "0") != "1"
     unit, head = m.visual_input_unit, m._head

@@ -568,7 +568,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
 
   // Two streams: `st` carries the critical path (the dX chain), `hs` the weight / bias gradients and the query
   // branch.  DVGR_OPT_SINGLE_STREAM (or a missing side stream) folds everything onto `st`.
-  SideStream* side = ((O.flags & DVGR_OPT_SINGLE_STREAM) || 4 * L + 16 > 256) ? nullptr : side_stream();
+  SideStream* side = ((O.flags & DVGR_OPT_SINGLE_STREAM) || 5 * L + 16 > 256) ? nullptr : side_stream();
   hipStream_t hs = side ? side->st : st;
   const Probe hprobe{O, hs};
   auto to_side = [&]() -> int { return side ? side->order(st, hs) : 0; };     // hs continues after st's work so far
@@ -833,6 +833,9 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     cb.chunks = 16;
     DVGR_TRY(colsum(hs, cb));
     if (l > 0 && layer_done_events && layer_done_events[l]) {
+      // layer l's gradients are written on BOTH streams (dWcat on `st`; dP1, the query branch and the column sums on
+      // `hs`): the event must not fire before the main stream's share is final
+      if (side) DVGR_TRY(side->order(st, hs));
       const hipError_t e = hipEventRecord((hipEvent_t)layer_done_events[l], hs);
       if (e != hipSuccess) return (int)e;
       if (O.layer_done_cb) O.layer_done_cb(l, O.layer_done_user);

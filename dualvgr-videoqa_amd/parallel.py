@@ -38,18 +38,28 @@ class LayerBucketReducer:
             # sharing the caller's queue, where its event waits sit in front of the backward's later launches
             self.stream = torch.cuda.Stream(device=device, priority=-1)
 
+    def _layer_order(self) -> List[int]:
+        """Layer index of bucket i (buckets are ordered MFB = L, then L-1 .. 0: `layer_buckets`)."""
+        L = len(self.buckets) - 1
+        return [L] + list(range(L - 1, -1, -1))
+
     def reduce(self, flat_grad: torch.Tensor, events: Optional[Sequence] = None) -> None:
-        """In-place average of `flat_grad`.  `events[i]` (torch.cuda.Event or None) gates bucket i
-        on the communication stream; with no events every bucket waits for the current stream."""
+        """In-place average of `flat_grad`.  `events` is the LAYER-indexed list handed to
+        `DualVGRUnit_multiple.set_layer_events` (events[l] = layer l's gradients are final, events[L] = the MFB block's):
+        the bucket of layer l is gated on events[l] on the communication stream.  Whatever the events do not cover
+        (no list, or a None entry) waits for the caller's current stream instead."""
         if self.world == 1 and not getattr(self, "force", False):
             return
+        if events is not None and len(events) != len(self.buckets):
+            raise ValueError(f"expected {len(self.buckets)} layer-indexed events (L + 1), got {len(events)}")
         if flat_grad.is_cuda and self.stream is not None:
             cur = torch.cuda.current_stream(flat_grad.device)
             works = []
             with torch.cuda.stream(self.stream):
-                for i, (a, b) in enumerate(self.buckets):
-                    if events is not None and events[i] is not None:
-                        self.stream.wait_event(events[i])
+                for (a, b), layer in zip(self.buckets, self._layer_order()):
+                    ev = events[layer] if events is not None else None
+                    if ev is not None:
+                        self.stream.wait_event(ev)
                     else:
                         self.stream.wait_stream(cur)
                     works.append(dist.all_reduce(flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
@@ -61,7 +71,6 @@ class LayerBucketReducer:
             for (a, b) in self.buckets:
                 dist.all_reduce(flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group)
             flat_grad.mul_(1.0 / self.world)
-
 
     # ---- the same reduction, launched bucket by bucket from the backward's host callback --------------------------------
     # (dvgr_opts.layer_done_cb / DualVGRUnit_multiple.set_layer_callback): the collective of a bucket enters the
@@ -95,14 +104,18 @@ class LayerBucketReducer:
             self._thread.start()
         self._threaded = bool(threaded) and getattr(self, "_q", None) is not None
 
-    def _launch_now(self, layer_index: int, flat_grad: torch.Tensor, event=None) -> None:
+    def _launch_now(self, layer_index: int, flat_grad: torch.Tensor, event=None, caller_stream=None) -> None:
         a, b = self.buckets[self._bucket_of_layer[layer_index]]
         if flat_grad.is_cuda and self.stream is not None:
             with torch.cuda.stream(self.stream):
                 if event is not None:
                     self.stream.wait_event(event)
                 else:
-                    self.stream.wait_stream(torch.cuda.current_stream(flat_grad.device))
+                    # no event: everything the CALLER's stream (captured by launch(): the helper thread's own current
+                    # stream is a different one) has enqueued so far
+                    self.stream.wait_stream(caller_stream if caller_stream is not None
+                                            else torch.cuda.current_stream(flat_grad.device))
+                flat_grad.record_stream(self.stream)           # may be a temporary of the caller: keep it alive for RCCL
                 w = dist.all_reduce(flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                 w.wait()                                   # stream-ordered, no host block
                 flat_grad[a:b].mul_(1.0 / self.world)
@@ -114,10 +127,11 @@ class LayerBucketReducer:
     def launch(self, layer_index: int, flat_grad: torch.Tensor, event=None) -> None:
         if self.world == 1 and not getattr(self, "force", False):
             return
+        cur = torch.cuda.current_stream(flat_grad.device) if flat_grad.is_cuda else None
         if getattr(self, "_threaded", False) and flat_grad.is_cuda:
-            self._q.put((layer_index, flat_grad, event))
+            self._q.put((layer_index, flat_grad, event, cur))
         else:
-            self._launch_now(layer_index, flat_grad, event)
+            self._launch_now(layer_index, flat_grad, event, cur)
 
     def finish(self) -> None:
         """After the backward call: scale every launched bucket and make the current stream wait for all of them."""

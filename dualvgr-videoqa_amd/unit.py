@@ -205,6 +205,11 @@ class _UnitFn(torch.autograd.Function):
         gwords = torch.empty_like(words)
         flat_mode = mod.grad_mode == "flat"
         gflat, deposit = mod._grad_target(flat) if flat_mode else (torch.empty_like(flat), None)
+        if deposit == "accumulate" and mod._layer_cb is not None:
+            # the callback hands `gflat` to an asynchronous reducer; adding a half-reduced temporary into the live
+            # buffer afterwards would race with the collectives
+            raise RuntimeError("gradient accumulation into a live flat buffer cannot be combined with the layer callback: "
+                               "call zero_grad_flat() (or zero_grad(set_to_none=True)) before every backward")
         ws = mod.workspace(lib.dvgr_workspace_bytes(C.byref(dims)), dev)
         io = L_.IO(A.data_ptr(), M.data_ptr(), dq.data_ptr(), words.data_ptr(), qlen.data_ptr(), vis.data_ptr(),
                    aqe.data_ptr(), mqe.data_ptr(), l0.data_ptr(), l1.data_ptr(), l2.data_ptr(), l3.data_ptr())

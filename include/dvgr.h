@@ -10,10 +10,15 @@
  * Conventions
  *   - every tensor is fp32, contiguous, row-major, last dimension fastest, resident in HBM;
  *   - the library never allocates, frees or retains device memory and never synchronises the
- *     device: it only enqueues kernels on the stream it is given (safe under hipGraph capture);
+ *     device: it only enqueues kernels on the stream it is given and, for work off the critical path, on its internal
+ *     side stream, which forks from and joins back into the given stream inside the same call (the caller sees ordinary
+ *     single-stream semantics; the fork / join is capturable by hipGraph stream capture);
  *   - functions return 0 on success, a negative DVGR_E_* code for invalid arguments, or the
  *     positive hipError_t value of a failed launch;
- *   - no mutable global state: calls are re-entrant (autograd calls backward from its own thread).
+ *   - calls are re-entrant and thread-safe (autograd calls backward from its own thread).  The library keeps exactly
+ *     one piece of process-wide state: per device, one internal lower-priority side stream (created on first use or by
+ *     dvgr_streams_init, shared by all threads, never destroyed) plus a per-thread pool of fork / join events on it.
+ *     It holds no pointer to caller memory between calls; DVGR_OPT_SINGLE_STREAM makes a call use neither.
  */
 #ifndef DVGR_H
 #define DVGR_H

@@ -139,9 +139,14 @@ def forward(sd: Dict[str, torch.Tensor], A, M, dq, words, qlen, L: int, masks: O
     return outs, cache
 
 
-def backward(sd, cache, words, dq, g_vis, g_aqe, g_mqe, g_ca, g_cm, g_aq, g_mq):
+def backward(sd, cache, words, dq, g_vis, g_aqe, g_mqe, g_ca, g_cm, g_aq, g_mq, pre_pos=None):
     """Upstream gradients for all 3 + 4L outputs -> gradients of the 4 float inputs and of every
-    parameter (keys of `sd`).  Returns (gin, gw, dbg) where dbg holds per-stage intermediates."""
+    parameter (keys of `sd`).  Returns (gin, gw, dbg) where dbg holds per-stage intermediates.
+
+    pre_pos: optional {(layer, mod): bool (B, 8, N, N)} -- the branch of LeakyReLU'(pre) to take for every attention
+    logit instead of this restatement's own `pre > 0`.  The derivative jumps at 0, so an implementation whose logits
+    differ by rounding can legitimately sit on the other side of the kink for a few entries; the parity tests count
+    those entries, check that they really lie at the kink, and compare gradients with the branches aligned."""
     B, N, D, T, L = cache["B"], cache["N"], cache["D"], cache["T"], cache["L"]
     Fh = D // 4
     gw = {k: torch.zeros_like(v) for k, v in sd.items()}
@@ -211,7 +216,8 @@ def backward(sd, cache, words, dq, g_vis, g_aqe, g_mqe, g_ca, g_cm, g_aq, g_mq):
                 dZ = torch.einsum("bhij,bihf->bjhf", alpha_d, dP)
                 de = alpha * (dalpha - (alpha * dalpha).sum(-1, keepdim=True))
                 pre = u[:, :, :, None] + v[:, :, None, :] + cc[g * 4:(g + 1) * 4][None, :, None, None]
-                dpre_a = de * torch.where(pre > 0, torch.ones_like(pre), torch.full_like(pre, SLOPE))
+                pos = pre > 0 if pre_pos is None else pre_pos[(l, mod)][:, g * 4:(g + 1) * 4]
+                dpre_a = de * torch.where(pos, torch.ones_like(pre), torch.full_like(pre, SLOPE))
                 du, dv = dpre_a.sum(-1), dpre_a.sum(-2)                 # (B,4,N)
                 dWh = dZ * s[:, :, None, None] \
                     + torch.einsum("bhn,hf->bnhf", du, al[g * 4:(g + 1) * 4]) \
@@ -220,6 +226,7 @@ def backward(sd, cache, words, dq, g_vis, g_aqe, g_mqe, g_ca, g_cm, g_aq, g_mq):
                 dal = torch.einsum("bhn,bnhf->hf", du, Wh)
                 dar = torch.einsum("bhn,bnhf->hf", dv, Wh)
                 dc = dpre_a.sum((0, 2, 3))
+                dl.setdefault(mod + ".dc_abs", []).append(dpre_a.abs().sum((0, 2, 3)))   # cancellation scale of a.bias' gradient
                 dWh8[:, :, g * 4:(g + 1) * 4] = dWh
                 xd = x * kx
                 dWh_flat = dWh.reshape(B, N, 4 * Fh)

@@ -1,0 +1,164 @@
+"""GPU: the BASELINE.json configurations at their OWN dimensions (D = 768, word_dim = 300, T = 15), in exact fp32 and in
+the benchmark's default operand mode (bf16x3), through the C ABI:
+
+  C3  MSVD-QA    num_clips =  8, unit_layers =  3, batch 128
+  C4  MSRVTT-QA  num_clips = 16, unit_layers =  6, batch 256 / 8 GPUs = 32 per GPU
+  C5  stress     num_clips = 64, unit_layers = 12, batch 512 / 8 GPUs = 64 per GPU
+
+(C1 / C2, num_clips = 20: tests/test_hip_parity.py.)  C3 and C4 are compared with the oracle at their full per-GPU batch,
+eval and training mode (masks of the device RNG injected into the oracle).  C5's oracle comparison runs on a 2-sample
+batch; its full batch of 64 is then tied to that comparison through properties the path offers: samples are independent
+(rows of the full-batch outputs and input gradients equal the small-batch run's), the parameter gradient of a batch is
+the sum of its shards' (linearity), and a run is deterministic.
+Gates: 1e-4 forward, 5e-4 gradients (max |err| / max |want| per tensor), both operand modes."""
+import numpy as np
+import pytest
+import torch
+
+import dualvgr_videoqa_amd as dv
+from dualvgr_videoqa_amd import _lib as L
+from dualvgr_videoqa_amd import dropout, synth
+from helpers import aligned_oracle_backward, assert_flips_at_kink, assert_grads, device_logit_signs, rel_err
+from oracle import unit_torch as O
+
+pytestmark = pytest.mark.gpu
+TOL, GTOL = 1e-4, 5e-4
+D, WD, T = 768, 300, 15
+
+
+def _module(N, Lr, dtype, sd_np, train):
+    m = dv.DualVGRUnit_multiple(word_dim=WD, module_dim=D, num_of_nodes=N, unit_layers=Lr, dtype=dtype)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
+    m = m.cuda().train(train)
+    m.keep_saved = True
+    return m
+
+
+def _upstream(o, R, N):
+    """train.py:148-154 shaped scalar: a weighted read-out of vis + common + 1e-8 * HSIC over the list outputs."""
+    c, d_ = O.aux_losses(o, N)
+    return (o[0] * R).sum() + 0.3 * ((o[1] * R).sum() + (o[2] * R).sum()) + c + 1e-8 * d_
+
+
+def _run(m, inp, R, N, seed=None):
+    t = {k: torch.from_numpy(v.copy()).cuda() for k, v in inp.items()}
+    for k in ("A", "M", "dq", "words"):
+        t[k].requires_grad_(True)
+    if seed is not None:
+        m.forced_seed = seed
+    m.zero_grad(set_to_none=True)
+    outs = m(t["A"], t["M"], t["dq"], t["words"], t["qlen"])
+    _upstream(outs, R.cuda(), N).backward()
+    torch.cuda.synchronize()
+    return t, outs
+
+
+def _against_oracle(name, B, N, Lr, dtype, train):
+    sd_np = synth.xavier_state_dict(O.param_shapes(WD, D, Lr), seed=31, bias_range=0.05)
+    inp = synth.unit_inputs(B, N, T, D, WD, seed=31)
+    R = torch.from_numpy(synth.normal("Rcfg", (B, N, D), 1.0, 31))
+    m = _module(N, Lr, dtype, sd_np, train)
+    seed = 0x5EED_0000 + N if train else None
+    t, outs = _run(m, inp, R, N, seed)
+    masks = None
+    if train:
+        masks = {k: torch.from_numpy(v) for k, v in dropout.site_masks(seed, B, N, D, Lr).items()}
+    sd = {k: torch.from_numpy(v.copy()) for k, v in sd_np.items()}
+    ti = {k: torch.from_numpy(v.copy()) for k, v in inp.items()}
+    signs = device_logit_signs(m, L.make_dims(B, N, T, D, WD, Lr), (B, N, Lr))
+    oo, gin, gw, dbg, stats = aligned_oracle_backward(sd, ti, Lr, masks, lambda o: _upstream(o, R, N), signs)
+    flat_h = [outs[0], outs[1], outs[2]] + outs[3] + outs[4] + outs[5] + outs[6]
+    flat_o = [oo[0], oo[1], oo[2]] + oo[3] + oo[4] + oo[5] + oo[6]
+    ferr = max(rel_err(h.detach().cpu(), o) for h, o in zip(flat_h, flat_o))
+    what = f"{name} B={B} N={N} L={Lr} {dtype} {'train' if train else 'eval'}"
+    print(f"  {what}: forward (all {len(flat_h)} outputs) {ferr:.2e}")
+    assert ferr < TOL, ferr
+    assert_flips_at_kink(stats, what)
+    assert_grads(m, t, gin, gw, dbg, Lr, GTOL, what)
+    return m, sd_np, t, outs
+
+
+@pytest.mark.parametrize("train", [False, True])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x3"])
+def test_c3_msvd_full_batch(dtype, train):
+    _against_oracle("C3", 128, 8, 3, dtype, train)
+
+
+@pytest.mark.parametrize("train", [False, True])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x3"])
+def test_c4_msrvtt_full_per_gpu_batch(dtype, train):
+    _against_oracle("C4", 32, 16, 6, dtype, train)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x3"])
+def test_c5_stress_oracle_on_a_shard_and_properties_at_full_batch(dtype):
+    N, Lr, Bs, Bf = 64, 12, 2, 64
+    # (1) the oracle comparison proper, on the first two samples of the full batch
+    full = synth.unit_inputs(Bf, N, T, D, WD, seed=31)
+    shard0 = {k: v[:Bs].copy() for k, v in full.items()}
+    sd_np = synth.xavier_state_dict(O.param_shapes(WD, D, Lr), seed=31, bias_range=0.05)
+    Rf = torch.from_numpy(synth.normal("Rc5", (Bf, N, D), 1.0, 31))
+
+    def lin_upstream(o, R):          # linear in the outputs, so that gradients add over shards exactly
+        return (o[0] * R).sum() + sum((x * R).sum() for x in o[3] + o[4] + o[5] + o[6]) + 0.3 * (o[1] * R).sum()
+
+    m = _module(N, Lr, dtype, sd_np, False)
+    t0 = {k: torch.from_numpy(v.copy()).cuda() for k, v in shard0.items()}
+    for k in ("A", "M", "dq", "words"):
+        t0[k].requires_grad_(True)
+    outs0 = m(t0["A"], t0["M"], t0["dq"], t0["words"], t0["qlen"])
+    lin_upstream(outs0, Rf[:Bs].cuda()).backward()
+    torch.cuda.synchronize()
+    sd = {k: torch.from_numpy(v.copy()) for k, v in sd_np.items()}
+    ti = {k: torch.from_numpy(v.copy()) for k, v in shard0.items()}
+    signs = device_logit_signs(m, L.make_dims(Bs, N, T, D, WD, Lr), (Bs, N, Lr))
+    oo, gin, gw, dbg, stats = aligned_oracle_backward(sd, ti, Lr, None, lambda o: lin_upstream(o, Rf[:Bs]), signs)
+    flat_h = [outs0[0], outs0[1], outs0[2]] + outs0[3] + outs0[4] + outs0[5] + outs0[6]
+    flat_o = [oo[0], oo[1], oo[2]] + oo[3] + oo[4] + oo[5] + oo[6]
+    ferr = max(rel_err(h.detach().cpu(), o) for h, o in zip(flat_h, flat_o))
+    print(f"  C5 shard B={Bs} {dtype}: forward (all {len(flat_h)} outputs) {ferr:.2e}")
+    assert ferr < TOL, ferr
+    assert_flips_at_kink(stats, f"C5 shard {dtype}")
+    assert_grads(m, t0, gin, gw, dbg, Lr, GTOL, f"C5 shard {dtype}")
+    g_shard0 = m.last_flat_grad.clone()
+    out0_keep = [x.detach().clone() for x in (outs0[0], outs0[3][-1], outs0[6][-1])]
+    gin0_keep = {k: t0[k].grad.clone() for k in ("A", "M", "dq", "words")}
+
+    # (2) the full per-GPU batch of 64
+    def run_full():
+        t = {k: torch.from_numpy(v.copy()).cuda() for k, v in full.items()}
+        for k in ("A", "M", "dq", "words"):
+            t[k].requires_grad_(True)
+        m.zero_grad(set_to_none=True)
+        outs = m(t["A"], t["M"], t["dq"], t["words"], t["qlen"])
+        lin_upstream(outs, Rf.cuda()).backward()
+        torch.cuda.synchronize()
+        return t, outs, m.last_flat_grad.clone()
+
+    tf, outsf, gfull = run_full()
+    # samples are independent: the first two rows of the full run are the shard run
+    for a, b in zip(out0_keep, (outsf[0], outsf[3][-1], outsf[6][-1])):
+        assert rel_err(b[:Bs].detach().cpu(), a.cpu()) < 2e-6
+    for k in ("A", "M", "dq", "words"):
+        assert rel_err(tf[k].grad[:Bs].cpu(), gin0_keep[k].cpu()) < 2e-5, k
+    # determinism of the forward; the backward's float atomics (split-K, column sums) may reorder
+    tf2, outsf2, gfull2 = run_full()
+    assert torch.equal(outsf[0], outsf2[0]) and torch.equal(outsf[5][-1], outsf2[5][-1])
+    assert rel_err(gfull2.cpu(), gfull.cpu()) < 2e-6
+    # linearity: the parameter gradient of the batch is the sum over its shards (8 shards of 8 samples)
+    acc = torch.zeros_like(gfull)
+    for s in range(0, Bf, 8):
+        part = {k: v[s:s + 8].copy() for k, v in full.items()}
+        tp = {k: torch.from_numpy(v).cuda() for k, v in part.items()}
+        for k in ("A", "M", "dq", "words"):
+            tp[k].requires_grad_(True)
+        m.zero_grad(set_to_none=True)
+        op = m(tp["A"], tp["M"], tp["dq"], tp["words"], tp["qlen"])
+        lin_upstream(op, Rf[s:s + 8].cuda()).backward()
+        acc += m.last_flat_grad
+    torch.cuda.synchronize()
+    for l in range(Lr + 1):                      # per layer block: one magnitude scale each
+        a, b = m.layer_param_range(l)
+        assert rel_err(acc[a:b].cpu(), gfull[a:b].cpu()) < 5e-5, l
+    assert torch.isfinite(gfull).all() and float(gfull.abs().max()) > 0
+    del g_shard0

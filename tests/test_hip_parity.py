@@ -13,7 +13,8 @@ import torch
 import dualvgr_videoqa_amd as dv
 from dualvgr_videoqa_amd import _lib as L
 from dualvgr_videoqa_amd import dropout, synth
-from helpers import REAL_CASES, GoldenCase, rel_err, scalar_loss
+from helpers import (REAL_CASES, GoldenCase, aligned_oracle_backward, assert_flips_at_kink, assert_grads,
+                     device_logit_signs, rel_err, scalar_loss)
 from oracle import unit_manual as MN
 from oracle import unit_torch as O
 
@@ -216,20 +217,22 @@ def test_train_mode_statistics_and_determinism():
     assert abs(drop - 0.15) < 0.01, drop
 
 
-def _full_config(B=64, N=20, T=15, Lr=3, D=768, Wd=300, seed=666):
+def _full_config(B=64, N=20, T=15, Lr=3, D=768, Wd=300, seed=666, dtype="fp32"):
     shapes = O.param_shapes(Wd, D, Lr)
     sd_np = synth.xavier_state_dict(shapes, seed=seed, bias_range=0.05)
     inp = synth.unit_inputs(B, N, T, D, Wd, seed=seed)
-    m = dv.DualVGRUnit_multiple(word_dim=Wd, module_dim=D, num_of_nodes=N, unit_layers=Lr)
+    m = dv.DualVGRUnit_multiple(word_dim=Wd, module_dim=D, num_of_nodes=N, unit_layers=Lr, dtype=dtype)
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
+    m.keep_saved = True
     return m.cuda().eval(), sd_np, inp
 
 
-def test_full_size_against_oracle_and_properties():
-    """BASELINE.json configs[1] shape (B=64, N=20, L=3, D=768): forward + backward against the
-    factorised oracle, then size-independent properties: batch-permutation equivariance,
-    bitwise run-to-run determinism, padding invariance of the question tensors."""
-    m, sd_np, inp = _full_config()
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x3"])
+def test_full_size_against_oracle_and_properties(dtype):
+    """BASELINE.json configs[1] shape (B=64, N=20, L=3, D=768), in exact fp32 AND in the benchmark's default operand
+    mode (bf16x3), same gates: forward + backward against the oracle, then size-independent properties:
+    batch-permutation equivariance, bitwise run-to-run determinism."""
+    m, sd_np, inp = _full_config(dtype=dtype)
     B, N, D = 64, 20, 768
     t = {k: torch.from_numpy(v.copy()).cuda() for k, v in inp.items()}
     for k in ("A", "M", "dq", "words"):
@@ -240,32 +243,22 @@ def test_full_size_against_oracle_and_properties():
     loss = (outs[0] * Rv).sum() + com + 1e-8 * dep
     loss.backward()
     torch.cuda.synchronize()
-    # oracle on the host
-    torch.set_num_threads(max(1, torch.get_num_threads()))
-    sd = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in sd_np.items()}
+    # oracle on the host (autograd form for the forward and the loss; hand-derived backward with aligned LeakyReLU branches)
+    sd = {k: torch.from_numpy(v.copy()) for k, v in sd_np.items()}
     ti = {k: torch.from_numpy(v.copy()) for k, v in inp.items()}
-    for k in ("A", "M", "dq", "words"):
-        ti[k].requires_grad_(True)
-    oo = O.unit_forward(sd, ti["A"], ti["M"], ti["dq"], ti["words"], ti["qlen"], 3, 1, naive=False)
-    ocom, odep = O.aux_losses(oo, N)
-    oloss = (oo[0] * Rv.cpu()).sum() + ocom + 1e-8 * odep
-    oloss.backward()
-    errs = {"vis": rel_err(outs[0].detach().cpu(), oo[0].detach()), "aq_embed": rel_err(outs[1].detach().cpu(), oo[1].detach()),
-            "com_app2": rel_err(outs[3][2].detach().cpu(), oo[3][2].detach()), "mq_fusion2": rel_err(outs[6][2].detach().cpu(), oo[6][2].detach())}
-    print("  forward:", {k: f"{v:.2e}" for k, v in errs.items()})
+
+    def upstream(o):
+        c, d_ = O.aux_losses(o, N)
+        return (o[0] * Rv.cpu()).sum() + c + 1e-8 * d_
+
+    signs = device_logit_signs(m, L.make_dims(B, N, 15, D, 300, 3), (B, N, 3))
+    oo, gin, gw, dbg, stats = aligned_oracle_backward(sd, ti, 3, None, upstream, signs)
+    errs = {"vis": rel_err(outs[0].detach().cpu(), oo[0]), "aq_embed": rel_err(outs[1].detach().cpu(), oo[1]),
+            "com_app2": rel_err(outs[3][2].detach().cpu(), oo[3][2]), "mq_fusion2": rel_err(outs[6][2].detach().cpu(), oo[6][2])}
+    print(f"  {dtype} forward:", {k: f"{v:.2e}" for k, v in errs.items()})
     assert max(errs.values()) < TOL, errs
-    gerrs = {k: rel_err(t[k].grad.cpu(), ti[k].grad) for k in ("A", "M", "dq", "words")}
-    print("  input grads:", {k: f"{v:.2e}" for k, v in gerrs.items()})
-    assert max(gerrs.values()) < GTOL, gerrs
-    werrs = {}
-    for k, p in m.named_parameters():
-        if k.endswith(".fc.bias"):
-            continue
-        want = sd[k].grad
-        werrs[k] = float((p.grad.cpu() - want).abs().max()) / max(float(want.abs().max()), 1e-3)
-    worst = sorted(werrs.items(), key=lambda kv: -kv[1])[:6]
-    print("  worst weight grads:", [(k, f"{v:.2e}") for k, v in worst])
-    assert worst[0][1] < GTOL, worst
+    assert_flips_at_kink(stats, f"C2 {dtype}")
+    assert_grads(m, t, gin, gw, dbg, 3, GTOL, f"C2 {dtype}")
     # ---- properties ---------------------------------------------------------------------------
     with torch.no_grad():
         base = m(t["A"], t["M"], t["dq"], t["words"], t["qlen"])
@@ -321,8 +314,9 @@ def test_bf16x3_meets_the_fp32_parity_gate(name):
                        float(np.abs(np.resize(g.flatten()[:8].numpy(), 8) - z["gw_head"][i]).max()) / (float(np.abs(z["gw_head"][i]).max()) + 1e-2))
     worst = sorted(werrs.items(), key=lambda kv: -kv[1])[:6]
     print("  bf16x3 worst weight grads:", [(k, f"{v:.2e}") for k, v in worst])
-    # the scalar a.bias gradients are sums of B*N*N signed terms that cancel to ~1e-3 of their magnitude
-    # (exact fp32 already shows 2.5e-4 on them): they get 4x the tolerance, everything else the plain one
+    # the scalar a.bias gradients are sums of B*N*N signed terms that cancel to ~1e-3 of their magnitude: against the
+    # golden (plain metric) they are only sanity-checked here; test_other_graph_sizes / test_full_size / test_hip_configs
+    # measure them against their cancellation scale (helpers.assert_grads, 1e-5 of the sum of absolute terms)
     assert max(v for k, v in werrs.items() if not k.endswith(".a.bias")) < GTOL, worst
     assert max(v for k, v in werrs.items() if k.endswith(".a.bias")) < 4 * GTOL, worst
 
@@ -350,38 +344,38 @@ def test_bf16_operands_stated_tolerance():
 def test_other_graph_sizes_against_oracle(N, D, Lr, B, T, dtype):
     """Clip counts / depths of the other BASELINE.json configs (N = 8, 16, 64; L up to 6), an odd N, and the corners
     (one sample with a one-word question; the largest graph at full width with a long question; a batch wider than
-    one 128-row tile of two-clip graphs), forward + backward against the factorised oracle on the same seeded inputs."""
+    one 128-row tile of two-clip graphs), forward + backward against the oracle on the same seeded inputs.  Both operand
+    modes are held to the SAME gates (1e-4 forward, 5e-4 gradients); the discontinuous LeakyReLU derivative is handled
+    by counting the logits that sit on the other side of the kink and aligning the oracle's branch on exactly those
+    (helpers.aligned_oracle_backward)."""
     Wd = 300 if D == 768 else 32
     sd_np = synth.xavier_state_dict(O.param_shapes(Wd, D, Lr), seed=11, bias_range=0.1)
     inp = synth.unit_inputs(B, N, T, D, Wd, seed=11)
     m = dv.DualVGRUnit_multiple(word_dim=Wd, module_dim=D, num_of_nodes=N, unit_layers=Lr, dtype=dtype)
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
     m = m.cuda().eval()
+    m.keep_saved = True
     t = {k: torch.from_numpy(v.copy()).cuda() for k, v in inp.items()}
     for k in ("A", "M", "dq", "words"):
         t[k].requires_grad_(True)
     outs = m(t["A"], t["M"], t["dq"], t["words"], t["qlen"])
-    Rv = torch.from_numpy(synth.normal("Rv", (B, N, D), 1.0, 11)).cuda()
-    (outs[0] * Rv).sum().add(sum((x * Rv).sum() for x in outs[3] + outs[6])).backward()
+    Rv = torch.from_numpy(synth.normal("Rv", (B, N, D), 1.0, 11))
+
+    def upstream(o, R):
+        return (o[0] * R).sum() + sum((x * R).sum() for x in list(o[3]) + list(o[6]))
+
+    upstream(outs, Rv.cuda()).backward()
     torch.cuda.synchronize()
-    sd = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in sd_np.items()}
+    sd = {k: torch.from_numpy(v.copy()) for k, v in sd_np.items()}
     ti = {k: torch.from_numpy(v.copy()) for k, v in inp.items()}
-    for k in ("A", "M", "dq", "words"):
-        ti[k].requires_grad_(True)
-    oo = O.unit_forward(sd, ti["A"], ti["M"], ti["dq"], ti["words"], ti["qlen"], Lr, 1, naive=False)
-    (oo[0] * Rv.cpu()).sum().add(sum((x * Rv.cpu()).sum() for x in oo[3] + oo[6])).backward()
-    errs = [rel_err(outs[0].detach().cpu(), oo[0].detach()), rel_err(outs[2].detach().cpu(), oo[2].detach()),
-            rel_err(outs[4][-1].detach().cpu(), oo[4][-1].detach())]
-    gerrs = [rel_err(t[k].grad.cpu(), ti[k].grad) for k in ("A", "M", "dq", "words")]
-    werr = max(float((p.grad.cpu() - sd[k].grad).abs().max()) / max(float(sd[k].grad.abs().max()), 1e-3)
-               for k, p in m.named_parameters() if not k.endswith(".fc.bias") and not k.endswith(".a.bias"))
-    print(f"  N={N} D={D} L={Lr} {dtype}: fwd {max(errs):.2e} gin {max(gerrs):.2e} gw {werr:.2e}")
-    # The forward is continuous in its inputs: both modes meet the 1e-4 gate.  The backward is not: the gradient
-    # of LeakyReLU(u_i + v_j + c) jumps at 0, and a logit that sits within ~1e-5 of the kink can take the other
-    # branch under bf16x3's ~1e-5 operand error (seen at N=16, L=6, T=5: a handful of entries flip and move single
-    # gradients by up to 1e-2, while plain bf16 moves them by O(1)).  Exact fp32 keeps the tight gradient bound.
-    gtol = GTOL if dtype == "fp32" else 2e-2
-    assert max(errs) < TOL and max(gerrs) < gtol and werr < gtol
+    signs = device_logit_signs(m, L.make_dims(B, N, T, D, Wd, Lr), (B, N, Lr))
+    oo, gin, gw, dbg, stats = aligned_oracle_backward(sd, ti, Lr, None, lambda o: upstream(o, Rv), signs)
+    errs = [rel_err(outs[0].detach().cpu(), oo[0]), rel_err(outs[2].detach().cpu(), oo[2]),
+            rel_err(outs[4][-1].detach().cpu(), oo[4][-1])]
+    print(f"  N={N} D={D} L={Lr} {dtype}: fwd {max(errs):.2e}")
+    assert max(errs) < TOL
+    assert_flips_at_kink(stats, f"N={N} D={D} L={Lr} {dtype}")
+    assert_grads(m, t, gin, gw, dbg, Lr, GTOL, f"N={N} D={D} L={Lr} {dtype}")
 
 
 @pytest.mark.parametrize("train", [False, True])

@@ -57,7 +57,14 @@ def _worker(rank, world, port, q):
         assert buckets[0] == m.layer_param_range(LR) and buckets[-1] == m.layer_param_range(0)
         assert sorted(buckets)[0][0] == 0 and sorted(buckets)[-1][1] == flat.numel()
         flat2 = flat.clone()
-        parallel.LayerBucketReducer(buckets).reduce(flat)
+        one_shot = parallel.LayerBucketReducer(buckets)
+        assert one_shot._layer_order() == [LR] + list(range(LR - 1, -1, -1))     # bucket i <-> layer-indexed event
+        try:
+            one_shot.reduce(flat, [None] * LR)                                   # L + 1 layer-indexed events expected
+            raise AssertionError("a short event list must be refused")
+        except ValueError:
+            pass
+        one_shot.reduce(flat, [None] * (LR + 1))
         # the same reduction driven bucket by bucket, in the order the backward's host callback fires (L, L-1, .., 0)
         red = parallel.LayerBucketReducer(buckets)
         red.start(LR)

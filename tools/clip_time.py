@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times the appearance encoder (forward + backward, training mode) at a bench shape: the HIP ClipEncoder against the
-stock nn.LSTM wrapper (MIOpen) of dualvgr_videoqa_amd.model.  usage: python tools/clip_time.py [B N T V D dtype]"""
+stock nn.LSTM wrapper (MIOpen) of tools/stock_encoders.py.  usage: python tools/clip_time.py [B N T V D dtype]"""
 import os
 import sys
 import time
@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 import dualvgr_videoqa_amd as dv
-from dualvgr_videoqa_amd.model import VisualAppearanceEncoder
+from tools.stock_encoders import VisualAppearanceEncoder
 
 a = sys.argv[1:]
 B, N, T, V, D = [int(v) for v in (a[:5] if len(a) >= 5 else (64, 20, 16, 2048, 768))]
@@ -34,5 +34,5 @@ hip = dv.ClipEncoder(V, D, dtype=dtype).cuda()
 print(f"shape B={B} N={N} T={T} V={V} D={D} dtype={dtype}")
 print(f"hip ClipEncoder      : {run(hip):8.3f} ms / step (fwd+bwd)")
 if os.environ.get("CLIP_STOCK", "1") == "1":
-    stock = VisualAppearanceEncoder(V, D, impl="miopen").cuda() if "impl" in VisualAppearanceEncoder.__init__.__code__.co_varnames else VisualAppearanceEncoder(V, D).cuda()
+    stock = VisualAppearanceEncoder(V, D).cuda()
     print(f"nn.LSTM (MIOpen)     : {run(stock):8.3f} ms / step (fwd+bwd)")
