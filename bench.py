@@ -1,18 +1,29 @@
 #!/usr/bin/env python3
 """Benchmark of the DualVGR reasoning unit on MI355X: QA-pairs/sec (forward+backward) per GPU,
 SVQA num_clips=20 (BASELINE.json).  One step = one forward + one backward of the stacked unit
-over one batch of synthetic inputs already resident in HBM (training mode, dropout on).
+over one batch of synthetic inputs already resident in HBM (training mode, dropout on), with the
+scope-U loss and its gradients evaluated inside the step.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]           # N > 1 via torch.distributed.run
+    python bench.py [--gpus N] [--steps K] [--warmup W]
 
-Prints ONE JSON line on rank 0 (contract in the task statement): whole-job QA-pairs/s, the
-roofline of the dominant kernel (forward GAT projection GEMM, timed live with HIP events on the
-launch stream) and the CPU baseline (the oracle's op-for-op PyTorch-CPU restatement of the
-reference, timed on this box's host cores, rank 0 at N = 1 only).
+N > 1: one process per GPU over RCCL.  Under `python -m torch.distributed.run ... bench.py --gpus N` the ranks read
+RANK / LOCAL_RANK / WORLD_SIZE from the environment; started plainly (`python bench.py --gpus N`) the parent process --
+before it makes any GPU call -- launches exactly that torchrun command as a child and relays rank 0's JSON line.  A run
+whose world size differs from --gpus fails; it never silently measures fewer GPUs.
+
+Timing: W untimed warm-up steps, then blocks of EXACTLY K steps, each bracketed by barrier + device synchronise on both
+sides and MAX-reduced over ranks; blocks repeat until >= 1 s has been timed and the line reports the MEDIAN block
+(`value` = world * B * K / median block time).  Rank 0 prints ONE JSON line: whole-job QA-pairs/s, the roofline of the
+dominant kernel (the forward GAT projection contraction, timed live with HIP events on its launch stream), the optimiser
+(clip + Adam) time reported separately, and the CPU baseline (the oracle's op-for-op PyTorch-CPU restatement of the
+reference in training mode, on this box's host cores; rank 0 at N = 1 only).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,8 +33,6 @@ if ROOT not in sys.path:
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
-import torch
-import torch.distributed as dist
 
 # BASELINE.json `configs` (per-GPU batch; D = 768, Wd = 300, T = 15 as in SURVEY.md section 8)
 CONFIGS = {
@@ -35,6 +44,8 @@ CONFIGS = {
 }
 D, WD = 768, 300
 PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0}     # /opt/skills/guides/MI355X_MICROARCH.md, dense MFMA
+MIN_TIMED_S = 1.0
+MAX_BLOCKS = 200
 
 
 def f_fwd(N, L, T):
@@ -42,11 +53,37 @@ def f_fwd(N, L, T):
     return L * (16 * N * D * D + 2 * T * D * D + 8 * N * N * D + 28 * N * D + 2 * T * D + 2 * T * WD + 4 * WD * D) + 2560 * N * D
 
 
+def build_id():
+    """sha256 over the kernel sources: ties a PMC record under profiles/ to THIS build."""
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "dualvgr-videoqa_amd", "csrc")
+    for fn in sorted(os.listdir(src)):
+        if fn.endswith((".hip", ".h")):
+            h.update(fn.encode())
+            h.update(open(os.path.join(src, fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_record(config, dtype, train):
+    """HBM traffic / MFMA-pipe counters of the probed kernel from the rocprofv3 --pmc passes of THIS build
+    (tools/pmc_collect.py writes profiles/pmc_<config>_<dtype>.json); None when there is no record for this build."""
+    path = os.path.join(ROOT, "profiles", f"pmc_{config}_{dtype}.json")
+    try:
+        rec = json.load(open(path))
+    except Exception:
+        return None
+    if rec.get("build") != build_id() or bool(rec.get("train", True)) != bool(train):
+        return None
+    return rec
+
+
 def cpu_baseline(cfg, seconds=15.0):
-    """Reference CPU path (oracle = op-for-op port, kind 'port') on the host cores: forward+backward
-    of the unit at the benchmark's N / L / T on a bounded sample of the batch."""
+    """Reference CPU path (oracle = op-for-op port, kind 'port') on the host cores: forward+backward of the unit at the
+    benchmark's N / L / T on a bounded sample of the batch, in TRAINING mode like the GPU step (dropout keep-masks injected,
+    generated outside the timed region: the reference draws them with torch's RNG inside)."""
+    import torch
     from oracle import unit_torch as O          # test infrastructure, used only as the timed baseline
-    from dualvgr_videoqa_amd import synth
+    from dualvgr_videoqa_amd import dropout, synth
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
@@ -57,7 +94,7 @@ def cpu_baseline(cfg, seconds=15.0):
           synth.xavier_state_dict(O.param_shapes(WD, D, cfg["L"]), seed=666).items()}
     inp = synth.unit_inputs(Bs, cfg["N"], cfg["T"], D, WD, seed=666)
     t = {k: torch.from_numpy(v) for k, v in inp.items()}
-    masks = None
+    masks = {k: torch.from_numpy(v) for k, v in dropout.site_masks(666, Bs, cfg["N"], D, cfg["L"]).items()}
 
     def step():
         for p in sd.values():
@@ -96,9 +133,66 @@ def cpu_baseline(cfg, seconds=15.0):
     except Exception:
         pass
     return {"value": Bs / dt, "unit": "QA-pairs/s", "cores": cores, "kind": "port",
-            "sample": f"B={Bs} of the {cfg['B']}-pair batch, N={cfg['N']} L={cfg['L']} T={cfg['T']} fp32 eval-mode "
-                      f"forward+backward, naive (B,N,N,2F) form, 2 warm-up + {n} timed steps, {dt * 1e3:.1f} ms/step, "
-                      f"{cores} threads on {model}"}
+            "sample": f"B={Bs} of the {cfg['B']}-pair batch, N={cfg['N']} L={cfg['L']} T={cfg['T']} fp32 TRAINING-mode "
+                      f"forward+backward (keep-masks injected), naive (B,N,N,2F) form, 2 warm-up + {n} timed steps, "
+                      f"{dt * 1e3:.1f} ms/step, {cores} threads on {model}; in the build container (8 cores) this port "
+                      f"times within +-5 % of the imported reference itself (DESIGN.md section 6)"}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """Parent of a plain `python bench.py --gpus N`: start N ranks with torchrun as a CHILD process (this process has made no
+    GPU call and makes none), relay their output, exit with the child's code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] starting", n, "ranks:", " ".join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:
+        out = out.rstrip("\n")
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+        else:
+            print(out, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if rc != 0 or line is None:
+        raise SystemExit(f"bench.py --gpus {n}: the rank processes failed (exit code {rc}); no result line")
+    print(line, flush=True)
+    return 0
+
+
+def timed_blocks(step, K, ddp, dev, min_seconds=MIN_TIMED_S):
+    """Blocks of exactly K steps, barrier + synchronise on both sides, MAX over ranks; repeated until min_seconds."""
+    import torch
+    import torch.distributed as dist
+    blocks = []
+    total = 0.0
+    while True:
+        if ddp:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(K):
+            step(i)
+        torch.cuda.synchronize()
+        if ddp:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if ddp:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        blocks.append(dt)
+        total += dt
+        if total >= min_seconds or len(blocks) >= MAX_BLOCKS:       # dt is identical on every rank: all ranks stop together
+            return blocks
 
 
 def main():
@@ -114,36 +208,48 @@ def main():
     ap.add_argument("--eval-mode", action="store_true", help="dropout off (default: training mode, dropout on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--min-seconds", type=float, default=MIN_TIMED_S, help="keep timing K-step blocks until this much is timed")
     ap.add_argument("--probe", default="fwd_gat_gemm")
     ap.add_argument("--head", action="store_true",
                     help="row f2: also run the clip read-out + classifier (AnswerHead, 1000 answers) and a cross-entropy "
                          "loss on its logits inside every step; the unit then gets d CE / d vis instead of ones")
     ap.add_argument("--model", action="store_true",
-                    help="row f3: the whole DualVGR model -- appearance BiLSTM, unit and answer head on HIP, question BiLSTMs "
-                         "and the motion Linear on stock PyTorch-ROCm (MIOpen, hipBLASLt) -- on raw (B, N, 16, 2048) / "
-                         "(B, N, 2048) features, cross-entropy + auxiliary losses, forward + backward")
+                    help="scope M: the whole DualVGR training step of train.py:139-159 (encoders, unit, head, CE + auxiliary "
+                         "losses, backward, clip 12, Adam) on raw (B, N, 16, 2048) / (B, N, 2048) features")
     ap.add_argument("--question-encoder", default="hip", choices=["hip", "miopen"],
-                    help="with --model: the two packed question BiLSTMs on this package's HIP path (default) or on nn.LSTM / MIOpen")
+                    help="with --model, A/B timing: swap tools/stock_encoders.py's nn.LSTM question encoder in")
     ap.add_argument("--appearance-encoder", default="hip", choices=["hip", "miopen"],
-                    help="with --model: the appearance BiLSTM on this package's HIP path (default) or on nn.LSTM / MIOpen")
+                    help="with --model, A/B timing: swap tools/stock_encoders.py's nn.LSTM appearance encoder in")
     ap.add_argument("--loss", default="fused", choices=["fused", "fused-after", "precomputed"],
                     help="fused: the scope-U loss and its gradients are computed inside every timed step by "
                          "dvgr_scope_u_loss; precomputed: fixed upstream gradients (unit kernels only)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args.gpus)            # nothing above touched the GPU
+
+    import torch
+    import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to measure a different number of GPUs")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (there is no CPU fallback of the product path)")
-    local = min(local, torch.cuda.device_count() - 1)          # (testing aid: several ranks may share one GPU with gloo)
+    if os.environ.get("DVGR_BENCH_SHARE_GPU", "0") == "1":       # testing aid: several gloo ranks on one GPU
+        local = min(local, torch.cuda.device_count() - 1)
+    elif local >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPUs are visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # DVGR_DDP_SELFTEST=1: run the data-parallel plumbing (process group, per-layer buckets gated by the library's events,
     # communication stream) with a single rank, to check it on a one-GPU box
     ddp = world > 1 or os.environ.get("DVGR_DDP_SELFTEST", "0") == "1"
+    dist_info = None
     if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -154,18 +260,26 @@ def main():
             dist.init_process_group("nccl", device_id=dev, pg_options=opts)
         else:
             dist.init_process_group(args.backend)
+        if dist.get_world_size() != args.gpus and world > 1:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
+        ver = None
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            pass
+        dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": ver}
 
     import dualvgr_videoqa_amd as dv
     from dualvgr_videoqa_amd import _lib as L_
-    from dualvgr_videoqa_amd import losses, parallel, synth
+    from dualvgr_videoqa_amd import losses, parallel, synth, trainer
 
     cfg = CONFIGS[args.config]
     B, N, Lr, T = cfg["B"], cfg["N"], cfg["L"], cfg["T"]
     if args.model:
-        bench_model(args, dev, rank, world, cfg)
+        bench_model(args, dev, rank, world, cfg, ddp, dist_info)
         if ddp:
             dist.destroy_process_group()
-        return
+        return 0
     shapes = {n: s for n, s, _ in dv.param_table(L_.make_dims(1, N, 1, D, WD, Lr))}
     sd_np = synth.xavier_state_dict(shapes, seed=666)          # same weights on every rank (as after a broadcast)
     m = dv.DualVGRUnit_multiple(word_dim=WD, module_dim=D, num_of_nodes=N, unit_layers=Lr, dtype=args.dtype)
@@ -173,6 +287,7 @@ def main():
     m = m.to(dev)
     m.train(not args.eval_mode)
     if args.loss == "fused":
+        # every rank's losses are means over its shard; the batch-SUM HSIC term is scaled by world under averaging
         m.loss_in_forward = (1.0, 1e-8, float(world), not args.head)
     head = None
     if args.head:
@@ -188,16 +303,16 @@ def main():
     for k in ("A", "M", "dq", "words"):
         t[k].requires_grad_(True)                              # the encoders upstream need these gradients
 
-    # upstream gradients of every output: the true gradient of the scope-U loss
-    # sum(vis) + common + 1e-8 * HSIC at the first forward, held fixed for the timed
-    # steps (the auxiliary-loss arithmetic is caller code, not the path: SURVEY.md 8f row f1)
-    raw = m.forward_raw(t["A"], t["M"], t["dq"], t["words"], t["qlen"])
-    det = [r.detach().clone().requires_grad_(True) for r in raw]
-    loss0 = losses.scope_u_loss((det[0], det[1], det[2], list(det[3].unbind(0)), list(det[4].unbind(0)),
-                                 list(det[5].unbind(0)), list(det[6].unbind(0))), N, world_size=world)
-    ups = list(torch.autograd.grad(loss0, det, allow_unused=True))
-    ups = [u if u is not None else torch.zeros_like(r) for u, r in zip(ups, raw)]
-    del raw, det, loss0
+    ups = None
+    if args.loss == "precomputed":
+        # upstream gradients of every output: the true gradient of the scope-U loss at the first forward, held fixed
+        raw = m.forward_raw(t["A"], t["M"], t["dq"], t["words"], t["qlen"])
+        det = [r.detach().clone().requires_grad_(True) for r in raw]
+        loss0 = losses.scope_u_loss((det[0], det[1], det[2], list(det[3].unbind(0)), list(det[4].unbind(0)),
+                                     list(det[5].unbind(0)), list(det[6].unbind(0))), N, world_size=world)
+        ups = list(torch.autograd.grad(loss0, det, allow_unused=True))
+        ups = [u if u is not None else torch.zeros_like(r) for u, r in zip(ups, raw)]
+        del raw, det, loss0
 
     events = None
     reducer = None
@@ -209,10 +324,10 @@ def main():
         # each bucket's all-reduce is enqueued from inside the backward call, right after its event (dvgr_opts.layer_done_cb)
         m.set_layer_callback(lambda idx, g: reducer.launch(idx, g, events[idx]))
 
-    probe_sites = {"fwd_gat_gemm": (L_.PROBE_FWD_GAT_GEMM, 8 * B * N * D * D, "gemm_planes_kernel<KC,KC,TAG_FWD_GAT=1,TERMS> / gemm_ring_kernel<KC,KC,1,F32> (Wh = X.Wcat^T, both modalities)"),
-                   "fwd_sf_gemm": (L_.PROBE_FWD_SF_GEMM, 8 * B * N * D * D, "gemm_kernel<KC,KC,*,*,TAG_FWD_SF=2>"),
-                   "bwd_gat_dw": (L_.PROBE_BWD_GAT_DW, 8 * B * N * D * D, "gemm_kernel<IC,IC,*,*,TAG_BWD_GAT_DW=3>"),
-                   "bwd_gat_dx": (L_.PROBE_BWD_GAT_DX, 8 * B * N * D * D, "gemm_kernel<KC,IC,*,*,TAG_BWD_GAT_DX=4>")}
+    probe_sites = {"fwd_gat_gemm": (L_.PROBE_FWD_GAT_GEMM, 8 * B * N * D * D, "S2 forward GAT projection Wh = X.Wcat^T, both modalities (TAG_FWD_GAT)"),
+                   "fwd_sf_gemm": (L_.PROBE_FWD_SF_GEMM, 8 * B * N * D * D, "S4 forward tanh(z.P1^T), 2 views x 2 modalities (TAG_FWD_SF)"),
+                   "bwd_gat_dw": (L_.PROBE_BWD_GAT_DW, 8 * B * N * D * D, "dWcat = dWh^T.X (TAG_BWD_GAT_DW)"),
+                   "bwd_gat_dx": (L_.PROBE_BWD_GAT_DX, 8 * B * N * D * D, "dX += dWh.Wcat (TAG_BWD_GAT_DX)")}
     site, probe_flops, probe_name = probe_sites[args.probe]
     # layer 0's Wh contraction shares the chip with the query-side chain on the side stream; layer 1's runs alone
     probe_layer = min(1, Lr - 1)
@@ -252,21 +367,23 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if ddp:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    if ddp:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if ddp:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    blocks = timed_blocks(step, args.steps, ddp, dev, args.min_seconds)
     m.set_probe(0)
+    dt = float(np.median(blocks))
+
+    # the optimiser of train.py:158-159 over the unit's flat buffers (clip 12 + Adam, two launches), reported separately:
+    # the headline metric is forward + backward
+    opt = trainer.ClipAdam(lr=1e-4, max_norm=12.0)
+    seg = [("unit", m.flat_params(), m.last_flat_grad, m.lowp_planes())]
+    for _ in range(3):
+        opt.step(seg)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        opt.step(seg)
+    e1.record()
+    torch.cuda.synchronize()
+    optimizer_ms = e0.elapsed_time(e1) / 20
 
     ms_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt
@@ -274,10 +391,7 @@ def main():
     achieved = probe_flops / (probe_ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[args.dtype]
     f_train = 3 * f_fwd(N, Lr, T)
-    # HBM bytes per launch of the probed kernel from PMC (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, separate
-    # passes; profiles/r01_v8_bf16x3_c2_pmc_hbm.txt): measured for this one configuration only
-    traffic = 90.0e6 if (args.config == "c2" and args.dtype == "bf16x3" and args.probe == "fwd_gat_gemm"
-                         and not args.eval_mode) else None
+    pmc = pmc_record(args.config, args.dtype, not args.eval_mode) if args.probe == "fwd_gat_gemm" else None
     out = {
         "metric": "QA-pairs/sec (forward+backward) per GPU, SVQA num_clips=20",
         "value": value, "unit": "QA-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -290,29 +404,39 @@ def main():
                    "loss": ("sum(vis)+common+1e-8*HSIC evaluated with its gradients inside every timed step "
                             "(fused HIP kernels, dvgr_opts.loss / dvgr_scope_u_loss)") if args.loss.startswith("fused") else
                            "upstream gradients of sum(vis)+common+1e-8*HSIC for all 3+4L outputs, precomputed once",
+                   "timing": {"blocks": len(blocks), "steps_per_block": args.steps, "timed_s": float(sum(blocks)),
+                              "ms_per_step_min_median_max": [min(blocks) / args.steps * 1e3, ms_step, max(blocks) / args.steps * 1e3]},
+                   "optimizer_ms": optimizer_ms,
+                   "optimizer": "clip_grad_norm_(12) + Adam over the unit's flat parameter / gradient buffers, two fused launches "
+                                "(dvgr_optim_*), OUTSIDE the timed step",
+                   "distributed": dist_info,
                    "algorithmic_gflop_per_qa_train": f_train / 1e9,
                    "unit_tflops": value / world * f_train / 1e12,
                    "unit_frac_of_mfma_peak": value / world * f_train / 1e12 / peak},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                     "traffic": traffic, "kernel": probe_name, "launch_ms": probe_ms,
-                     "algorithmic_gflop_per_launch": probe_flops / 1e9,
-                     # SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GRBM_GUI_ACTIVE per XCD of this kernel, collected with
-                     # rocprofv3 --pmc at C2; not re-measured by this run
-                     "mfma_pipe_busy_pmc": ({"bf16x3": 0.20, "fp32": 0.55}.get(args.dtype)
-                                            if args.config == "c2" and args.probe == "fwd_gat_gemm" else None)},
+                     # HBM bytes per launch of the probed kernel (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes) and the
+                     # MFMA pipe's busy share, from the rocprofv3 record of THIS build under profiles/ -- null without one
+                     "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
+                     "mfma_pipe_busy_pmc": pmc.get("mfma_busy") if pmc else None,
+                     "pmc_source": pmc.get("source") if pmc else None,
+                     "kernel": probe_name, "launch_ms": probe_ms,
+                     "algorithmic_gflop_per_launch": probe_flops / 1e9, "build": build_id()},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if ddp:
         dist.destroy_process_group()
+    return 0
 
 
-def bench_model(args, dev, rank, world, cfg):
-    """Scope M: the whole model at the DualVGR.forward boundary (synthetic inputs as listed there)."""
+def bench_model(args, dev, rank, world, cfg, ddp, dist_info):
+    """Scope M: the whole training step at the DualVGR.forward boundary: trainer.TrainStep =
+    train.py:139-159 (forward, CE + auxiliary losses, backward, gradient averaging, clip 12, Adam)."""
+    import torch
     import dualvgr_videoqa_amd as dv
-    from dualvgr_videoqa_amd import synth
+    from dualvgr_videoqa_amd import parallel, synth
     B, N, Lr, T = cfg["B"], cfg["N"], cfg["L"], cfg["T"]
     V, FR, VQ, VA = 2048, 16, 4000, 1000
     vocab = {"question_token_to_idx": {str(i): i for i in range(VQ)}, "answer_token_to_idx": {str(i): i for i in range(VA)}}
@@ -324,8 +448,7 @@ def bench_model(args, dev, rank, world, cfg):
         use_stock_encoders(m, appearance=args.appearance_encoder == "miopen", question=args.question_encoder == "miopen")
     m.train(not args.eval_mode)
     m.overlap_encoders = os.environ.get("DVGR_NO_ENCODER_OVERLAP", "0") != "1"
-    unit, head = m.visual_input_unit, m._head
-    unit.loss_in_forward = (1.0, 1e-8, float(world), False)
+    unit = m.visual_input_unit
     app = torch.from_numpy(np.abs(synth.normal("b_app", (B, N, FR, V), 0.5, 666 + rank))).to(dev)
     mot = torch.from_numpy(np.abs(synth.normal("b_mot", (B, N, V), 0.5, 666 + rank))).to(dev)
     qlen = torch.from_numpy((3 + (synth.uniform("b_ql", (B,), 0.0, 1.0, 666 + rank) * (T - 2)).astype(np.int64)).clip(1, T)).to(dev)
@@ -334,45 +457,44 @@ def bench_model(args, dev, rank, world, cfg):
     q = q * (torch.arange(T, device=dev)[None, :] < qlen[:, None])
     answers = torch.from_numpy((synth.uniform("b_ans", (B,), 0.0, float(VA), 666 + rank)).astype(np.int64)).to(dev)
 
-    def step():
-        m.zero_grad(set_to_none=True)
-        logits, _, _, ca, cm, aq, mq = m(app, mot, q, qlen)
-        _, g_logits = head.cross_entropy(logits, answers, scale=1.0 / world)
-        _, g = unit.last_loss
-        torch.autograd.backward([logits, *ca, *cm, *aq, *mq],
-                                [g_logits, *g[3].unbind(0), *g[4].unbind(0), *g[5].unbind(0), *g[6].unbind(0)])
-        if world > 1:      # data parallel: one flattened all-reduce of every gradient (losses are already scaled by 1/world)
-            grads = [p.grad for p in m.parameters() if p.grad is not None]
-            flat = torch._utils._flatten_dense_tensors(grads)
-            dist.all_reduce(flat)
-            for gr, red in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
-                gr.copy_(red)
+    unit_red = param_red = None
+    if ddp:
+        # the unit's gradients: per-layer buckets launched from the backward's host callback; everything else: buckets of
+        # ordinary parameters launched from autograd's post-accumulate hooks -- both overlap the remaining backward
+        events = [torch.cuda.Event() for _ in range(Lr + 1)]
+        for ev in events:
+            ev.record()
+        unit.set_layer_events(events)
+        unit_red = parallel.LayerBucketReducer(parallel.layer_buckets(unit), device=dev)
+        param_red = parallel.ParamBucketReducer(parallel.model_param_buckets(m), device=dev)
+        unit_red.force = param_red.force = world == 1
+        unit.set_layer_callback(lambda idx, g: unit_red.launch(idx, g, events[idx]))
+    ts = dv.TrainStep(m, lr=1e-4, alpha=1.0, beta=1e-8, max_norm=12.0, world=world, unit_reducer=unit_red, param_reducer=param_red)
+    opt_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i=None):
+        ts.timing = {"begin": opt_ev[i][0], "end": opt_ev[i][1]} if i is not None else None
+        ts(app, mot, q, qlen, answers)
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    out = {"metric": "QA-pairs/sec (forward+backward) per GPU, whole model (scope M), SVQA num_clips=20",
+    blocks = timed_blocks(step, args.steps, ddp, dev, args.min_seconds)
+    dt = float(np.median(blocks))
+    optimizer_ms = float(np.mean([a.elapsed_time(b) for a, b in opt_ev]))
+    out = {"metric": "QA-pairs/sec (whole training step, scope M) per GPU, SVQA num_clips=20",
            "value": world * B * args.steps / dt, "unit": "QA-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": args.dtype, "data": "synthetic",
-           "config": {"workload": f"{cfg['name']}: whole DualVGR model forward+backward, per-GPU batch {B}, raw features "
-                                  f"(B,{N},{FR},{V}) + (B,{N},{V}), T={T}, vocab {VQ}/{VA}; appearance encoder on {args.appearance_encoder}, question encoder on {args.question_encoder}, unit + head on hip"}}
+           "config": {"workload": f"{cfg['name']}: whole DualVGR training step of train.py:139-159 (forward, CE + auxiliary losses, "
+                                  f"backward, clip 12, Adam 1e-4), per-GPU batch {B}, raw features (B,{N},{FR},{V}) + (B,{N},{V}), "
+                                  f"T={T}, vocab {VQ}/{VA}; appearance encoder on {args.appearance_encoder}, question encoder on "
+                                  f"{args.question_encoder}, unit + head on hip",
+                      "optimizer_ms": optimizer_ms, "forward_backward_ms": dt / args.steps * 1e3 - optimizer_ms,
+                      "timing": {"blocks": len(blocks), "steps_per_block": args.steps, "timed_s": float(sum(blocks))},
+                      "distributed": dist_info, "global_batch": world * B, "parallelism": f"dp{world}"}}
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

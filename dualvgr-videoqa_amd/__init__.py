@@ -9,6 +9,7 @@ from .unit import DualVGRUnit_multiple, param_table  # noqa: F401
 from .head import AnswerHead  # noqa: F401
 from .clip import ClipEncoder  # noqa: F401
 from .store import FeatureStore, VideoQAFlatLoader, write_flat  # noqa: F401
-from .model import DualVGR  # noqa: F401
+from .model import DualVGR, init_modules  # noqa: F401
+from .trainer import ClipAdam, TrainStep  # noqa: F401
 
 __version__ = "0.1.0"

@@ -92,7 +92,7 @@ class _LstmFn(torch.autograd.Function):
         seq = torch.empty((S, T, 2 * H), device=dev, dtype=torch.float32) if want_seq else None
         saved = torch.empty(lib.dvgr_clip_saved_bytes(C.byref(dims)), device=dev, dtype=torch.uint8)
         ws = mod.workspace(lib.dvgr_clip_workspace_bytes(C.byref(dims)), dev)
-        train = bool(mod.training)
+        train = bool(mod.training) and mod.dropout_enabled     # the only training-mode behaviour of the LSTM is dropout
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if train and flags else 0
         if mod.forced_seed is not None:
             seed = int(mod.forced_seed)
@@ -151,6 +151,7 @@ class BiLSTM(nn.Module):
             shape = (4 * H, V) if "weight_ih" in name else (4 * H, H) if "weight_hh" in name else (4 * H,)
             setattr(self, name, nn.Parameter(torch.empty(shape).uniform_(-k, k)))
         self.forced_seed = None
+        self.dropout_enabled = True   # False: training mode without the dropout sites (deterministic step comparisons)
         self.last_seed = 0
         self._plist = [getattr(self, n) for n in CP_NAMES]
         self._table = None

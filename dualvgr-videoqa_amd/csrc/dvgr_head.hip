@@ -315,9 +315,11 @@ int dvgr_head_forward(const dvgr_head_dims* dp, const float* params, const dvgr_
   const HeadSaved S = head_saved(d);
   float* sv = (float*)saved_v;
   const int B = d.B, N = d.N, D = d.D, C = d.C, BN = B * N, prec = d.dtype;
+  const int drop = (train & 1) && !(train & DVGR_HEAD_TRAIN_NO_DROPOUT);   // the three nn.Dropout(0.15) sites
+  const int bn_train = train & 1;                                         // BatchNorm1d: batch statistics + running update
   // read-out
   const float* xd = io->vis;
-  if (train) {
+  if (drop) {
     HEAD_TRY(head_drop(st, io->vis, sv + S.xd, head_key(1, seed, 0), (int64_t)BN, D, D));
     xd = sv + S.xd;
   }
@@ -326,10 +328,10 @@ int dvgr_head_forward(const dvgr_head_dims* dp, const float* params, const dvgr_
   HEAD_LAUNCH_OK();
   // classifier
   HEAD_TRY(launch1(st, KC, KC, nt(io->qe, D, params + P.wq, D, sv + S.cat + D, 2 * D, params + P.bq, B, D, D, ACT_NONE), prec));
-  if (train) HEAD_TRY(head_drop(st, sv + S.cat, sv + S.cat, head_key(1, seed, 1), B, 2 * D, 2 * D));
+  if (drop) HEAD_TRY(head_drop(st, sv + S.cat, sv + S.cat, head_key(1, seed, 1), B, 2 * D, 2 * D));
   HEAD_TRY(launch1(st, KC, KC, nt(sv + S.cat, 2 * D, params + P.w1, 2 * D, sv + S.he, D, params + P.b1, B, D, 2 * D, ACT_ELU), prec));
   hipLaunchKernelGGL(k_bn_fwd, dim3((D + 63) / 64), dim3(64), 0, st, sv + S.he, params + P.gamma, params + P.beta, io->run_mean,
-                     io->run_var, sv + S.mean, sv + S.istd, sv + S.yd, head_key(train, seed, 2), B, D, train);
+                     io->run_var, sv + S.mean, sv + S.istd, sv + S.yd, head_key(drop, seed, 2), B, D, bn_train);
   HEAD_LAUNCH_OK();
   HEAD_TRY(launch1(st, KC, KC, nt(sv + S.yd, D, params + P.w2, D, io->logits, C, params + P.b2, B, C, D, ACT_NONE), prec));
   return 0;
@@ -352,7 +354,9 @@ int dvgr_head_backward(const dvgr_head_dims* dp, const float* params, const dvgr
   float* ws = (float*)ws_v;
   float* gp = g->gparams;
   const int B = d.B, N = d.N, D = d.D, C = d.C, BN = B * N, prec = d.dtype;
-  const float* xd = train ? sv + S.xd : io->vis;
+  const int drop = (train & 1) && !(train & DVGR_HEAD_TRAIN_NO_DROPOUT);
+  const int bn_train = train & 1;
+  const float* xd = drop ? sv + S.xd : io->vis;
   {
     const hipError_t e = hipMemsetAsync(gp, 0, (size_t)P.total * sizeof(float), st);
     if (e != hipSuccess) return (int)e;
@@ -367,7 +371,7 @@ int dvgr_head_backward(const dvgr_head_dims* dp, const float* params, const dvgr
   HEAD_TRY(launch1(st, KC, IC, nn(g->g_logits, C, params + P.w2, D, ws + W.dyd, D, B, D, C, 0), prec));
   // dropout 2, BatchNorm1d, ELU
   hipLaunchKernelGGL(k_bn_bwd, dim3((D + 63) / 64), dim3(64), 0, st, ws + W.dyd, sv + S.he, params + P.gamma, sv + S.mean,
-                     sv + S.istd, gp + P.gamma, gp + P.beta, ws + W.dpre1, head_key(train, seed, 2), B, D, train);
+                     sv + S.istd, gp + P.gamma, gp + P.beta, ws + W.dpre1, head_key(drop, seed, 2), B, D, bn_train);
   HEAD_LAUNCH_OK();
   if (side) HEAD_TRY(side->order(st, hs));                  // fork 1: gparams is zeroed, dpre1 final
   HEAD_TRY(launch1(hs, IC, IC, tn(g->g_logits, C, sv + S.yd, D, gp + P.w2, D, C, D, B), prec));
@@ -375,7 +379,7 @@ int dvgr_head_backward(const dvgr_head_dims* dp, const float* params, const dvgr
   cb.j[cb.n++] = ColsumJob{ws + W.dpre1, nullptr, nullptr, nullptr, B, 0, D, D, gp + P.b1};
   // he = ELU(cat W1^T + b1)
   HEAD_TRY(launch1(st, KC, IC, nn(ws + W.dpre1, D, params + P.w1, 2 * D, ws + W.dcat, 2 * D, B, 2 * D, D, 0), prec));
-  if (train) HEAD_TRY(head_drop(st, ws + W.dcat, ws + W.dcat, head_key(1, seed, 1), B, 2 * D, 2 * D));
+  if (drop) HEAD_TRY(head_drop(st, ws + W.dcat, ws + W.dcat, head_key(1, seed, 1), B, 2 * D, 2 * D));
   // question_proj: right half of dcat
   cb.j[cb.n++] = ColsumJob{ws + W.dcat + D, nullptr, nullptr, nullptr, B, 0, D, 2 * D, gp + P.bq};
   HEAD_TRY(launch1(st, KC, IC, nn(ws + W.dcat + D, 2 * D, params + P.wq, D, g->g_qe, D, B, D, D, 0), prec));
@@ -391,7 +395,7 @@ int dvgr_head_backward(const dvgr_head_dims* dp, const float* params, const dvgr
   cb.chunks = 8;
   HEAD_TRY(colsum(hs, cb));
   HEAD_TRY(launch1(st, KC, IC, nn(ws + W.dvp, D, params + P.wv, D, g->g_vis, D, BN, D, D, 1), prec));
-  if (train) HEAD_TRY(head_drop(st, g->g_vis, g->g_vis, head_key(1, seed, 0), (int64_t)BN, D, D));
+  if (drop) HEAD_TRY(head_drop(st, g->g_vis, g->g_vis, head_key(1, seed, 0), (int64_t)BN, D, D));
   if (side) HEAD_TRY(side->order(hs, st));                  // join
   return 0;
 }

@@ -20,6 +20,9 @@ from .unit import _Holder
  HP_KINDS) = range(12)
 
 
+HEAD_TRAIN_NO_DROPOUT = 2      # include/dvgr_head.h
+
+
 class HeadDims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("B", "N", "D", "C", "dtype")]
 
@@ -113,11 +116,12 @@ class _HeadFn(torch.autograd.Function):
             seed = int(mod.forced_seed)
         io = HeadIO(vis.data_ptr(), qe.data_ptr(), logits.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr())
         stream = torch.cuda.current_stream(dev).cuda_stream
+        tflag = int(train) | (0 if mod.dropout_enabled else HEAD_TRAIN_NO_DROPOUT)
         L_.check(lib.dvgr_head_forward(C.byref(dims), flat.data_ptr(), C.byref(io), saved.data_ptr(), saved.numel(), ws.data_ptr(),
-                                       ws.numel(), int(train), seed, stream), "dvgr_head_forward")
+                                       ws.numel(), tflag, seed, stream), "dvgr_head_forward")
         if train:
             bn.num_batches_tracked += 1
-        ctx.mod, ctx.dims, ctx.train, ctx.seed = mod, dims, train, seed
+        ctx.mod, ctx.dims, ctx.train, ctx.seed = mod, dims, tflag, seed
         ctx.save_for_backward(vis, qe, saved, flat)
         mod.last_logits_padded = logits
         return logits[:, :mod.num_answers]
@@ -161,6 +165,7 @@ class AnswerHead(nn.Module):
         self.feature_aggregation = _Readout(D)
         self.output_unit = _Classifier(D, self.num_answers)
         self.forced_seed = None
+        self.dropout_enabled = True    # False: training-mode BatchNorm with the dropout sites off (DVGR_HEAD_TRAIN_NO_DROPOUT)
         self.last_logits_padded = None
         cl = self.output_unit.classifier
         self._plist = [self.feature_aggregation.v_proj.weight, self.feature_aggregation.attn.weight,

@@ -63,8 +63,19 @@ class DualVGR(nn.Module):
         self.output_unit = head.output_unit
         object.__setattr__(self, "_head", head)
         self.overlap_encoders = True
+        self.last_raw = None
         init_modules(self)
         nn.init.uniform_(self.linguistic_input_unit.encoder_embed.weight, -1.0, 1.0)
+
+    def set_dropout_enabled(self, flag: bool):
+        """Training mode with every dropout site switched off (BatchNorm keeps using batch statistics): what a
+        deterministic comparison with the reference's training step needs (tests/golden/make_golden_step.py)."""
+        for m in self.modules():
+            if hasattr(m, "dropout_enabled"):
+                m.dropout_enabled = bool(flag)
+        self._head.dropout_enabled = bool(flag)
+        self.linguistic_input_unit.embedding_dropout.p = 0.15 if flag else 0.0
+        return self
 
     def _encoder_stream(self, dev):
         return _lib.streams(dev)["encoder"]
@@ -94,7 +105,9 @@ class DualVGR(nn.Module):
             question_embedding, word_embedding, dynamic_question_embedding = self.linguistic_input_unit(question, question_len)
             app = self.visual_appearance_input_unit(video_appearance_feat)
             mot = self.visual_motion_input_unit(video_motion_feat)
-        visual_embedding, aq_embed, mq_embed, com_app, com_motion, aq_fusion, mq_fusion = self.visual_input_unit(
-            app, mot, dynamic_question_embedding, word_embedding, question_len)
+        raw = self.visual_input_unit.forward_raw(app, mot, dynamic_question_embedding, word_embedding, question_len)
+        self.last_raw = raw                      # the four lists as the (L, B, N, D) tensors the kernels wrote (trainer.TrainStep)
+        visual_embedding, aq_embed, mq_embed = raw[0], raw[1], raw[2]
+        com_app, com_motion, aq_fusion, mq_fusion = (list(t.unbind(0)) for t in raw[3:])
         out = self._head(question_embedding, visual_embedding)
         return out, aq_embed, mq_embed, com_app, com_motion, aq_fusion, mq_fusion

@@ -152,3 +152,127 @@ def shard_batch(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     base, rem = divmod(n_items, world)
     first = rank * base + min(rank, rem)
     return first, first + base + (1 if rank < rem else 0)
+
+
+class ParamBucketReducer:
+    """Averages the gradients of ordinary nn.Parameters (the encoders and the answer head around the unit) across ranks,
+    one all-reduce per bucket, each launched as soon as the LAST gradient of its bucket has been accumulated -- while the
+    rest of the backward is still running (what torch's DistributedDataParallel does with its buckets; here on the same
+    helper-thread / high-priority-stream plumbing as LayerBucketReducer, and without wrapping the module).
+
+    buckets: lists of parameters, ideally in the order the backward finishes them (head first, encoders last).
+    Usage per step: start(); loss.backward(); finish()."""
+
+    def __init__(self, buckets: Sequence[Sequence[torch.nn.Parameter]], group=None, device: Optional[torch.device] = None):
+        self.buckets = [list(b) for b in buckets if len(b)]
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.stream = None
+        if device is not None and device.type == "cuda":
+            self.stream = torch.cuda.Stream(device=device, priority=-1)
+        self._bucket_of = {}
+        for bi, b in enumerate(self.buckets):
+            for p in b:
+                self._bucket_of[id(p)] = bi
+                p.register_post_accumulate_grad_hook(self._hook)
+        self._pending = None
+        self._active = False
+        self._error = None
+        self._q = None
+        self._events = []
+        self.force = False
+
+    # -- autograd thread --------------------------------------------------------------------------------------------------
+    def _hook(self, p):
+        if not self._active:
+            return
+        bi = self._bucket_of[id(p)]
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0:
+            self._bucket_ready(bi)
+
+    def _bucket_ready(self, bi):
+        if self.world == 1 and not self.force:
+            return
+        grads = [p.grad for p in self.buckets[bi] if p.grad is not None]
+        if not grads:
+            return
+        if grads[0].is_cuda and self.stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(grads[0].device))     # the stream this bucket's last gradient was produced on
+            self._events.append(ev)
+            self._q.put((grads, ev))
+        else:
+            self._done_cpu.append(grads)
+
+    # -- helper thread ----------------------------------------------------------------------------------------------------
+    def _reduce_now(self, grads, ev):
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ev)
+            flat = torch._utils._flatten_dense_tensors(grads)
+            w = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            w.wait()                                              # stream-ordered
+            flat.mul_(1.0 / self.world)
+            for g, red in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
+                g.copy_(red)
+                g.record_stream(self.stream)
+
+    def start(self) -> None:
+        self._pending = [sum(1 for p in b if p.requires_grad) for b in self.buckets]
+        self._done_cpu = []
+        self._events = []
+        self._error = None
+        self._active = True
+        if self.stream is not None and self._q is None:
+            import queue
+            import threading
+            self._q = queue.Queue()
+            dev = self.stream.device
+
+            def worker():
+                torch.cuda.set_device(dev)
+                while True:
+                    item = self._q.get()
+                    try:
+                        if item is None:
+                            return
+                        self._reduce_now(*item)
+                    except BaseException as e:
+                        self._error = e
+                    finally:
+                        self._q.task_done()
+
+            threading.Thread(target=worker, daemon=True).start()
+
+    def finish(self) -> None:
+        """After backward(): buckets whose parameters did not all receive a gradient are reduced now; then the current
+        stream waits for every collective."""
+        self._active = False
+        if self.world == 1 and not self.force:
+            return
+        for bi, left in enumerate(self._pending):
+            if left > 0:
+                self._pending[bi] = 0
+                self._bucket_ready(bi)
+        if self._q is not None:
+            self._q.join()
+        if self._error is not None:
+            err, self._error = self._error, None
+            raise err
+        for grads in self._done_cpu:                              # CPU / gloo path (tests): synchronous
+            flat = torch._utils._flatten_dense_tensors(grads)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            flat.mul_(1.0 / self.world)
+            for g, red in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
+                g.copy_(red)
+        if self.stream is not None and self._events:
+            torch.cuda.current_stream(self.stream.device).wait_stream(self.stream)
+
+
+def model_param_buckets(model) -> List[List[torch.nn.Parameter]]:
+    """Buckets of a DualVGR's non-unit parameters in the order its backward finishes them: answer head; motion Linear +
+    appearance encoder; question encoder (embedding included)."""
+    head = list(model.feature_aggregation.parameters()) + list(model.output_unit.parameters())
+    visual = list(model.visual_motion_input_unit.parameters()) + list(model.visual_appearance_input_unit.parameters())
+    ling = list(model.linguistic_input_unit.parameters())
+    return [head, visual, ling]

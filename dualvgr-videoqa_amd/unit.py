@@ -162,7 +162,7 @@ class _UnitFn(torch.autograd.Function):
         lists = [torch.empty((Lr, B, N, D), device=dev, dtype=torch.float32) for _ in range(4)]
         saved = torch.empty(lib.dvgr_saved_bytes(C.byref(dims)), device=dev, dtype=torch.uint8)
         ws = mod.workspace(lib.dvgr_workspace_bytes(C.byref(dims)), dev)
-        train = bool(mod.training)
+        train = bool(mod.training) and mod.dropout_enabled     # the unit's only training-mode behaviour is dropout
         seed = mod._next_seed() if train else 0
         if mod.forced_seed is not None:
             seed = int(mod.forced_seed)
@@ -304,6 +304,7 @@ class DualVGRUnit_multiple(nn.Module):
         self._backward_gflat = None
         self.no_planes = False       # diagnostics: bf16 modes convert inside the contraction kernels instead
         self.forced_seed = None      # tests: fix the dropout seed of the next forward
+        self.dropout_enabled = True  # False: training mode without the 24 dropout sites per layer
         self.keep_saved = False      # tests: keep a handle on the saved-for-backward buffer
         self.single_stream = bool(int(os.environ.get("DVGR_SINGLE_STREAM", "0")))   # DVGR_OPT_SINGLE_STREAM
         # (alpha, beta, dep_scale[, with_sum_vis = True]) or None: when set, forward_raw() also evaluates the scope-U loss
@@ -415,6 +416,20 @@ class DualVGRUnit_multiple(nn.Module):
                                                  torch.cuda.current_stream(flat.device).cuda_stream), "dvgr_pack_weights")
             self._lowp_version = ver
         return self._lowp.data_ptr()
+
+    def lowp_planes(self):
+        """The bf16 hi / lo planes tensor of the flat parameter buffer (None in fp32 mode), allocated if need be; for a
+        caller that rewrites it together with the parameters (trainer.ClipAdam) and then calls planes_written()."""
+        if self.dtype_code == L_.DVGR_F32 or self.no_planes:
+            return None
+        self.lowp_ptr()
+        return self._lowp
+
+    def params_changed(self):
+        """The flat parameter buffer was modified behind autograd's back (no `_version` bump, e.g. by a raw kernel): the
+        bf16 planes are repacked at the next forward.  trainer.ClipAdam needs no such call when it is handed
+        lowp_planes(): it rewrites the planes itself, in the pass that updates the parameters."""
+        self._lowp_version = None
 
     def _next_seed(self) -> int:
         """Dropout seed of one forward, drawn from torch's CPU generator (so torch.manual_seed reproduces a run) in

@@ -58,10 +58,13 @@ typedef struct dvgr_head_grads {
   float *gparams;        /* flat, layout of the parameter buffer; every element written */
 } dvgr_head_grads;
 
-/* train != 0: the three nn.Dropout(0.15) sites are active (counter-hash RNG of the unit, keyed by `seed`) and
+/* train & 1: the three nn.Dropout(0.15) sites are active (counter-hash RNG of the unit, keyed by `seed`) and
  * BatchNorm1d uses batch statistics and updates the running ones (momentum 0.1, eps 1e-5).
+ * train & DVGR_HEAD_TRAIN_NO_DROPOUT: training-mode BatchNorm with the dropout sites switched off (p = 0) -- what a
+ * deterministic comparison with the reference's training step needs (tests/golden/make_golden_step.py patches p to 0).
  * The backward enqueues the weight gradients and column sums on the library's internal side stream (see
  * DVGR_OPT_SINGLE_STREAM in dvgr.h); it forks from and joins back into `stream` inside the call. */
+#define DVGR_HEAD_TRAIN_NO_DROPOUT 2
 int dvgr_head_forward(const dvgr_head_dims *d, const float *params, const dvgr_head_io *io, void *saved,
                       size_t saved_bytes, void *workspace, size_t workspace_bytes, int train, uint64_t seed,
                       void *stream);

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared_symbols():
     names = set()
-    for h in ("dvgr.h", "dvgr_debug.h", "dvgr_head.h", "dvgr_clip.h", "dvgr_store.h"):
+    for h in sorted(os.listdir(os.path.join(ROOT, "include"))):          # every header under include/
         text = open(os.path.join(ROOT, "include", h)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         names |= set(re.findall(r"\b(dvgr_[a-z_0-9]+)\s*\(", text))
@@ -33,15 +33,34 @@ def test_library_exports_every_declared_symbol():
     from dualvgr_videoqa_amd import head as HD
     from dualvgr_videoqa_amd import clip as CL
     from dualvgr_videoqa_amd import store as ST
+    from dualvgr_videoqa_amd import trainer as TR
     HD.load()
     CL.load()
     ST.load()
+    TR.load()
     bound = ({n for n, _, _ in L.SYMBOLS} | {n for n, _, _ in HD.HEAD_SYMBOLS} | {n for n, _, _ in CL.CLIP_SYMBOLS}
-             | {n for n, _, _ in ST.STORE_SYMBOLS})
+             | {n for n, _, _ in ST.STORE_SYMBOLS} | {n for n, _, _ in TR.OPTIM_SYMBOLS})
     assert declared == bound, declared ^ bound
     for name in declared:
         assert getattr(lib, name) is not None
     assert lib.dvgr_version().startswith(b"dvgr-hip")
+
+
+def test_optimizer_refuses_bad_segments_without_touching_the_gpu():
+    from dualvgr_videoqa_amd import trainer as TR
+    lib = TR.load()
+    assert C.sizeof(TR.OptimSeg) == 7 * 8
+    segs = (TR.OptimSeg * 1)()
+    buf = (C.c_float * 8)()
+    assert lib.dvgr_optim_grad_sqnorm(segs, 1, None, None) == -2                 # no output
+    segs[0].n = 4
+    assert lib.dvgr_optim_adam_step(segs, 1, None, 12.0, 1e-4, 0.9, 0.999, 1e-8, 1, None) == -2     # NULL gradient
+    segs[0].grad = C.addressof(buf)
+    assert lib.dvgr_optim_adam_step(segs, 1, None, 12.0, 1e-4, 0.9, 0.999, 1e-8, 1, None) == -2     # NULL param / moments
+    segs[0].param = segs[0].exp_avg = segs[0].exp_avg_sq = C.addressof(buf)
+    assert lib.dvgr_optim_adam_step(segs, 1, None, 12.0, 1e-4, 0.9, 0.999, 1e-8, 0, None) == -1     # step must be >= 1
+    assert lib.dvgr_optim_adam_step(segs, 1, None, 12.0, 1e-4, 1.0, 0.999, 1e-8, 1, None) == -1     # beta1 < 1
+    assert lib.dvgr_optim_adam_step(segs, -1, None, 12.0, 1e-4, 0.9, 0.999, 1e-8, 1, None) == -1
 
 
 def test_struct_sizes_match_header():

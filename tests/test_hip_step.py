@@ -1,0 +1,117 @@
+"""GPU: the training step around the path: `dualvgr_videoqa_amd.TrainStep` against
+  (1) two iterations of the IMPORTED reference's loop, train.py:139-159, recorded in tests/golden/g_step_small.npz
+      (make_golden_step.py: training-mode BatchNorm, dropout probabilities patched to 0): loss and its terms, the total
+      gradient norm of clip_grad_norm_, every parameter and BatchNorm buffer after the last step;
+  (2) torch.nn.utils.clip_grad_norm_ + torch.optim.Adam run on the device for the fused clip + Adam launches alone."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import dualvgr_videoqa_amd as dv
+from dualvgr_videoqa_amd import synth, trainer
+from test_hip_model import model_inputs, seeded_state
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g_step_small.npz")
+
+
+@pytest.mark.parametrize("case", ["a/", "b/"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x3"])
+def test_two_training_steps_match_the_reference_loop(case, dtype):
+    z = np.load(GOLDEN)
+    V, D, Wd, N, Fr, L, B, T, vq, va, seed, steps = [int(v) for v in z[case + "meta"]]
+    lr, alpha, beta, max_norm = [float(v) for v in z[case + "meta_f"]]
+    vocab = {"question_token_to_idx": {str(i): i for i in range(vq)}, "answer_token_to_idx": {str(i): i for i in range(va)}}
+    m = dv.DualVGR(vision_dim=V, module_dim=D, word_dim=Wd, vocab=vocab, num_of_nodes=N, graph_module="GAT", graph_layers=1,
+                   unit_layers=L, dtype=dtype)
+    keys = [str(k) for k in z[case + "keys"]]
+    before = seeded_state(keys, [str(s) for s in z[case + "shapes"]], seed)
+    m.load_state_dict(before, strict=True)
+    m = m.cuda().train()
+    m.set_dropout_enabled(False)                 # the fixture was recorded with p = 0 at every site
+    app, mot, q, qlen = [torch.from_numpy(x).cuda() for x in model_inputs(B, N, Fr, V, T, vq, seed)]
+    answers = torch.from_numpy((synth.uniform("s_ans", (B,), 0.0, float(va), seed)).astype(np.int64)).cuda()
+    step = dv.TrainStep(m, lr=lr, alpha=alpha, beta=beta, max_norm=max_norm)
+    for i in range(steps):
+        out = step(app, mot, q, qlen, answers)
+        got = {k: float(out[k]) for k in ("loss", "ce", "common", "dependence")}
+        norm = float(out["grad_sqnorm"]) ** 0.5
+        print(f"  {case} {dtype} step {i}: {got} norm {norm:.6g} (reference loss {z[case + 'loss'][i]:.6g} norm {z[case + 'norm'][i]:.6g})")
+        assert abs(got["loss"] - z[case + "loss"][i]) < 2e-4 * abs(z[case + "loss"][i])
+        assert abs(got["ce"] - z[case + "ce"][i]) < 2e-4 * abs(z[case + "ce"][i])
+        assert abs(got["common"] - z[case + "common"][i]) < 2e-4 * abs(z[case + "common"][i])
+        assert abs(got["dependence"] - z[case + "dep"][i]) < 1e-3 * abs(z[case + "dep"][i])
+        assert abs(norm - z[case + "norm"][i]) < 5e-4 * z[case + "norm"][i]
+    torch.cuda.synchronize()
+    # every parameter / buffer after the last step.  Adam's first steps move each element by ~lr * sign(g): an element whose
+    # gradient is rounding noise (analytically zero: queryAttn.*.fc.bias) may move the other way, so such tensors are
+    # skipped and the rest is measured in units of lr.
+    sd = m.state_dict()
+    worst = {}
+    for k in keys:
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == steps
+            continue
+        if k.endswith(".fc.bias") and "queryAttn" in k:
+            continue
+        got = sd[k].detach().float().cpu().numpy().reshape(-1)
+        want = z[case + "after/" + k]
+        moved = np.abs(want - before[k].numpy().reshape(-1)[:2048])
+        err = np.abs(got[:2048] - want)
+        tol = 0.02 * lr * steps if not k.endswith(("running_mean", "running_var")) else 2e-4 * max(1.0, float(np.abs(want).max()))
+        worst[k] = (float(err.max()), float(moved.max()))
+        frac_bad = float((err > tol).mean())
+        assert frac_bad <= 2e-3, (k, frac_bad, float(err.max()), tol)
+        s_want = z[case + "sum/" + k]
+        assert abs(float(got.astype(np.float64).sum()) - s_want[0]) <= 1e-4 * s_want[1] + 1e-6, k
+    top = sorted(worst.items(), key=lambda kv: -kv[1][0])[:4]
+    print("  worst |err| (|moved|):", [(k, f"{e:.2e} ({mv:.2e})") for k, (e, mv) in top])
+    assert any(mv > 0.5 * lr for _, (e, mv) in worst.items())          # the step really moved the weights
+
+
+@pytest.mark.parametrize("max_norm", [12.0, 0.5, 0.0])
+def test_fused_clip_and_adam_match_torch(max_norm):
+    """Three segments of awkward sizes (vector path, scalar tail, a 1-element bias), four steps, against
+    clip_grad_norm_ + torch.optim.Adam (foreach=False) on the same device."""
+    g = torch.Generator().manual_seed(3)
+    sizes = [4096 * 37 + 3, 1, 1028, 5_000_000]
+    ps = [torch.randn(n, generator=g).cuda() for n in sizes]
+    ref = [torch.nn.Parameter(p.clone()) for p in ps]
+    opt = torch.optim.Adam(ref, lr=3e-3, foreach=False)
+    mine = trainer.ClipAdam(lr=3e-3, max_norm=max_norm)
+    for it in range(4):
+        grads = [(torch.randn(n, generator=g) * (10.0 if it % 2 else 0.01)).cuda() for n in sizes]
+        for r, gr in zip(ref, grads):
+            r.grad = gr.clone()
+        want_norm = float(torch.nn.utils.clip_grad_norm_(ref, max_norm, foreach=False)) if max_norm > 0 else \
+            float(torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(gr) for gr in grads])))
+        opt.step()
+        sq = mine.step([(i, p, gr) for i, (p, gr) in enumerate(zip(ps, grads))])
+        assert abs(float(sq) ** 0.5 - want_norm) < 1e-5 * want_norm
+        for p, r, gr in zip(ps, ref, grads):
+            assert float((p - r.detach()).abs().max()) < 2e-6 * max(1.0, float(r.abs().max()))
+            if max_norm > 0:
+                assert torch.allclose(gr, r.grad, rtol=1e-5, atol=1e-9)      # the clipped gradient is written back
+
+
+def test_adam_pass_keeps_the_units_bf16_planes_in_step():
+    """The unit's contraction kernels read bf16 hi / lo planes of the weights; TrainStep's Adam pass rewrites them from the
+    updated values, so the next forward equals a forward after an explicit repack."""
+    z = np.load(GOLDEN)
+    V, D, Wd, N, Fr, L, B, T, vq, va, seed, steps = [int(v) for v in z["a/meta"]]
+    vocab = {"question_token_to_idx": {str(i): i for i in range(vq)}, "answer_token_to_idx": {str(i): i for i in range(va)}}
+    m = dv.DualVGR(vision_dim=V, module_dim=D, word_dim=Wd, vocab=vocab, num_of_nodes=N, graph_module="GAT", graph_layers=1,
+                   unit_layers=L, dtype="bf16x3").cuda().train()
+    m.set_dropout_enabled(False)
+    app, mot, q, qlen = [torch.from_numpy(x).cuda() for x in model_inputs(B, N, Fr, V, T, vq, seed)]
+    answers = torch.zeros(B, dtype=torch.int64, device="cuda")
+    step = dv.TrainStep(m, lr=1e-2)
+    step(app, mot, q, qlen, answers)
+    m.eval()
+    with torch.no_grad():
+        a = m(app, mot, q, qlen)[0].clone()
+        m.visual_input_unit.params_changed()            # force dvgr_pack_weights from the fp32 parameters
+        b = m(app, mot, q, qlen)[0]
+    assert torch.equal(a, b)

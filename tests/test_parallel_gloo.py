@@ -103,6 +103,54 @@ def test_two_rank_gradient_average_equals_full_batch():
         assert float(np.abs(got - want).max()) < 2e-4 * scale, name
 
 
+def _worker_params(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+        unused = torch.nn.Parameter(torch.ones(4))                  # a bucket member that never gets a gradient
+        buckets = [list(net[3].parameters()), list(net[2].parameters()) + [unused], list(net[0].parameters())]
+        red = parallel.ParamBucketReducer(buckets)
+        x = torch.arange(24, dtype=torch.float32).reshape(4, 6) / 10 + rank
+        for _ in range(2):                                          # two steps: the hooks re-arm
+            net.zero_grad(set_to_none=True)
+            red.start()
+            net(x).pow(2).mean().backward()
+            red.finish()
+        if rank == 0:
+            q.put([p.grad.numpy().copy() for p in net.parameters()])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_param_bucket_reducer_averages_ordinary_parameters():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_params, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+    want = [torch.zeros_like(p) for p in net.parameters()]
+    for rank in range(world):
+        net.zero_grad(set_to_none=True)
+        x = torch.arange(24, dtype=torch.float32).reshape(4, 6) / 10 + rank
+        net(x).pow(2).mean().backward()
+        for w, p in zip(want, net.parameters()):
+            w += p.grad / world
+    for g, w in zip(got, want):
+        assert np.allclose(g, w.numpy(), rtol=1e-6, atol=1e-7)
+
+
 def test_shard_batch_partitions():
     for n in (1, 7, 64, 512):
         for w in (1, 2, 3, 8):

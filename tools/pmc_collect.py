@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 --pmc passes of ONE build into the record bench.py reads (profiles/pmc_<config>_<dtype>.json) and a
+per-kernel traffic table (profiles/<prefix>_pmc_hbm.txt).
+
+    tools/pmc_collect.py <out_prefix> <config> <dtype> <steps_profiled> <fetch_csv> <write_csv> [<sq_csv>]
+
+fetch_csv / write_csv / sq_csv: counter_collection CSVs of `rocprofv3 --pmc FETCH_SIZE`, `--pmc WRITE_SIZE` and
+`--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE` (separate passes) over `bench.py --config <config> --dtype <dtype>`.
+gfx950: FETCH_SIZE reads exactly half of a wide coalesced stream (MI355X_MICROARCH.md, HBM) -> doubled; both are in KB.
+MFMA pipe busy = (SQ_VALU_MFMA_BUSY_CYCLES / (256 CUs x 4 SIMDs)) / (GRBM_GUI_ACTIVE / 8 XCDs)."""
+import collections
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (build_id)
+
+
+def per_kernel(path):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+def main():
+    prefix, config, dtype, steps = sys.argv[1], sys.argv[2], sys.argv[3], float(sys.argv[4])
+    fetch, write = per_kernel(sys.argv[5]), per_kernel(sys.argv[6])
+    sq = per_kernel(sys.argv[7]) if len(sys.argv) > 7 else {}
+    names = sorted(set(fetch) | set(write))
+    rows = []
+    for n in names:
+        f = fetch.get(n, {}).get("FETCH_SIZE", [])
+        w = write.get(n, {}).get("WRITE_SIZE", [])
+        fk = sum(f) / len(f) if f else 0.0
+        wk = sum(w) / len(w) if w else 0.0
+        launches = max(len(f), len(w)) / steps
+        rows.append((n, launches, fk, wk, (2 * fk + wk) * 1024))
+    rows.sort(key=lambda r: -r[4] * r[1])
+    total = sum(r[4] * r[1] for r in rows)
+    lines = [f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), {config} {dtype}, build {bench.build_id()}",
+             "# per launch: bytes = 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE; per step = x launches per step",
+             f"{'kernel':90s} {'launch/step':>11s} {'fetch_KB':>10s} {'write_KB':>10s} {'MB/launch':>10s} {'MB/step':>9s}"]
+    for n, l, fk, wk, b in rows:
+        lines.append(f"{n[:90]:90s} {l:11.2f} {fk:10.1f} {wk:10.1f} {b / 1e6:10.2f} {b * l / 1e6:9.1f}")
+    lines.append(f"total fabric bytes per step: {total / 1e9:.3f} GB")
+    open(prefix + "_pmc_hbm.txt", "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines[-12:]))
+    # the probed kernel: the forward GAT projection contraction (template TAG 1 of the KC x KC engine)
+    probe = [r for r in rows if "TAG" not in r[0] and ("<0, 0, 1," in r[0] or "fwd_gat" in r[0].lower())]
+    rec = {"build": bench.build_id(), "config": config, "dtype": dtype, "train": True,
+           "source": os.path.relpath(prefix + "_pmc_hbm.txt", ROOT), "fabric_bytes_per_step": total}
+    if probe:
+        n, l, fk, wk, b = probe[0]
+        rec.update({"kernel": n, "traffic_bytes_per_launch": b, "fetch_kb": fk, "write_kb": wk})
+        s = sq.get(n, {})
+        if s.get("SQ_VALU_MFMA_BUSY_CYCLES") and s.get("GRBM_GUI_ACTIVE"):
+            busy = sum(s["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(s["SQ_VALU_MFMA_BUSY_CYCLES"])
+            act = sum(s["GRBM_GUI_ACTIVE"]) / len(s["GRBM_GUI_ACTIVE"])
+            rec["mfma_busy"] = (busy / (256 * 4)) / (act / 8)
+    out = os.path.join(ROOT, "profiles", f"pmc_{config}_{dtype}.json")
+    json.dump(rec, open(out, "w"), indent=1)
+    print("wrote", out, rec.get("traffic_bytes_per_launch"), rec.get("mfma_busy"))
+
+
+if __name__ == "__main__":
+    main()
