@@ -139,6 +139,19 @@ def cpu_baseline(cfg, seconds=15.0):
                       f"times within +-5 % of the imported reference itself (DESIGN.md section 6)"}
 
 
+_RESULT_FD = None
+
+
+def emit(obj):
+    """The ONE result line, on the process's original stdout."""
+    line = (json.dumps(obj) + "\n").encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_RESULT_FD, line)
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -229,6 +242,12 @@ def main():
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return spawn_ranks(args.gpus)            # nothing above touched the GPU
+    # stdout carries exactly ONE line, the result: whatever libraries print there (RCCL's version banner at init) goes to
+    # stderr instead -- file descriptor 1 is pointed at stderr for the run and the JSON line is written to the saved one
+    global _RESULT_FD
+    sys.stdout.flush()
+    _RESULT_FD = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -425,7 +444,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if ddp:
         dist.destroy_process_group()
     return 0
@@ -493,7 +512,7 @@ def bench_model(args, dev, rank, world, cfg, ddp, dist_info):
                       "timing": {"blocks": len(blocks), "steps_per_block": args.steps, "timed_s": float(sum(blocks))},
                       "distributed": dist_info, "global_batch": world * B, "parallelism": f"dp{world}"}}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
 
 
 if __name__ == "__main__":

@@ -923,6 +923,32 @@ int dvgr_dbg_gemm_planes(int mode, int M, int N, int K, const float* A, const vo
   return gemm_launch((hipStream_t)stream, la, lb, gb, TAG_GENERIC, prec);
 }
 
+// timing aid (tools/gemm_shapes.py): `count` copies of one pre-split problem in ONE launch (outputs count * M rows apart),
+// as the unit's launch sites batch the modalities / views; kseg < K selects the two-segment reduction (segment 1 = A2 / B2)
+int dvgr_dbg_gemm_planes_batch(int mode, int M, int N, int K, int kseg, const float* A, const void* A_hi, int64_t lda,
+                               int64_t a_lo_off, const float* B, const void* B_hi, int64_t ldb, int64_t b_lo_off, float* C,
+                               int64_t ldc, int act, int accumulate, int atomic_ok, int prec, int count, int tag, void* stream) {
+  if (!A || !B || !C || !A_hi || !B_hi) return DVGR_E_NULL;
+  if (count < 1 || count > kMaxBatch) return DVGR_E_DIMS;
+  GemmBatch gb{};
+  for (int i = 0; i < count; ++i) {
+    GemmProblem p{};
+    p.A = operand(A, lda);
+    p.B = operand(B, ldb);
+    p.A.h0 = p.A.h1 = reinterpret_cast<const uint16_t*>(A_hi); p.A.lo_off = a_lo_off;
+    p.B.h0 = p.B.h1 = reinterpret_cast<const uint16_t*>(B_hi); p.B.lo_off = b_lo_off;
+    p.C = C + (int64_t)i * M * ldc; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.kseg = (kseg > 0 && kseg < K) ? kseg : K;
+    if (p.kseg < K) {      // second segment: the same rows again (timing only)
+      if (mode == 2) { p.A.p1 = A; p.A.h1 = p.A.h0; }
+      p.B.p1 = B; p.B.h1 = p.B.h0;
+    }
+    p.act = act; p.accumulate = accumulate; p.atomic_ok = atomic_ok;
+    gb.p[gb.n++] = p;
+  }
+  const int la = mode == 2 ? IC : KC, lb = mode == 0 ? KC : IC;
+  return gemm_launch((hipStream_t)stream, la, lb, gb, tag, prec);
+}
+
 int dvgr_dbg_colsum(const float* M, const float* w, int rows, int cols, int64_t ld, float* out, void* stream) {
   if (!M || !out) return DVGR_E_NULL;
   ColsumBatch cb{};

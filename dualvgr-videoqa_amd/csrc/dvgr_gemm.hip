@@ -435,7 +435,11 @@ __global__ __launch_bounds__(256) void gemm_lp_kernel(const GemmBatch batch) {
 //   Lane (r, g) of an MFMA operand owns k = 4g+j and 16+4g+j (j = 0..3) of row/column r, for A and B
 //   alike.  Operands are converted fp32 -> bf16 (hi [+ lo]) in registers right before the MFMAs.
 // =================================================================================================
-constexpr int RS = 4;                       // ring slots
+#ifndef DVGR_NS
+#define DVGR_NS 4
+#endif
+constexpr int RS = DVGR_NS;                 // ring slots (A/B experiments: -DDVGR_NS=5 = all 160 KB of LDS)
+static_assert(RS >= 3 && RS <= 5, "the counted vmcnt waits cover at most three younger tiles");
 constexpr int RT = 128;                     // tile extent (M and N)
 constexpr int kRingTile = RT * BK;          // floats per operand tile (16 KB)
 constexpr int kRingSlot = 2 * kRingTile;    // A tile + B tile
@@ -566,8 +570,9 @@ __global__ __launch_bounds__(768) void gemm_ring_kernel(const GemmBatch batch) {
     for (int kt = 0; kt < nk; ++kt) {
       // 8 DMA instructions per K-tile from this wave, in order: wait until tile kt has landed while
       // leaving the (up to two) younger tiles in flight
-      const int younger = nk - 1 - kt;
-      if (younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      const int younger = (nk - 1 - kt) < RS - 2 ? (nk - 1 - kt) : RS - 2;
+      if (younger >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      else if (younger == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -837,11 +842,13 @@ __global__ __launch_bounds__(768) void gemm_planes_kernel(const GemmBatch batch)
       const int younger = (nk - 1 - kt) < NS - 2 ? (nk - 1 - kt) : NS - 2;
       GCLK_ADD(2);                                 // DMA issue (back-pressure of the vector memory path)
       if (TERMS == 3) {
-        if (younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if (younger >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else if (younger == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       } else {
-        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (younger >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }

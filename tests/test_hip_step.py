@@ -22,12 +22,15 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g_s
 def test_two_training_steps_match_the_reference_loop(case, dtype):
     z = np.load(GOLDEN)
     V, D, Wd, N, Fr, L, B, T, vq, va, seed, steps = [int(v) for v in z[case + "meta"]]
-    lr, alpha, beta, max_norm = [float(v) for v in z[case + "meta_f"]]
+    lr, alpha, beta, max_norm, a_scale = [float(v) for v in z[case + "meta_f"]]
     vocab = {"question_token_to_idx": {str(i): i for i in range(vq)}, "answer_token_to_idx": {str(i): i for i in range(va)}}
     m = dv.DualVGR(vision_dim=V, module_dim=D, word_dim=Wd, vocab=vocab, num_of_nodes=N, graph_module="GAT", graph_layers=1,
                    unit_layers=L, dtype=dtype)
     keys = [str(k) for k in z[case + "keys"]]
     before = seeded_state(keys, [str(s) for s in z[case + "shapes"]], seed)
+    for k in before:                             # make_golden_step.step_state: logits that straddle the LeakyReLU kink
+        if k.endswith(".a.weight"):
+            before[k] = before[k] * a_scale
     m.load_state_dict(before, strict=True)
     m = m.cuda().train()
     m.set_dropout_enabled(False)                 # the fixture was recorded with p = 0 at every site
@@ -39,22 +42,26 @@ def test_two_training_steps_match_the_reference_loop(case, dtype):
         got = {k: float(out[k]) for k in ("loss", "ce", "common", "dependence")}
         norm = float(out["grad_sqnorm"]) ** 0.5
         print(f"  {case} {dtype} step {i}: {got} norm {norm:.6g} (reference loss {z[case + 'loss'][i]:.6g} norm {z[case + 'norm'][i]:.6g})")
-        assert abs(got["loss"] - z[case + "loss"][i]) < 2e-4 * abs(z[case + "loss"][i])
+        # common_loss normalises rows centred over the nodes; the smallest such row of this fixture is 5e-3 of the row
+        # norm, so operand rounding (1e-7 fp32, 1e-5 bf16x3) is amplified 200x in that row: the term gets 1e-3 / 1e-2
+        ctol = 1e-3 if dtype == "fp32" else 1e-2
         assert abs(got["ce"] - z[case + "ce"][i]) < 2e-4 * abs(z[case + "ce"][i])
-        assert abs(got["common"] - z[case + "common"][i]) < 2e-4 * abs(z[case + "common"][i])
+        assert abs(got["common"] - z[case + "common"][i]) < ctol * abs(z[case + "common"][i])
         assert abs(got["dependence"] - z[case + "dep"][i]) < 1e-3 * abs(z[case + "dep"][i])
+        assert abs(got["loss"] - z[case + "loss"][i]) < 2e-4 * abs(z[case + "loss"][i]) + alpha * ctol * abs(z[case + "common"][i])
         assert abs(norm - z[case + "norm"][i]) < 5e-4 * z[case + "norm"][i]
     torch.cuda.synchronize()
     # every parameter / buffer after the last step.  Adam's first steps move each element by ~lr * sign(g): an element whose
-    # gradient is rounding noise (analytically zero: queryAttn.*.fc.bias) may move the other way, so such tensors are
-    # skipped and the rest is measured in units of lr.
+    # gradient is rounding noise may move the other way, so the two biases whose gradient is analytically zero (a constant
+    # added to every logit of a softmax: queryAttn.*.fc.bias, feature_aggregation.attn.bias) are skipped and the rest is
+    # measured in units of lr.
     sd = m.state_dict()
     worst = {}
     for k in keys:
         if k.endswith("num_batches_tracked"):
             assert int(sd[k]) == steps
             continue
-        if k.endswith(".fc.bias") and "queryAttn" in k:
+        if (k.endswith(".fc.bias") and "queryAttn" in k) or k == "feature_aggregation.attn.bias":
             continue
         got = sd[k].detach().float().cpu().numpy().reshape(-1)
         want = z[case + "after/" + k]
