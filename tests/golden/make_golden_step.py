@@ -6,7 +6,7 @@
     loss.backward(); nn.utils.clip_grad_norm_(model.parameters(), max_norm); optimizer.step()   # optim.Adam(params, lr)
 
 -- in training mode (BatchNorm uses batch statistics) with every dropout probability patched to 0, so that the step is
-deterministic.  Recorded per step: loss, its three terms, the total gradient norm clip_grad_norm_ returned; after the last
+deterministic.  Recorded: the gradients of the first step (first 2048 elements per parameter); per step: loss, its three terms, the total gradient norm clip_grad_norm_ returned; after the last
 step: every parameter and BatchNorm buffer (first 2048 elements + sum and sum of magnitudes).  Two cases: max_norm = 12 (train.py:158) and a
 large max_norm that leaves the gradient unclipped (at 12 the clip bites in both steps: norms 22.8, 21.0).
 
@@ -55,7 +55,7 @@ def step_state(model, seed):
     return sd
 
 
-def run_case(prefix, out, *, V, D, Wd, N, Fr, L, B, T, vocab_q, vocab_a, lr, alpha, beta, max_norm, steps, seed=224):
+def run_case(prefix, out, *, V, D, Wd, N, Fr, L, B, T, vocab_q, vocab_a, lr, alpha, beta, max_norm, steps, seed=224, full=True):
     vocab = {"question_token_to_idx": {str(i): i for i in range(vocab_q)}, "answer_token_to_idx": {str(i): i for i in range(vocab_a)}}
     model = MG.ref_models.DualVGR(vision_dim=V, module_dim=D, word_dim=Wd, vocab=vocab, num_of_nodes=N, graph_module="GAT",
                                   graph_layers=1, unit_layers=L)
@@ -78,6 +78,10 @@ def run_case(prefix, out, *, V, D, Wd, N, Fr, L, B, T, vocab_q, vocab_a, lr, alp
             loss_com = loss_com + ref_utils.common_loss(com_app[i], com_motion[i])
         loss = ce + alpha * loss_com / temp + beta * loss_dep / temp
         loss.backward()                                                                # :155
+        if len(rec["loss"]) == 0 and full:                                             # first step: the raw gradients
+            for k, p_ in model.named_parameters():
+                g = p_.grad if p_.grad is not None else torch.zeros_like(p_)
+                out[prefix + "g0/" + k] = g.numpy().reshape(-1)[:2048].copy()
         norm = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=max_norm)   # :158
         opt.step()                                                                     # :159
         for k, v in (("loss", loss), ("ce", ce), ("common", loss_com / temp), ("dep", loss_dep / temp), ("norm", norm)):
@@ -91,6 +95,8 @@ def run_case(prefix, out, *, V, D, Wd, N, Fr, L, B, T, vocab_q, vocab_a, lr, alp
     out[prefix + "shapes"] = np.array([str(tuple(sd[k].shape)) for k in sorted(sd.keys())])
     for k in sorted(sd.keys()):                       # whole tensor up to 2048 elements, else its first 2048 + two checksums
         v = sd[k].numpy().reshape(-1)
+        if not full and v.size > 1024:                # the second case keeps the small tensors only
+            continue
         out[prefix + "after/" + k] = v[:2048].copy()
         out[prefix + "sum/" + k] = np.array([v.astype(np.float64).sum(), np.abs(v.astype(np.float64)).sum()])
     print(prefix, {k: [f"{x:.6g}" for x in v] for k, v in rec.items()})
@@ -101,5 +107,5 @@ if __name__ == "__main__":
     out = {}
     dims = dict(V=32, D=64, Wd=32, N=8, Fr=4, L=2, B=6, T=7, vocab_q=30, vocab_a=12)
     run_case("a/", out, **dims, lr=1e-3, alpha=1.0, beta=10.0, max_norm=12.0, steps=2)
-    run_case("b/", out, **dims, lr=1e-3, alpha=1.0, beta=10.0, max_norm=100.0, steps=2)
+    run_case("b/", out, **dims, lr=1e-3, alpha=1.0, beta=10.0, max_norm=100.0, steps=2, full=False)
     np.savez_compressed(os.path.join(HERE, "g_step_small.npz"), **out)
