@@ -336,7 +336,7 @@ def main():
     events = None
     reducer = None
     if ddp:
-        events = [torch.cuda.Event() for _ in range(Lr + 1)]
+        events = [torch.cuda.Event() for _ in range(Lr + 2)]
         m.set_layer_events(events)
         reducer = parallel.LayerBucketReducer(parallel.layer_buckets(m), device=dev)
         reducer.force = world == 1          # self-test: run the collectives even with one rank
@@ -480,7 +480,7 @@ def bench_model(args, dev, rank, world, cfg, ddp, dist_info):
     if ddp:
         # the unit's gradients: per-layer buckets launched from the backward's host callback; everything else: buckets of
         # ordinary parameters launched from autograd's post-accumulate hooks -- both overlap the remaining backward
-        events = [torch.cuda.Event() for _ in range(Lr + 1)]
+        events = [torch.cuda.Event() for _ in range(Lr + 2)]
         for ev in events:
             ev.record()
         unit.set_layer_events(events)

@@ -98,7 +98,7 @@ SYMBOLS += [
     ("dvgr_dbg_event_create", C.c_int, [C.POINTER(C.c_void_p)]),
     ("dvgr_dbg_event_elapsed_ms", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
     ("dvgr_dbg_gemm_planes_batch", C.c_int, [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
-                                                 C.c_int64, C.c_int64, C.c_void_p, C.c_int64] + [C.c_int] * 6 + [C.c_void_p]),
+                                                 C.c_int64, C.c_int64, C.c_void_p, C.c_int64] + [C.c_int] * 6 + [C.c_void_p, C.c_int, C.c_void_p]),
     ("dvgr_dbg_event_destroy", C.c_int, [C.c_void_p]),
 ]
 

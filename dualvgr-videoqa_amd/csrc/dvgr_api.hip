@@ -37,15 +37,16 @@ FwdWs fwd_ws(const dvgr_dims& d) {
 }
 
 // Buffers written by the critical path of layer l and read by the side stream (weight / bias gradients) exist
-// twice, indexed by l & 1: the critical path may run one layer ahead of the side stream.
+// twice, indexed by l & 1: the critical path may run one layer ahead of the side stream.  The query branch runs once,
+// after the last layer, for ALL layers: its inputs (d p of every layer) and intermediates are kept per layer.
 struct BwdWs {
   int64_t dpo, dzf, dp0, dp1, dz[2], dxtmp[2];
-  int64_t dw[2][2], dpre[2][2], dWh[2][2], ds_part[2][2], da_part[2][2], dc_part[2][2], dp_cat[2];   // [set][modality]
-  int64_t dqbar[2], dr, dy, qdots, total;
+  int64_t dw[2][2], dpre[2][2], dWh[2][2], ds_part[2][2], da_part[2][2], dc_part[2][2];   // [set][modality]
+  int64_t dp_cat, dqbar, dr, dy, qdots, total;                                             // [L] each
 };
 BwdWs bwd_ws(const dvgr_dims& d) {
   BwdWs w{};
-  const int64_t BN = (int64_t)d.B * d.N, D = d.D, F = d.D / 4;
+  const int64_t BN = (int64_t)d.B * d.N, D = d.D, F = d.D / 4, L = d.L;
   int64_t o = 0;
   w.dpo = o; o += round64(BN * D);
   w.dzf = o; o += round64(BN * kMfbPooled);
@@ -62,12 +63,12 @@ BwdWs bwd_ws(const dvgr_dims& d) {
       w.da_part[s][m] = o; o += round64((int64_t)d.B * kHeads * 2 * F);
       w.dc_part[s][m] = o; o += round64((int64_t)d.B * kHeads);
     }
-    w.dp_cat[s] = o; o += round64((int64_t)d.B * 2 * D);
   }
-  for (int s = 0; s < 2; ++s) { w.dqbar[s] = o; o += round64((int64_t)d.B * d.Wd); }
-  w.dr = o;     o += round64((int64_t)d.B * d.T);
-  w.dy = o;     o += round64((int64_t)d.B * d.T * D);
-  w.qdots = o;  o += round64(2 * (int64_t)d.B * d.T);
+  w.dp_cat = o; o += round64(L * d.B * 2 * D);
+  w.dqbar = o;  o += round64(L * d.B * d.Wd);
+  w.dr = o;     o += round64(L * d.B * d.T);
+  w.dy = o;     o += round64(L * d.B * d.T * D);
+  w.qdots = o;  o += round64(2 * L * d.B * d.T);
   w.total = o;
   return w;
 }
@@ -236,14 +237,16 @@ int dvgr_param_offset(const dvgr_dims* d, int kind, int layer, int mod, int64_t*
   const int64_t D = d->D, Wd = d->Wd, F = d->D / 4;
   if (kind < 0 || kind >= DVGR_P_KINDS) return DVGR_E_KIND;
   if (kind < DVGR_P_MFB_W0 && (layer < 0 || layer >= d->L || mod < 0 || mod > 1)) return DVGR_E_KIND;
-  const int64_t lb = p.layer_stride * layer, mb = lb + p.mod_base + p.mod_stride * mod;
+  const int64_t mb = p.layer_stride * layer + p.mod_stride * mod;                  // layer block (GAT / SF parameters)
+  const int64_t lb = p.q_base + p.q_layer_stride * layer;                          // query block (QueryAttn / QueryPunish)
+  const int64_t qmb = lb + p.q_mod_base + p.q_mod_stride * mod;
   switch (kind) {
     case DVGR_P_QA_W1: *offset = lb + p.qa_w1; *rows = D; *cols = D; break;
     case DVGR_P_QA_B1: *offset = lb + p.qa_b1; *rows = 1; *cols = D; break;
     case DVGR_P_QA_W2: *offset = lb + p.qa_w2; *rows = 1; *cols = D; break;
     case DVGR_P_QA_B2: *offset = lb + p.qa_b2; *rows = 1; *cols = 1; break;
-    case DVGR_P_WQ: *offset = mb + p.wq; *rows = D; *cols = Wd; break;
-    case DVGR_P_BQ: *offset = mb + p.bq; *rows = 1; *cols = D; break;
+    case DVGR_P_WQ: *offset = qmb + p.wq; *rows = D; *cols = Wd; break;
+    case DVGR_P_BQ: *offset = qmb + p.bq; *rows = 1; *cols = D; break;
     case DVGR_P_GAT_W: *offset = mb + p.gat_w; *rows = kHeads * F; *cols = D; break;
     case DVGR_P_GAT_B: *offset = mb + p.gat_b; *rows = 1; *cols = kHeads * F; break;
     case DVGR_P_GAT_A: *offset = mb + p.gat_a; *rows = kHeads; *cols = 2 * F; break;
@@ -265,8 +268,9 @@ int dvgr_param_offset(const dvgr_dims* d, int kind, int layer, int mod, int64_t*
 int dvgr_param_layer_range(const dvgr_dims* d, int layer, int64_t* first, int64_t* last) {
   if (!d || !first || !last) return DVGR_E_NULL;
   const ParamLayout p = param_layout(*d);
-  if (layer < 0 || layer > d->L) return DVGR_E_KIND;
-  if (layer == d->L) { *first = p.mfb_base; *last = p.total; }
+  if (layer < 0 || layer > d->L + 1) return DVGR_E_KIND;
+  if (layer == d->L + 1) { *first = p.q_base; *last = p.total; }           // query block of all layers
+  else if (layer == d->L) { *first = p.mfb_base; *last = p.q_base; }       // MFB block
   else { *first = p.layer_stride * layer; *last = p.layer_stride * (layer + 1); }
   return 0;
 }
@@ -343,8 +347,9 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
   const int B = d.B, N = d.N, T = d.T, D = d.D, Wd = d.Wd, L = d.L, F = D / 4, HF = kHeads * F;
   const int BN = B * N, BT = B * T;
   const int64_t BND = (int64_t)BN * D;
-  auto lp = [&](int l) { return params + P.layer_stride * l; };
-  auto mp = [&](int l, int m) { return params + P.layer_stride * l + P.mod_base + P.mod_stride * m; };
+  auto lp = [&](int l) { return params + P.q_base + P.q_layer_stride * l; };                                        // query block
+  auto qp = [&](int l, int m) { return params + P.q_base + P.q_layer_stride * l + P.q_mod_base + P.q_mod_stride * m; };
+  auto mp = [&](int l, int m) { return params + P.layer_stride * l + P.mod_stride * m; };                          // layer block
   auto ls = [&](int l) { return saved + S.layer_stride * l; };
   auto ms = [&](int l, int m) { return saved + S.layer_stride * l + S.mod_base + S.mod_stride * m; };
 
@@ -378,7 +383,7 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
   }
   {
     QaRowsArgs a{};
-    a.Y = ws + W.Y; a.logit = ws + W.R; a.params = params; a.off_w2 = P.qa_w2; a.off_b2 = P.qa_b2; a.layer_stride = P.layer_stride;
+    a.Y = ws + W.Y; a.logit = ws + W.R; a.params = params + P.q_base; a.off_w2 = P.qa_w2; a.off_b2 = P.qa_b2; a.layer_stride = P.q_layer_stride;
     a.words = io->words; a.qlen = io->qlen; a.saved = saved; a.s_layer_stride = S.layer_stride;
     a.s_d = S.qa_d; a.s_nrm = S.qa_nrm; a.s_a = S.qa_a; a.s_ah = S.qa_ah; a.s_S = S.qa_s; a.s_q = S.qa_q;
     a.B = B; a.T = T; a.D = D; a.Wd = Wd; a.L = L;
@@ -388,7 +393,7 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
     GemmBatch gb{};
     for (int l = 0; l < L; ++l)
       for (int m = 0; m < 2; ++m) {
-        gb.p[gb.n++] = nt(ls(l) + S.qa_q, Wd, mp(l, m) + P.wq, Wd, ms(l, m) + S.p, D, mp(l, m) + P.bq, B, D, Wd, ACT_NONE);
+        gb.p[gb.n++] = nt(ls(l) + S.qa_q, Wd, qp(l, m) + P.wq, Wd, ms(l, m) + S.p, D, qp(l, m) + P.bq, B, D, Wd, ACT_NONE);
         if (gb.n == kMaxBatch || (l == L - 1 && m == 1)) { DVGR_TRY(gemm_launch(hs, KC, KC, gb, TAG_GENERIC, prec)); gb.n = 0; }
       }
   }
@@ -548,33 +553,55 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
   const int B = d.B, N = d.N, T = d.T, D = d.D, Wd = d.Wd, L = d.L, F = D / 4, HF = kHeads * F;
   const int BN = B * N, BT = B * T;
   const int64_t BND = (int64_t)BN * D;
-  auto lp = [&](int l) { return params + P.layer_stride * l; };
-  auto mp = [&](int l, int m) { return params + P.layer_stride * l + P.mod_base + P.mod_stride * m; };
-  auto glp = [&](int l) { return gp + P.layer_stride * l; };
-  auto gmp = [&](int l, int m) { return gp + P.layer_stride * l + P.mod_base + P.mod_stride * m; };
+  auto lp = [&](int l) { return params + P.q_base + P.q_layer_stride * l; };                                       // query block
+  auto qp = [&](int l, int m) { return params + P.q_base + P.q_layer_stride * l + P.q_mod_base + P.q_mod_stride * m; };
+  auto mp = [&](int l, int m) { return params + P.layer_stride * l + P.mod_stride * m; };                          // layer block
+  auto glp = [&](int l) { return gp + P.q_base + P.q_layer_stride * l; };
+  auto gqp = [&](int l, int m) { return gp + P.q_base + P.q_layer_stride * l + P.q_mod_base + P.q_mod_stride * m; };
+  auto gmp = [&](int l, int m) { return gp + P.layer_stride * l + P.mod_stride * m; };
   auto ls = [&](int l) { return saved + S.layer_stride * l; };
   auto ms = [&](int l, int m) { return saved + S.layer_stride * l + S.mod_base + S.mod_stride * m; };
   float* dXacc[2] = {g->gA, g->gM};     // running gradient w.r.t. the current layer boundary
   const PlaneMap PM = make_plane_map(d, P, S, params, params_lp, io, saved, ws);
   int64_t plo = 0;
 
-  // every element of gparams is written: the tensors below, zeros in the alignment padding.  gdq is the sum
-  // over layers of split-K partial tiles, so it starts from zero as well.
+  // every element of gparams is written: the tensors below, zeros in the alignment padding (and bias gradients are
+  // ADDED by the weight-gradient contractions, GemmProblem::rowsum).  gdq is the sum over layers of partial tiles added
+  // atomically, so it starts from zero as well.
   {
     hipError_t e = hipMemsetAsync(gp, 0, (size_t)P.total * sizeof(float), st);
     if (e == hipSuccess) e = hipMemsetAsync(g->gdq, 0, (size_t)BT * D * sizeof(float), st);
     if (e != hipSuccess) return (int)e;
   }
 
-  // Two streams: `st` carries the critical path (the dX chain), `hs` the weight / bias gradients and the query
-  // branch.  DVGR_OPT_SINGLE_STREAM (or a missing side stream) folds everything onto `st`.
-  SideStream* side = ((O.flags & DVGR_OPT_SINGLE_STREAM) || 5 * L + 16 > 256) ? nullptr : side_stream();
+  // Two streams: `st` carries the critical path (the dX chain), `hs` every weight / bias gradient.
+  // DVGR_OPT_SINGLE_STREAM (or a missing side stream) folds everything onto `st`.
+  SideStream* side = ((O.flags & DVGR_OPT_SINGLE_STREAM) || 4 * L + 16 > 256) ? nullptr : side_stream();
   hipStream_t hs = side ? side->st : st;
   const Probe hprobe{O, hs};
   auto to_side = [&]() -> int { return side ? side->order(st, hs) : 0; };     // hs continues after st's work so far
   auto to_main = [&]() -> int { return side ? side->order(hs, st) : 0; };     // st continues after hs's work so far
   // (every fork costs the main stream a ~6 us bubble -- the event's barrier packet -- so there is one per layer, not one
   // per dependency: the side stream's work of a layer is enqueued behind the layer's last producer it needs)
+  auto layer_done = [&](int index, hipStream_t on) -> int {
+    if (!layer_done_events || !layer_done_events[index]) return 0;
+    const hipError_t e = hipEventRecord((hipEvent_t)layer_done_events[index], on);
+    if (e != hipSuccess) return (int)e;
+    if (O.layer_done_cb) O.layer_done_cb(index, O.layer_done_user);
+    return 0;
+  };
+  // A weight gradient dW = dY^T . X carries its bias gradient dY^T . 1 along (GemmProblem::rowsum) where the engine
+  // supports it for the batch; otherwise the bias gets a column-sum job.
+  struct BiasOf { const float* dY; int rows; int cols; int64_t ld; float* out; };
+  auto launch_dw = [&](hipStream_t on, GemmBatch& gb, const BiasOf* bias, int tag, ColsumBatch& cb) -> int {
+    const bool fused = gemm_rowsum_supported(IC, IC, gb, prec);
+    for (int i = 0; i < gb.n; ++i) {
+      if (!bias[i].out) continue;
+      if (fused) gb.p[i].rowsum = bias[i].out;
+      else cb.j[cb.n++] = ColsumJob{bias[i].dY, nullptr, nullptr, nullptr, bias[i].rows, 0, bias[i].cols, bias[i].ld, bias[i].out};
+    }
+    return gemm_launch(on, IC, IC, gb, tag, prec);
+  };
 
   // ---- S6 backward ------------------------------------------------------------------------------------
   {
@@ -592,36 +619,27 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     uint16_t* q1 = PM.out(ws + W.dp1, &plo);
     DVGR_TRY(mfb_pool_bwd(st, ws + W.dzf, saved + S.mfb_x0, saved + S.mfb_x1, ws + W.dp0, ws + W.dp1, BN, q0, q1, plo));
     DVGR_TRY(to_side());
-    GemmBatch gb{};   // dWo = dpo^T . z
-    gb.p[gb.n] = tn(ws + W.dpo, D, saved + S.mfb_z, kMfbPooled, gp + P.mfb_wo, kMfbPooled, D, kMfbPooled, BN);
-    PM.attach(gb.p[gb.n++]);
-    DVGR_TRY(gemm_launch(hs, IC, IC, gb, TAG_GENERIC, prec));
-  }
-  {
     GemmBatch gd{};   // dA = dp0 . W0, dM = dp1 . W1
     gd.p[gd.n] = nn(ws + W.dp0, kMfbHidden, params + P.mfb_w0, D, dXacc[0], D, BN, D, kMfbHidden, 0);
     PM.attach(gd.p[gd.n++]);
     gd.p[gd.n] = nn(ws + W.dp1, kMfbHidden, params + P.mfb_w1, D, dXacc[1], D, BN, D, kMfbHidden, 0);
     PM.attach(gd.p[gd.n++]);
     DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_GENERIC, prec));
-    GemmBatch gb{};   // dW0 = dp0^T . A_final, dW1 = dp1^T . M_final
+    // the three MFB weight gradients (+ their biases) in ONE launch on the side stream
+    GemmBatch gb{};
+    BiasOf bias[3] = {{ws + W.dpo, BN, D, D, gp + P.mfb_bo}, {ws + W.dp0, BN, kMfbHidden, kMfbHidden, gp + P.mfb_b0},
+                      {ws + W.dp1, BN, kMfbHidden, kMfbHidden, gp + P.mfb_b1}};
+    gb.p[gb.n] = tn(ws + W.dpo, D, saved + S.mfb_z, kMfbPooled, gp + P.mfb_wo, kMfbPooled, D, kMfbPooled, BN);
+    PM.attach(gb.p[gb.n++]);
     gb.p[gb.n] = tn(ws + W.dp0, kMfbHidden, ms(L - 1, 0) + S.x, D, gp + P.mfb_w0, D, kMfbHidden, D, BN);
     PM.attach(gb.p[gb.n++]);
     gb.p[gb.n] = tn(ws + W.dp1, kMfbHidden, ms(L - 1, 1) + S.x, D, gp + P.mfb_w1, D, kMfbHidden, D, BN);
     PM.attach(gb.p[gb.n++]);
-    DVGR_TRY(gemm_launch(hs, IC, IC, gb, TAG_GENERIC, prec));
     ColsumBatch cb{};
-    cb.j[cb.n++] = ColsumJob{ws + W.dpo, nullptr, nullptr, nullptr, BN, 0, D, D, gp + P.mfb_bo};
-    cb.j[cb.n++] = ColsumJob{ws + W.dp0, nullptr, nullptr, nullptr, BN, 0, kMfbHidden, kMfbHidden, gp + P.mfb_b0};
-    cb.j[cb.n++] = ColsumJob{ws + W.dp1, nullptr, nullptr, nullptr, BN, 0, kMfbHidden, kMfbHidden, gp + P.mfb_b1};
-    cb.chunks = 16;
-    DVGR_TRY(colsum(hs, cb));
+    DVGR_TRY(launch_dw(hs, gb, bias, TAG_GENERIC, cb));
+    if (cb.n) { cb.chunks = 16; DVGR_TRY(colsum(hs, cb)); }
   }
-  if (layer_done_events && layer_done_events[L]) {
-    const hipError_t e = hipEventRecord((hipEvent_t)layer_done_events[L], hs);
-    if (e != hipSuccess) return (int)e;
-    if (O.layer_done_cb) O.layer_done_cb(L, O.layer_done_user);
-  }
+  DVGR_TRY(layer_done(L, hs));
 
   // ---- layers, last to first -----------------------------------------------------------------------
   hipEvent_t side_done[2] = {nullptr, nullptr};   // side stream finished the layer that used buffer set 0 / 1
@@ -631,9 +649,6 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     const float* Xin[2] = {l == 0 ? io->A : ms(l - 1, 0) + S.x, l == 0 ? io->M : ms(l - 1, 1) + S.x};
     const float* outc[2] = {io->com_app + l * BND, io->com_mot + l * BND};
     const float* outs[2] = {io->aq_fusion + l * BND, io->mq_fusion + l * BND};
-    ColsumBatch cb{};
-    GemmBatch sf_dw{};
-    bool sf_dw_main = false;
     if (side && side_done[set]) {      // layer l + 2 shared this buffer set
       const hipError_t e = hipStreamWaitEvent(st, side_done[set], 0);
       if (e != hipSuccess) return (int)e;
@@ -657,10 +672,6 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       a.rows = BN; a.D = D;
       DVGR_TRY(sf_bwd(st, a));
     }
-    for (int m = 0; m < 2; ++m) {
-      cb.j[cb.n++] = ColsumJob{ms(l, m) + S.tn, nullptr, ws + W.dw[set][m], nullptr, 2 * BN, 0, D, D, gmp(l, m) + P.sf_p2};
-      cb.j[cb.n++] = ColsumJob{ws + W.dpre[set][m], nullptr, nullptr, nullptr, 2 * BN, 0, D, D, gmp(l, m) + P.sf_bp};
-    }
     {
       GemmBatch gd{};   // dz_v += dpre_v . P1
       for (int m = 0; m < 2; ++m) {
@@ -670,17 +681,6 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       DVGR_TRY(probe.begin(DVGR_PROBE_BWD_SF_DX, l));
       DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_BWD_SF_DX, prec));
       DVGR_TRY(probe.end(DVGR_PROBE_BWD_SF_DX, l));
-      GemmBatch gb{};   // dP1 = sum_v dpre_v^T . z_v   (reduction over the two views = two row segments)
-      for (int m = 0; m < 2; ++m) {
-        GemmProblem p = tn(ws + W.dpre[set][m], D, outc[m], D, gmp(l, m) + P.sf_p1, D, D, D, 2 * BN);
-        p.kseg = BN;
-        p.A.p1 = ws + W.dpre[set][m] + BND;
-        p.B.p1 = outs[m];
-        PM.attach(p);
-        gb.p[gb.n++] = p;
-      }
-      sf_dw = gb;
-      sf_dw_main = (l == 0);
     }
     // S3 backward
     {
@@ -701,80 +701,80 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       DVGR_TRY(gat_attn_bwd(st, a));
       DVGR_TRY(probe.end(DVGR_PROBE_BWD_GAT_ATTN, l));
     }
-    {                                      // S1 backward, dp part: everything the query branch needs
-      PunishBwdArgs a{};
-      for (int m = 0; m < 2; ++m) {
-        a.ds_part[m] = ws + W.ds_part[set][m]; a.s[m] = ms(l, m) + S.s; a.p[m] = ms(l, m) + S.p;
-        a.X[m] = Xin[m]; a.dX[m] = dXacc[m];
-      }
-      a.dp_cat = ws + W.dp_cat[set]; a.B = B; a.N = N; a.D = D; a.parts = 1;
-      a.zero = ws + W.dqbar[set]; a.zero_cols = Wd;          // dq-bar accumulates split-K partials: cleared here
-      DVGR_TRY(punish_bwd(st, a));
-      DVGR_TRY(to_side());                 // dpre, dWh and dp are final: the side stream takes dP1 and the query branch
-      if (!sf_dw_main) {
-        DVGR_TRY(hprobe.begin(DVGR_PROBE_BWD_SF_DW, l));
-        DVGR_TRY(gemm_launch(hs, IC, IC, sf_dw, TAG_BWD_SF_DW, prec));
-        DVGR_TRY(hprobe.end(DVGR_PROBE_BWD_SF_DW, l));
-      }
-    }
-    for (int m = 0; m < 2; ++m) {
-      cb.j[cb.n++] = ColsumJob{ws + W.da_part[set][m], nullptr, nullptr, nullptr, B, 0, kHeads * 2 * F, kHeads * 2 * F, gmp(l, m) + P.gat_a};
-      cb.j[cb.n++] = ColsumJob{ws + W.dc_part[set][m], nullptr, nullptr, nullptr, B, 0, kHeads, kHeads, gmp(l, m) + P.gat_c};
-      cb.j[cb.n++] = ColsumJob{ws + W.dWh[set][m], nullptr, nullptr, nullptr, BN, 0, HF, HF, gmp(l, m) + P.gat_b};
-    }
-    // S2 backward: dX += drop_x(dWh . Wcat) on the critical path;  dWcat = dWh^T . drop_x(X) on the side stream
+    // dpre and dWh are final: every weight gradient of the layer goes to the side stream as ONE launch --
+    // dP1 = sum_v dpre_v^T . z_v (two row segments) and dWcat = dWh^T . drop_x(X), both modalities, with the bias gradients
+    // d bP and d bcat as row sums of their dY operands -- followed by the small vector gradients (p2, a, c)
+    DVGR_TRY(to_side());
     {
+      GemmBatch gb{};
+      BiasOf bias[kMaxBatch] = {};
+      for (int m = 0; m < 2; ++m) {
+        GemmProblem p = tn(ws + W.dpre[set][m], D, outc[m], D, gmp(l, m) + P.sf_p1, D, D, D, 2 * BN);
+        p.kseg = BN;
+        p.A.p1 = ws + W.dpre[set][m] + BND;
+        p.B.p1 = outs[m];
+        PM.attach(p);
+        bias[gb.n] = BiasOf{ws + W.dpre[set][m], 2 * BN, D, D, gmp(l, m) + P.sf_bp};
+        gb.p[gb.n++] = p;
+      }
+      for (int m = 0; m < 2; ++m) {
+        if (!train) {
+          gb.p[gb.n] = tn(ws + W.dWh[set][m], HF, Xin[m], D, gmp(l, m) + P.gat_w, D, HF, D, BN);
+          PM.attach(gb.p[gb.n]);
+          bias[gb.n++] = BiasOf{ws + W.dWh[set][m], BN, HF, HF, gmp(l, m) + P.gat_b};
+        } else {
+          for (int gi = 0; gi < 2; ++gi) {
+            gb.p[gb.n] = tn(ws + W.dWh[set][m] + gi * 4 * F, HF, ms(l, m) + S.xd + gi * BND, D,
+                            gmp(l, m) + P.gat_w + (int64_t)gi * 4 * F * D, D, 4 * F, D, BN);
+            PM.attach(gb.p[gb.n]);
+            bias[gb.n++] = BiasOf{ws + W.dWh[set][m] + gi * 4 * F, BN, 4 * F, HF, gmp(l, m) + P.gat_b + gi * 4 * F};
+          }
+        }
+      }
+      ColsumBatch cb{};
+      DVGR_TRY(hprobe.begin(DVGR_PROBE_BWD_GAT_DW, l));
+      DVGR_TRY(launch_dw(hs, gb, bias, TAG_BWD_GAT_DW, cb));
+      DVGR_TRY(hprobe.end(DVGR_PROBE_BWD_GAT_DW, l));
+      for (int m = 0; m < 2; ++m) {
+        cb.j[cb.n++] = ColsumJob{ms(l, m) + S.tn, nullptr, ws + W.dw[set][m], nullptr, 2 * BN, 0, D, D, gmp(l, m) + P.sf_p2};
+        cb.j[cb.n++] = ColsumJob{ws + W.da_part[set][m], nullptr, nullptr, nullptr, B, 0, kHeads * 2 * F, kHeads * 2 * F, gmp(l, m) + P.gat_a};
+        cb.j[cb.n++] = ColsumJob{ws + W.dc_part[set][m], nullptr, nullptr, nullptr, B, 0, kHeads, kHeads, gmp(l, m) + P.gat_c};
+      }
+      cb.chunks = 16;
+      DVGR_TRY(colsum(hs, cb));
+      DVGR_TRY(layer_done(l, hs));             // every gradient of layer block l is written on the side stream
+      if (side) {
+        side_done[set] = side->next();
+        if (!side_done[set]) return (int)hipErrorOutOfMemory;
+        const hipError_t e = hipEventRecord(side_done[set], hs);
+        if (e != hipSuccess) return (int)e;
+      }
+    }
+    // S2 backward on the critical path: dX += drop_x(dWh . Wcat)
+    {
+      GemmBatch gd{};
       if (!train) {
-        GemmBatch gd{};
         for (int m = 0; m < 2; ++m) {
           gd.p[gd.n] = nn(ws + W.dWh[set][m], HF, mp(l, m) + P.gat_w, D, dXacc[m], D, BN, D, HF, 1);
           PM.attach(gd.p[gd.n++]);
         }
-        DVGR_TRY(probe.begin(DVGR_PROBE_BWD_GAT_DX, l));
-        DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_BWD_GAT_DX, prec));
-        DVGR_TRY(probe.end(DVGR_PROBE_BWD_GAT_DX, l));
       } else {
         // the two GATs dropped x with different masks: the common GAT's partial accumulates into dX, the specific GAT's
         // goes to a scratch tensor in the same launch (two tiles may not read-modify-write one output), and the punish
         // backward, which rewrites every element of dX anyway, folds it in
-        GemmBatch gd{};
         for (int gi = 0; gi < 2; ++gi)
           for (int m = 0; m < 2; ++m) {
             gd.p[gd.n] = nn(ws + W.dWh[set][m] + gi * 4 * F, HF, mp(l, m) + P.gat_w + (int64_t)gi * 4 * F * D, D,
                             gi == 0 ? dXacc[m] : ws + W.dxtmp[m], D, BN, D, 4 * F, gi == 0 ? 1 : 0, K.x[m][gi]);
             PM.attach(gd.p[gd.n++]);
           }
-        DVGR_TRY(probe.begin(DVGR_PROBE_BWD_GAT_DX, l));
-        DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_BWD_GAT_DX, prec));
-        DVGR_TRY(probe.end(DVGR_PROBE_BWD_GAT_DX, l));
       }
-      GemmBatch gb{};
-      for (int m = 0; m < 2; ++m) {
-        if (!train) {
-          gb.p[gb.n] = tn(ws + W.dWh[set][m], HF, Xin[m], D, gmp(l, m) + P.gat_w, D, HF, D, BN);
-          PM.attach(gb.p[gb.n++]);
-        } else {
-          for (int gi = 0; gi < 2; ++gi) {
-            gb.p[gb.n] = tn(ws + W.dWh[set][m] + gi * 4 * F, HF, ms(l, m) + S.xd + gi * BND, D,
-                            gmp(l, m) + P.gat_w + (int64_t)gi * 4 * F * D, D, 4 * F, D, BN);
-            PM.attach(gb.p[gb.n++]);
-          }
-        }
-      }
-      // the last layer processed has no successor to overlap with: its dP1 contraction follows the dX chain on the main
-      // stream while the side stream works through the query branch
-      if (sf_dw_main) {
-        DVGR_TRY(probe.begin(DVGR_PROBE_BWD_SF_DW, l));
-        DVGR_TRY(gemm_launch(st, IC, IC, sf_dw, TAG_BWD_SF_DW, prec));
-        DVGR_TRY(probe.end(DVGR_PROBE_BWD_SF_DW, l));
-      }
-      // dWcat stays on the main stream in every layer: with it the side stream (dP1, the query branch, all column sums)
-      // and the main stream carry about the same load (measured: +5 % over dWcat on the side stream)
-      DVGR_TRY(probe.begin(DVGR_PROBE_BWD_GAT_DW, l));
-      DVGR_TRY(gemm_launch(st, IC, IC, gb, TAG_BWD_GAT_DW, prec));
-      DVGR_TRY(probe.end(DVGR_PROBE_BWD_GAT_DW, l));
+      DVGR_TRY(probe.begin(DVGR_PROBE_BWD_GAT_DX, l));
+      DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_BWD_GAT_DX, prec));
+      DVGR_TRY(probe.end(DVGR_PROBE_BWD_GAT_DX, l));
     }
-    // S1 backward, dX part (folds the specific GAT's partial of the training-mode S2 backward in)
+    // S1 backward in one launch: d p of this layer (kept for the query branch below), the dX update (folding the specific
+    // GAT's partial of the training-mode S2 backward in), and the clearing of this layer's dq-bar accumulator
     {
       PunishBwdArgs a{};
       for (int m = 0; m < 2; ++m) {
@@ -782,77 +782,87 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
         a.X[m] = Xin[m]; a.dX[m] = dXacc[m];
         a.add[m] = train ? ws + W.dxtmp[m] : nullptr;
       }
-      a.dp_cat = ws + W.dp_cat[set]; a.B = B; a.N = N; a.D = D; a.parts = 2;
+      a.dp_cat = ws + W.dp_cat + (int64_t)l * B * 2 * D; a.B = B; a.N = N; a.D = D; a.parts = 3;
+      a.zero = ws + W.dqbar + (int64_t)l * B * Wd; a.zero_cols = Wd;
       DVGR_TRY(punish_bwd(st, a));
     }
-    // ---- everything below is off the critical path: query branch of this layer, bias gradients ----
-    {
-      GemmBatch gb{};   // dWq[m] = dp[m]^T . q
-      for (int m = 0; m < 2; ++m)
-        gb.p[gb.n++] = tn(ws + W.dp_cat[set] + m * D, 2 * D, ls(l) + S.qa_q, Wd, gmp(l, m) + P.wq, Wd, D, Wd, B);
-      DVGR_TRY(gemm_launch(hs, IC, IC, gb, TAG_GENERIC, prec));
-      for (int m = 0; m < 2; ++m)
-        cb.j[cb.n++] = ColsumJob{ws + W.dp_cat[set] + m * D, nullptr, nullptr, nullptr, B, 0, D, 2 * D, gmp(l, m) + P.bq};
-      GemmBatch gd{};   // dqbar = [dp_app | dp_mot] . [Wq_app ; Wq_mot]
-      GemmProblem p = nn(ws + W.dp_cat[set], 2 * D, mp(l, 0) + P.wq, Wd, ws + W.dqbar[set], Wd, B, Wd, 2 * D, 0);
+  }
+
+  // ---- query branch of ALL layers (S1 tail and S0 backward), batched over the layers: d Wq, d q-bar, the row kernels,
+  // d W1, d(dq) and the bias / vector gradients of the query block.  It needs every layer's d p, so it follows the last
+  // layer; the main stream takes the d(dq) contraction while the side stream does the weight gradients.
+  DVGR_TRY(to_side());
+  {
+    ColsumBatch cb{};
+    auto flush_cb = [&]() -> int {
+      if (!cb.n) return 0;
+      cb.chunks = 16;
+      const int e = colsum(hs, cb);
+      cb.n = 0;
+      return e;
+    };
+    GemmBatch gb{};   // dWq[l][m] = dp[l][m]^T . q[l]
+    for (int l = 0; l < L; ++l)
+      for (int m = 0; m < 2; ++m) {
+        const float* dpc = ws + W.dp_cat + (int64_t)l * B * 2 * D + m * D;
+        gb.p[gb.n++] = tn(dpc, 2 * D, ls(l) + S.qa_q, Wd, gqp(l, m) + P.wq, Wd, D, Wd, B);
+        if (gb.n == kMaxBatch || (l == L - 1 && m == 1)) { DVGR_TRY(gemm_launch(hs, IC, IC, gb, TAG_GENERIC, prec)); gb.n = 0; }
+        cb.j[cb.n++] = ColsumJob{dpc, nullptr, nullptr, nullptr, B, 0, D, 2 * D, gqp(l, m) + P.bq};
+        if (cb.n == kMaxColsumJobs) DVGR_TRY(flush_cb());
+      }
+    GemmBatch gd{};   // dqbar[l] = [dp_app | dp_mot] . [Wq_app ; Wq_mot]
+    for (int l = 0; l < L; ++l) {
+      GemmProblem p = nn(ws + W.dp_cat + (int64_t)l * B * 2 * D, 2 * D, qp(l, 0) + P.wq, Wd, ws + W.dqbar + (int64_t)l * B * Wd, Wd,
+                         B, Wd, 2 * D, 0);
       p.kseg = D;
-      p.B.p1 = mp(l, 1) + P.wq;
+      p.B.p1 = qp(l, 1) + P.wq;
       p.atomic_ok = 1;                       // 3 output tiles x 48 K-tiles: split K, partials added atomically
       p.accumulate = 1;
       gd.p[gd.n++] = p;
-      DVGR_TRY(gemm_launch(hs, KC, IC, gd, TAG_GENERIC, prec));
+      if (gd.n == kMaxBatch || l == L - 1) { DVGR_TRY(gemm_launch(hs, KC, IC, gd, TAG_GENERIC, prec)); gd.n = 0; }
     }
-    // S0 backward for this layer
-    {
-      QaBwdArgs a{};
-      a.dqbar = ws + W.dqbar[set]; a.words = io->words; a.qlen = io->qlen;
-      a.params = lp(l); a.off_w2 = P.qa_w2; a.layer_stride = 0;
-      a.saved = ls(l); a.s_layer_stride = 0; a.s_d = S.qa_d; a.s_nrm = S.qa_nrm; a.s_a = S.qa_a; a.s_ah = S.qa_ah; a.s_S = S.qa_s;
-      a.gwords = g->gwords; a.dr = ws + W.dr; a.dy = ws + W.dy; a.rowdots = ws + W.qdots;
-      a.B = B; a.T = T; a.D = D; a.Wd = Wd; a.L = 1;
-      a.first = (l == L - 1) ? 1 : 0;
-      a.dy_p = PM.out(ws + W.dy, &plo);
-      a.lo_off = plo;
-      DVGR_TRY(qa_bwd(hs, a));
-      GemmBatch gb{};   // dW1 = dy^T . dq
-      gb.p[gb.n] = tn(ws + W.dy, D, io->dq, D, glp(l) + P.qa_w1, D, D, D, BT);
-      PM.attach(gb.p[gb.n++]);
-      GemmBatch gd{};   // d(dq) (+)= dy . W1
-      gd.p[gd.n] = nn(ws + W.dy, D, lp(l) + P.qa_w1, D, g->gdq, D, BT, D, D, 1);
-      PM.attach(gd.p[gd.n++]);
-      gd.p[0].atomic_ok = 1;
-      // last layer processed: the main stream is idle by now and takes this contraction while the side stream does dW1
-      hipStream_t qs = hs;
-      if (l == 0 && side) { DVGR_TRY(side->order(hs, st)); qs = st; }
-      DVGR_TRY(gemm_launch(qs, KC, IC, gd, TAG_GENERIC, prec));
-      DVGR_TRY(gemm_launch(hs, IC, IC, gb, TAG_GENERIC, prec));
-      cb.j[cb.n++] = ColsumJob{ws + W.dy, nullptr, nullptr, nullptr, BT, 0, D, D, glp(l) + P.qa_b1};
-      cb.j[cb.n++] = ColsumJob{ls(l) + S.qa_d, nullptr, ws + W.dr, nullptr, BT, 0, D, D, glp(l) + P.qa_w2};
-      cb.j[cb.n++] = ColsumJob{ws + W.dr, nullptr, nullptr, nullptr, BT, 0, 1, 1, glp(l) + P.qa_b2};
+    QaBwdArgs a{};
+    a.dqbar = ws + W.dqbar; a.words = io->words; a.qlen = io->qlen;
+    a.params = params + P.q_base; a.off_w2 = P.qa_w2; a.layer_stride = P.q_layer_stride;
+    a.saved = saved; a.s_layer_stride = S.layer_stride; a.s_d = S.qa_d; a.s_nrm = S.qa_nrm; a.s_a = S.qa_a; a.s_ah = S.qa_ah; a.s_S = S.qa_s;
+    a.gwords = g->gwords; a.dr = ws + W.dr; a.dy = ws + W.dy; a.rowdots = ws + W.qdots;
+    a.B = B; a.T = T; a.D = D; a.Wd = Wd; a.L = L;
+    a.first = 1;
+    a.dy_p = PM.out(ws + W.dy, &plo);
+    a.lo_off = plo;
+    DVGR_TRY(qa_bwd(hs, a));
+    if (side) DVGR_TRY(side->order(hs, st));    // dy is final: the idle main stream takes d(dq)
+    GemmBatch gq{};   // d(dq) += dy[l] . W1[l]: L problems into ONE output -> partial tiles are added atomically (gdq is zeroed)
+    for (int l = 0; l < L; ++l) {
+      gq.p[gq.n] = nn(ws + W.dy + (int64_t)l * BT * D, D, lp(l) + P.qa_w1, D, g->gdq, D, BT, D, D, 1);
+      PM.attach(gq.p[gq.n]);
+      gq.p[gq.n].atomic_ok = 1;
+      gq.p[gq.n++].atomic_out = (L > 1);
+      if (gq.n == kMaxBatch || l == L - 1) { DVGR_TRY(gemm_launch(st, KC, IC, gq, TAG_GENERIC, prec)); gq.n = 0; }
     }
-    cb.chunks = 16;
-    DVGR_TRY(colsum(hs, cb));
-    if (l > 0 && layer_done_events && layer_done_events[l]) {
-      // layer l's gradients are written on BOTH streams (dWcat on `st`; dP1, the query branch and the column sums on
-      // `hs`): the event must not fire before the main stream's share is final
-      if (side) DVGR_TRY(side->order(st, hs));
-      const hipError_t e = hipEventRecord((hipEvent_t)layer_done_events[l], hs);
-      if (e != hipSuccess) return (int)e;
-      if (O.layer_done_cb) O.layer_done_cb(l, O.layer_done_user);
+    GemmBatch gw{};   // dW1[l] = dy[l]^T . dq  (+ d b1 = dy[l]^T . 1)
+    BiasOf bias[kMaxBatch] = {};
+    for (int l = 0; l < L; ++l) {
+      gw.p[gw.n] = tn(ws + W.dy + (int64_t)l * BT * D, D, io->dq, D, glp(l) + P.qa_w1, D, D, D, BT);
+      PM.attach(gw.p[gw.n]);
+      bias[gw.n++] = BiasOf{ws + W.dy + (int64_t)l * BT * D, BT, D, D, glp(l) + P.qa_b1};
+      if (gw.n == kMaxBatch || l == L - 1) {
+        ColsumBatch cb2{};
+        DVGR_TRY(launch_dw(hs, gw, bias, TAG_GENERIC, cb2));
+        if (cb2.n) { cb2.chunks = 16; DVGR_TRY(colsum(hs, cb2)); }
+        gw.n = 0;
+      }
     }
-    if (side) {
-      side_done[set] = side->next();
-      if (!side_done[set]) return (int)hipErrorOutOfMemory;
-      const hipError_t e = hipEventRecord(side_done[set], hs);
-      if (e != hipSuccess) return (int)e;
+    for (int l = 0; l < L; ++l) {
+      cb.j[cb.n++] = ColsumJob{ls(l) + S.qa_d, nullptr, ws + W.dr + (int64_t)l * BT, nullptr, BT, 0, D, D, glp(l) + P.qa_w2};
+      if (cb.n == kMaxColsumJobs) DVGR_TRY(flush_cb());
+      cb.j[cb.n++] = ColsumJob{ws + W.dr + (int64_t)l * BT, nullptr, nullptr, nullptr, BT, 0, 1, 1, glp(l) + P.qa_b2};
+      if (cb.n == kMaxColsumJobs) DVGR_TRY(flush_cb());
     }
+    DVGR_TRY(flush_cb());
   }
-  DVGR_TRY(to_main());   // the caller's stream sees every gradient
-  if (layer_done_events && layer_done_events[0]) {   // layer 0's weight gradients were split over both streams
-    const hipError_t e = hipEventRecord((hipEvent_t)layer_done_events[0], st);
-    if (e != hipSuccess) return (int)e;
-    if (O.layer_done_cb) O.layer_done_cb(0, O.layer_done_user);
-  }
+  DVGR_TRY(layer_done(L + 1, hs));        // the query block
+  DVGR_TRY(to_main());                    // the caller's stream sees every gradient
   return 0;
 }
 
@@ -927,7 +937,8 @@ int dvgr_dbg_gemm_planes(int mode, int M, int N, int K, const float* A, const vo
 // as the unit's launch sites batch the modalities / views; kseg < K selects the two-segment reduction (segment 1 = A2 / B2)
 int dvgr_dbg_gemm_planes_batch(int mode, int M, int N, int K, int kseg, const float* A, const void* A_hi, int64_t lda,
                                int64_t a_lo_off, const float* B, const void* B_hi, int64_t ldb, int64_t b_lo_off, float* C,
-                               int64_t ldc, int act, int accumulate, int atomic_ok, int prec, int count, int tag, void* stream) {
+                               int64_t ldc, int act, int accumulate, int atomic_ok, int prec, int count, int tag, float* rowsum,
+                               int same_output, void* stream) {
   if (!A || !B || !C || !A_hi || !B_hi) return DVGR_E_NULL;
   if (count < 1 || count > kMaxBatch) return DVGR_E_DIMS;
   GemmBatch gb{};
@@ -937,7 +948,9 @@ int dvgr_dbg_gemm_planes_batch(int mode, int M, int N, int K, int kseg, const fl
     p.B = operand(B, ldb);
     p.A.h0 = p.A.h1 = reinterpret_cast<const uint16_t*>(A_hi); p.A.lo_off = a_lo_off;
     p.B.h0 = p.B.h1 = reinterpret_cast<const uint16_t*>(B_hi); p.B.lo_off = b_lo_off;
-    p.C = C + (int64_t)i * M * ldc; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.kseg = (kseg > 0 && kseg < K) ? kseg : K;
+    p.C = same_output ? C : C + (int64_t)i * M * ldc;
+    p.atomic_out = same_output;            // every problem adds its tiles into ONE pre-zeroed output
+    p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.kseg = (kseg > 0 && kseg < K) ? kseg : K;
     if (p.kseg < K) {      // second segment: the same rows again (timing only)
       if (mode == 2) { p.A.p1 = A; p.A.h1 = p.A.h0; }
       p.B.p1 = B; p.B.h1 = p.B.h0;
@@ -946,6 +959,10 @@ int dvgr_dbg_gemm_planes_batch(int mode, int M, int N, int K, int kseg, const fl
     gb.p[gb.n++] = p;
   }
   const int la = mode == 2 ? IC : KC, lb = mode == 0 ? KC : IC;
+  if (rowsum) {
+    if (!gemm_rowsum_supported(la, lb, gb, prec)) return DVGR_E_DIMS;
+    for (int i = 0; i < count; ++i) gb.p[i].rowsum = rowsum + (int64_t)i * M;
+  }
   return gemm_launch((hipStream_t)stream, la, lb, gb, tag, prec);
 }
 

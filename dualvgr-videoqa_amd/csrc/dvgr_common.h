@@ -18,14 +18,22 @@ constexpr float kSlope = 0.01f;    // LeakyReLU slope, model/models.py:95-100
 
 // ---------------------------------------------------------------------------------------------
 // Flat parameter layout.  Every tensor starts at a multiple of 64 floats.
+//   [ layer 0 | layer 1 | ... | layer L-1 | MFB | query block ]
+//   layer block  = per modality: Wcat, bcat, a, c (the two punish-GATs, 8 heads), P1, bP, p2 (SF attention)
+//   query block  = per layer: QueryAttn W1, b1, w2, b2; per modality: QueryPunish Wq, bq
+// The query-side parameters sit in a block of their own because their gradients become final together, at the very end
+// of the backward (the query branch of ALL layers runs as one batch of launches once every layer's d p is known), while
+// a layer block is final as soon as that layer's weight-gradient contractions are: the blocks are the buckets of the
+// data-parallel gradient all-reduce (dvgr_param_layer_range).
 // ---------------------------------------------------------------------------------------------
 struct ParamLayout {
-  int64_t layer_stride;            // floats per unit layer
-  int64_t mod_stride;              // floats per modality block inside a layer
-  int64_t qa_w1, qa_b1, qa_w2, qa_b2;                       // offsets inside a layer block
-  int64_t mod_base;                                          // first modality block inside a layer
-  int64_t wq, bq, gat_w, gat_b, gat_a, gat_c, sf_p1, sf_bp, sf_p2;  // offsets inside a modality block
+  int64_t layer_stride;            // floats per layer block
+  int64_t mod_stride;              // floats per modality block inside a layer block
+  int64_t gat_w, gat_b, gat_a, gat_c, sf_p1, sf_bp, sf_p2;          // offsets inside a modality block
   int64_t mfb_base, mfb_w0, mfb_b0, mfb_w1, mfb_b1, mfb_wo, mfb_bo;  // absolute offsets
+  int64_t q_base, q_layer_stride, q_mod_base, q_mod_stride;          // query block
+  int64_t qa_w1, qa_b1, qa_w2, qa_b2;                                // offsets inside a query layer block
+  int64_t wq, bq;                                                    // offsets inside a query modality block
   int64_t total;
 };
 
@@ -34,15 +42,7 @@ __host__ __device__ inline int64_t round64(int64_t x) { return (x + 63) / 64 * 6
 inline ParamLayout param_layout(const dvgr_dims& d) {
   ParamLayout p{};
   const int64_t D = d.D, Wd = d.Wd, F = d.D / 4;
-  int64_t o = 0;
-  p.qa_w1 = o; o += round64(D * D);
-  p.qa_b1 = o; o += round64(D);
-  p.qa_w2 = o; o += round64(D);
-  p.qa_b2 = o; o += 64;
-  p.mod_base = o;
   int64_t m = 0;
-  p.wq = m;    m += round64(D * Wd);
-  p.bq = m;    m += round64(D);
   p.gat_w = m; m += round64(kHeads * F * D);
   p.gat_b = m; m += round64(kHeads * F);
   p.gat_a = m; m += round64(kHeads * 2 * F);
@@ -51,7 +51,7 @@ inline ParamLayout param_layout(const dvgr_dims& d) {
   p.sf_bp = m; m += round64(D);
   p.sf_p2 = m; m += round64(D);
   p.mod_stride = m;
-  p.layer_stride = o + 2 * m;
+  p.layer_stride = 2 * m;
   p.mfb_base = p.layer_stride * d.L;
   int64_t q = p.mfb_base;
   p.mfb_w0 = q; q += round64((int64_t)kMfbHidden * D);
@@ -60,7 +60,19 @@ inline ParamLayout param_layout(const dvgr_dims& d) {
   p.mfb_b1 = q; q += round64(kMfbHidden);
   p.mfb_wo = q; q += round64(D * (int64_t)kMfbPooled);
   p.mfb_bo = q; q += round64(D);
-  p.total = q;
+  p.q_base = q;
+  int64_t o = 0;
+  p.qa_w1 = o; o += round64(D * D);
+  p.qa_b1 = o; o += round64(D);
+  p.qa_w2 = o; o += round64(D);
+  p.qa_b2 = o; o += 64;
+  p.q_mod_base = o;
+  int64_t w = 0;
+  p.wq = w; w += round64(D * Wd);
+  p.bq = w; w += round64(D);
+  p.q_mod_stride = w;
+  p.q_layer_stride = o + 2 * w;
+  p.total = p.q_base + p.q_layer_stride * d.L;
   return p;
 }
 

@@ -46,6 +46,12 @@ struct GemmProblem {
   int dbg;             // profiling aid (tools/): bit 0 skip the epilogue, bit 1 skip the K loop; 0 in production
   int atomic_ok;       // the output is pre-zeroed (or accumulates) and has no bias/act/mask: the launcher may split K
                        // over several workgroups that add their partial tiles with float atomics
+  int atomic_out;      // several problems of one batch ADD into this same (pre-zeroed) output: every tile is added with
+                       // float atomics whether or not K is split
+  float* rowsum;       // nullable, TN only (A = dY[k][m]): rowsum[m] += sum_k A[k][m], i.e. the bias gradient dY^T . 1 that
+                       // belongs to the weight gradient C = dY^T . X, taken from the A fragments the kernel already holds
+                       // (one extra MFMA against a ones fragment per A fragment, in the workgroups of output column 0).
+                       // ADDED atomically: the target must be zeroed beforehand.  Only set it when gemm_rowsum_supported().
 };
 
 constexpr int kMaxBatch = 8;
@@ -57,6 +63,10 @@ struct GemmBatch {
 // Launch-site tags: each tag is a separate instantiation (= its own kernel symbol in a profile).
 enum : int { TAG_GENERIC = 0, TAG_FWD_GAT = 1, TAG_FWD_SF = 2, TAG_BWD_GAT_DW = 3, TAG_BWD_GAT_DX = 4,
              TAG_BWD_SF_DW = 5, TAG_BWD_SF_DX = 6 };
+
+// True when gemm_launch will honour GemmProblem::rowsum for this batch (the LDS-DMA ring kernels do; the register-staged
+// fallbacks for odd shapes and the batch-sized kernels do not: their callers use a column-sum job instead).
+bool gemm_rowsum_supported(int la, int lb, const GemmBatch& batch, int prec);
 
 // Enqueue the batch on `stream`.  la / lb in {KC, IC}.  Returns hipError_t as int.
 int gemm_launch(hipStream_t stream, int la, int lb, const GemmBatch& batch, int tag = TAG_GENERIC, int prec = DVGR_F32);

@@ -145,6 +145,7 @@ __device__ __forceinline__ void epilogue(const GemmProblem& P, const f32x4 (&acc
         else if (P.act == ACT_ELU) v = elu_f(v);
         const int64_t o = (int64_t)row * P.ldc + col;
         if (P.drop_key_c) v *= drop_factor(P.drop_key_c, (uint32_t)o);
+        if (P.atomic_out) { atomicAdd(P.C + o, v); continue; }
         if (P.accumulate) v += P.C[o];
         P.C[o] = v;
       }
@@ -225,6 +226,20 @@ __device__ __forceinline__ void epilogue_rows(const GemmProblem& P, const f32x4 
   }
 }
 
+// GemmProblem::rowsum: every column of rs[i] holds sum_k A[row][k] of rows 16 i + 4 (lane >> 4) + r; the lanes of
+// column 0 add them into the (pre-zeroed) target -- atomically, since split-K workgroups hold partial sums.
+template <int MT>
+__device__ __forceinline__ void store_rowsum(const GemmProblem& P, const f32x4 (&rs)[MT], int row0, int lane) {
+  if ((lane & 15) != 0) return;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + i * 16 + (lane >> 4) * 4 + r;
+      if (row < P.M) atomicAdd(P.rowsum + row, rs[i][r]);
+    }
+}
+
 // =================================================================================================
 // fp32 kernel.  TAG only gives a launch site its own kernel symbol (rocprofv3 then reports it separately).
 // =================================================================================================
@@ -288,7 +303,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch batch) {
     }
     __syncthreads();
   }
-  epilogue_rows<MT, NT>(P, acc, m0 + wm, n0 + wn, lane, smem + wave * (32 * (16 * NT + 4)));
+  epilogue_rows<MT, NT>(P, acc, m0 + wm, n0 + wn, lane, smem + wave * (32 * (16 * NT + 4)), P.atomic_out != 0);
 }
 
 // =================================================================================================
@@ -419,7 +434,7 @@ __global__ __launch_bounds__(256) void gemm_lp_kernel(const GemmBatch batch) {
     }
     __syncthreads();
   }
-  epilogue_rows<MT, NT>(P, acc, m0 + wm, n0 + wn, lane, reinterpret_cast<float*>(smem) + wave * (32 * (16 * NT + 4)));
+  epilogue_rows<MT, NT>(P, acc, m0 + wm, n0 + wn, lane, reinterpret_cast<float*>(smem) + wave * (32 * (16 * NT + 4)), P.atomic_out != 0);
 }
 
 // =================================================================================================
@@ -592,6 +607,11 @@ __global__ __launch_bounds__(768) void gemm_ring_kernel(const GemmBatch batch) {
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // row sums of the A operand (GemmProblem::rowsum): one wave per 64-row group, on different SIMDs
+  const bool do_rs = (LA == IC) && (PREC == DVGR_F32) && P.rowsum != nullptr && n0 == 0 && (wave & 3) == (wave >> 2);
+  f32x4 rs[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) rs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   bf16x8 ah[MT], al[MT], bh, bl;       // bf16 modes: operands carried from one K-tile into the next (see below)
   {
@@ -618,6 +638,12 @@ __global__ __launch_bounds__(768) void gemm_ring_kernel(const GemmBatch batch) {
 #pragma unroll
           for (int j = 0; j < NT; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+      if (do_rs) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+          for (int i = 0; i < MT; ++i) rs[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], 1.0f, rs[i], 0, 0, 0);
+      }
     } else {
       // Rotated, column-blocked schedule.  Per K-tile a wave converts 8 fragments fp32 -> bf16 hi (+ lo)
       // (~24 VALU each) and issues 16 x 3 MFMAs; written naively hipcc emits all conversions, then all MFMAs,
@@ -694,7 +720,8 @@ __global__ __launch_bounds__(768) void gemm_ring_kernel(const GemmBatch batch) {
   }
   __builtin_amdgcn_s_barrier();      // every consumer is done reading the ring; the loaders leave here
   if (P.dbg & 1) { if (acc[0][0][0] == 12345.678f) P.C[0] = 1.f; return; }
-  epilogue_rows<MT, NT>(P, acc, m0 + wm, n0 + wn, lane, smem + wave * (32 * (16 * NT + 4)), gridDim.y > 1);
+  if (do_rs) store_rowsum<MT>(P, rs, m0 + wm, lane);
+  epilogue_rows<MT, NT>(P, acc, m0 + wm, n0 + wn, lane, smem + wave * (32 * (16 * NT + 4)), gridDim.y > 1 || P.atomic_out);
 }
 
 // =================================================================================================
@@ -872,6 +899,14 @@ __global__ __launch_bounds__(768) void gemm_planes_kernel(const GemmBatch batch)
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // row sums of the A operand (GemmProblem::rowsum): A fragments x a ones fragment, one wave per 64-row group (waves 0
+  // and 5: different SIMDs), only in the workgroups of output column 0
+  const bool do_rs = (LA == IC) && P.rowsum != nullptr && n0 == 0 && (wave & 3) == (wave >> 2);
+  f32x4 rs[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) rs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  typedef short ones_s16x8 __attribute__((ext_vector_type(8)));
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s16x8{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80});
 
   GCLK_DECL;
   GCLK_START();
@@ -902,11 +937,19 @@ __global__ __launch_bounds__(768) void gemm_planes_kernel(const GemmBatch batch)
         }
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
       }
+    if (do_rs) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        if (TERMS == 3) rs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], ones, rs[i], 0, 0, 0);
+        rs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], ones, rs[i], 0, 0, 0);
+      }
+    }
   }
   __builtin_amdgcn_s_barrier();
   GCLK_ADD(1);
   if (P.dbg & 1) { if (acc[0][0][0] == 12345.678f) P.C[0] = 1.f; return; }
-  epilogue_rows<MT, NT>(P, acc, m0 + wm, n0 + wn, lane, reinterpret_cast<float*>(smem) + wave * (32 * (16 * NT + 4)), gridDim.y > 1);
+  if (do_rs) store_rowsum<MT>(P, rs, m0 + wm, lane);
+  epilogue_rows<MT, NT>(P, acc, m0 + wm, n0 + wn, lane, reinterpret_cast<float*>(smem) + wave * (32 * (16 * NT + 4)), gridDim.y > 1 || P.atomic_out);
   GCLK_ADD(2);
   if (wave == 0) GCLK_FLUSH(0);
 }
@@ -1009,7 +1052,7 @@ __global__ __launch_bounds__(768) void gemm_planes_wide_kernel(const GemmBatch b
       }
   }
   __builtin_amdgcn_s_barrier();
-  epilogue_rows<MT, NT>(P, acc, m0 + wm, n0 + wn, lane, reinterpret_cast<float*>(smem) + wave * (32 * (16 * NT + 4)), gridDim.y > 1);
+  epilogue_rows<MT, NT>(P, acc, m0 + wm, n0 + wn, lane, reinterpret_cast<float*>(smem) + wave * (32 * (16 * NT + 4)), gridDim.y > 1 || P.atomic_out);
 }
 
 #ifdef DVGR_CLK
@@ -1034,6 +1077,10 @@ static bool planes_eligible(const GemmBatch& b, int la, int lb) {
 
 static bool dbg_any(const GemmBatch& b) {
   for (int i = 0; i < b.n; ++i) if (b.p[i].dbg) return true;
+  return false;
+}
+static bool rowsum_any(const GemmBatch& b) {
+  for (int i = 0; i < b.n; ++i) if (b.p[i].rowsum) return true;
   return false;
 }
 
@@ -1074,7 +1121,7 @@ static int launch_ring(hipStream_t stream, const GemmBatch& b, int prec) {
       if (cost < best) { best = cost; split = s; }
     }
   }
-  if (prec != DVGR_F32 && planes_eligible(b, LA, LB) && !dbg_any(b)) {
+  if (prec != DVGR_F32 && planes_eligible(b, LA, LB) && !dbg_any(b) && !rowsum_any(b)) {
     // thousands of tiles: the 128 x 256 variant (a third fewer LDS bytes per MFMA)
     int tiles_w = 0;
     long total_w = 0;
@@ -1155,6 +1202,12 @@ static int launch_layout(hipStream_t stream, const GemmBatch& b, int prec) {
 
 bool small_eligible(const GemmBatch& b, int la, int lb);
 int small_launch(hipStream_t st, int la, int lb, const GemmBatch& b);
+
+bool gemm_rowsum_supported(int la, int lb, const GemmBatch& b, int prec) {
+  if (la != IC || lb != IC) return false;
+  if (small_eligible(b, la, lb) || !ring_eligible(b)) return false;
+  return prec == DVGR_F32 || planes_eligible(b, la, lb);      // the converting ring variants do not carry the row sums
+}
 
 int gemm_launch(hipStream_t stream, int la, int lb, const GemmBatch& b, int tag, int prec) {
   if (b.n < 1 || b.n > kMaxBatch) return DVGR_E_DIMS;

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void k_small_nn(const GemmBatch batch, int row
     if (row < P.M) {
       const float v = (red[0][I][tid] + red[1][I][tid]) + (red[2][I][tid] + red[3][I][tid]);
       float* c = P.C + (int64_t)row * P.ldc + col;
-      if (ksplit > 1) atomicAdd(c, v);
+      if (ksplit > 1 || P.atomic_out) atomicAdd(c, v);
       else *c = P.accumulate ? *c + v : v;
     }
   }

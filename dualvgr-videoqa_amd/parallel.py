@@ -18,11 +18,16 @@ import torch
 import torch.distributed as dist
 
 
+def block_order(num_layers: int) -> List[int]:
+    """Block indices (dvgr_param_layer_range) in the order the backward finalises them: the MFB block (L), the layer
+    blocks L-1 .. 0, then the query block (L+1: QueryAttn / QueryPunish parameters of all layers)."""
+    L = num_layers
+    return [L] + list(range(L - 1, -1, -1)) + [L + 1]
+
+
 def layer_buckets(module) -> List[Tuple[int, int]]:
-    """[first, last) element ranges of the flat gradient buffer, in the order the backward
-    finalises them: MFB block first, then layers L-1 .. 0."""
-    L = module.layers
-    return [module.layer_param_range(l) for l in [L] + list(range(L - 1, -1, -1))]
+    """[first, last) element ranges of the flat gradient buffer, in the order the backward finalises them."""
+    return [module.layer_param_range(l) for l in block_order(module.layers)]
 
 
 class LayerBucketReducer:
@@ -39,19 +44,19 @@ class LayerBucketReducer:
             self.stream = torch.cuda.Stream(device=device, priority=-1)
 
     def _layer_order(self) -> List[int]:
-        """Layer index of bucket i (buckets are ordered MFB = L, then L-1 .. 0: `layer_buckets`)."""
-        L = len(self.buckets) - 1
-        return [L] + list(range(L - 1, -1, -1))
+        """Block index of bucket i (`layer_buckets` order: MFB = L, then L-1 .. 0, then the query block L+1)."""
+        return block_order(len(self.buckets) - 2)
 
     def reduce(self, flat_grad: torch.Tensor, events: Optional[Sequence] = None) -> None:
         """In-place average of `flat_grad`.  `events` is the LAYER-indexed list handed to
-        `DualVGRUnit_multiple.set_layer_events` (events[l] = layer l's gradients are final, events[L] = the MFB block's):
+        `DualVGRUnit_multiple.set_layer_events` (events[l] = layer block l is final, events[L] = the MFB block, events[L+1]
+        = the query block):
         the bucket of layer l is gated on events[l] on the communication stream.  Whatever the events do not cover
         (no list, or a None entry) waits for the caller's current stream instead."""
         if self.world == 1 and not getattr(self, "force", False):
             return
         if events is not None and len(events) != len(self.buckets):
-            raise ValueError(f"expected {len(self.buckets)} layer-indexed events (L + 1), got {len(events)}")
+            raise ValueError(f"expected {len(self.buckets)} block-indexed events (L + 2), got {len(events)}")
         if flat_grad.is_cuda and self.stream is not None:
             cur = torch.cuda.current_stream(flat_grad.device)
             works = []
@@ -79,7 +84,7 @@ class LayerBucketReducer:
         """Begin one step.  threaded: the collectives are enqueued by a helper thread, so that their host cost (tens of
         microseconds each) does not sit in the backward's launch path -- the callback only posts the bucket."""
         self._works = []
-        self._bucket_of_layer = {layer: i for i, layer in enumerate([num_layers] + list(range(num_layers - 1, -1, -1)))}
+        self._bucket_of_layer = {layer: i for i, layer in enumerate(block_order(num_layers))}
         self._error = None
         if threaded and self.stream is not None and getattr(self, "_q", None) is None:
             import queue

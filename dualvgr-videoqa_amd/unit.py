@@ -444,8 +444,11 @@ class DualVGRUnit_multiple(nn.Module):
         return self._ws
 
     def set_layer_events(self, events):
-        """events: list of L+1 torch.cuda.Event (recorded by the backward as each layer's parameter
-        gradients become final; index L = the MFB block).  None disables."""
+        """events: list of L+2 torch.cuda.Event, one per block of the flat gradient buffer (layer_param_range), recorded
+        by the backward as the blocks become final: index L = the MFB block, L-1 .. 0 = the layer blocks, L+1 = the query
+        block (last).  None disables."""
+        if events is not None and len(events) != self.layers + 2:
+            raise ValueError(f"expected {self.layers + 2} events (L layer blocks, the MFB block, the query block)")
         for ev in events or []:
             if not ev.cuda_event:
                 ev.record()          # torch creates the hipEvent lazily at the first record
@@ -453,7 +456,7 @@ class DualVGRUnit_multiple(nn.Module):
 
     def set_layer_callback(self, fn):
         """fn(layer_index, flat_grad) is called on the host, from inside the backward call, right after the event of
-        `layer_index` (set_layer_events; index L = the MFB block) has been enqueued: the place to launch that slice's
+        `layer_index` (set_layer_events; index L = the MFB block, L+1 = the query block) has been enqueued: the place to launch that slice's
         all-reduce (parallel.LayerBucketReducer.launch).  None disables."""
         self._layer_cb = fn
         self._layer_cb_error = None
@@ -488,7 +491,7 @@ class DualVGRUnit_multiple(nn.Module):
                 o.probe_site, o.probe_layer = site, layer
                 o.probe_begin, o.probe_end = b.cuda_event, e.cuda_event
         if backward and self._events:
-            arr = (C.c_void_p * (self.layers + 1))()
+            arr = (C.c_void_p * (self.layers + 2))()
             for i, ev in enumerate(self._events):
                 arr[i] = ev.cuda_event
             self._events_arr = arr               # keep alive for the duration of the call

@@ -165,10 +165,10 @@ enum dvgr_probe_site {
   DVGR_PROBE_FWD_GAT_ATTN,   /* S3  attention + aggregation               (forward)  */
   DVGR_PROBE_FWD_SF_GEMM,    /* S4  tanh(z . P1^T), 2 views x 2 modalities (forward) */
   DVGR_PROBE_FWD_MFB_GEMM,   /* S6  linear0 / linear1                     (forward)  */
-  DVGR_PROBE_BWD_SF_DW,      /* dP1 = dpre^T . z                          (backward) */
+  DVGR_PROBE_BWD_SF_DW,      /* (merged into DVGR_PROBE_BWD_GAT_DW: one launch per layer)     */
   DVGR_PROBE_BWD_SF_DX,      /* dz += dpre . P1                           (backward) */
   DVGR_PROBE_BWD_GAT_ATTN,   /* attention backward                        (backward) */
-  DVGR_PROBE_BWD_GAT_DW,     /* dWcat = dWh^T . X                         (backward) */
+  DVGR_PROBE_BWD_GAT_DW,     /* dWcat = dWh^T . X and dP1 = dpre^T . z    (backward) */
   DVGR_PROBE_BWD_GAT_DX,     /* dX += dWh . Wcat                          (backward) */
   DVGR_PROBE_SITES
 };
@@ -199,10 +199,12 @@ typedef struct dvgr_opts {
   uint64_t seed;       /* key of the counter-based dropout RNG; masks are recomputed, never stored         */
   void *probe_begin;   /* hipEvent_t, recorded before the probed launch (nullable)                         */
   void *probe_end;     /* hipEvent_t, recorded after it                                                    */
-  void *const *layer_done_events; /* backward only, nullable: L+1 hipEvent_t; event[L] is recorded when the
-                          MFB parameter gradients are final, event[l] when layer l's are, so a data-parallel
-                          caller can start the RCCL all-reduce of that slice of `gparams` while the earlier
-                          layers are still running */
+  void *const *layer_done_events; /* backward only, nullable: L+2 hipEvent_t, one per block of the flat gradient buffer
+                          (dvgr_param_layer_range), recorded in the order the blocks become final: event[L] the MFB
+                          block, event[L-1] .. event[0] the layer blocks (GAT + SF-attention parameters), event[L+1] the
+                          query block (QueryAttn / QueryPunish parameters of all layers: their branch runs once, batched
+                          over the layers, after the last layer) -- so a data-parallel caller can start the RCCL
+                          all-reduce of a block while the rest of the backward is still running */
   const dvgr_loss_spec *loss;     /* forward only, nullable: also evaluate the scope-U loss and its gradients */
   void (*layer_done_cb)(int32_t index, void *user); /* backward only, nullable: called ON THE HOST, in the calling thread,
                           right after layer_done_events[index] has been enqueued -- the place to enqueue that slice's
@@ -229,8 +231,9 @@ int dvgr_unit_backward(const dvgr_dims *d, const float *params, const void *para
                        void *workspace, size_t workspace_bytes,
                        const dvgr_opts *opts, void *stream);
 
-/* [first, last) element range of the flat buffer that holds layer `layer`'s parameters
- * (layer == L: the MFB block). */
+/* [first, last) element range of one block of the flat parameter / gradient buffer: layer < L: that layer's GAT and
+ * SF-attention parameters; layer == L: the MFB block; layer == L + 1: the query block (QueryAttn and QueryPunish
+ * parameters of all layers).  The blocks tile the buffer: [layer 0 | ... | layer L-1 | MFB | query]. */
 int dvgr_param_layer_range(const dvgr_dims *d, int layer, int64_t *first, int64_t *last);
 
 /* Scope-U scalar loss on the unit's outputs, value and gradient in one pass:

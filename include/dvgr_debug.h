@@ -34,10 +34,13 @@ int dvgr_dbg_gemm_planes(int mode, int M, int N, int K, const float *A, const vo
 
 /* Timing aid (tools/gemm_shapes.py): `count` (<= 8) copies of one pre-split problem in ONE launch, outputs count * M rows
  * apart, as the unit's launch sites batch modalities / views; kseg in (0, K): two-segment reduction; tag: launch-site tag
- * (0 generic .. 6, csrc/dvgr_gemm.h). */
+ * (0 generic .. 6, csrc/dvgr_gemm.h).  rowsum (nullable, mode 2 only; count * M floats, pre-zeroed): the bias gradient
+ * sum_k A[k][m] is ADDED there (GemmProblem::rowsum; DVGR_E_DIMS when the engine cannot do it for this shape).
+ * same_output != 0: every copy adds its tiles atomically into the FIRST output (pre-zeroed), as the batched d(dq). */
 int dvgr_dbg_gemm_planes_batch(int mode, int M, int N, int K, int kseg, const float *A, const void *A_hi, int64_t lda,
                                int64_t a_lo_off, const float *B, const void *B_hi, int64_t ldb, int64_t b_lo_off, float *C,
-                               int64_t ldc, int act, int accumulate, int atomic_ok, int prec, int count, int tag, void *stream);
+                               int64_t ldc, int act, int accumulate, int atomic_ok, int prec, int count, int tag, float *rowsum,
+                               int same_output, void *stream);
 
 /* out[c] = sum_r w[r] * M[r][c]  (w nullable) */
 int dvgr_dbg_colsum(const float *M, const float *w, int rows, int cols, int64_t ld, float *out, void *stream);

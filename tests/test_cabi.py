@@ -106,15 +106,30 @@ def test_param_layout_is_disjoint_and_aligned(D, Wd, Lr):
     for kind in range(L.P_KINDS):
         off, rows, cols = L.param_offset(d, kind, 0, 0)
         assert off % 64 == 0
-    # layer ranges tile the buffer
+    # the blocks tile the buffer: layer blocks 0 .. L-1, the MFB block (L), the query block (L + 1)
     lib = L.load()
     prev = 0
-    for l in range(Lr + 1):
+    for l in range(Lr + 2):
         a, b = C.c_int64(), C.c_int64()
         assert lib.dvgr_param_layer_range(C.byref(d), l, C.byref(a), C.byref(b)) == 0
         assert a.value == prev and b.value > a.value
         prev = b.value
     assert prev == total
+    a, b = C.c_int64(), C.c_int64()
+    assert lib.dvgr_param_layer_range(C.byref(d), Lr + 2, C.byref(a), C.byref(b)) == -5
+    # which parameter lives in which block
+    rng = {}
+    for l in range(Lr + 2):
+        assert lib.dvgr_param_layer_range(C.byref(d), l, C.byref(a), C.byref(b)) == 0
+        rng[l] = (a.value, b.value)
+    for name, shape, off in tab:
+        blk = next(l for l, (x, y) in rng.items() if x <= off < y)
+        if name.startswith(("queryAttn.", "queryPunish_")):
+            assert blk == Lr + 1, name
+        elif name.startswith("visualfusion."):
+            assert blk == Lr, name
+        else:
+            assert blk == int(name.split(".")[1]), name
     n_real = sum(int(np.prod(s)) for s in shapes.values())
     assert int(used.sum()) == n_real
 

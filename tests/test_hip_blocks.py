@@ -317,3 +317,58 @@ def test_gemm_planes_wide_splitk(mode, M, N, K):
     C0 = _ints((M, N), seed=63)
     got = _gemm_planes(mode, A, B, M, N, K, 2, accumulate=True, C0=C0)
     assert torch.equal(got, (C0.double() + want).float()), float((got.double() - C0.double() - want).abs().max())
+
+
+# ---- bias gradients inside the weight-gradient contraction, several problems into one output ------------------------------
+def _planes(x):
+    lib, st = L.load(), _stream
+    n = x.numel()
+    pl = torch.empty(2 * n, device="cuda", dtype=torch.bfloat16)
+    assert lib.dvgr_dbg_split(x.data_ptr(), pl.data_ptr(), n, n, st()) == 0
+    return pl, n
+
+
+@pytest.mark.parametrize("prec", [L.DVGR_F32, L.DVGR_BF16X3])
+@pytest.mark.parametrize("M,N,K,count", [(768, 768, 1280, 4), (256, 128, 2560, 2), (200, 72, 96, 3), (1536, 768, 1280, 2)])
+def test_gemm_tn_carries_the_bias_gradient(M, N, K, count, prec):
+    """dW = dY^T . X with d b = dY^T . 1 taken from the A fragments (GemmProblem::rowsum): `count` problems in one launch
+    (split-K included: K = 2560 with few tiles), odd extents, both operand modes; against float64."""
+    lib, st = L.load(), _stream
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(K, M, generator=g).cuda()            # dY [k][m]
+    Bm = torch.randn(K, N, generator=g).cuda()           # X  [k][n]
+    pa, na = _planes(A)
+    pb, nb = _planes(Bm)
+    Cm = torch.zeros(count * M, N, device="cuda")
+    rs = torch.zeros(count * M, device="cuda")
+    rc = lib.dvgr_dbg_gemm_planes_batch(2, M, N, K, 0, A.data_ptr(), pa.data_ptr(), A.stride(0), na, Bm.data_ptr(), pb.data_ptr(),
+                                        Bm.stride(0), nb, Cm.data_ptr(), N, 0, 0, 1, prec, count, 3, rs.data_ptr(), 0, st())
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    want = (A.double().T @ Bm.double()).cpu()
+    want_rs = A.double().sum(0).cpu()
+    tol = 2e-6 if prec == L.DVGR_F32 else 2e-5
+    for i in range(count):
+        assert float((Cm[i * M:(i + 1) * M].double().cpu() - want).abs().max()) < tol * float(want.abs().max())
+        assert float((rs[i * M:(i + 1) * M].double().cpu() - want_rs).abs().max()) < tol * float(A.abs().sum(0).max())
+
+
+@pytest.mark.parametrize("prec", [L.DVGR_F32, L.DVGR_BF16X3])
+@pytest.mark.parametrize("M,N,K,count", [(960, 768, 768, 3), (90, 64, 64, 2), (36, 64, 128, 5)])
+def test_gemm_nn_several_problems_add_into_one_output(M, N, K, count, prec):
+    """The batched d(dq): `count` problems of one launch ADD their tiles atomically into one pre-zeroed output
+    (GemmProblem::atomic_out), on the ring kernels and on the batch-sized kernels (M <= 128)."""
+    lib, st = L.load(), _stream
+    g = torch.Generator().manual_seed(6)
+    A = torch.randn(M, K, generator=g).cuda()
+    Bm = torch.randn(K, N, generator=g).cuda()
+    pa, na = _planes(A)
+    pb, nb = _planes(Bm)
+    Cm = torch.zeros(M, N, device="cuda")
+    rc = lib.dvgr_dbg_gemm_planes_batch(1, M, N, K, 0, A.data_ptr(), pa.data_ptr(), A.stride(0), na, Bm.data_ptr(), pb.data_ptr(),
+                                        Bm.stride(0), nb, Cm.data_ptr(), N, 0, 1, 1, prec, count, 0, None, 1, st())
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    want = count * (A.double() @ Bm.double()).cpu()
+    tol = 2e-6 if prec == L.DVGR_F32 else 2e-5
+    assert float((Cm.double().cpu() - want).abs().max()) < tol * float(want.abs().max())

@@ -43,7 +43,7 @@ def test_layer_event_fires_only_when_the_whole_layer_block_is_final():
     the final gradient bit for bit -- also for the tensors written on the backward's MAIN stream (dWcat) while the event is
     recorded on the side stream.  Several steps back to back, training mode, full C2 size."""
     m, t = _module()
-    events = [torch.cuda.Event() for _ in range(Lr + 1)]
+    events = [torch.cuda.Event() for _ in range(Lr + 2)]
     m.set_layer_events(events)
     third = torch.cuda.Stream()
     snaps = {}
@@ -60,7 +60,7 @@ def test_layer_event_fires_only_when_the_whole_layer_block_is_final():
         m.zero_grad_flat()
         _step(m, t)
         torch.cuda.synchronize()
-        assert sorted(snaps) == list(range(Lr + 1))
+        assert sorted(snaps) == list(range(Lr + 2))
         for idx, snap in snaps.items():
             a, b = m.layer_param_range(idx)
             assert torch.equal(snap, m.last_flat_grad[a:b]), (rep, idx)
@@ -69,7 +69,7 @@ def test_layer_event_fires_only_when_the_whole_layer_block_is_final():
 
 def test_accumulation_with_the_layer_callback_is_refused():
     m, t = _module(train=False)
-    events = [torch.cuda.Event() for _ in range(Lr + 1)]
+    events = [torch.cuda.Event() for _ in range(Lr + 2)]
     m.set_layer_events(events)
     m.set_layer_callback(lambda idx, g: None)
     m.zero_grad_flat()
@@ -97,7 +97,7 @@ def test_reducer_gates_each_bucket_on_its_own_layers_event():
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         m, t = _module(train=False)
-        events = [torch.cuda.Event() for _ in range(Lr + 1)]
+        events = [torch.cuda.Event() for _ in range(Lr + 2)]
         m.set_layer_events(events)
         m.zero_grad_flat()
         _step(m, t)
@@ -110,14 +110,14 @@ def test_reducer_gates_each_bucket_on_its_own_layers_event():
         got = m.last_flat_grad.clone()
         red.reduce(got, events)
         torch.cuda.synchronize()
-        assert [id(e) for e in waited] == [id(events[l]) for l in [Lr] + list(range(Lr - 1, -1, -1))]
+        assert [id(e) for e in waited] == [id(events[l]) for l in parallel.block_order(Lr)]
         assert torch.equal(got, want)
         with pytest.raises(ValueError):
             red.reduce(got, events[:-1])
         # bucket-by-bucket form without events: waits for the CALLER's stream (captured in launch(), not the helper thread's)
         got2 = m.last_flat_grad.clone()
         red.start(Lr)
-        for layer in [Lr] + list(range(Lr - 1, -1, -1)):
+        for layer in parallel.block_order(Lr):
             red.launch(layer, got2)
         red.finish()
         torch.cuda.synchronize()

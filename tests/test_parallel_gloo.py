@@ -54,21 +54,21 @@ def _worker(rank, world, port, q):
         for (name, shape, off) in m._table:
             flat[off:off + g[name].numel()] = g[name].reshape(-1)
         buckets = parallel.layer_buckets(m)
-        assert buckets[0] == m.layer_param_range(LR) and buckets[-1] == m.layer_param_range(0)
+        assert buckets[0] == m.layer_param_range(LR) and buckets[-2] == m.layer_param_range(0) and buckets[-1] == m.layer_param_range(LR + 1)
         assert sorted(buckets)[0][0] == 0 and sorted(buckets)[-1][1] == flat.numel()
         flat2 = flat.clone()
         one_shot = parallel.LayerBucketReducer(buckets)
-        assert one_shot._layer_order() == [LR] + list(range(LR - 1, -1, -1))     # bucket i <-> layer-indexed event
+        assert one_shot._layer_order() == [LR] + list(range(LR - 1, -1, -1)) + [LR + 1]    # bucket i <-> block-indexed event
         try:
-            one_shot.reduce(flat, [None] * LR)                                   # L + 1 layer-indexed events expected
+            one_shot.reduce(flat, [None] * LR)                                   # L + 2 block-indexed events expected
             raise AssertionError("a short event list must be refused")
         except ValueError:
             pass
-        one_shot.reduce(flat, [None] * (LR + 1))
+        one_shot.reduce(flat, [None] * (LR + 2))
         # the same reduction driven bucket by bucket, in the order the backward's host callback fires (L, L-1, .., 0)
         red = parallel.LayerBucketReducer(buckets)
         red.start(LR)
-        for layer in [LR] + list(range(LR - 1, -1, -1)):
+        for layer in parallel.block_order(LR):
             red.launch(layer, flat2)
         red.finish()
         assert torch.equal(flat, flat2)

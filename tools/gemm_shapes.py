@@ -24,16 +24,18 @@ def planes(x):
     return pl, n
 
 
-def run(name, mode, M, Nn, K, count, tag, kseg=0, act=0, acc=0, atomic=0):
+def run(name, mode, M, Nn, K, count, tag, kseg=0, act=0, acc=0, atomic=0, rowsum=0):
     shp = {0: ((M, K), (Nn, K)), 1: ((M, K), (K, Nn)), 2: ((K, M), (K, Nn))}[mode]
     A, Bm = torch.randn(*shp[0], device="cuda"), torch.randn(*shp[1], device="cuda")
     pa, na = planes(A)
     pb, nb = planes(Bm)
     Cm = torch.zeros(count * M, Nn, device="cuda")
+    rs = torch.zeros(count * M, device="cuda")
 
     def call():
         rc = lib.dvgr_dbg_gemm_planes_batch(mode, M, Nn, K, kseg, A.data_ptr(), pa.data_ptr(), A.stride(0), na, Bm.data_ptr(),
-                                            pb.data_ptr(), Bm.stride(0), nb, Cm.data_ptr(), Nn, act, acc, atomic, prec, count, tag, st())
+                                            pb.data_ptr(), Bm.stride(0), nb, Cm.data_ptr(), Nn, act, acc, atomic, prec, count, tag,
+                                            rs.data_ptr() if rowsum else None, 0, st())
         assert rc == 0, rc
     for _ in range(5):
         call()
@@ -69,3 +71,4 @@ if __name__ == "__main__":
     run("bwd MFB dA, dM (K = 512)", 1, BN, D, 512, 2, 0)
     run("bwd MFB dW0, dW1", 2, 512, D, BN, 2, 0, atomic=1)
     run("dW all of one layer in ONE launch (6 problems)", 2, 768, D, BN, 6, 3, atomic=1)
+    run("  ... with the bias gradients (row sums) fused", 2, 768, D, BN, 6, 3, atomic=1, rowsum=1)
