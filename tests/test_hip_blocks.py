@@ -343,6 +343,9 @@ def test_gemm_tn_carries_the_bias_gradient(M, N, K, count, prec):
     rs = torch.zeros(count * M, device="cuda")
     rc = lib.dvgr_dbg_gemm_planes_batch(2, M, N, K, 0, A.data_ptr(), pa.data_ptr(), A.stride(0), na, Bm.data_ptr(), pb.data_ptr(),
                                         Bm.stride(0), nb, Cm.data_ptr(), N, 0, 0, 1, prec, count, 3, rs.data_ptr(), 0, st())
+    if K <= 256:                       # batch-sized reductions run on the small kernels, which carry no row sums: the
+        assert rc == -1                # engine says so (gemm_rowsum_supported) and the caller uses a column-sum job
+        return
     assert rc == 0, rc
     torch.cuda.synchronize()
     want = (A.double().T @ Bm.double()).cpu()
