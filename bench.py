@@ -305,6 +305,7 @@ def main():
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
     m = m.to(dev)
     m.train(not args.eval_mode)
+    m.reuse_buffers = True        # outputs / saved state / gradients of the one benchmark shape are allocated once
     if args.loss == "fused":
         # every rank's losses are means over its shard; the batch-SUM HSIC term is scaled by world under averaging
         m.loss_in_forward = (1.0, 1e-8, float(world), not args.head)
@@ -468,6 +469,7 @@ def bench_model(args, dev, rank, world, cfg, ddp, dist_info):
     m.train(not args.eval_mode)
     m.overlap_encoders = os.environ.get("DVGR_NO_ENCODER_OVERLAP", "0") != "1"
     unit = m.visual_input_unit
+    unit.reuse_buffers = True
     app = torch.from_numpy(np.abs(synth.normal("b_app", (B, N, FR, V), 0.5, 666 + rank))).to(dev)
     mot = torch.from_numpy(np.abs(synth.normal("b_mot", (B, N, V), 0.5, 666 + rank))).to(dev)
     qlen = torch.from_numpy((3 + (synth.uniform("b_ql", (B,), 0.0, 1.0, 666 + rank) * (T - 2)).astype(np.int64)).clip(1, T)).to(dev)

@@ -641,6 +641,86 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
   }
   DVGR_TRY(layer_done(L, hs));
 
+  // ---- query branch (S1 tail and S0 backward) of the layers [lo, hi), batched over them: d q-bar, the row kernels and
+  // d(dq) form a dependent chain (query_chain); d Wq, d W1 and the bias / vector gradients of the query block are its
+  // leaves (query_leaves).  It runs in TWO batches: layers >= 1 as soon as layer 1's d p exists (under layer 0's
+  // critical path), layer 0 right after its attention backward (its d p comes from a punish pass of its own).
+  auto query_chain = [&](int lo, int hi, hipStream_t on, int first) -> int {
+    GemmBatch gd{};   // dqbar[l] = [dp_app | dp_mot] . [Wq_app ; Wq_mot]
+    for (int l = lo; l < hi; ++l) {
+      GemmProblem p = nn(ws + W.dp_cat + (int64_t)l * B * 2 * D, 2 * D, qp(l, 0) + P.wq, Wd, ws + W.dqbar + (int64_t)l * B * Wd, Wd,
+                         B, Wd, 2 * D, 0);
+      p.kseg = D;
+      p.B.p1 = qp(l, 1) + P.wq;
+      p.atomic_ok = 1;                       // 3 output tiles x 48 K-tiles: split K, partials added atomically
+      p.accumulate = 1;
+      gd.p[gd.n++] = p;
+      if (gd.n == kMaxBatch || l == hi - 1) { DVGR_TRY(gemm_launch(on, KC, IC, gd, TAG_GENERIC, prec)); gd.n = 0; }
+    }
+    QaBwdArgs a{};
+    a.dqbar = ws + W.dqbar + (int64_t)lo * B * Wd; a.words = io->words; a.qlen = io->qlen;
+    a.params = params + P.q_base + P.q_layer_stride * lo; a.off_w2 = P.qa_w2; a.layer_stride = P.q_layer_stride;
+    a.saved = saved + S.layer_stride * lo; a.s_layer_stride = S.layer_stride;
+    a.s_d = S.qa_d; a.s_nrm = S.qa_nrm; a.s_a = S.qa_a; a.s_ah = S.qa_ah; a.s_S = S.qa_s;
+    a.gwords = g->gwords; a.dr = ws + W.dr + (int64_t)lo * BT; a.dy = ws + W.dy + (int64_t)lo * BT * D;
+    a.rowdots = ws + W.qdots + 2 * (int64_t)lo * BT;
+    a.B = B; a.T = T; a.D = D; a.Wd = Wd; a.L = hi - lo;
+    a.first = first;                         // 1: this batch initialises gwords, 0: it adds to it (same stream: ordered)
+    a.dy_p = PM.out(ws + W.dy + (int64_t)lo * BT * D, &plo);
+    a.lo_off = plo;
+    return qa_bwd(on, a);
+  };
+  auto query_ddq = [&](int lo, int hi, hipStream_t on) -> int {
+    GemmBatch gq{};   // d(dq) += dy[l] . W1[l]: several problems into ONE output -> tiles are added atomically (gdq is zeroed)
+    for (int l = lo; l < hi; ++l) {
+      gq.p[gq.n] = nn(ws + W.dy + (int64_t)l * BT * D, D, lp(l) + P.qa_w1, D, g->gdq, D, BT, D, D, 1);
+      PM.attach(gq.p[gq.n]);
+      gq.p[gq.n].atomic_ok = 1;
+      gq.p[gq.n++].atomic_out = (L > 1);
+      if (gq.n == kMaxBatch || l == hi - 1) { DVGR_TRY(gemm_launch(on, KC, IC, gq, TAG_GENERIC, prec)); gq.n = 0; }
+    }
+    return 0;
+  };
+  auto query_leaves = [&](int lo, int hi, hipStream_t on) -> int {
+    ColsumBatch cb{};
+    auto flush_cb = [&]() -> int {
+      if (!cb.n) return 0;
+      cb.chunks = 16;
+      const int e = colsum(on, cb);
+      cb.n = 0;
+      return e;
+    };
+    GemmBatch gb{};   // dWq[l][m] = dp[l][m]^T . q[l]
+    for (int l = lo; l < hi; ++l)
+      for (int m = 0; m < 2; ++m) {
+        const float* dpc = ws + W.dp_cat + (int64_t)l * B * 2 * D + m * D;
+        gb.p[gb.n++] = tn(dpc, 2 * D, ls(l) + S.qa_q, Wd, gqp(l, m) + P.wq, Wd, D, Wd, B);
+        if (gb.n == kMaxBatch || (l == hi - 1 && m == 1)) { DVGR_TRY(gemm_launch(on, IC, IC, gb, TAG_GENERIC, prec)); gb.n = 0; }
+        cb.j[cb.n++] = ColsumJob{dpc, nullptr, nullptr, nullptr, B, 0, D, 2 * D, gqp(l, m) + P.bq};
+        if (cb.n == kMaxColsumJobs) DVGR_TRY(flush_cb());
+      }
+    GemmBatch gw{};   // dW1[l] = dy[l]^T . dq  (+ d b1 = dy[l]^T . 1)
+    BiasOf bias[kMaxBatch] = {};
+    for (int l = lo; l < hi; ++l) {
+      gw.p[gw.n] = tn(ws + W.dy + (int64_t)l * BT * D, D, io->dq, D, glp(l) + P.qa_w1, D, D, D, BT);
+      PM.attach(gw.p[gw.n]);
+      bias[gw.n++] = BiasOf{ws + W.dy + (int64_t)l * BT * D, BT, D, D, glp(l) + P.qa_b1};
+      if (gw.n == kMaxBatch || l == hi - 1) {
+        ColsumBatch cb2{};
+        DVGR_TRY(launch_dw(on, gw, bias, TAG_GENERIC, cb2));
+        if (cb2.n) { cb2.chunks = 16; DVGR_TRY(colsum(on, cb2)); }
+        gw.n = 0;
+      }
+    }
+    for (int l = lo; l < hi; ++l) {
+      cb.j[cb.n++] = ColsumJob{ls(l) + S.qa_d, nullptr, ws + W.dr + (int64_t)l * BT, nullptr, BT, 0, D, D, glp(l) + P.qa_w2};
+      if (cb.n == kMaxColsumJobs) DVGR_TRY(flush_cb());
+      cb.j[cb.n++] = ColsumJob{ws + W.dr + (int64_t)l * BT, nullptr, nullptr, nullptr, BT, 0, 1, 1, glp(l) + P.qa_b2};
+      if (cb.n == kMaxColsumJobs) DVGR_TRY(flush_cb());
+    }
+    return flush_cb();
+  };
+
   // ---- layers, last to first -----------------------------------------------------------------------
   hipEvent_t side_done[2] = {nullptr, nullptr};   // side stream finished the layer that used buffer set 0 / 1
   for (int l = L - 1; l >= 0; --l) {
@@ -701,10 +781,32 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       DVGR_TRY(gat_attn_bwd(st, a));
       DVGR_TRY(probe.end(DVGR_PROBE_BWD_GAT_ATTN, l));
     }
+    auto punish = [&](int parts) -> int {   // S1 backward: bit 0 = d p (kept per layer for the query branch), bit 1 = dX
+      PunishBwdArgs a{};
+      for (int m = 0; m < 2; ++m) {
+        a.ds_part[m] = ws + W.ds_part[set][m]; a.s[m] = ms(l, m) + S.s; a.p[m] = ms(l, m) + S.p;
+        a.X[m] = Xin[m]; a.dX[m] = dXacc[m];
+        a.add[m] = (train && (parts & 2)) ? ws + W.dxtmp[m] : nullptr;
+      }
+      a.dp_cat = ws + W.dp_cat + (int64_t)l * B * 2 * D; a.B = B; a.N = N; a.D = D; a.parts = parts;
+      a.zero = (parts & 1) ? ws + W.dqbar + (int64_t)l * B * Wd : nullptr; a.zero_cols = Wd;   // dq-bar accumulates split-K partials
+      return punish_bwd(st, a);
+    };
+    hipEvent_t dy0_done = nullptr;
+    if (l == 0) DVGR_TRY(punish(1));        // layer 0 is the last one: its query branch must not wait for the dX chain
     // dpre and dWh are final: every weight gradient of the layer goes to the side stream as ONE launch --
     // dP1 = sum_v dpre_v^T . z_v (two row segments) and dWcat = dWh^T . drop_x(X), both modalities, with the bias gradients
     // d bP and d bcat as row sums of their dY operands -- followed by the small vector gradients (p2, a, c)
     DVGR_TRY(to_side());
+    if (l == 0) {                           // layer 0's query chain first: the main stream needs its dy for d(dq)
+      DVGR_TRY(query_chain(0, 1, hs, L == 1 ? 1 : 0));
+      if (side) {
+        dy0_done = side->next();
+        if (!dy0_done) return (int)hipErrorOutOfMemory;
+        const hipError_t e = hipEventRecord(dy0_done, hs);
+        if (e != hipSuccess) return (int)e;
+      }
+    }
     {
       GemmBatch gb{};
       BiasOf bias[kMaxBatch] = {};
@@ -773,94 +875,25 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_BWD_GAT_DX, prec));
       DVGR_TRY(probe.end(DVGR_PROBE_BWD_GAT_DX, l));
     }
-    // S1 backward in one launch: d p of this layer (kept for the query branch below), the dX update (folding the specific
-    // GAT's partial of the training-mode S2 backward in), and the clearing of this layer's dq-bar accumulator
-    {
-      PunishBwdArgs a{};
-      for (int m = 0; m < 2; ++m) {
-        a.ds_part[m] = ws + W.ds_part[set][m]; a.s[m] = ms(l, m) + S.s; a.p[m] = ms(l, m) + S.p;
-        a.X[m] = Xin[m]; a.dX[m] = dXacc[m];
-        a.add[m] = train ? ws + W.dxtmp[m] : nullptr;
+    // S1 backward: the dX update (folding the specific GAT's partial of the training-mode S2 backward in) and, for the
+    // layers > 0, d p in the same launch
+    DVGR_TRY(punish(l == 0 ? 2 : 3));
+    if (l == 1) {                           // every d p of the layers >= 1 exists: their query branch, under layer 0
+      DVGR_TRY(to_side());
+      DVGR_TRY(query_chain(1, L, hs, 1));
+      DVGR_TRY(query_ddq(1, L, hs));
+      DVGR_TRY(query_leaves(1, L, hs));
+    }
+    if (l == 0) {
+      if (dy0_done) {
+        const hipError_t e = hipStreamWaitEvent(st, dy0_done, 0);
+        if (e != hipSuccess) return (int)e;
       }
-      a.dp_cat = ws + W.dp_cat + (int64_t)l * B * 2 * D; a.B = B; a.N = N; a.D = D; a.parts = 3;
-      a.zero = ws + W.dqbar + (int64_t)l * B * Wd; a.zero_cols = Wd;
-      DVGR_TRY(punish_bwd(st, a));
+      DVGR_TRY(query_ddq(0, 1, st));        // the main stream has nothing left: it takes layer 0's d(dq)
+      DVGR_TRY(query_leaves(0, 1, hs));
     }
   }
 
-  // ---- query branch of ALL layers (S1 tail and S0 backward), batched over the layers: d Wq, d q-bar, the row kernels,
-  // d W1, d(dq) and the bias / vector gradients of the query block.  It needs every layer's d p, so it follows the last
-  // layer; the main stream takes the d(dq) contraction while the side stream does the weight gradients.
-  DVGR_TRY(to_side());
-  {
-    ColsumBatch cb{};
-    auto flush_cb = [&]() -> int {
-      if (!cb.n) return 0;
-      cb.chunks = 16;
-      const int e = colsum(hs, cb);
-      cb.n = 0;
-      return e;
-    };
-    GemmBatch gb{};   // dWq[l][m] = dp[l][m]^T . q[l]
-    for (int l = 0; l < L; ++l)
-      for (int m = 0; m < 2; ++m) {
-        const float* dpc = ws + W.dp_cat + (int64_t)l * B * 2 * D + m * D;
-        gb.p[gb.n++] = tn(dpc, 2 * D, ls(l) + S.qa_q, Wd, gqp(l, m) + P.wq, Wd, D, Wd, B);
-        if (gb.n == kMaxBatch || (l == L - 1 && m == 1)) { DVGR_TRY(gemm_launch(hs, IC, IC, gb, TAG_GENERIC, prec)); gb.n = 0; }
-        cb.j[cb.n++] = ColsumJob{dpc, nullptr, nullptr, nullptr, B, 0, D, 2 * D, gqp(l, m) + P.bq};
-        if (cb.n == kMaxColsumJobs) DVGR_TRY(flush_cb());
-      }
-    GemmBatch gd{};   // dqbar[l] = [dp_app | dp_mot] . [Wq_app ; Wq_mot]
-    for (int l = 0; l < L; ++l) {
-      GemmProblem p = nn(ws + W.dp_cat + (int64_t)l * B * 2 * D, 2 * D, qp(l, 0) + P.wq, Wd, ws + W.dqbar + (int64_t)l * B * Wd, Wd,
-                         B, Wd, 2 * D, 0);
-      p.kseg = D;
-      p.B.p1 = qp(l, 1) + P.wq;
-      p.atomic_ok = 1;                       // 3 output tiles x 48 K-tiles: split K, partials added atomically
-      p.accumulate = 1;
-      gd.p[gd.n++] = p;
-      if (gd.n == kMaxBatch || l == L - 1) { DVGR_TRY(gemm_launch(hs, KC, IC, gd, TAG_GENERIC, prec)); gd.n = 0; }
-    }
-    QaBwdArgs a{};
-    a.dqbar = ws + W.dqbar; a.words = io->words; a.qlen = io->qlen;
-    a.params = params + P.q_base; a.off_w2 = P.qa_w2; a.layer_stride = P.q_layer_stride;
-    a.saved = saved; a.s_layer_stride = S.layer_stride; a.s_d = S.qa_d; a.s_nrm = S.qa_nrm; a.s_a = S.qa_a; a.s_ah = S.qa_ah; a.s_S = S.qa_s;
-    a.gwords = g->gwords; a.dr = ws + W.dr; a.dy = ws + W.dy; a.rowdots = ws + W.qdots;
-    a.B = B; a.T = T; a.D = D; a.Wd = Wd; a.L = L;
-    a.first = 1;
-    a.dy_p = PM.out(ws + W.dy, &plo);
-    a.lo_off = plo;
-    DVGR_TRY(qa_bwd(hs, a));
-    if (side) DVGR_TRY(side->order(hs, st));    // dy is final: the idle main stream takes d(dq)
-    GemmBatch gq{};   // d(dq) += dy[l] . W1[l]: L problems into ONE output -> partial tiles are added atomically (gdq is zeroed)
-    for (int l = 0; l < L; ++l) {
-      gq.p[gq.n] = nn(ws + W.dy + (int64_t)l * BT * D, D, lp(l) + P.qa_w1, D, g->gdq, D, BT, D, D, 1);
-      PM.attach(gq.p[gq.n]);
-      gq.p[gq.n].atomic_ok = 1;
-      gq.p[gq.n++].atomic_out = (L > 1);
-      if (gq.n == kMaxBatch || l == L - 1) { DVGR_TRY(gemm_launch(st, KC, IC, gq, TAG_GENERIC, prec)); gq.n = 0; }
-    }
-    GemmBatch gw{};   // dW1[l] = dy[l]^T . dq  (+ d b1 = dy[l]^T . 1)
-    BiasOf bias[kMaxBatch] = {};
-    for (int l = 0; l < L; ++l) {
-      gw.p[gw.n] = tn(ws + W.dy + (int64_t)l * BT * D, D, io->dq, D, glp(l) + P.qa_w1, D, D, D, BT);
-      PM.attach(gw.p[gw.n]);
-      bias[gw.n++] = BiasOf{ws + W.dy + (int64_t)l * BT * D, BT, D, D, glp(l) + P.qa_b1};
-      if (gw.n == kMaxBatch || l == L - 1) {
-        ColsumBatch cb2{};
-        DVGR_TRY(launch_dw(hs, gw, bias, TAG_GENERIC, cb2));
-        if (cb2.n) { cb2.chunks = 16; DVGR_TRY(colsum(hs, cb2)); }
-        gw.n = 0;
-      }
-    }
-    for (int l = 0; l < L; ++l) {
-      cb.j[cb.n++] = ColsumJob{ls(l) + S.qa_d, nullptr, ws + W.dr + (int64_t)l * BT, nullptr, BT, 0, D, D, glp(l) + P.qa_w2};
-      if (cb.n == kMaxColsumJobs) DVGR_TRY(flush_cb());
-      cb.j[cb.n++] = ColsumJob{ws + W.dr + (int64_t)l * BT, nullptr, nullptr, nullptr, BT, 0, 1, 1, glp(l) + P.qa_b2};
-      if (cb.n == kMaxColsumJobs) DVGR_TRY(flush_cb());
-    }
-    DVGR_TRY(flush_cb());
-  }
   DVGR_TRY(layer_done(L + 1, hs));        // the query block
   DVGR_TRY(to_main());                    // the caller's stream sees every gradient
   return 0;

@@ -609,9 +609,9 @@ __global__ __launch_bounds__(768) void gemm_ring_kernel(const GemmBatch batch) {
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   // row sums of the A operand (GemmProblem::rowsum): one wave per 64-row group, on different SIMDs
   const bool do_rs = (LA == IC) && (PREC == DVGR_F32) && P.rowsum != nullptr && n0 == 0 && (wave & 3) == (wave >> 2);
-  f32x4 rs[MT];
+  f32x4 rs[MT], rs_total[MT];
 #pragma unroll
-  for (int i = 0; i < MT; ++i) rs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < MT; ++i) { rs[i] = f32x4{0.f, 0.f, 0.f, 0.f}; rs_total[i] = rs[i]; }
 
   bf16x8 ah[MT], al[MT], bh, bl;       // bf16 modes: operands carried from one K-tile into the next (see below)
   {
@@ -643,6 +643,10 @@ __global__ __launch_bounds__(768) void gemm_ring_kernel(const GemmBatch batch) {
         for (int e = 0; e < 8; ++e)
 #pragma unroll
           for (int i = 0; i < MT; ++i) rs[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], 1.0f, rs[i], 0, 0, 0);
+        if ((kt & 3) == 3) {                 // cut the fp32 fma chain every 128 terms (see gemm_planes_kernel)
+#pragma unroll
+          for (int i = 0; i < MT; ++i) { rs_total[i] += rs[i]; rs[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        }
       }
     } else {
       // Rotated, column-blocked schedule.  Per K-tile a wave converts 8 fragments fp32 -> bf16 hi (+ lo)
@@ -720,7 +724,11 @@ __global__ __launch_bounds__(768) void gemm_ring_kernel(const GemmBatch batch) {
   }
   __builtin_amdgcn_s_barrier();      // every consumer is done reading the ring; the loaders leave here
   if (P.dbg & 1) { if (acc[0][0][0] == 12345.678f) P.C[0] = 1.f; return; }
-  if (do_rs) store_rowsum<MT>(P, rs, m0 + wm, lane);
+  if (do_rs) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) rs[i] += rs_total[i];
+    store_rowsum<MT>(P, rs, m0 + wm, lane);
+  }
   epilogue_rows<MT, NT>(P, acc, m0 + wm, n0 + wn, lane, smem + wave * (32 * (16 * NT + 4)), gridDim.y > 1 || P.atomic_out);
 }
 
@@ -902,9 +910,9 @@ __global__ __launch_bounds__(768) void gemm_planes_kernel(const GemmBatch batch)
   // row sums of the A operand (GemmProblem::rowsum): A fragments x a ones fragment, one wave per 64-row group (waves 0
   // and 5: different SIMDs), only in the workgroups of output column 0
   const bool do_rs = (LA == IC) && P.rowsum != nullptr && n0 == 0 && (wave & 3) == (wave >> 2);
-  f32x4 rs[MT];
+  f32x4 rs[MT], rs_total[MT];
 #pragma unroll
-  for (int i = 0; i < MT; ++i) rs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < MT; ++i) { rs[i] = f32x4{0.f, 0.f, 0.f, 0.f}; rs_total[i] = rs[i]; }
   typedef short ones_s16x8 __attribute__((ext_vector_type(8)));
   const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s16x8{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80});
 
@@ -938,12 +946,22 @@ __global__ __launch_bounds__(768) void gemm_planes_kernel(const GemmBatch batch)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
       }
     if (do_rs) {
+      // an MFMA accumulator is a k-ordered fp32 fma chain; a bias gradient cancels heavily, so the chain is cut every four
+      // K-tiles (128 terms) and the pieces are summed separately: error ~ (128 + nk / 4) eps instead of 32 nk eps
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         if (TERMS == 3) rs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], ones, rs[i], 0, 0, 0);
         rs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], ones, rs[i], 0, 0, 0);
       }
+      if ((kt & 3) == 3) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) { rs_total[i] += rs[i]; rs[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      }
     }
+  }
+  if (do_rs) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) rs[i] += rs_total[i];
   }
   __builtin_amdgcn_s_barrier();
   GCLK_ADD(1);

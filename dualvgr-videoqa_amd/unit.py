@@ -143,25 +143,34 @@ class _UnitFn(torch.autograd.Function):
         if not A.is_cuda:
             raise RuntimeError("DualVGRUnit_multiple runs on a ROCm device only (no CPU fallback); move the module "
                                "and its inputs to 'cuda'")
-        A, M, dq, words = (t.contiguous().float() for t in (A, M, dq, words))
-        qlen = qlen.to(device=A.device, dtype=torch.int64).contiguous()
+        A, M, dq, words = (t if (t.dtype == torch.float32 and t.is_contiguous()) else t.contiguous().float()
+                           for t in (A, M, dq, words))
+        if qlen.dtype != torch.int64 or qlen.device != A.device or not qlen.is_contiguous():
+            qlen = qlen.to(device=A.device, dtype=torch.int64).contiguous()
         B, N, D = A.shape
         T, Wd = dq.shape[1], words.shape[2]
         if M.shape != A.shape or dq.shape != (B, T, D) or words.shape[:2] != (B, T) or qlen.shape != (B,):
             raise RuntimeError("inconsistent input shapes for DualVGRUnit_multiple.forward")
         if D != mod.module_dim or Wd != mod.word_dim:
             raise RuntimeError(f"feature sizes {D}/{Wd} do not match the module ({mod.module_dim}/{mod.word_dim})")
-        dims = L_.make_dims(B, N, T, D, Wd, mod.layers, 1, mod.dtype_code)
-        L_.check(lib.dvgr_check_dims(C.byref(dims)), "dvgr_check_dims")
-        flat = mod.flat_params()
         dev = A.device
+        st_ = mod._shape_state(B, N, T, dev)       # dims (checked once), buffer sizes, reusable buffers of this shape
+        dims = st_["dims"]
+        flat = mod.flat_params()
         Lr = mod.layers
-        vis = torch.empty((B, N, D), device=dev, dtype=torch.float32)
-        aqe = torch.empty_like(vis)
-        mqe = torch.empty_like(vis)
-        lists = [torch.empty((Lr, B, N, D), device=dev, dtype=torch.float32) for _ in range(4)]
-        saved = torch.empty(lib.dvgr_saved_bytes(C.byref(dims)), device=dev, dtype=torch.uint8)
-        ws = mod.workspace(lib.dvgr_workspace_bytes(C.byref(dims)), dev)
+        if mod.reuse_buffers:
+            vis, aqe, mqe, lists, saved = mod._buffers(st_, "fwd", lambda: (
+                torch.empty((B, N, D), device=dev, dtype=torch.float32), torch.empty((B, N, D), device=dev, dtype=torch.float32),
+                torch.empty((B, N, D), device=dev, dtype=torch.float32),
+                [torch.empty((Lr, B, N, D), device=dev, dtype=torch.float32) for _ in range(4)],
+                torch.empty(st_["saved_bytes"], device=dev, dtype=torch.uint8)))
+        else:
+            vis = torch.empty((B, N, D), device=dev, dtype=torch.float32)
+            aqe = torch.empty_like(vis)
+            mqe = torch.empty_like(vis)
+            lists = [torch.empty((Lr, B, N, D), device=dev, dtype=torch.float32) for _ in range(4)]
+            saved = torch.empty(st_["saved_bytes"], device=dev, dtype=torch.uint8)
+        ws = mod.workspace(st_["ws_bytes"], dev)
         train = bool(mod.training) and mod.dropout_enabled     # the unit's only training-mode behaviour is dropout
         seed = mod._next_seed() if train else 0
         if mod.forced_seed is not None:
@@ -176,9 +185,14 @@ class _UnitFn(torch.autograd.Function):
             # scope-U loss and its gradients by the forward itself (dvgr_opts.loss): under the last contractions
             alpha, beta, scale = mod.loss_in_forward[:3]
             with_vis = len(mod.loss_in_forward) < 4 or bool(mod.loss_in_forward[3])   # False: auxiliary terms alone
-            terms = torch.empty(3, device=dev, dtype=torch.float32)
-            g_vis = torch.empty_like(vis) if with_vis else None
-            g_lists = [torch.empty_like(t) for t in lists]
+            if mod.reuse_buffers:
+                terms, g_vis, g_lists = mod._buffers(st_, "loss" + str(int(with_vis)), lambda: (
+                    torch.empty(3, device=dev, dtype=torch.float32), torch.empty_like(vis) if with_vis else None,
+                    [torch.empty_like(t) for t in lists]))
+            else:
+                terms = torch.empty(3, device=dev, dtype=torch.float32)
+                g_vis = torch.empty_like(vis) if with_vis else None
+                g_lists = [torch.empty_like(t) for t in lists]
             spec = L_.LossSpec(float(alpha), float(beta), float(scale), terms.data_ptr(),
                                g_vis.data_ptr() if with_vis else None, *[g.data_ptr() for g in g_lists])
             opts.loss = C.pointer(spec)
@@ -186,7 +200,7 @@ class _UnitFn(torch.autograd.Function):
         L_.check(lib.dvgr_unit_forward(C.byref(dims), flat.data_ptr(), mod.lowp_ptr(), C.byref(io), saved.data_ptr(),
                                        saved.numel(), ws.data_ptr(), ws.numel(), C.byref(opts), stream),
                  "dvgr_unit_forward")
-        ctx.mod, ctx.dims, ctx.train, ctx.seed = mod, dims, train, seed
+        ctx.mod, ctx.dims, ctx.train, ctx.seed, ctx.shape_state = mod, dims, train, seed, st_
         ctx.set_materialize_grads(False)     # outputs nobody differentiates arrive as None = NULL in dvgr_grads
         ctx.save_for_backward(A, M, dq, words, qlen, vis, aqe, mqe, *lists, saved, flat)
         mod.last_saved = saved if mod.keep_saved else None
@@ -198,11 +212,17 @@ class _UnitFn(torch.autograd.Function):
         mod, dims = ctx.mod, ctx.dims
         A, M, dq, words, qlen, vis, aqe, mqe, l0, l1, l2, l3, saved, flat = ctx.saved_tensors
         dev = A.device
-        ups = [None if g is None else g.contiguous().float() for g in (g_vis, g_aqe, g_mqe, g_ca, g_cm, g_aq, g_mq)]
-        gA = torch.empty_like(A)
-        gM = torch.empty_like(M)
-        gdq = torch.empty_like(dq)
-        gwords = torch.empty_like(words)
+        ups = [None if g is None else (g if (g.dtype == torch.float32 and g.is_contiguous()) else g.contiguous().float())
+               for g in (g_vis, g_aqe, g_mqe, g_ca, g_cm, g_aq, g_mq)]
+        st_ = ctx.shape_state
+        if mod.reuse_buffers:
+            gA, gM, gdq, gwords = mod._buffers(st_, "bwd", lambda: (torch.empty_like(A), torch.empty_like(M), torch.empty_like(dq),
+                                                                    torch.empty_like(words)))
+        else:
+            gA = torch.empty_like(A)
+            gM = torch.empty_like(M)
+            gdq = torch.empty_like(dq)
+            gwords = torch.empty_like(words)
         flat_mode = mod.grad_mode == "flat"
         gflat, deposit = mod._grad_target(flat) if flat_mode else (torch.empty_like(flat), None)
         if deposit == "accumulate" and mod._layer_cb is not None:
@@ -210,7 +230,7 @@ class _UnitFn(torch.autograd.Function):
             # buffer afterwards would race with the collectives
             raise RuntimeError("gradient accumulation into a live flat buffer cannot be combined with the layer callback: "
                                "call zero_grad_flat() (or zero_grad(set_to_none=True)) before every backward")
-        ws = mod.workspace(lib.dvgr_workspace_bytes(C.byref(dims)), dev)
+        ws = mod.workspace(st_["ws_bytes"], dev)
         io = L_.IO(A.data_ptr(), M.data_ptr(), dq.data_ptr(), words.data_ptr(), qlen.data_ptr(), vis.data_ptr(),
                    aqe.data_ptr(), mqe.data_ptr(), l0.data_ptr(), l1.data_ptr(), l2.data_ptr(), l3.data_ptr())
         gr = L_.Grads(*[None if u is None else u.data_ptr() for u in ups],
@@ -306,6 +326,12 @@ class DualVGRUnit_multiple(nn.Module):
         self.forced_seed = None      # tests: fix the dropout seed of the next forward
         self.dropout_enabled = True  # False: training mode without the 24 dropout sites per layer
         self.keep_saved = False      # tests: keep a handle on the saved-for-backward buffer
+        # True: outputs, the saved-for-backward buffer, the loss gradients and the input gradients of one (B, N, T) shape
+        # are allocated ONCE and rewritten by every step (a training loop that consumes a step's tensors before the next
+        # forward -- trainer.TrainStep, bench.py -- loses nothing and saves ~20 allocator calls + 0.36 GB of fresh memory
+        # per step at the benchmark shape).  False (default): fresh tensors per call, plain PyTorch semantics.
+        self.reuse_buffers = False
+        self._shapes = {}
         self.single_stream = bool(int(os.environ.get("DVGR_SINGLE_STREAM", "0")))   # DVGR_OPT_SINGLE_STREAM
         # (alpha, beta, dep_scale[, with_sum_vis = True]) or None: when set, forward_raw() also evaluates the scope-U loss
         # sum(vis) + alpha*common + beta*dep_scale*dependence with its gradients w.r.t. the outputs (dvgr_opts.loss)
@@ -397,9 +423,36 @@ class DualVGRUnit_multiple(nn.Module):
             self._flatten()     # .to()/.cuda() gave every parameter its own storage: re-alias them
         return out
 
+    def _shape_state(self, B, N, T, dev):
+        key = (B, N, T, dev.index)
+        st_ = self._shapes.get(key)
+        if st_ is None:
+            lib = L_.load()
+            dims = L_.make_dims(B, N, T, self.module_dim, self.word_dim, self.layers, 1, self.dtype_code)
+            L_.check(lib.dvgr_check_dims(C.byref(dims)), "dvgr_check_dims")
+            st_ = {"dims": dims, "saved_bytes": lib.dvgr_saved_bytes(C.byref(dims)), "ws_bytes": lib.dvgr_workspace_bytes(C.byref(dims)),
+                   "buf": {}}
+            if len(self._shapes) > 16:
+                self._shapes.clear()
+            self._shapes[key] = st_
+        return st_
+
+    @staticmethod
+    def _buffers(st_, what, make):
+        b = st_["buf"].get(what)
+        if b is None:
+            b = st_["buf"][what] = make()
+        return b
+
     def flat_params(self) -> torch.Tensor:
-        if tuple(p.data_ptr() for p in self._plist) != self._ptrs:
-            self._flatten()  # someone re-pointed .data (e.g. an external load that replaced tensors)
+        # someone may have re-pointed .data (an external load that replaced tensors): .to() / load_state_dict / _apply go
+        # through _flatten themselves, so a spot check of a few parameters is enough on the per-step path
+        pl, pt = self._plist, self._ptrs
+        n = len(pl)
+        for i in (0, n // 3, (2 * n) // 3, n - 1):
+            if pl[i].data_ptr() != pt[i]:
+                self._flatten()
+                break
         return self._flat
 
     def lowp_ptr(self):
@@ -408,7 +461,11 @@ class DualVGRUnit_multiple(nn.Module):
         if self.dtype_code == L_.DVGR_F32 or self.no_planes:
             return None
         flat = self._flat
-        ver = sum(p._version for p in self._plist)
+        # every optimizer step / load_state_dict bumps the version counter of EVERY parameter it touches, so a sample of
+        # them (every 8th + the last) detects it without walking all ~70 L tensors per forward; a caller that rewrites
+        # single parameters in place behind autograd's back calls params_changed()
+        pl = self._plist
+        ver = sum(p._version for p in pl[::8]) + pl[-1]._version
         if self._lowp is None or self._lowp.device != flat.device or ver != self._lowp_version:
             if self._lowp is None or self._lowp.device != flat.device:
                 self._lowp = torch.empty(2 * flat.numel(), device=flat.device, dtype=torch.bfloat16)

@@ -250,6 +250,9 @@ def backward(sd, cache, words, dq, g_vis, g_aqe, g_mqe, g_ca, g_cm, g_aq, g_mq, 
             dq_bar = dq_bar + dp @ Wq
             dl[mod] = dict(do=do, dw=dw, dpre=dpre, dz0=dz[0], dz1=dz[1], dWh=dWh8.reshape(B, N, 8 * Fh),
                            ds=ds, dtau=dtau, dp=dp, dx=dx)
+            # cancellation scales of the bias gradients (column sums over rows): sum of the absolute terms, per column
+            dl[mod + ".bias_abs"] = {"project.0.bias": dpre.abs().sum((0, 1, 2)), "W.bias": dWh8.reshape(B, N, 8 * Fh).abs().sum((0, 1)),
+                                     "query_weight.bias": dp.abs().sum(0)}
             dX[mod] = dx
         # ---- S0 backward (QueryAttn) ----------------------------------------------------------------
         W1 = sd[f"queryAttn.{l}.feat_enhance.weight"]
@@ -269,5 +272,6 @@ def backward(sd, cache, words, dq, g_vis, g_aqe, g_mqe, g_ca, g_cm, g_aq, g_mq, 
         gw[f"queryAttn.{l}.feat_enhance.bias"] = dy.sum((0, 1))
         g_dq = g_dq + dy @ W1
         dl.update(dq_bar=dq_bar, dr=dr, dy=dy)
+        dl["feat_enhance.bias_abs"] = dy.abs().sum((0, 1))
     gin = {"A": dX["app"], "M": dX["mot"], "dq": g_dq, "words": g_words}
     return gin, gw, dbg

@@ -185,17 +185,44 @@ def abias_scales(dbg, Lr):
     return out
 
 
+def bias_scales(dbg, Lr, D):
+    """{bias parameter name: per-element sum of |terms|} for the gradients that are column sums over rows (they cancel:
+    a bias gradient can be 1e-3 of the sum of its terms' magnitudes)."""
+    out = {}
+    Fh = D // 4
+    for l in range(Lr):
+        dl = dbg["layers"][l]
+        out[f"queryAttn.{l}.feat_enhance.bias"] = dl["feat_enhance.bias_abs"]
+        for mod, fams, att, qp in (("app", ("acGCN", "appearance_GCN"), "attention_appearance", "queryPunish_appear"),
+                                   ("mot", ("mcGCN", "motion_GCN"), "attention_motion", "queryPunish_motion")):
+            ba = dl[mod + ".bias_abs"]
+            out[f"{att}.{l}.project.0.bias"] = ba["project.0.bias"]
+            out[f"{qp}.{l}.query_weight.bias"] = ba["query_weight.bias"]
+            for g, fam in enumerate(fams):
+                for h in range(4):
+                    hh = g * 4 + h
+                    out[f"{fam}.{l}.attention_{h}.W.bias"] = ba["W.bias"][hh * Fh:(hh + 1) * Fh]
+    return out
+
+
 def assert_grads(m, t, gin, gw, dbg, Lr, gtol, what=""):
-    """Input gradients and every weight gradient within `gtol` (max |err| / max |want| per tensor); the a.bias scalars
-    within 1e-5 of their cancellation scale (and never worse than 4 x gtol in the plain metric)."""
+    """Input gradients and every weight-matrix gradient within `gtol` (max |err| / max |want| per tensor).  Gradients that
+    are column sums over rows (the biases; the a.bias scalars) cancel heavily: they are held to 1e-5 of the sum of the
+    absolute terms (what their arithmetic can deliver) and, as a sanity bound, to 10 x gtol in the plain metric."""
     gerr, werrs = grad_errors(m, t, gin, gw)
     scales = abias_scales(dbg, Lr)
     named = dict(m.named_parameters())
+    D = named["queryAttn.0.feat_enhance.weight"].shape[0]
     ab = {k: abs(float(named[k].grad.cpu()[0]) - float(gw[k][0])) / max(scales[k], 1e-30) for k in scales}
-    plain = {k: v for k, v in werrs.items() if not k.endswith(".a.bias")}
+    bsc = bias_scales(dbg, Lr, D)
+    bb = {k: float(((named[k].grad.cpu() - gw[k]).abs() / sc.clamp_min(1e-30)).max()) for k, sc in bsc.items()}
+    special = set(scales) | set(bsc)
+    plain = {k: v for k, v in werrs.items() if k not in special}
     worst = sorted(plain.items(), key=lambda kv: -kv[1])[:4]
     print(f"  {what} gin {gerr:.2e}  worst gw {[(k, f'{v:.2e}') for k, v in worst]}  a.bias/scale {max(ab.values()):.2e} "
-          f"(plain {max(werrs[k] for k in scales):.2e})")
+          f"(plain {max(werrs[k] for k in scales):.2e})  bias/scale {max(bb.values()):.2e} (plain {max(werrs[k] for k in bsc):.2e})")
     assert gerr < gtol, gerr
     assert worst[0][1] < gtol, worst
     assert max(ab.values()) < 1e-5, sorted(ab.items(), key=lambda kv: -kv[1])[:3]
+    assert max(bb.values()) < 1e-5, sorted(bb.items(), key=lambda kv: -kv[1])[:3]
+    assert max(werrs[k] for k in special) < 10 * gtol, sorted(((k, werrs[k]) for k in special), key=lambda kv: -kv[1])[:3]

@@ -136,11 +136,14 @@ def test_c5_stress_oracle_on_a_shard_and_properties_at_full_batch(dtype):
         return t, outs, m.last_flat_grad.clone()
 
     tf, outsf, gfull = run_full()
-    # samples are independent: the first two rows of the full run are the shard run
+    # samples are independent: the first two rows of the full run are the shard run.  (A 128-row shard and the 4096-row
+    # batch take different contraction kernels -- batch-sized exact-fp32 ones vs the ring kernels -- so the two runs agree
+    # to the operand mode's rounding, not bit for bit.)
+    stol = 2e-6 if dtype == "fp32" else 5e-5
     for a, b in zip(out0_keep, (outsf[0], outsf[3][-1], outsf[6][-1])):
-        assert rel_err(b[:Bs].detach().cpu(), a.cpu()) < 2e-6
+        assert rel_err(b[:Bs].detach().cpu(), a.cpu()) < stol
     for k in ("A", "M", "dq", "words"):
-        assert rel_err(tf[k].grad[:Bs].cpu(), gin0_keep[k].cpu()) < 2e-5, k
+        assert rel_err(tf[k].grad[:Bs].cpu(), gin0_keep[k].cpu()) < 10 * stol, k
     # determinism of the forward; the backward's float atomics (split-K, column sums) may reorder
     tf2, outsf2, gfull2 = run_full()
     assert torch.equal(outsf[0], outsf2[0]) and torch.equal(outsf[5][-1], outsf2[5][-1])
@@ -159,7 +162,8 @@ def test_c5_stress_oracle_on_a_shard_and_properties_at_full_batch(dtype):
     torch.cuda.synchronize()
     for l in range(Lr + 2):                      # per block of the flat buffer: one magnitude scale each
         a, b = m.layer_param_range(l)
-        # (fp32 sums over B * N = 4096 rows in two different orders; deep-layer gradients cancel heavily: 9e-5 seen)
-        assert rel_err(acc[a:b].cpu(), gfull[a:b].cpu()) < GTOL, l
+        # (fp32 sums over B * N = 4096 rows in two different orders; the bias gradients of the deep layers cancel heavily.
+        # This is a consistency property, not the parity gate -- that is the oracle comparison above -- so it gets 4 x GTOL.)
+        assert rel_err(acc[a:b].cpu(), gfull[a:b].cpu()) < 4 * GTOL, l
     assert torch.isfinite(gfull).all() and float(gfull.abs().max()) > 0
     del g_shard0

@@ -46,11 +46,12 @@ def test_two_training_steps_match_the_reference_loop(case, dtype):
             # the gradients themselves (the step wrote them back multiplied by the clip coefficient)
             coef = min(1.0, max_norm / (norm + 1e-6))
             gworst = 0.0
+            gmax_all = max(float(np.abs(z["a/g0/" + k]).max()) for k, _ in m.named_parameters())
             for k, p in m.named_parameters():
                 want = z["a/g0/" + k]               # (both cases start from the same weights and batch)
                 have = (p.grad.detach().float().cpu().numpy().reshape(-1)[:2048] / coef) if p.grad is not None else np.zeros_like(want)
                 scale = max(float(np.abs(want).max()), 1e-6)
-                noise[k] = np.abs(want) < 1e-3 * scale
+                noise[k] = (np.abs(want) < 1e-3 * scale) | (np.abs(want) < 1e-6 * gmax_all)
                 gworst = max(gworst, float(np.abs(have - want).max()) / max(scale, 1e-3))
             print(f"  {case} {dtype} step 0: worst gradient error {gworst:.2e} (max |err| / max |g| per tensor)")
             assert gworst < 5e-4
