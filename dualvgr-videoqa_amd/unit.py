@@ -159,7 +159,7 @@ class _UnitFn(torch.autograd.Function):
         flat = mod.flat_params()
         Lr = mod.layers
         if mod.reuse_buffers:
-            vis, aqe, mqe, lists, saved = mod._buffers(st_, "fwd", lambda: (
+            vis, aqe, mqe, lists, saved = mod._shape_buffers(st_, "fwd", lambda: (
                 torch.empty((B, N, D), device=dev, dtype=torch.float32), torch.empty((B, N, D), device=dev, dtype=torch.float32),
                 torch.empty((B, N, D), device=dev, dtype=torch.float32),
                 [torch.empty((Lr, B, N, D), device=dev, dtype=torch.float32) for _ in range(4)],
@@ -186,7 +186,7 @@ class _UnitFn(torch.autograd.Function):
             alpha, beta, scale = mod.loss_in_forward[:3]
             with_vis = len(mod.loss_in_forward) < 4 or bool(mod.loss_in_forward[3])   # False: auxiliary terms alone
             if mod.reuse_buffers:
-                terms, g_vis, g_lists = mod._buffers(st_, "loss" + str(int(with_vis)), lambda: (
+                terms, g_vis, g_lists = mod._shape_buffers(st_, "loss" + str(int(with_vis)), lambda: (
                     torch.empty(3, device=dev, dtype=torch.float32), torch.empty_like(vis) if with_vis else None,
                     [torch.empty_like(t) for t in lists]))
             else:
@@ -216,7 +216,7 @@ class _UnitFn(torch.autograd.Function):
                for g in (g_vis, g_aqe, g_mqe, g_ca, g_cm, g_aq, g_mq)]
         st_ = ctx.shape_state
         if mod.reuse_buffers:
-            gA, gM, gdq, gwords = mod._buffers(st_, "bwd", lambda: (torch.empty_like(A), torch.empty_like(M), torch.empty_like(dq),
+            gA, gM, gdq, gwords = mod._shape_buffers(st_, "bwd", lambda: (torch.empty_like(A), torch.empty_like(M), torch.empty_like(dq),
                                                                     torch.empty_like(words)))
         else:
             gA = torch.empty_like(A)
@@ -438,7 +438,7 @@ class DualVGRUnit_multiple(nn.Module):
         return st_
 
     @staticmethod
-    def _buffers(st_, what, make):
+    def _shape_buffers(st_, what, make):
         b = st_["buf"].get(what)
         if b is None:
             b = st_["buf"][what] = make()

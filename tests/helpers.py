@@ -208,7 +208,8 @@ def bias_scales(dbg, Lr, D):
 def assert_grads(m, t, gin, gw, dbg, Lr, gtol, what=""):
     """Input gradients and every weight-matrix gradient within `gtol` (max |err| / max |want| per tensor).  Gradients that
     are column sums over rows (the biases; the a.bias scalars) cancel heavily: they are held to 1e-5 of the sum of the
-    absolute terms (what their arithmetic can deliver) and, as a sanity bound, to 10 x gtol in the plain metric."""
+    absolute terms (what their arithmetic can deliver) and, as a sanity bound only, to 40 x gtol in the plain metric
+    (a scalar a.bias gradient that cancels to 1e-3 of its terms shows 6e-3 there at bf16x3's 1e-5 operand error)."""
     gerr, werrs = grad_errors(m, t, gin, gw)
     scales = abias_scales(dbg, Lr)
     named = dict(m.named_parameters())
@@ -225,4 +226,4 @@ def assert_grads(m, t, gin, gw, dbg, Lr, gtol, what=""):
     assert worst[0][1] < gtol, worst
     assert max(ab.values()) < 1e-5, sorted(ab.items(), key=lambda kv: -kv[1])[:3]
     assert max(bb.values()) < 1e-5, sorted(bb.items(), key=lambda kv: -kv[1])[:3]
-    assert max(werrs[k] for k in special) < 10 * gtol, sorted(((k, werrs[k]) for k in special), key=lambda kv: -kv[1])[:3]
+    assert max(werrs[k] for k in special) < 40 * gtol, sorted(((k, werrs[k]) for k in special), key=lambda kv: -kv[1])[:3]
