@@ -252,7 +252,7 @@ def backward(sd, cache, words, dq, g_vis, g_aqe, g_mqe, g_ca, g_cm, g_aq, g_mq, 
                            ds=ds, dtau=dtau, dp=dp, dx=dx)
             # cancellation scales of the bias gradients (column sums over rows): sum of the absolute terms, per column
             dl[mod + ".bias_abs"] = {"project.0.bias": dpre.abs().sum((0, 1, 2)), "W.bias": dWh8.reshape(B, N, 8 * Fh).abs().sum((0, 1)),
-                                     "query_weight.bias": dp.abs().sum(0)}
+                                     "query_weight.bias": torch.einsum("bn,bnd->d", dtau.abs(), x.abs())}
             dX[mod] = dx
         # ---- S0 backward (QueryAttn) ----------------------------------------------------------------
         W1 = sd[f"queryAttn.{l}.feat_enhance.weight"]

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_synthetic_training_learns():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_synthetic.py"), "8"], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_synthetic.py"), "30"], capture_output=True, text=True,
                        timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "training check ok" in r.stdout

@@ -42,7 +42,7 @@ loader = dv.VideoQAFlatLoader(vocab_json=os.path.join(root, "v.json"), question_
 model = dv.DualVGR(vision_dim=FEAT, module_dim=768, word_dim=300, vocab=vocab, num_of_nodes=N, graph_module="GAT", graph_layers=1,
                    unit_layers=2, dtype="bf16x3").cuda().train()
 model.visual_input_unit.reuse_buffers = True
-step = dv.TrainStep(model, lr=5e-4, alpha=1.0, beta=1e-8, max_norm=12.0)          # train.py:139-159 on the package's kernels
+step = dv.TrainStep(model, lr=1e-3, alpha=1.0, beta=1e-8, max_norm=12.0)          # train.py:139-159 on the package's kernels
 first = last = None
 for ep in range(epochs):
     t0, tot, correct, n = time.perf_counter(), 0.0, 0, 0
