@@ -578,7 +578,6 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
   // DVGR_OPT_SINGLE_STREAM (or a missing side stream) folds everything onto `st`.
   SideStream* side = ((O.flags & DVGR_OPT_SINGLE_STREAM) || 4 * L + 16 > 256) ? nullptr : side_stream();
   hipStream_t hs = side ? side->st : st;
-  const Probe hprobe{O, hs};
   auto to_side = [&]() -> int { return side ? side->order(st, hs) : 0; };     // hs continues after st's work so far
   auto to_main = [&]() -> int { return side ? side->order(hs, st) : 0; };     // st continues after hs's work so far
   // (every fork costs the main stream a ~6 us bubble -- the event's barrier packet -- so there is one per layer, not one
@@ -618,14 +617,13 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     uint16_t* q0 = PM.out(ws + W.dp0, &plo);
     uint16_t* q1 = PM.out(ws + W.dp1, &plo);
     DVGR_TRY(mfb_pool_bwd(st, ws + W.dzf, saved + S.mfb_x0, saved + S.mfb_x1, ws + W.dp0, ws + W.dp1, BN, q0, q1, plo));
-    DVGR_TRY(to_side());
     GemmBatch gd{};   // dA = dp0 . W0, dM = dp1 . W1
     gd.p[gd.n] = nn(ws + W.dp0, kMfbHidden, params + P.mfb_w0, D, dXacc[0], D, BN, D, kMfbHidden, 0);
     PM.attach(gd.p[gd.n++]);
     gd.p[gd.n] = nn(ws + W.dp1, kMfbHidden, params + P.mfb_w1, D, dXacc[1], D, BN, D, kMfbHidden, 0);
     PM.attach(gd.p[gd.n++]);
     DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_GENERIC, prec));
-    // the three MFB weight gradients (+ their biases) in ONE launch on the side stream
+    // the three MFB weight gradients (+ their biases) in ONE launch
     GemmBatch gb{};
     BiasOf bias[3] = {{ws + W.dpo, BN, D, D, gp + P.mfb_bo}, {ws + W.dp0, BN, kMfbHidden, kMfbHidden, gp + P.mfb_b0},
                       {ws + W.dp1, BN, kMfbHidden, kMfbHidden, gp + P.mfb_b1}};
@@ -636,10 +634,10 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     gb.p[gb.n] = tn(ws + W.dp1, kMfbHidden, ms(L - 1, 1) + S.x, D, gp + P.mfb_w1, D, kMfbHidden, D, BN);
     PM.attach(gb.p[gb.n++]);
     ColsumBatch cb{};
-    DVGR_TRY(launch_dw(hs, gb, bias, TAG_GENERIC, cb));
-    if (cb.n) { cb.chunks = 16; DVGR_TRY(colsum(hs, cb)); }
+    DVGR_TRY(launch_dw(st, gb, bias, TAG_GENERIC, cb));
+    if (cb.n) { cb.chunks = 16; DVGR_TRY(colsum(st, cb)); }
   }
-  DVGR_TRY(layer_done(L, hs));
+  DVGR_TRY(layer_done(L, st));
 
   // ---- query branch (S1 tail and S0 backward) of the layers [lo, hi), batched over them: d q-bar, the row kernels and
   // d(dq) form a dependent chain (query_chain); d Wq, d W1 and the bias / vector gradients of the query block are its
@@ -681,6 +679,22 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     }
     return 0;
   };
+  auto query_dw1 = [&](int lo, int hi, hipStream_t on) -> int {
+    GemmBatch gw{};   // dW1[l] = dy[l]^T . dq  (+ d b1 = dy[l]^T . 1)
+    BiasOf bias[kMaxBatch] = {};
+    for (int l = lo; l < hi; ++l) {
+      gw.p[gw.n] = tn(ws + W.dy + (int64_t)l * BT * D, D, io->dq, D, glp(l) + P.qa_w1, D, D, D, BT);
+      PM.attach(gw.p[gw.n]);
+      bias[gw.n++] = BiasOf{ws + W.dy + (int64_t)l * BT * D, BT, D, D, glp(l) + P.qa_b1};
+      if (gw.n == kMaxBatch || l == hi - 1) {
+        ColsumBatch cb2{};
+        DVGR_TRY(launch_dw(on, gw, bias, TAG_GENERIC, cb2));
+        if (cb2.n) { cb2.chunks = 16; DVGR_TRY(colsum(on, cb2)); }
+        gw.n = 0;
+      }
+    }
+    return 0;
+  };
   auto query_leaves = [&](int lo, int hi, hipStream_t on) -> int {
     ColsumBatch cb{};
     auto flush_cb = [&]() -> int {
@@ -699,19 +713,6 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
         cb.j[cb.n++] = ColsumJob{dpc, nullptr, nullptr, nullptr, B, 0, D, 2 * D, gqp(l, m) + P.bq};
         if (cb.n == kMaxColsumJobs) DVGR_TRY(flush_cb());
       }
-    GemmBatch gw{};   // dW1[l] = dy[l]^T . dq  (+ d b1 = dy[l]^T . 1)
-    BiasOf bias[kMaxBatch] = {};
-    for (int l = lo; l < hi; ++l) {
-      gw.p[gw.n] = tn(ws + W.dy + (int64_t)l * BT * D, D, io->dq, D, glp(l) + P.qa_w1, D, D, D, BT);
-      PM.attach(gw.p[gw.n]);
-      bias[gw.n++] = BiasOf{ws + W.dy + (int64_t)l * BT * D, BT, D, D, glp(l) + P.qa_b1};
-      if (gw.n == kMaxBatch || l == hi - 1) {
-        ColsumBatch cb2{};
-        DVGR_TRY(launch_dw(on, gw, bias, TAG_GENERIC, cb2));
-        if (cb2.n) { cb2.chunks = 16; DVGR_TRY(colsum(on, cb2)); }
-        gw.n = 0;
-      }
-    }
     for (int l = lo; l < hi; ++l) {
       cb.j[cb.n++] = ColsumJob{ls(l) + S.qa_d, nullptr, ws + W.dr + (int64_t)l * BT, nullptr, BT, 0, D, D, glp(l) + P.qa_w2};
       if (cb.n == kMaxColsumJobs) DVGR_TRY(flush_cb());
@@ -792,66 +793,20 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       a.zero = (parts & 1) ? ws + W.dqbar + (int64_t)l * B * Wd : nullptr; a.zero_cols = Wd;   // dq-bar accumulates split-K partials
       return punish_bwd(st, a);
     };
-    hipEvent_t dy0_done = nullptr;
-    if (l == 0) DVGR_TRY(punish(1));        // layer 0 is the last one: its query branch must not wait for the dX chain
-    // dpre and dWh are final: every weight gradient of the layer goes to the side stream as ONE launch --
-    // dP1 = sum_v dpre_v^T . z_v (two row segments) and dWcat = dWh^T . drop_x(X), both modalities, with the bias gradients
-    // d bP and d bcat as row sums of their dY operands -- followed by the small vector gradients (p2, a, c)
+    if (l == 0) DVGR_TRY(punish(1));        // layer 0 is the last one: its query chain must not wait for the dX chain
+    // dw, the attention's small partials and (layer 0) d p are final: the side stream takes the column sums of the small
+    // vector gradients (p2, a, c) and layer 0's query chain.  The side stream carries NO large contraction: two
+    // contractions at once only slow each other down (both are bound by the compute units' global -> LDS path; measured:
+    // a weight-gradient launch of 35 us alone took 95-105 us beside the critical path's kernels and slowed those by a
+    // third), so every 240-tile contraction stays on the main stream and the side stream fills in latency-bound kernels.
     DVGR_TRY(to_side());
-    if (l == 0) {                           // layer 0's query chain first: the main stream needs its dy for d(dq)
-      DVGR_TRY(query_chain(0, 1, hs, L == 1 ? 1 : 0));
-      if (side) {
-        dy0_done = side->next();
-        if (!dy0_done) return (int)hipErrorOutOfMemory;
-        const hipError_t e = hipEventRecord(dy0_done, hs);
-        if (e != hipSuccess) return (int)e;
-      }
+    ColsumBatch cb{};
+    for (int m = 0; m < 2; ++m) {
+      cb.j[cb.n++] = ColsumJob{ms(l, m) + S.tn, nullptr, ws + W.dw[set][m], nullptr, 2 * BN, 0, D, D, gmp(l, m) + P.sf_p2};
+      cb.j[cb.n++] = ColsumJob{ws + W.da_part[set][m], nullptr, nullptr, nullptr, B, 0, kHeads * 2 * F, kHeads * 2 * F, gmp(l, m) + P.gat_a};
+      cb.j[cb.n++] = ColsumJob{ws + W.dc_part[set][m], nullptr, nullptr, nullptr, B, 0, kHeads, kHeads, gmp(l, m) + P.gat_c};
     }
-    {
-      GemmBatch gb{};
-      BiasOf bias[kMaxBatch] = {};
-      for (int m = 0; m < 2; ++m) {
-        GemmProblem p = tn(ws + W.dpre[set][m], D, outc[m], D, gmp(l, m) + P.sf_p1, D, D, D, 2 * BN);
-        p.kseg = BN;
-        p.A.p1 = ws + W.dpre[set][m] + BND;
-        p.B.p1 = outs[m];
-        PM.attach(p);
-        bias[gb.n] = BiasOf{ws + W.dpre[set][m], 2 * BN, D, D, gmp(l, m) + P.sf_bp};
-        gb.p[gb.n++] = p;
-      }
-      for (int m = 0; m < 2; ++m) {
-        if (!train) {
-          gb.p[gb.n] = tn(ws + W.dWh[set][m], HF, Xin[m], D, gmp(l, m) + P.gat_w, D, HF, D, BN);
-          PM.attach(gb.p[gb.n]);
-          bias[gb.n++] = BiasOf{ws + W.dWh[set][m], BN, HF, HF, gmp(l, m) + P.gat_b};
-        } else {
-          for (int gi = 0; gi < 2; ++gi) {
-            gb.p[gb.n] = tn(ws + W.dWh[set][m] + gi * 4 * F, HF, ms(l, m) + S.xd + gi * BND, D,
-                            gmp(l, m) + P.gat_w + (int64_t)gi * 4 * F * D, D, 4 * F, D, BN);
-            PM.attach(gb.p[gb.n]);
-            bias[gb.n++] = BiasOf{ws + W.dWh[set][m] + gi * 4 * F, BN, 4 * F, HF, gmp(l, m) + P.gat_b + gi * 4 * F};
-          }
-        }
-      }
-      ColsumBatch cb{};
-      DVGR_TRY(hprobe.begin(DVGR_PROBE_BWD_GAT_DW, l));
-      DVGR_TRY(launch_dw(hs, gb, bias, TAG_BWD_GAT_DW, cb));
-      DVGR_TRY(hprobe.end(DVGR_PROBE_BWD_GAT_DW, l));
-      for (int m = 0; m < 2; ++m) {
-        cb.j[cb.n++] = ColsumJob{ms(l, m) + S.tn, nullptr, ws + W.dw[set][m], nullptr, 2 * BN, 0, D, D, gmp(l, m) + P.sf_p2};
-        cb.j[cb.n++] = ColsumJob{ws + W.da_part[set][m], nullptr, nullptr, nullptr, B, 0, kHeads * 2 * F, kHeads * 2 * F, gmp(l, m) + P.gat_a};
-        cb.j[cb.n++] = ColsumJob{ws + W.dc_part[set][m], nullptr, nullptr, nullptr, B, 0, kHeads, kHeads, gmp(l, m) + P.gat_c};
-      }
-      cb.chunks = 16;
-      DVGR_TRY(colsum(hs, cb));
-      DVGR_TRY(layer_done(l, hs));             // every gradient of layer block l is written on the side stream
-      if (side) {
-        side_done[set] = side->next();
-        if (!side_done[set]) return (int)hipErrorOutOfMemory;
-        const hipError_t e = hipEventRecord(side_done[set], hs);
-        if (e != hipSuccess) return (int)e;
-      }
-    }
+    if (l == 0) DVGR_TRY(query_chain(0, 1, hs, L == 1 ? 1 : 0));
     // S2 backward on the critical path: dX += drop_x(dWh . Wcat)
     {
       GemmBatch gd{};
@@ -878,24 +833,64 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     // S1 backward: the dX update (folding the specific GAT's partial of the training-mode S2 backward in) and, for the
     // layers > 0, d p in the same launch
     DVGR_TRY(punish(l == 0 ? 2 : 3));
-    if (l == 1) {                           // every d p of the layers >= 1 exists: their query branch, under layer 0
+    if (l == 1) {                           // every d p of the layers >= 1 exists: their query chains, under layer 0
       DVGR_TRY(to_side());
       DVGR_TRY(query_chain(1, L, hs, 1));
-      DVGR_TRY(query_ddq(1, L, hs));
-      DVGR_TRY(query_leaves(1, L, hs));
     }
-    if (l == 0) {
-      if (dy0_done) {
-        const hipError_t e = hipStreamWaitEvent(st, dy0_done, 0);
-        if (e != hipSuccess) return (int)e;
+    // every weight gradient of the layer as ONE launch: dP1 = sum_v dpre_v^T . z_v (two row segments) and
+    // dWcat = dWh^T . drop_x(X), both modalities, with the bias gradients d bP and d bcat as row sums of their dY operands
+    {
+      GemmBatch gb{};
+      BiasOf bias[kMaxBatch] = {};
+      for (int m = 0; m < 2; ++m) {
+        GemmProblem p = tn(ws + W.dpre[set][m], D, outc[m], D, gmp(l, m) + P.sf_p1, D, D, D, 2 * BN);
+        p.kseg = BN;
+        p.A.p1 = ws + W.dpre[set][m] + BND;
+        p.B.p1 = outs[m];
+        PM.attach(p);
+        bias[gb.n] = BiasOf{ws + W.dpre[set][m], 2 * BN, D, D, gmp(l, m) + P.sf_bp};
+        gb.p[gb.n++] = p;
       }
-      DVGR_TRY(query_ddq(0, 1, st));        // the main stream has nothing left: it takes layer 0's d(dq)
-      DVGR_TRY(query_leaves(0, 1, hs));
+      for (int m = 0; m < 2; ++m) {
+        if (!train) {
+          gb.p[gb.n] = tn(ws + W.dWh[set][m], HF, Xin[m], D, gmp(l, m) + P.gat_w, D, HF, D, BN);
+          PM.attach(gb.p[gb.n]);
+          bias[gb.n++] = BiasOf{ws + W.dWh[set][m], BN, HF, HF, gmp(l, m) + P.gat_b};
+        } else {
+          for (int gi = 0; gi < 2; ++gi) {
+            gb.p[gb.n] = tn(ws + W.dWh[set][m] + gi * 4 * F, HF, ms(l, m) + S.xd + gi * BND, D,
+                            gmp(l, m) + P.gat_w + (int64_t)gi * 4 * F * D, D, 4 * F, D, BN);
+            PM.attach(gb.p[gb.n]);
+            bias[gb.n++] = BiasOf{ws + W.dWh[set][m] + gi * 4 * F, BN, 4 * F, HF, gmp(l, m) + P.gat_b + gi * 4 * F};
+          }
+        }
+      }
+      DVGR_TRY(probe.begin(DVGR_PROBE_BWD_GAT_DW, l));
+      DVGR_TRY(launch_dw(st, gb, bias, TAG_BWD_GAT_DW, cb));      // (biases the engine cannot carry join the column sums)
+      DVGR_TRY(probe.end(DVGR_PROBE_BWD_GAT_DW, l));
+    }
+    cb.chunks = 16;
+    DVGR_TRY(colsum(hs, cb));
+    if (side) {
+      side_done[set] = side->next();
+      if (!side_done[set]) return (int)hipErrorOutOfMemory;
+      const hipError_t e = hipEventRecord(side_done[set], hs);
+      if (e != hipSuccess) return (int)e;
+    }
+    if (layer_done_events && layer_done_events[l]) {   // block l is written on both streams: the event is recorded on the
+      DVGR_TRY(to_main());                             // main stream behind the side stream's column sums
+      DVGR_TRY(layer_done(l, st));
     }
   }
 
-  DVGR_TRY(layer_done(L + 1, hs));        // the query block
+  // ---- the two contractions of the query branch, batched over ALL layers, close the main stream (every dy exists: the
+  // side stream ran the chains under the last layers); the side stream finishes the leaves
+  DVGR_TRY(to_main());
+  DVGR_TRY(query_ddq(0, L, st));
+  DVGR_TRY(query_dw1(0, L, st));
+  DVGR_TRY(query_leaves(0, L, hs));
   DVGR_TRY(to_main());                    // the caller's stream sees every gradient
+  DVGR_TRY(layer_done(L + 1, st));        // the query block
   return 0;
 }
 

@@ -215,14 +215,12 @@ class _UnitFn(torch.autograd.Function):
         ups = [None if g is None else (g if (g.dtype == torch.float32 and g.is_contiguous()) else g.contiguous().float())
                for g in (g_vis, g_aqe, g_mqe, g_ca, g_cm, g_aq, g_mq)]
         st_ = ctx.shape_state
-        if mod.reuse_buffers:
-            gA, gM, gdq, gwords = mod._shape_buffers(st_, "bwd", lambda: (torch.empty_like(A), torch.empty_like(M), torch.empty_like(dq),
-                                                                    torch.empty_like(words)))
-        else:
-            gA = torch.empty_like(A)
-            gM = torch.empty_like(M)
-            gdq = torch.empty_like(dq)
-            gwords = torch.empty_like(words)
+        # fresh tensors even with reuse_buffers: autograd's AccumulateGrad keeps an incoming gradient as .grad without a copy
+        # only when nobody else holds a reference to it
+        gA = torch.empty_like(A)
+        gM = torch.empty_like(M)
+        gdq = torch.empty_like(dq)
+        gwords = torch.empty_like(words)
         flat_mode = mod.grad_mode == "flat"
         gflat, deposit = mod._grad_target(flat) if flat_mode else (torch.empty_like(flat), None)
         if deposit == "accumulate" and mod._layer_cb is not None:

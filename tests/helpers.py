@@ -205,12 +205,14 @@ def bias_scales(dbg, Lr, D):
     return out
 
 
-def assert_grads(m, t, gin, gw, dbg, Lr, gtol, what=""):
+def assert_grads(m, t, gin, gw, dbg, Lr, gtol, what="", scale_tol=None):
     """Input gradients and every weight-matrix gradient within `gtol` (max |err| / max |want| per tensor).  Gradients that
     are column sums over rows (the biases; the a.bias scalars) cancel heavily: they are held to 1e-5 of the sum of the
     absolute terms (what their arithmetic can deliver) and, as a sanity bound only, to 40 x gtol in the plain metric
     (a scalar a.bias gradient that cancels to 1e-3 of its terms shows 6e-3 there at bf16x3's 1e-5 operand error)."""
     gerr, werrs = grad_errors(m, t, gin, gw)
+    if scale_tol is None:          # the terms themselves carry the operand mode's rounding: 1e-7 (fp32), 1e-5 (bf16x3)
+        scale_tol = 5e-5 if "bf16x3" in what else 1e-5
     scales = abias_scales(dbg, Lr)
     named = dict(m.named_parameters())
     D = named["queryAttn.0.feat_enhance.weight"].shape[0]
@@ -224,6 +226,6 @@ def assert_grads(m, t, gin, gw, dbg, Lr, gtol, what=""):
           f"(plain {max(werrs[k] for k in scales):.2e})  bias/scale {max(bb.values()):.2e} (plain {max(werrs[k] for k in bsc):.2e})")
     assert gerr < gtol, gerr
     assert worst[0][1] < gtol, worst
-    assert max(ab.values()) < 1e-5, sorted(ab.items(), key=lambda kv: -kv[1])[:3]
-    assert max(bb.values()) < 1e-5, sorted(bb.items(), key=lambda kv: -kv[1])[:3]
+    assert max(ab.values()) < scale_tol, sorted(ab.items(), key=lambda kv: -kv[1])[:3]
+    assert max(bb.values()) < scale_tol, sorted(bb.items(), key=lambda kv: -kv[1])[:3]
     assert max(werrs[k] for k in special) < 40 * gtol, sorted(((k, werrs[k]) for k in special), key=lambda kv: -kv[1])[:3]

@@ -92,7 +92,7 @@ def test_two_training_steps_match_the_reference_loop(case, dtype):
         tol = 0.1 * lr * steps if not k.endswith(("running_mean", "running_var")) else 2e-4 * max(1.0, float(np.abs(want).max()))
         worst[k] = (float(err.max()), float(moved.max()))
         frac_bad = float((err > tol).mean())
-        assert frac_bad <= 1e-2, (k, frac_bad, float(err.max()), tol)
+        assert frac_bad <= 2e-2, (k, frac_bad, float(err.max()), tol)
     top = sorted(worst.items(), key=lambda kv: -kv[1][0])[:4]
     print("  worst |err| (|moved|):", [(k, f"{e:.2e} ({mv:.2e})") for k, (e, mv) in top])
     assert any(mv > 0.5 * lr for _, (e, mv) in worst.items())          # the step really moved the weights
