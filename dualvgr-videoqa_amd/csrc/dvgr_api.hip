@@ -578,6 +578,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
   // DVGR_OPT_SINGLE_STREAM (or a missing side stream) folds everything onto `st`.
   SideStream* side = ((O.flags & DVGR_OPT_SINGLE_STREAM) || 4 * L + 16 > 256) ? nullptr : side_stream();
   hipStream_t hs = side ? side->st : st;
+  static const bool dw_on_side = []() { const char* e = getenv("DVGR_DW_MAIN"); return !(e && e[0] == '1'); }();
   auto to_side = [&]() -> int { return side ? side->order(st, hs) : 0; };     // hs continues after st's work so far
   auto to_main = [&]() -> int { return side ? side->order(hs, st) : 0; };     // st continues after hs's work so far
   // (every fork costs the main stream a ~6 us bubble -- the event's barrier packet -- so there is one per layer, not one
@@ -865,21 +866,31 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
           }
         }
       }
-      DVGR_TRY(probe.begin(DVGR_PROBE_BWD_GAT_DW, l));
-      DVGR_TRY(launch_dw(st, gb, bias, TAG_BWD_GAT_DW, cb));      // (biases the engine cannot carry join the column sums)
-      DVGR_TRY(probe.end(DVGR_PROBE_BWD_GAT_DW, l));
-    }
-    cb.chunks = 16;
-    DVGR_TRY(colsum(hs, cb));
-    if (side) {
-      side_done[set] = side->next();
-      if (!side_done[set]) return (int)hipErrorOutOfMemory;
-      const hipError_t e = hipEventRecord(side_done[set], hs);
-      if (e != hipSuccess) return (int)e;
-    }
-    if (layer_done_events && layer_done_events[l]) {   // block l is written on both streams: the event is recorded on the
-      DVGR_TRY(to_main());                             // main stream behind the side stream's column sums
-      DVGR_TRY(layer_done(l, st));
+      // Where: the launch is unbalanced (the dP1 tiles reduce over 2 B N rows, the dWcat tiles over B N: 72 tiles run twice
+      // as long as the other 144), so beside the next layer's critical-path kernels it fills compute units that would idle
+      // behind its short tiles -- the layers > 0 put it on the side stream; layer 0 has no next layer and keeps it on
+      // the main stream, which is idle by then.
+      hipStream_t dws = (side && l > 0 && dw_on_side) ? hs : st;
+      const Probe dprobe{O, dws};
+      DVGR_TRY(dprobe.begin(DVGR_PROBE_BWD_GAT_DW, l));
+      DVGR_TRY(launch_dw(dws, gb, bias, TAG_BWD_GAT_DW, cb));     // (biases the engine cannot carry join the column sums)
+      DVGR_TRY(dprobe.end(DVGR_PROBE_BWD_GAT_DW, l));
+      cb.chunks = 16;
+      DVGR_TRY(colsum(hs, cb));
+      if (side) {
+        side_done[set] = side->next();
+        if (!side_done[set]) return (int)hipErrorOutOfMemory;
+        const hipError_t e = hipEventRecord(side_done[set], hs);
+        if (e != hipSuccess) return (int)e;
+      }
+      if (layer_done_events && layer_done_events[l]) {
+        if (dws == hs || !side) {
+          DVGR_TRY(layer_done(l, hs));                   // every gradient of block l was written on the side stream
+        } else {                                         // block l is written on both streams: the event is recorded on the
+          DVGR_TRY(to_main());                           // main stream behind the side stream's column sums
+          DVGR_TRY(layer_done(l, st));
+        }
+      }
     }
   }
 
