@@ -119,7 +119,7 @@ GemmProblem nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* 
                const float* bias, int M, int N, int K, int act, uint32_t drop_a = 0) {
   GemmProblem p{};
   p.A = operand(A, lda, drop_a); p.B = operand(B, ldb);
-  p.C = C; p.ldc = ldc; p.bias = bias; p.M = M; p.N = N; p.K = K; p.kseg = K; p.act = act;
+  p.C = C; p.ldc = ldc; p.bias = bias; p.M = M; p.N = N; p.K = K; p.kseg = K; p.act = act; p.layout = LAYOUT_NT;
   return p;
 }
 // C (+)= A[M,K] . B[K,N]                                  (backward data)
@@ -128,6 +128,7 @@ GemmProblem nn(const float* A, int64_t lda, const float* B, int64_t ldb, float* 
   GemmProblem p{};
   p.A = operand(A, lda); p.B = operand(B, ldb);
   p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.kseg = K; p.accumulate = accumulate; p.drop_key_c = drop_c;
+  p.layout = LAYOUT_NN;
   return p;
 }
 // C = A[K,M]^T . B[K,N]                                   (backward weight)
@@ -135,7 +136,7 @@ GemmProblem tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* 
                int M, int N, int K, uint32_t drop_b = 0) {
   GemmProblem p{};
   p.A = operand(A, lda); p.B = operand(B, ldb, drop_b);
-  p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.kseg = K;
+  p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.kseg = K; p.layout = LAYOUT_TN;
   p.atomic_ok = 1;   // every weight gradient lands in gparams, which the backward zeroes first
   return p;
 }
@@ -578,7 +579,6 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
   // DVGR_OPT_SINGLE_STREAM (or a missing side stream) folds everything onto `st`.
   SideStream* side = ((O.flags & DVGR_OPT_SINGLE_STREAM) || 4 * L + 16 > 256) ? nullptr : side_stream();
   hipStream_t hs = side ? side->st : st;
-  static const bool dw_on_side = []() { const char* e = getenv("DVGR_DW_MAIN"); return !(e && e[0] == '1'); }();
   auto to_side = [&]() -> int { return side ? side->order(st, hs) : 0; };     // hs continues after st's work so far
   auto to_main = [&]() -> int { return side ? side->order(hs, st) : 0; };     // st continues after hs's work so far
   // (every fork costs the main stream a ~6 us bubble -- the event's barrier packet -- so there is one per layer, not one
@@ -603,6 +603,25 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     return gemm_launch(on, IC, IC, gb, tag, prec);
   };
 
+  // Data-gradient (NN) and weight-gradient (TN) problems that become ready together go out as ONE launch where the engine
+  // can mix layouts (gemm_launch_mixed); otherwise one launch per kind.  bias[i] belongs to gb.p[i] (TN problems only).
+  auto launch_mixed = [&](hipStream_t on, GemmBatch& gb, const BiasOf* bias, int tag, ColsumBatch& cb) -> int {
+    if (gemm_mixed_supported(gb, prec)) {
+      for (int i = 0; i < gb.n; ++i)
+        if (bias[i].out) gb.p[i].rowsum = bias[i].out;
+      return gemm_launch_mixed(on, gb, tag, prec);
+    }
+    GemmBatch gn{}, gt{};
+    BiasOf bt[kMaxBatch] = {};
+    for (int i = 0; i < gb.n; ++i) {
+      if (gb.p[i].layout == LAYOUT_TN) { bt[gt.n] = bias[i]; gt.p[gt.n++] = gb.p[i]; }
+      else gn.p[gn.n++] = gb.p[i];
+    }
+    if (gn.n) DVGR_TRY(gemm_launch(on, KC, IC, gn, tag, prec));
+    if (gt.n) DVGR_TRY(launch_dw(on, gt, bt, tag == TAG_BWD_GAT_DX ? TAG_BWD_GAT_DW : tag, cb));
+    return 0;
+  };
+
   // ---- S6 backward ------------------------------------------------------------------------------------
   {
     uint16_t* dpop = PM.out(ws + W.dpo, &plo);
@@ -618,24 +637,24 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     uint16_t* q0 = PM.out(ws + W.dp0, &plo);
     uint16_t* q1 = PM.out(ws + W.dp1, &plo);
     DVGR_TRY(mfb_pool_bwd(st, ws + W.dzf, saved + S.mfb_x0, saved + S.mfb_x1, ws + W.dp0, ws + W.dp1, BN, q0, q1, plo));
-    GemmBatch gd{};   // dA = dp0 . W0, dM = dp1 . W1
-    gd.p[gd.n] = nn(ws + W.dp0, kMfbHidden, params + P.mfb_w0, D, dXacc[0], D, BN, D, kMfbHidden, 0);
-    PM.attach(gd.p[gd.n++]);
-    gd.p[gd.n] = nn(ws + W.dp1, kMfbHidden, params + P.mfb_w1, D, dXacc[1], D, BN, D, kMfbHidden, 0);
-    PM.attach(gd.p[gd.n++]);
-    DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_GENERIC, prec));
-    // the three MFB weight gradients (+ their biases) in ONE launch
+    // dA = dp0 . W0, dM = dp1 . W1 and the three MFB weight gradients (+ their biases) in ONE launch
     GemmBatch gb{};
-    BiasOf bias[3] = {{ws + W.dpo, BN, D, D, gp + P.mfb_bo}, {ws + W.dp0, BN, kMfbHidden, kMfbHidden, gp + P.mfb_b0},
-                      {ws + W.dp1, BN, kMfbHidden, kMfbHidden, gp + P.mfb_b1}};
+    BiasOf bias[kMaxBatch] = {};
+    gb.p[gb.n] = nn(ws + W.dp0, kMfbHidden, params + P.mfb_w0, D, dXacc[0], D, BN, D, kMfbHidden, 0);
+    PM.attach(gb.p[gb.n++]);
+    gb.p[gb.n] = nn(ws + W.dp1, kMfbHidden, params + P.mfb_w1, D, dXacc[1], D, BN, D, kMfbHidden, 0);
+    PM.attach(gb.p[gb.n++]);
+    bias[gb.n] = BiasOf{ws + W.dpo, BN, D, D, gp + P.mfb_bo};
     gb.p[gb.n] = tn(ws + W.dpo, D, saved + S.mfb_z, kMfbPooled, gp + P.mfb_wo, kMfbPooled, D, kMfbPooled, BN);
     PM.attach(gb.p[gb.n++]);
+    bias[gb.n] = BiasOf{ws + W.dp0, BN, kMfbHidden, kMfbHidden, gp + P.mfb_b0};
     gb.p[gb.n] = tn(ws + W.dp0, kMfbHidden, ms(L - 1, 0) + S.x, D, gp + P.mfb_w0, D, kMfbHidden, D, BN);
     PM.attach(gb.p[gb.n++]);
+    bias[gb.n] = BiasOf{ws + W.dp1, BN, kMfbHidden, kMfbHidden, gp + P.mfb_b1};
     gb.p[gb.n] = tn(ws + W.dp1, kMfbHidden, ms(L - 1, 1) + S.x, D, gp + P.mfb_w1, D, kMfbHidden, D, BN);
     PM.attach(gb.p[gb.n++]);
     ColsumBatch cb{};
-    DVGR_TRY(launch_dw(st, gb, bias, TAG_GENERIC, cb));
+    DVGR_TRY(launch_mixed(st, gb, bias, TAG_GENERIC, cb));
     if (cb.n) { cb.chunks = 16; DVGR_TRY(colsum(st, cb)); }
   }
   DVGR_TRY(layer_done(L, st));
@@ -669,30 +688,28 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     a.lo_off = plo;
     return qa_bwd(on, a);
   };
-  auto query_ddq = [&](int lo, int hi, hipStream_t on) -> int {
-    GemmBatch gq{};   // d(dq) += dy[l] . W1[l]: several problems into ONE output -> tiles are added atomically (gdq is zeroed)
-    for (int l = lo; l < hi; ++l) {
-      gq.p[gq.n] = nn(ws + W.dy + (int64_t)l * BT * D, D, lp(l) + P.qa_w1, D, g->gdq, D, BT, D, D, 1);
-      PM.attach(gq.p[gq.n]);
-      gq.p[gq.n].atomic_ok = 1;
-      gq.p[gq.n++].atomic_out = (L > 1);
-      if (gq.n == kMaxBatch || l == hi - 1) { DVGR_TRY(gemm_launch(on, KC, IC, gq, TAG_GENERIC, prec)); gq.n = 0; }
-    }
-    return 0;
-  };
-  auto query_dw1 = [&](int lo, int hi, hipStream_t on) -> int {
-    GemmBatch gw{};   // dW1[l] = dy[l]^T . dq  (+ d b1 = dy[l]^T . 1)
-    BiasOf bias[kMaxBatch] = {};
-    for (int l = lo; l < hi; ++l) {
-      gw.p[gw.n] = tn(ws + W.dy + (int64_t)l * BT * D, D, io->dq, D, glp(l) + P.qa_w1, D, D, D, BT);
-      PM.attach(gw.p[gw.n]);
-      bias[gw.n++] = BiasOf{ws + W.dy + (int64_t)l * BT * D, BT, D, D, glp(l) + P.qa_b1};
-      if (gw.n == kMaxBatch || l == hi - 1) {
-        ColsumBatch cb2{};
-        DVGR_TRY(launch_dw(on, gw, bias, TAG_GENERIC, cb2));
-        if (cb2.n) { cb2.chunks = 16; DVGR_TRY(colsum(on, cb2)); }
-        gw.n = 0;
+  auto query_gemms = [&](int lo, int hi, hipStream_t on) -> int {
+    // d(dq) += dy[l] . W1[l] (several problems into ONE output: tiles are added atomically, gdq is zeroed) and
+    // dW1[l] = dy[l]^T . dq (+ d b1 = dy[l]^T . 1), all layers, one launch per 6 layers
+    const int per = kMaxBatch / 2;
+    for (int l0 = lo; l0 < hi; l0 += per) {
+      GemmBatch gb{};
+      BiasOf bias[kMaxBatch] = {};
+      const int l1 = (l0 + per) < hi ? (l0 + per) : hi;
+      for (int l = l0; l < l1; ++l) {
+        gb.p[gb.n] = nn(ws + W.dy + (int64_t)l * BT * D, D, lp(l) + P.qa_w1, D, g->gdq, D, BT, D, D, 1);
+        PM.attach(gb.p[gb.n]);
+        gb.p[gb.n].atomic_ok = 1;
+        gb.p[gb.n++].atomic_out = (L > 1);
       }
+      for (int l = l0; l < l1; ++l) {
+        gb.p[gb.n] = tn(ws + W.dy + (int64_t)l * BT * D, D, io->dq, D, glp(l) + P.qa_w1, D, D, D, BT);
+        PM.attach(gb.p[gb.n]);
+        bias[gb.n++] = BiasOf{ws + W.dy + (int64_t)l * BT * D, BT, D, D, glp(l) + P.qa_b1};
+      }
+      ColsumBatch cb2{};
+      DVGR_TRY(launch_mixed(on, gb, bias, TAG_GENERIC, cb2));
+      if (cb2.n) { cb2.chunks = 16; DVGR_TRY(colsum(on, cb2)); }
     }
     return 0;
   };
@@ -808,13 +825,17 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       cb.j[cb.n++] = ColsumJob{ws + W.dc_part[set][m], nullptr, nullptr, nullptr, B, 0, kHeads, kHeads, gmp(l, m) + P.gat_c};
     }
     if (l == 0) DVGR_TRY(query_chain(0, 1, hs, L == 1 ? 1 : 0));
-    // S2 backward on the critical path: dX += drop_x(dWh . Wcat)
+    // S2 backward: dX += drop_x(dWh . Wcat) -- the critical path -- together with every weight gradient of the layer,
+    // dP1 = sum_v dpre_v^T . z_v (two row segments) and dWcat = dWh^T . drop_x(X), both modalities, bias gradients d bP and
+    // d bcat as row sums of their dY operands: all of them need only dpre and dWh, so they are ONE launch (the dX tiles
+    // are dispatched first)
     {
-      GemmBatch gd{};
+      GemmBatch gb{};
+      BiasOf bias[kMaxBatch] = {};
       if (!train) {
         for (int m = 0; m < 2; ++m) {
-          gd.p[gd.n] = nn(ws + W.dWh[set][m], HF, mp(l, m) + P.gat_w, D, dXacc[m], D, BN, D, HF, 1);
-          PM.attach(gd.p[gd.n++]);
+          gb.p[gb.n] = nn(ws + W.dWh[set][m], HF, mp(l, m) + P.gat_w, D, dXacc[m], D, BN, D, HF, 1);
+          PM.attach(gb.p[gb.n++]);
         }
       } else {
         // the two GATs dropped x with different masks: the common GAT's partial accumulates into dX, the specific GAT's
@@ -822,27 +843,11 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
         // backward, which rewrites every element of dX anyway, folds it in
         for (int gi = 0; gi < 2; ++gi)
           for (int m = 0; m < 2; ++m) {
-            gd.p[gd.n] = nn(ws + W.dWh[set][m] + gi * 4 * F, HF, mp(l, m) + P.gat_w + (int64_t)gi * 4 * F * D, D,
+            gb.p[gb.n] = nn(ws + W.dWh[set][m] + gi * 4 * F, HF, mp(l, m) + P.gat_w + (int64_t)gi * 4 * F * D, D,
                             gi == 0 ? dXacc[m] : ws + W.dxtmp[m], D, BN, D, 4 * F, gi == 0 ? 1 : 0, K.x[m][gi]);
-            PM.attach(gd.p[gd.n++]);
+            PM.attach(gb.p[gb.n++]);
           }
       }
-      DVGR_TRY(probe.begin(DVGR_PROBE_BWD_GAT_DX, l));
-      DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_BWD_GAT_DX, prec));
-      DVGR_TRY(probe.end(DVGR_PROBE_BWD_GAT_DX, l));
-    }
-    // S1 backward: the dX update (folding the specific GAT's partial of the training-mode S2 backward in) and, for the
-    // layers > 0, d p in the same launch
-    DVGR_TRY(punish(l == 0 ? 2 : 3));
-    if (l == 1) {                           // every d p of the layers >= 1 exists: their query chains, under layer 0
-      DVGR_TRY(to_side());
-      DVGR_TRY(query_chain(1, L, hs, 1));
-    }
-    // every weight gradient of the layer as ONE launch: dP1 = sum_v dpre_v^T . z_v (two row segments) and
-    // dWcat = dWh^T . drop_x(X), both modalities, with the bias gradients d bP and d bcat as row sums of their dY operands
-    {
-      GemmBatch gb{};
-      BiasOf bias[kMaxBatch] = {};
       for (int m = 0; m < 2; ++m) {
         GemmProblem p = tn(ws + W.dpre[set][m], D, outc[m], D, gmp(l, m) + P.sf_p1, D, D, D, 2 * BN);
         p.kseg = BN;
@@ -866,39 +871,35 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
           }
         }
       }
-      // Where: the launch is unbalanced (the dP1 tiles reduce over 2 B N rows, the dWcat tiles over B N: 72 tiles run twice
-      // as long as the other 144), so beside the next layer's critical-path kernels it fills compute units that would idle
-      // behind its short tiles -- the layers > 0 put it on the side stream; layer 0 has no next layer and keeps it on
-      // the main stream, which is idle by then.
-      hipStream_t dws = (side && l > 0 && dw_on_side) ? hs : st;
-      const Probe dprobe{O, dws};
-      DVGR_TRY(dprobe.begin(DVGR_PROBE_BWD_GAT_DW, l));
-      DVGR_TRY(launch_dw(dws, gb, bias, TAG_BWD_GAT_DW, cb));     // (biases the engine cannot carry join the column sums)
-      DVGR_TRY(dprobe.end(DVGR_PROBE_BWD_GAT_DW, l));
-      cb.chunks = 16;
-      DVGR_TRY(colsum(hs, cb));
-      if (side) {
-        side_done[set] = side->next();
-        if (!side_done[set]) return (int)hipErrorOutOfMemory;
-        const hipError_t e = hipEventRecord(side_done[set], hs);
-        if (e != hipSuccess) return (int)e;
-      }
-      if (layer_done_events && layer_done_events[l]) {
-        if (dws == hs || !side) {
-          DVGR_TRY(layer_done(l, hs));                   // every gradient of block l was written on the side stream
-        } else {                                         // block l is written on both streams: the event is recorded on the
-          DVGR_TRY(to_main());                           // main stream behind the side stream's column sums
-          DVGR_TRY(layer_done(l, st));
-        }
-      }
+      DVGR_TRY(probe.begin(DVGR_PROBE_BWD_GAT_DX, l));
+      DVGR_TRY(launch_mixed(st, gb, bias, TAG_BWD_GAT_DX, cb));   // (biases the engine cannot carry join the column sums)
+      DVGR_TRY(probe.end(DVGR_PROBE_BWD_GAT_DX, l));
+    }
+    // S1 backward: the dX update (folding the specific GAT's partial of the training-mode S2 backward in) and, for the
+    // layers > 0, d p in the same launch
+    DVGR_TRY(punish(l == 0 ? 2 : 3));
+    if (l == 1) {                           // every d p of the layers >= 1 exists: their query chains, under layer 0
+      DVGR_TRY(to_side());
+      DVGR_TRY(query_chain(1, L, hs, 1));
+    }
+    cb.chunks = 16;
+    DVGR_TRY(colsum(hs, cb));
+    if (side) {
+      side_done[set] = side->next();
+      if (!side_done[set]) return (int)hipErrorOutOfMemory;
+      const hipError_t e2 = hipEventRecord(side_done[set], hs);
+      if (e2 != hipSuccess) return (int)e2;
+    }
+    if (layer_done_events && layer_done_events[l]) {   // block l is written on both streams: the event is recorded on the
+      DVGR_TRY(to_main());                             // main stream behind the side stream's column sums
+      DVGR_TRY(layer_done(l, st));
     }
   }
 
   // ---- the two contractions of the query branch, batched over ALL layers, close the main stream (every dy exists: the
   // side stream ran the chains under the last layers); the side stream finishes the leaves
   DVGR_TRY(to_main());
-  DVGR_TRY(query_ddq(0, L, st));
-  DVGR_TRY(query_dw1(0, L, st));
+  DVGR_TRY(query_gemms(0, L, st));
   DVGR_TRY(query_leaves(0, L, hs));
   DVGR_TRY(to_main());                    // the caller's stream sees every gradient
   DVGR_TRY(layer_done(L + 1, st));        // the query block

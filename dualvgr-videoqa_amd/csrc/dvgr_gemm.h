@@ -19,6 +19,7 @@
 namespace dvgr {
 
 enum : int { KC = 0, IC = 1 };
+enum : int { LAYOUT_NT = 0, LAYOUT_NN = 1, LAYOUT_TN = 2 };   // GemmProblem::layout (gemm_launch_mixed)
 enum : int { ACT_NONE = 0, ACT_TANH = 1, ACT_ELU = 2 };
 
 struct GemmOperand {
@@ -46,6 +47,7 @@ struct GemmProblem {
   int dbg;             // profiling aid (tools/): bit 0 skip the epilogue, bit 1 skip the K loop; 0 in production
   int atomic_ok;       // the output is pre-zeroed (or accumulates) and has no bias/act/mask: the launcher may split K
                        // over several workgroups that add their partial tiles with float atomics
+  int layout;          // LAYOUT_*: only read by gemm_launch_mixed (gemm_launch takes the layouts as arguments)
   int atomic_out;      // several problems of one batch ADD into this same (pre-zeroed) output: every tile is added with
                        // float atomics whether or not K is split
   float* rowsum;       // nullable, TN only (A = dY[k][m]): rowsum[m] += sum_k A[k][m], i.e. the bias gradient dY^T . 1 that
@@ -54,7 +56,7 @@ struct GemmProblem {
                        // ADDED atomically: the target must be zeroed beforehand.  Only set it when gemm_rowsum_supported().
 };
 
-constexpr int kMaxBatch = 8;
+constexpr int kMaxBatch = 12;
 struct GemmBatch {
   GemmProblem p[kMaxBatch];
   int n;
@@ -67,6 +69,12 @@ enum : int { TAG_GENERIC = 0, TAG_FWD_GAT = 1, TAG_FWD_SF = 2, TAG_BWD_GAT_DW = 
 // True when gemm_launch will honour GemmProblem::rowsum for this batch (the LDS-DMA ring kernels do; the register-staged
 // fallbacks for odd shapes and the batch-sized kernels do not: their callers use a column-sum job instead).
 bool gemm_rowsum_supported(int la, int lb, const GemmBatch& batch, int prec);
+
+// Problems of different layouts (GemmProblem::layout) in ONE launch where every problem qualifies for the planes kernel
+// (bf16 modes, pre-split operands, K % 32 == 0, not batch-sized); otherwise one gemm_launch per layout.  rowsum is honoured
+// when gemm_mixed_supported().
+bool gemm_mixed_supported(const GemmBatch& batch, int prec);
+int gemm_launch_mixed(hipStream_t stream, const GemmBatch& batch, int tag = TAG_GENERIC, int prec = DVGR_F32);
 
 // Enqueue the batch on `stream`.  la / lb in {KC, IC}.  Returns hipError_t as int.
 int gemm_launch(hipStream_t stream, int la, int lb, const GemmBatch& batch, int tag = TAG_GENERIC, int prec = DVGR_F32);

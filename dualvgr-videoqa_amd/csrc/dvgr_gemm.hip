@@ -836,17 +836,22 @@ __device__ long long g_gemm_clk[4096 * 8];
 #define GCLK_FLUSH(base) do { } while (0)
 #endif
 
-template <int LA, int LB, int TAG, int TERMS, int NS = RS>
-__global__ __launch_bounds__(768) void gemm_planes_kernel(const GemmBatch batch) {
-  const GemmProblem P = batch.p[blockIdx.z];
+template <int TERMS, int NS>
+struct PlanesLds {
+  static constexpr int kPlanes = (TERMS == 3) ? 2 : 1;
+  static constexpr int kSlot = 2 * kPlanes * kPlaneTile;       // A planes, then B planes
+  static constexpr int kEpi = 8 * 32 * (16 * 2 + 4) * 2;       // epilogue scratch (8 waves), in bf16-sized elements
+  static constexpr int kLds = (NS * kSlot) > kEpi ? (NS * kSlot) : kEpi;
+};
+
+// one 128 x 128 output tile of problem P (the whole workgroup: 8 computing + 4 loader waves)
+template <int LA, int LB, int TERMS, int NS>
+__device__ __forceinline__ void planes_tile(const GemmProblem& P, uint16_t* smem) {
   int m0, n0;
   if (!tile_coords(P.M, P.N, RT, RT, &m0, &n0)) return;
 
-  constexpr int kPlanes = (TERMS == 3) ? 2 : 1;
-  constexpr int kSlot = 2 * kPlanes * kPlaneTile;              // A planes, then B planes
-  constexpr int kEpi = 8 * 32 * (16 * 2 + 4) * 2;              // epilogue scratch (8 waves), in bf16-sized elements
-  constexpr int kLds = (NS * kSlot) > kEpi ? (NS * kSlot) : kEpi;
-  __shared__ __attribute__((aligned(16))) uint16_t smem[kLds];
+  constexpr int kPlanes = PlanesLds<TERMS, NS>::kPlanes;
+  constexpr int kSlot = PlanesLds<TERMS, NS>::kSlot;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave12 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool loader = wave12 >= 8;
@@ -970,6 +975,27 @@ __global__ __launch_bounds__(768) void gemm_planes_kernel(const GemmBatch batch)
   epilogue_rows<MT, NT>(P, acc, m0 + wm, n0 + wn, lane, reinterpret_cast<float*>(smem) + wave * (32 * (16 * NT + 4)), gridDim.y > 1 || P.atomic_out);
   GCLK_ADD(2);
   if (wave == 0) GCLK_FLUSH(0);
+}
+
+template <int LA, int LB, int TAG, int TERMS, int NS = RS>
+__global__ __launch_bounds__(768) void gemm_planes_kernel(const GemmBatch batch) {
+  __shared__ __attribute__((aligned(16))) uint16_t smem[PlanesLds<TERMS, NS>::kLds];
+  const GemmProblem P = batch.p[blockIdx.z];
+  planes_tile<LA, LB, TERMS, NS>(P, smem);
+}
+
+// Problems of DIFFERENT operand layouts in one launch (GemmProblem::layout): the backward's data gradient dX += dWh . Wcat
+// (NN) and the weight gradients dWcat = dWh^T . X, dP1 = dpre^T . z (TN) all become ready together, after the attention
+// backward.  One launch instead of two saves a launch boundary with its ~10 us of epilogue / drain / prologue, and the
+// short tiles of one problem fill the compute units the long tiles of another leave idle (the dP1 tiles reduce over 2 B N
+// rows, everything else over B N or D).  The branch is uniform per workgroup.
+template <int TAG, int TERMS>
+__global__ __launch_bounds__(768) void gemm_planes_mixed_kernel(const GemmBatch batch) {
+  __shared__ __attribute__((aligned(16))) uint16_t smem[PlanesLds<TERMS, RS>::kLds];
+  const GemmProblem P = batch.p[blockIdx.z];
+  if (P.layout == LAYOUT_NT) planes_tile<KC, KC, TERMS, RS>(P, smem);
+  else if (P.layout == LAYOUT_NN) planes_tile<KC, IC, TERMS, RS>(P, smem);
+  else planes_tile<IC, IC, TERMS, RS>(P, smem);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1220,6 +1246,55 @@ static int launch_layout(hipStream_t stream, const GemmBatch& b, int prec) {
 
 bool small_eligible(const GemmBatch& b, int la, int lb);
 int small_launch(hipStream_t st, int la, int lb, const GemmBatch& b);
+
+static void layout_of(int layout, int* la, int* lb) {
+  *la = layout == LAYOUT_TN ? IC : KC;
+  *lb = layout == LAYOUT_NT ? KC : IC;
+}
+
+bool gemm_mixed_supported(const GemmBatch& b, int prec) {
+  if (prec == DVGR_F32 || b.n < 1 || b.n > kMaxBatch || dbg_any(b)) return false;
+  for (int i = 0; i < b.n; ++i) {
+    GemmBatch one{};
+    one.p[0] = b.p[i];
+    one.n = 1;
+    int la, lb;
+    layout_of(b.p[i].layout, &la, &lb);
+    if (small_eligible(one, la, lb) || !ring_eligible(one) || !planes_eligible(one, la, lb)) return false;
+  }
+  return true;
+}
+
+int gemm_launch_mixed(hipStream_t stream, const GemmBatch& b, int tag, int prec) {
+  if (!gemm_mixed_supported(b, prec)) {       // one launch per layout instead (rowsum must then be unset by the caller)
+    for (int lay = 0; lay < 3; ++lay) {
+      GemmBatch part{};
+      for (int i = 0; i < b.n; ++i)
+        if (b.p[i].layout == lay) part.p[part.n++] = b.p[i];
+      if (!part.n) continue;
+      int la, lb;
+      layout_of(lay, &la, &lb);
+      const int e = gemm_launch(stream, la, lb, part, tag, prec);
+      if (e) return e;
+    }
+    return 0;
+  }
+  int tiles = 0;
+  for (int i = 0; i < b.n; ++i) {
+    const int t = ((b.p[i].M + RT - 1) / RT) * ((b.p[i].N + RT - 1) / RT);
+    tiles = t > tiles ? t : tiles;
+  }
+  if (tiles == 0) return 0;
+  const dim3 grid(8 * ((tiles + 7) / 8), 1, b.n), block(768);
+  if (tag == TAG_BWD_GAT_DX) {
+    if (prec == DVGR_BF16X3) hipLaunchKernelGGL((gemm_planes_mixed_kernel<TAG_BWD_GAT_DX, 3>), grid, block, 0, stream, b);
+    else hipLaunchKernelGGL((gemm_planes_mixed_kernel<TAG_BWD_GAT_DX, 1>), grid, block, 0, stream, b);
+  } else {
+    if (prec == DVGR_BF16X3) hipLaunchKernelGGL((gemm_planes_mixed_kernel<TAG_GENERIC, 3>), grid, block, 0, stream, b);
+    else hipLaunchKernelGGL((gemm_planes_mixed_kernel<TAG_GENERIC, 1>), grid, block, 0, stream, b);
+  }
+  return (int)hipGetLastError();
+}
 
 bool gemm_rowsum_supported(int la, int lb, const GemmBatch& b, int prec) {
   if (la != IC || lb != IC) return false;
