@@ -837,17 +837,13 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       cb.j[cb.n++] = ColsumJob{ws + W.dc_part[set][m], nullptr, nullptr, nullptr, B, 0, kHeads, kHeads, gmp(l, m) + P.gat_c};
     }
     if (l == 0) DVGR_TRY(query_chain(0, 1, hs, L == 1 ? 1 : 0));
-    // S2 backward: dX += drop_x(dWh . Wcat) -- the critical path -- together with every weight gradient of the layer,
-    // dP1 = sum_v dpre_v^T . z_v (two row segments) and dWcat = dWh^T . drop_x(X), both modalities, bias gradients d bP and
-    // d bcat as row sums of their dY operands: all of them need only dpre and dWh, so they are ONE launch (the dX tiles
-    // are dispatched first)
+    // S2 backward on the critical path: dX += drop_x(dWh . Wcat)
     {
-      GemmBatch gb{};
-      BiasOf bias[kMaxBatch] = {};
+      GemmBatch gd{};
       if (!train) {
         for (int m = 0; m < 2; ++m) {
-          gb.p[gb.n] = nn(ws + W.dWh[set][m], HF, mp(l, m) + P.gat_w, D, dXacc[m], D, BN, D, HF, 1);
-          PM.attach(gb.p[gb.n++]);
+          gd.p[gd.n] = nn(ws + W.dWh[set][m], HF, mp(l, m) + P.gat_w, D, dXacc[m], D, BN, D, HF, 1);
+          PM.attach(gd.p[gd.n++]);
         }
       } else {
         // the two GATs dropped x with different masks: the common GAT's partial accumulates into dX, the specific GAT's
@@ -855,11 +851,27 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
         // backward, which rewrites every element of dX anyway, folds it in
         for (int gi = 0; gi < 2; ++gi)
           for (int m = 0; m < 2; ++m) {
-            gb.p[gb.n] = nn(ws + W.dWh[set][m] + gi * 4 * F, HF, mp(l, m) + P.gat_w + (int64_t)gi * 4 * F * D, D,
+            gd.p[gd.n] = nn(ws + W.dWh[set][m] + gi * 4 * F, HF, mp(l, m) + P.gat_w + (int64_t)gi * 4 * F * D, D,
                             gi == 0 ? dXacc[m] : ws + W.dxtmp[m], D, BN, D, 4 * F, gi == 0 ? 1 : 0, K.x[m][gi]);
-            PM.attach(gb.p[gb.n++]);
+            PM.attach(gd.p[gd.n++]);
           }
       }
+      DVGR_TRY(probe.begin(DVGR_PROBE_BWD_GAT_DX, l));
+      DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_BWD_GAT_DX, prec));
+      DVGR_TRY(probe.end(DVGR_PROBE_BWD_GAT_DX, l));
+    }
+    // S1 backward: the dX update (folding the specific GAT's partial of the training-mode S2 backward in) and, for the
+    // layers > 0, d p in the same launch
+    DVGR_TRY(punish(l == 0 ? 2 : 3));
+    if (l == 1) {                           // every d p of the layers >= 1 exists: their query chains, under layer 0
+      DVGR_TRY(to_side());
+      DVGR_TRY(query_chain(1, L, hs, 1));
+    }
+    // every weight gradient of the layer as ONE launch: dP1 = sum_v dpre_v^T . z_v (two row segments) and
+    // dWcat = dWh^T . drop_x(X), both modalities, with the bias gradients d bP and d bcat as row sums of their dY operands
+    {
+      GemmBatch gb{};
+      BiasOf bias[kMaxBatch] = {};
       for (int m = 0; m < 2; ++m) {
         GemmProblem p = tn(ws + W.dpre[set][m], D, outc[m], D, gmp(l, m) + P.sf_p1, D, D, D, 2 * BN);
         p.kseg = BN;
@@ -883,28 +895,32 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
           }
         }
       }
-      DVGR_TRY(probe.begin(DVGR_PROBE_BWD_GAT_DX, l));
-      DVGR_TRY(launch_mixed(st, gb, bias, TAG_BWD_GAT_DX, cb));   // (biases the engine cannot carry join the column sums)
-      DVGR_TRY(probe.end(DVGR_PROBE_BWD_GAT_DX, l));
-    }
-    // S1 backward: the dX update (folding the specific GAT's partial of the training-mode S2 backward in) and, for the
-    // layers > 0, d p in the same launch
-    DVGR_TRY(punish(l == 0 ? 2 : 3));
-    if (l == 1) {                           // every d p of the layers >= 1 exists: their query chains, under layer 0
-      DVGR_TRY(to_side());
-      DVGR_TRY(query_chain(1, L, hs, 1));
-    }
-    cb.chunks = 16;
-    DVGR_TRY(colsum(hs, cb));
-    if (side) {
-      side_done[set] = side->next();
-      if (!side_done[set]) return (int)hipErrorOutOfMemory;
-      const hipError_t e2 = hipEventRecord(side_done[set], hs);
-      if (e2 != hipSuccess) return (int)e2;
-    }
-    if (layer_done_events && layer_done_events[l]) {   // block l is written on both streams: the event is recorded on the
-      DVGR_TRY(to_main());                             // main stream behind the side stream's column sums
-      DVGR_TRY(layer_done(l, st));
+      // Where: the launch is unbalanced (the dP1 tiles reduce over 2 B N rows, the dWcat tiles over B N: 72 tiles run twice
+      // as long as the other 144), so beside the next layer's critical-path kernels it fills compute units that would idle
+      // behind its short tiles -- the layers > 0 put it on the side stream (measured: 1.245 ms per step against 1.272 with
+      // it on the main stream, and 1.27 merged with the dX launch); layer 0 has no next layer and keeps it on the main
+      // stream, which is idle by then.
+      hipStream_t dws = (side && l > 0) ? hs : st;
+      const Probe dprobe{O, dws};
+      DVGR_TRY(dprobe.begin(DVGR_PROBE_BWD_GAT_DW, l));
+      DVGR_TRY(launch_dw(dws, gb, bias, TAG_BWD_GAT_DW, cb));     // (biases the engine cannot carry join the column sums)
+      DVGR_TRY(dprobe.end(DVGR_PROBE_BWD_GAT_DW, l));
+      cb.chunks = 16;
+      DVGR_TRY(colsum(hs, cb));
+      if (side) {
+        side_done[set] = side->next();
+        if (!side_done[set]) return (int)hipErrorOutOfMemory;
+        const hipError_t e2 = hipEventRecord(side_done[set], hs);
+        if (e2 != hipSuccess) return (int)e2;
+      }
+      if (layer_done_events && layer_done_events[l]) {
+        if (dws == hs || !side) {
+          DVGR_TRY(layer_done(l, hs));                   // every gradient of block l was written on the side stream
+        } else {                                         // block l is written on both streams: the event is recorded on the
+          DVGR_TRY(to_main());                           // main stream behind the side stream's column sums
+          DVGR_TRY(layer_done(l, st));
+        }
+      }
     }
   }
 

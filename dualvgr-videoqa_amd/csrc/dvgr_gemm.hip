@@ -1175,7 +1175,8 @@ static int launch_ring(hipStream_t stream, const GemmBatch& b, int prec) {
       total_w += t;
     }
     const bool long_k = atomic_ok && nk_min >= 256;
-    if (total_w >= 480 || (long_k && total_w >= 128)) {
+    static const bool force_wide = []() { const char* e = getenv("DVGR_FORCE_WIDE"); return e && e[0] == '1'; }();   // A/B timing aid
+    if (total_w >= 480 || (long_k && total_w >= 128) || force_wide) {
       int split_w = 1;
       if (long_k) {
         long best = ((total_w + 255) / 256) * (long)(2 * nk_min + 6);
