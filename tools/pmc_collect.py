@@ -2,7 +2,7 @@
 """Turns the rocprofv3 --pmc passes of ONE build into the record bench.py reads (profiles/pmc_<config>_<dtype>.json) and a
 per-kernel traffic table (profiles/<prefix>_pmc_hbm.txt).
 
-    tools/pmc_collect.py <out_prefix> <config> <dtype> <steps_profiled> <fetch_csv> <write_csv> [<sq_csv>]
+    tools/pmc_collect.py <out_prefix> <config> <dtype> <steps_profiled|auto> <fetch_csv> <write_csv> [<sq_csv>]
 
 fetch_csv / write_csv / sq_csv: counter_collection CSVs of `rocprofv3 --pmc FETCH_SIZE`, `--pmc WRITE_SIZE` and
 `--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE` (separate passes) over `bench.py --config <config> --dtype <dtype>`.
@@ -27,8 +27,19 @@ def per_kernel(path):
 
 
 def main():
-    prefix, config, dtype, steps = sys.argv[1], sys.argv[2], sys.argv[3], float(sys.argv[4])
+    prefix, config, dtype = sys.argv[1], sys.argv[2], sys.argv[3]
     fetch, write = per_kernel(sys.argv[5]), per_kernel(sys.argv[6])
+
+    def steps_of(acc, counter):
+        # "auto": bench.py times blocks of >= 1 s, so each pass ran its own number of steps; k_mfb_pool_fwd runs once a step
+        if sys.argv[4] != "auto":
+            return float(sys.argv[4])
+        n = [len(v[counter]) for k, v in acc.items() if "k_mfb_pool_fwd" in k]
+        if not n:
+            sys.exit("steps 'auto' needs the once-per-step kernel k_mfb_pool_fwd in the trace")
+        return float(n[0])
+
+    steps_f, steps_w = steps_of(fetch, "FETCH_SIZE"), steps_of(write, "WRITE_SIZE")
     sq = per_kernel(sys.argv[7]) if len(sys.argv) > 7 else {}
     names = sorted(set(fetch) | set(write))
     rows = []
@@ -37,7 +48,7 @@ def main():
         w = write.get(n, {}).get("WRITE_SIZE", [])
         fk = sum(f) / len(f) if f else 0.0
         wk = sum(w) / len(w) if w else 0.0
-        launches = max(len(f), len(w)) / steps
+        launches = max(len(f) / steps_f, len(w) / steps_w)
         rows.append((n, launches, fk, wk, (2 * fk + wk) * 1024))
     rows.sort(key=lambda r: -r[4] * r[1])
     total = sum(r[4] * r[1] for r in rows)
