@@ -137,7 +137,8 @@ GemmProblem tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* 
   GemmProblem p{};
   p.A = operand(A, lda); p.B = operand(B, ldb, drop_b);
   p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.kseg = K; p.layout = LAYOUT_TN;
-  p.atomic_ok = 1;   // every weight gradient lands in gparams, which the backward zeroes first
+  p.atomic_ok = 1;   // a long reduction may be split over workgroups; the matrices of gparams are not pre-zeroed,
+  p.zero_on_split = 1;   //   so such a launch zeroes its outputs first
   return p;
 }
 
@@ -214,7 +215,7 @@ int dvgr_streams_init(void) {
   const hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return (int)e;
   if (dev < 0 || dev >= 16) return DVGR_E_DIMS;
-  return shared_side_stream(dev) ? 0 : (int)hipErrorOutOfMemory;
+  return (shared_side_stream(dev, 0) && shared_side_stream(dev, 1)) ? 0 : (int)hipErrorOutOfMemory;
 }
 
 int dvgr_check_dims(const dvgr_dims* d) {
@@ -366,22 +367,24 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
     DVGR_TRY(split_planes(st, sb));
   }
 
-  // ---- S0: query side of every layer.  It does not depend on A / M and layer 0's Wh contraction does not depend on
-  // it, so it runs on the side stream and joins the main stream in front of layer 0's punish gate.
+  // ---- S0: query side of every layer.  Its contraction (Y_l = dq . W1_l^T, every layer in one launch) runs FIRST and
+  // alone on the main stream -- beside layer 0's Wh contraction each takes twice as long and the punish gate waits for
+  // the slower one (measured: gate at 102 us with the two side by side, 62 us this way); the row kernels and the small
+  // Wq contraction behind it go to the side stream, under layer 0's Wh contraction, and join in front of the gate.
   SideStream* side = (O.flags & DVGR_OPT_SINGLE_STREAM) ? nullptr : side_stream();
   hipStream_t hs = side ? side->st : st;
-  const Probe hprobe{O, hs};
-  if (side) DVGR_TRY(side->order(st, hs));
+  const Probe fprobe{O, st};
   for (int l0 = 0; l0 < L; l0 += kMaxBatch) {
     GemmBatch gb{};
     for (int l = l0; l < L && l < l0 + kMaxBatch; ++l) {
       gb.p[gb.n] = nt(io->dq, D, lp(l) + P.qa_w1, D, ws + W.Y + (int64_t)l * BT * D, D, lp(l) + P.qa_b1, BT, D, D, ACT_NONE);
       PM.attach(gb.p[gb.n++]);
     }
-    DVGR_TRY(hprobe.begin(DVGR_PROBE_FWD_QA_GEMM, l0));
-    DVGR_TRY(gemm_launch(hs, KC, KC, gb, TAG_GENERIC, prec));
-    DVGR_TRY(hprobe.end(DVGR_PROBE_FWD_QA_GEMM, l0));
+    DVGR_TRY(fprobe.begin(DVGR_PROBE_FWD_QA_GEMM, l0));
+    DVGR_TRY(gemm_launch(st, KC, KC, gb, TAG_GENERIC, prec));
+    DVGR_TRY(fprobe.end(DVGR_PROBE_FWD_QA_GEMM, l0));
   }
+  if (side) DVGR_TRY(side->order(st, hs));
   {
     QaRowsArgs a{};
     a.Y = ws + W.Y; a.logit = ws + W.R; a.params = params + P.q_base; a.off_w2 = P.qa_w2; a.off_b2 = P.qa_b2; a.layer_stride = P.q_layer_stride;
@@ -399,7 +402,6 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
       }
   }
 
-  const Probe fprobe{O, st};
   // ---- layers ---------------------------------------------------------------------------------------
   for (int l = 0; l < L; ++l) {
     const Keys K = layer_keys(train, seed, l);
@@ -566,21 +568,51 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
   const PlaneMap PM = make_plane_map(d, P, S, params, params_lp, io, saved, ws);
   int64_t plo = 0;
 
-  // every element of gparams is written: the tensors below, zeros in the alignment padding (and bias gradients are
-  // ADDED by the weight-gradient contractions, GemmProblem::rowsum).  gdq is the sum over layers of partial tiles added
-  // atomically, so it starts from zero as well.
+  // every element of gparams is written: the matrices by their contractions, everything between them (bias and vector
+  // gradients, which contractions and column sums ADD into -- GemmProblem::rowsum -- and the alignment padding) is zeroed
+  // here in one launch; gdq is the sum over layers of partial tiles added atomically, so it starts from zero as well.
+  // (Two hipMemsetAsync over the whole buffers took 17 us at the head of the backward's critical path.)
   {
-    hipError_t e = hipMemsetAsync(gp, 0, (size_t)P.total * sizeof(float), st);
-    if (e == hipSuccess) e = hipMemsetAsync(g->gdq, 0, (size_t)BT * D * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
+    ZeroList z{};
+    auto add = [&](float* p, int64_t n) -> int {
+      if (n <= 0) return 0;
+      if (z.count == kMaxZeroSegs) { DVGR_TRY(zero_ranges(st, z)); z.count = 0; }
+      z.p[z.count] = p; z.n[z.count++] = n;
+      return 0;
+    };
+    DVGR_TRY(add(g->gdq, (int64_t)BT * D));
+    for (int l = 0; l < L; ++l)
+      for (int m = 0; m < 2; ++m) {
+        DVGR_TRY(add(gmp(l, m) + P.gat_b, P.sf_p1 - P.gat_b));
+        DVGR_TRY(add(gmp(l, m) + P.sf_bp, P.mod_stride - P.sf_bp));
+      }
+    DVGR_TRY(add(gp + P.mfb_b0, P.mfb_w1 - P.mfb_b0));
+    DVGR_TRY(add(gp + P.mfb_b1, P.mfb_wo - P.mfb_b1));
+    DVGR_TRY(add(gp + P.mfb_bo, P.q_base - P.mfb_bo));
+    for (int l = 0; l < L; ++l) {
+      DVGR_TRY(add(glp(l) + P.qa_b1, P.q_mod_base - P.qa_b1));
+      for (int m = 0; m < 2; ++m) DVGR_TRY(add(gqp(l, m) + P.bq, P.q_mod_stride - P.bq));
+    }
+    DVGR_TRY(zero_ranges(st, z));
   }
 
   // Two streams: `st` carries the critical path (the dX chain), `hs` every weight / bias gradient.
   // DVGR_OPT_SINGLE_STREAM (or a missing side stream) folds everything onto `st`.
   SideStream* side = ((O.flags & DVGR_OPT_SINGLE_STREAM) || 4 * L + 16 > 256) ? nullptr : side_stream();
   hipStream_t hs = side ? side->st : st;
+  hipStream_t qs = side ? side->st2 : st;                                      // query branch (see dvgr_side.h)
   auto to_side = [&]() -> int { return side ? side->order(st, hs) : 0; };     // hs continues after st's work so far
   auto to_main = [&]() -> int { return side ? side->order(hs, st) : 0; };     // st continues after hs's work so far
+  auto to_side_and_query = [&]() -> int {                                     // one record on st, both other streams wait
+    if (!side) return 0;
+    hipEvent_t e = side->next();
+    if (!e) return (int)hipErrorOutOfMemory;
+    hipError_t r = hipEventRecord(e, st);
+    if (r == hipSuccess) r = hipStreamWaitEvent(hs, e, 0);
+    if (r == hipSuccess) r = hipStreamWaitEvent(qs, e, 0);
+    return (int)r;
+  };
+  auto to_query = [&]() -> int { return side ? side->order(st, qs) : 0; };
   // (every fork costs the main stream a ~6 us bubble -- the event's barrier packet -- so there is one per layer, not one
   // per dependency: the side stream's work of a layer is enqueued behind the layer's last producer it needs)
   auto layer_done = [&](int index, hipStream_t on) -> int {
@@ -752,6 +784,17 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     return flush_cb();
   };
 
+  // The whole branch of the layers [lo, hi) on the query stream, in dependency order.  Its kernels are small (a few dozen
+  // tiles, latency bound), so they run beside the main stream's contractions instead of after them: queued behind the side
+  // stream's weight-gradient launches and with its two contractions at the very end of the main stream the branch cost a
+  // ~170 us tail after the last dX contraction (rocprofv3 timeline, profiles/r02_v1); on its own stream it ends under
+  // layer 0's weight-gradient launch.
+  auto query_branch = [&](int lo, int hi, int first) -> int {
+    DVGR_TRY(query_chain(lo, hi, qs, first));
+    DVGR_TRY(query_gemms(lo, hi, qs));
+    return query_leaves(lo, hi, qs);
+  };
+
   // ---- layers, last to first -----------------------------------------------------------------------
   hipEvent_t side_done[2] = {nullptr, nullptr};   // side stream finished the layer that used buffer set 0 / 1
   for (int l = L - 1; l >= 0; --l) {
@@ -829,14 +872,14 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     // contractions at once only slow each other down (both are bound by the compute units' global -> LDS path; measured:
     // a weight-gradient launch of 35 us alone took 95-105 us beside the critical path's kernels and slowed those by a
     // third), so every 240-tile contraction stays on the main stream and the side stream fills in latency-bound kernels.
-    DVGR_TRY(to_side());
+    if (l == 0) DVGR_TRY(to_side_and_query()); else DVGR_TRY(to_side());
     ColsumBatch cb{};
     for (int m = 0; m < 2; ++m) {
       cb.j[cb.n++] = ColsumJob{ms(l, m) + S.tn, nullptr, ws + W.dw[set][m], nullptr, 2 * BN, 0, D, D, gmp(l, m) + P.sf_p2};
       cb.j[cb.n++] = ColsumJob{ws + W.da_part[set][m], nullptr, nullptr, nullptr, B, 0, kHeads * 2 * F, kHeads * 2 * F, gmp(l, m) + P.gat_a};
       cb.j[cb.n++] = ColsumJob{ws + W.dc_part[set][m], nullptr, nullptr, nullptr, B, 0, kHeads, kHeads, gmp(l, m) + P.gat_c};
     }
-    if (l == 0) DVGR_TRY(query_chain(0, 1, hs, L == 1 ? 1 : 0));
+    if (l == 0) DVGR_TRY(query_branch(0, 1, L == 1 ? 1 : 0));
     // S2 backward on the critical path: dX += drop_x(dWh . Wcat)
     {
       GemmBatch gd{};
@@ -863,9 +906,9 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     // S1 backward: the dX update (folding the specific GAT's partial of the training-mode S2 backward in) and, for the
     // layers > 0, d p in the same launch
     DVGR_TRY(punish(l == 0 ? 2 : 3));
-    if (l == 1) {                           // every d p of the layers >= 1 exists: their query chains, under layer 0
-      DVGR_TRY(to_side());
-      DVGR_TRY(query_chain(1, L, hs, 1));
+    if (l == 1) {                           // every d p of the layers >= 1 exists: their query branch, under layer 0
+      DVGR_TRY(to_query());
+      DVGR_TRY(query_branch(1, L, 1));
     }
     // every weight gradient of the layer as ONE launch: dP1 = sum_v dpre_v^T . z_v (two row segments) and
     // dWcat = dWh^T . drop_x(X), both modalities, with the bias gradients d bP and d bcat as row sums of their dY operands
@@ -924,12 +967,9 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     }
   }
 
-  // ---- the two contractions of the query branch, batched over ALL layers, close the main stream (every dy exists: the
-  // side stream ran the chains under the last layers); the side stream finishes the leaves
+  // ---- the caller's stream sees every gradient: it waits for the side stream and the query stream
   DVGR_TRY(to_main());
-  DVGR_TRY(query_gemms(0, L, st));
-  DVGR_TRY(query_leaves(0, L, hs));
-  DVGR_TRY(to_main());                    // the caller's stream sees every gradient
+  if (side) DVGR_TRY(side->order(qs, st));
   DVGR_TRY(layer_done(L + 1, st));        // the query block
   return 0;
 }

@@ -48,6 +48,7 @@ struct GemmProblem {
   int atomic_ok;       // the output is pre-zeroed (or accumulates) and has no bias/act/mask: the launcher may split K
                        // over several workgroups that add their partial tiles with float atomics
   int layout;          // LAYOUT_*: only read by gemm_launch_mixed (gemm_launch takes the layouts as arguments)
+  int zero_on_split;   // atomic_ok with an output that is NOT pre-zeroed: a launch that does split K zeroes it first (own launch)
   int atomic_out;      // several problems of one batch ADD into this same (pre-zeroed) output: every tile is added with
                        // float atomics whether or not K is split
   float* rowsum;       // nullable, TN only (A = dY[k][m]): rowsum[m] += sum_k A[k][m], i.e. the bias gradient dY^T . 1 that

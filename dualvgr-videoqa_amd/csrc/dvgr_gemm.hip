@@ -1128,6 +1128,22 @@ static bool rowsum_any(const GemmBatch& b) {
   return false;
 }
 
+// Outputs of a split-K launch that the caller did not zero (GemmProblem::zero_on_split)
+__global__ __launch_bounds__(256) void k_zero_outputs(const GemmBatch batch) {
+  const GemmProblem P = batch.p[blockIdx.y];
+  if (!P.zero_on_split || P.accumulate) return;
+  const int64_t total = (int64_t)P.M * P.N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+    P.C[(i / P.N) * P.ldc + (i % P.N)] = 0.f;
+}
+static int zero_split_outputs(hipStream_t stream, const GemmBatch& b) {
+  bool any = false;
+  for (int i = 0; i < b.n; ++i) any = any || (b.p[i].zero_on_split && !b.p[i].accumulate);
+  if (!any) return 0;
+  hipLaunchKernelGGL(k_zero_outputs, dim3(128, b.n), dim3(256), 0, stream, b);
+  return (int)hipGetLastError();
+}
+
 template <int LA, int LB, int TAG>
 static int launch_ring(hipStream_t stream, const GemmBatch& b, int prec) {
   int tiles = 0;
@@ -1187,12 +1203,14 @@ static int launch_ring(hipStream_t stream, const GemmBatch& b, int prec) {
         }
       }
       const dim3 grid_w(8 * ((tiles_w + 7) / 8), split_w, b.n);
+      if (split_w > 1) { const int ez = zero_split_outputs(stream, b); if (ez) return ez; }
       if (prec == DVGR_BF16X3) hipLaunchKernelGGL((gemm_planes_wide_kernel<LA, LB, 3>), grid_w, dim3(768), 0, stream, b);
       else hipLaunchKernelGGL((gemm_planes_wide_kernel<LA, LB, 1>), grid_w, dim3(768), 0, stream, b);
       return (int)hipGetLastError();
     }
   }
   const dim3 grid(8 * ((tiles + 7) / 8), split, b.n), block(768);
+  if (split > 1) { const int ez = zero_split_outputs(stream, b); if (ez) return ez; }
   if (prec != DVGR_F32 && planes_eligible(b, LA, LB)) {
     // (2 ring slots = 64 KB would let two workgroups share a CU; measured slower alone and under the side stream)
     if (prec == DVGR_BF16X3) hipLaunchKernelGGL((gemm_planes_kernel<LA, LB, TAG, 3>), grid, block, 0, stream, b);

@@ -14,27 +14,32 @@ namespace dvgr {
 // share it); the event pools are per thread.  The runtime maps streams onto its few hardware queues in creation order,
 // and that mapping decides what a cross-stream dependency costs: dvgr_streams_init() lets the host side create this
 // stream at a fixed place in the order of all the package's streams (dualvgr-videoqa_amd/_lib.py: streams()).
-inline hipStream_t shared_side_stream(int dev) {
-  static hipStream_t st[16] = {};
+// `which` = 0: the side stream proper; 1: the query stream of the unit's backward (the query branch is a chain of
+// latency-bound kernels that must not queue behind the side stream's weight-gradient contractions).
+inline hipStream_t shared_side_stream(int dev, int which = 0) {
+  static hipStream_t st[16][2] = {};
   static std::mutex mu;
   std::lock_guard<std::mutex> lk(mu);
-  if (!st[dev]) {
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    if (hipStreamCreateWithPriority(&st[dev], hipStreamNonBlocking, lo) != hipSuccess) st[dev] = nullptr;
-  }
-  return st[dev];
+  for (int w = 0; w <= which; ++w)             // always created in the same order
+    if (!st[dev][w]) {
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      if (hipStreamCreateWithPriority(&st[dev][w], hipStreamNonBlocking, lo) != hipSuccess) st[dev][w] = nullptr;
+    }
+  return st[dev][which];
 }
 // The events only order streams of ONE device: no system-scope fence (host / peer visibility) at the record.
 constexpr unsigned kEventFlags = hipEventDisableTiming | hipEventDisableSystemFence;
 struct SideStream {
   hipStream_t st = nullptr;
+  hipStream_t st2 = nullptr;      // query stream (see shared_side_stream)
   hipEvent_t ev[256] = {};
   int used = 0;
   int init(int dev) {
     if (st) return 0;
-    st = shared_side_stream(dev);
-    return st ? 0 : (int)hipErrorOutOfMemory;
+    st = shared_side_stream(dev, 0);
+    st2 = shared_side_stream(dev, 1);
+    return (st && st2) ? 0 : (int)hipErrorOutOfMemory;
   }
   hipEvent_t next() {
     if (used >= 256) used = 0;

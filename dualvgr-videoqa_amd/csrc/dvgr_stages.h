@@ -178,6 +178,12 @@ constexpr int kMaxColsumJobs = 16;
 struct ColsumBatch { ColsumJob j[kMaxColsumJobs]; int n; int chunks; };
 int colsum(hipStream_t st, const ColsumBatch& b);
 
+// Zero a list of fp32 ranges in ONE launch (the bias / vector gradients that contractions add into, the alignment padding
+// of the flat gradient buffer, d(dq)): replaces hipMemsetAsync over whole buffers whose large tensors are overwritten anyway.
+constexpr int kMaxZeroSegs = 40;
+struct ZeroList { float* p[kMaxZeroSegs]; int64_t n[kMaxZeroSegs]; int count; };
+int zero_ranges(hipStream_t st, const ZeroList& z);
+
 // fp32 -> bf16 shadow copy (round to nearest even)
 int to_bf16(hipStream_t st, const float* src, void* dst, int64_t n);
 

@@ -1027,6 +1027,32 @@ int keep_mask_launch(hipStream_t st, uint32_t key, int64_t n, float* keep) {
   hipLaunchKernelGGL(k_keep_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, key, n, keep);
   return (int)hipGetLastError();
 }
+// ---- zero a list of ranges -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_zero_ranges(const ZeroList z) {
+  float* p = z.p[blockIdx.y];
+  const int64_t n = z.n[blockIdx.y];
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
+      reinterpret_cast<float4*>(p)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] = 0.f;
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] = 0.f;
+  }
+}
+
+int zero_ranges(hipStream_t st, const ZeroList& z) {
+  if (z.count <= 0) return 0;
+  if (z.count > kMaxZeroSegs) return DVGR_E_DIMS;
+  int64_t longest = 0;
+  for (int i = 0; i < z.count; ++i) longest = z.n[i] > longest ? z.n[i] : longest;
+  int gx = (int)((longest / 4 + 255) / 256);
+  gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+  hipLaunchKernelGGL(k_zero_ranges, dim3(gx, z.count), dim3(256), 0, st, z);
+  return (int)hipGetLastError();
+}
+
 }  // namespace dvgr
 
 #ifdef DVGR_CLK

@@ -6,7 +6,7 @@ import torch
 import dualvgr_videoqa_amd as dv
 from dualvgr_videoqa_amd import _lib as L_, synth
 
-B, N, Lr, T, D, WD = 64, 20, 3, 15, 768, 300
+B, N, Lr, T, D, WD = (int(sys.argv[1]) if len(sys.argv) > 1 else 64), 20, (int(sys.argv[2]) if len(sys.argv) > 2 else 3), 15, 768, 300
 m = dv.DualVGRUnit_multiple(word_dim=WD, module_dim=D, num_of_nodes=N, unit_layers=Lr, dtype="bf16x3").cuda().train()
 m.loss_in_forward = (1.0, 1e-8, 1.0)
 m.reuse_buffers = True
