@@ -789,10 +789,13 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
   // stream's weight-gradient launches and with its two contractions at the very end of the main stream the branch cost a
   // ~170 us tail after the last dX contraction (rocprofv3 timeline, profiles/r02_v1); on its own stream it ends under
   // layer 0's weight-gradient launch.
+  // Order on the query stream: chain and contractions of the layers >= 1 (issued at layer 1, they finish in the gap
+  // before layer 0's d p exists), then layer 0's chain and contractions, then the leaves of ALL layers in one small
+  // contraction launch and one column-sum launch.
   auto query_branch = [&](int lo, int hi, int first) -> int {
     DVGR_TRY(query_chain(lo, hi, qs, first));
     DVGR_TRY(query_gemms(lo, hi, qs));
-    return query_leaves(lo, hi, qs);
+    return lo == 0 ? query_leaves(0, L, qs) : 0;
   };
 
   // ---- layers, last to first -----------------------------------------------------------------------
@@ -943,7 +946,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       // behind its short tiles -- the layers > 0 put it on the side stream (measured: 1.245 ms per step against 1.272 with
       // it on the main stream, and 1.27 merged with the dX launch); layer 0 has no next layer and keeps it on the main
       // stream, which is idle by then.
-      hipStream_t dws = (side && l > 0) ? hs : st;
+      hipStream_t dws = (side && l > 0) ? hs : st;      // (layer 0's on the side stream too: no difference, 1.179 ms both)
       const Probe dprobe{O, dws};
       DVGR_TRY(dprobe.begin(DVGR_PROBE_BWD_GAT_DW, l));
       DVGR_TRY(launch_dw(dws, gb, bias, TAG_BWD_GAT_DW, cb));     // (biases the engine cannot carry join the column sums)
@@ -1063,7 +1066,7 @@ int dvgr_dbg_gemm_planes_batch(int mode, int M, int N, int K, int kseg, const fl
       if (mode == 2) { p.A.p1 = A; p.A.h1 = p.A.h0; }
       p.B.p1 = B; p.B.h1 = p.B.h0;
     }
-    p.act = act; p.accumulate = accumulate; p.atomic_ok = atomic_ok;
+    p.act = act & 15; p.dbg = act >> 4; p.accumulate = accumulate; p.atomic_ok = atomic_ok;
     gb.p[gb.n++] = p;
   }
   const int la = mode == 2 ? IC : KC, lb = mode == 0 ? KC : IC;

@@ -869,9 +869,10 @@ __device__ __forceinline__ void planes_tile(const GemmProblem& P, uint16_t* smem
     uint32_t offA[2], offB[2];
     planes_prep<LA>(P.A, m0, P.M, wave, lane, offA);
     planes_prep<LB>(P.B, n0, P.N, wave, lane, offB);
+    const bool nodma = (P.dbg & 8) != 0;         // timing aid (tools/gemm_shapes.py): barriers only
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
-      if (s < nk) {
+      if (s < nk && !nodma) {
         planes_issue<LA, TERMS>(P.A, (kbeg + s) * BK, P.kseg, wave, lane, offA, smem + s * kSlot);
         planes_issue<LB, TERMS>(P.B, (kbeg + s) * BK, P.kseg, wave, lane, offB, smem + s * kSlot + kPlanes * kPlaneTile);
       }
@@ -895,7 +896,7 @@ __device__ __forceinline__ void planes_tile(const GemmProblem& P, uint16_t* smem
       GCLK_ADD(0);                                 // waiting for the DMA of tile kt
       __builtin_amdgcn_s_barrier();
       GCLK_ADD(1);                                 // waiting for the consumers at the barrier
-      if (kt + NS - 1 < nk) {
+      if (kt + NS - 1 < nk && !nodma) {
         uint16_t* dst = smem + ((kt + NS - 1) % NS) * kSlot;
         planes_issue<LA, TERMS>(P.A, (kbeg + kt + NS - 1) * BK, P.kseg, wave, lane, offA, dst);
         planes_issue<LB, TERMS>(P.B, (kbeg + kt + NS - 1) * BK, P.kseg, wave, lane, offB, dst + kPlanes * kPlaneTile);
@@ -927,6 +928,7 @@ __device__ __forceinline__ void planes_tile(const GemmProblem& P, uint16_t* smem
     GCLK_ADD(1);                                   // fragment reads + MFMAs of the previous tile
     __builtin_amdgcn_s_barrier();
     GCLK_ADD(0);                                   // waiting for tile kt
+    if (P.dbg & 4) continue;                       // timing aid: barriers only, no fragment reads, no MFMAs
     const uint16_t* curA = smem + (kt % NS) * kSlot;
     const uint16_t* curB = curA + kPlanes * kPlaneTile;
     bf16x8 ah[MT], al[MT], bh[NT], bl[NT];

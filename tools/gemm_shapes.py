@@ -25,6 +25,7 @@ def planes(x):
 
 
 def run(name, mode, M, Nn, K, count, tag, kseg=0, act=0, acc=0, atomic=0, rowsum=0):
+    act |= int(os.environ.get("DVGR_GEMM_DBG", "0")) << 4      # timing aids of the planes kernel: 4 = no compute, 8 = no DMA
     shp = {0: ((M, K), (Nn, K)), 1: ((M, K), (K, Nn)), 2: ((K, M), (K, Nn))}[mode]
     A, Bm = torch.randn(*shp[0], device="cuda"), torch.randn(*shp[1], device="cuda")
     pa, na = planes(A)
@@ -49,7 +50,7 @@ def run(name, mode, M, Nn, K, count, tag, kseg=0, act=0, acc=0, atomic=0, rowsum
     us = e0.elapsed_time(e1) / reps * 1e3
     gf = 2.0 * M * Nn * K * count / 1e9
     tiles = count * ((M + 127) // 128) * ((Nn + 127) // 128)
-    print(f"{name:44s} mode {mode} {count} x ({M:5d} x {Nn:5d} x {K:5d})  tiles {tiles:4d}  {us:7.1f} us  {gf / us * 1e-3 * 1e3:7.1f} TFLOP/s (algorithmic)")
+    print(f"{name:44s} mode {mode} {count} x ({M:5d} x {Nn:5d} x {K:5d})  tiles {tiles:4d}  {us:7.1f} us  {gf / us * 1e3:7.1f} TFLOP/s (algorithmic)")
 
 
 if __name__ == "__main__":
