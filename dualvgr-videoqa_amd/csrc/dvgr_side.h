@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <stdlib.h>
+
 #include <mutex>
 
 namespace dvgr {
@@ -38,8 +40,18 @@ struct SideStream {
   int init(int dev) {
     if (st) return 0;
     st = shared_side_stream(dev, 0);
-    st2 = shared_side_stream(dev, 1);
-    return (st && st2) ? 0 : (int)hipErrorOutOfMemory;
+    return st ? 0 : (int)hipErrorOutOfMemory;
+  }
+  // the query stream, created on first use (DVGR_OPT_NO_QUERY_STREAM / DVGR_NO_QUERY_STREAM=1: the side stream instead)
+  hipStream_t query(bool allowed) {
+    static const bool env_off = []() { const char* e = getenv("DVGR_NO_QUERY_STREAM"); return e && e[0] == '1'; }();
+    if (!allowed || env_off) return st;
+    if (!st2) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return st;
+      st2 = shared_side_stream(dev, 1);
+    }
+    return st2 ? st2 : st;
   }
   hipEvent_t next() {
     if (used >= 256) used = 0;

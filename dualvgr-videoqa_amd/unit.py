@@ -540,6 +540,8 @@ class DualVGRUnit_multiple(nn.Module):
         o.train, o.seed = int(bool(train)), int(seed)
         if self.single_stream:
             o.flags |= L_.OPT_SINGLE_STREAM
+        if self._events or getattr(self, "_layer_cb", None) is not None:
+            o.flags |= L_.OPT_NO_QUERY_STREAM      # a reducer's streams run beside the call (include/dvgr.h)
         if self._probe is not None:
             site, layer, b, e = self._probe
             if (site >= L_.PROBE_BWD_SF_DW) == backward:

@@ -179,6 +179,13 @@ enum dvgr_probe_site {
  * latency-bound kernels of the critical path; the side stream forks from and joins back into `stream` inside the call,
  * so the caller sees ordinary single-stream semantics.  DVGR_OPT_SINGLE_STREAM keeps every launch on `stream`. */
 #define DVGR_OPT_SINGLE_STREAM 1
+/* The backward additionally runs its query branch (S1 tail and S0 backward: a chain of small, latency-bound kernels) on a
+ * second internal stream, created on first use.  DVGR_OPT_NO_QUERY_STREAM keeps that branch on the side stream and never
+ * creates the second one: set it when the process drives further streams of its own beside the call (a gradient
+ * reducer's: with this stream present as well a data-parallel step took 3.5 ms instead of 1.4 ms on ROCm 7.0 -- the
+ * runtime then spends the time on the host between launches; dualvgr-videoqa_amd/unit.py sets it whenever layer events
+ * are installed).  The environment variable DVGR_NO_QUERY_STREAM=1 has the same effect for every call. */
+#define DVGR_OPT_NO_QUERY_STREAM 2
 
 /* Scope-U loss evaluated by the forward itself (dvgr_opts.loss): the same arithmetic and outputs as
  * dvgr_scope_u_loss below, but the kernels are enqueued as soon as the last layer's list outputs exist and run on the
