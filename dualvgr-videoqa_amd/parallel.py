@@ -60,6 +60,7 @@ class LayerBucketReducer:
         if flat_grad.is_cuda and self.stream is not None:
             cur = torch.cuda.current_stream(flat_grad.device)
             works = []
+            avg = dist.get_backend(self.group) == "nccl"       # RCCL averages inside the collective (ncclAvg)
             with torch.cuda.stream(self.stream):
                 for (a, b), layer in zip(self.buckets, self._layer_order()):
                     ev = events[layer] if events is not None else None
@@ -67,10 +68,12 @@ class LayerBucketReducer:
                         self.stream.wait_event(ev)
                     else:
                         self.stream.wait_stream(cur)
-                    works.append(dist.all_reduce(flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-                for w, (a, b) in zip(works, self.buckets):     # scale bucket i while bucket i+1 is still on the wire
+                    works.append(dist.all_reduce(flat_grad[a:b], op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM,
+                                                 group=self.group, async_op=True))
+                for w, (a, b) in zip(works, self.buckets):     # (gloo: scale bucket i while bucket i+1 is still on the wire)
                     w.wait()
-                    flat_grad[a:b].mul_(1.0 / self.world)
+                    if not avg:
+                        flat_grad[a:b].mul_(1.0 / self.world)
             cur.wait_stream(self.stream)
         else:
             for (a, b) in self.buckets:
@@ -121,9 +124,13 @@ class LayerBucketReducer:
                     self.stream.wait_stream(caller_stream if caller_stream is not None
                                             else torch.cuda.current_stream(flat_grad.device))
                 flat_grad.record_stream(self.stream)           # may be a temporary of the caller: keep it alive for RCCL
-                w = dist.all_reduce(flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                # RCCL averages inside the collective (ncclAvg): no separate scaling pass over the bucket
+                avg = dist.get_backend(self.group) == "nccl"
+                w = dist.all_reduce(flat_grad[a:b], op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.group,
+                                    async_op=True)
                 w.wait()                                   # stream-ordered, no host block
-                flat_grad[a:b].mul_(1.0 / self.world)
+                if not avg:
+                    flat_grad[a:b].mul_(1.0 / self.world)
             self._works.append((w, a, b, flat_grad))
         else:
             dist.all_reduce(flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group)
@@ -215,9 +222,11 @@ class ParamBucketReducer:
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(ev)
             flat = torch._utils._flatten_dense_tensors(grads)
-            w = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            avg = dist.get_backend(self.group) == "nccl"
+            w = dist.all_reduce(flat, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.group, async_op=True)
             w.wait()                                              # stream-ordered
-            flat.mul_(1.0 / self.world)
+            if not avg:
+                flat.mul_(1.0 / self.world)
             for g, red in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
                 g.copy_(red)
                 g.record_stream(self.stream)

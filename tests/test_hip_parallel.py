@@ -124,3 +124,46 @@ def test_reducer_gates_each_bucket_on_its_own_layers_event():
         assert torch.equal(got2, want)
     finally:
         dist.destroy_process_group()
+
+
+def test_the_reducers_streams_do_not_stall_the_step():
+    """Guard for a regression seen in round 2: with one more internal stream in the backward, a data-parallel step (helper
+    thread + reducer stream + RCCL beside the call) took 2.6 x the time of the plain step -- the time went to the host
+    between launches.  The module now drops that stream whenever layer events are installed; here the step with the
+    reducer running (one rank over RCCL, collectives forced) must stay within 1.6 x of the plain step."""
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        m, t = _module()
+        m.reuse_buffers = True
+
+        def run(reducer, steps=40):
+            def one():
+                m.zero_grad_flat()
+                if reducer is not None:
+                    reducer.start(Lr)
+                _step(m, t)
+                if reducer is not None:
+                    reducer.finish()
+            for _ in range(10):
+                one()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                one()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / steps
+
+        plain = run(None)
+        events = [torch.cuda.Event() for _ in range(Lr + 2)]
+        m.set_layer_events(events)
+        red = parallel.LayerBucketReducer(parallel.layer_buckets(m), device=torch.device("cuda", 0))
+        red.force = True
+        m.set_layer_callback(lambda idx, g: red.launch(idx, g, events[idx]))
+        with_reducer = run(red)
+        print(f"  plain {plain * 1e3:.3f} ms, with the reducer {with_reducer * 1e3:.3f} ms per step")
+        assert with_reducer < 1.6 * plain, (plain, with_reducer)
+    finally:
+        dist.destroy_process_group()
