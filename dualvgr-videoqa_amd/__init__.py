@@ -8,6 +8,7 @@ from . import _lib  # noqa: F401
 from .unit import DualVGRUnit_multiple, param_table  # noqa: F401
 from .head import AnswerHead  # noqa: F401
 from .clip import ClipEncoder  # noqa: F401
+from .inputs import HipLinear, WordFeatures  # noqa: F401
 from .store import FeatureStore, VideoQAFlatLoader, write_flat  # noqa: F401
 from .model import DualVGR, init_modules  # noqa: F401
 from .trainer import ClipAdam, TrainStep  # noqa: F401

@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L_
+from .inputs import WordFeatures
 
 CP_NAMES = ["weight_ih_l0", "weight_ih_l0_reverse", "weight_hh_l0", "weight_hh_l0_reverse", "bias_ih_l0",
             "bias_ih_l0_reverse", "bias_hh_l0", "bias_hh_l0_reverse"]          # enum dvgr_clip_param order
@@ -253,20 +254,24 @@ class _PackedRNN(nn.Module):
 
 class QuestionEncoder(nn.Module):
     """Drop-in for the reference's InputUnitLinguisticDynamic (model/Preprocessing.py:89-127): embedding -> dropout -> tanh =
-    word features; one BiLSTM gives the per-word dynamic embedding (zero past the question length), a second one the
-    question embedding (final states -> dropout 0.18).  The two LSTMs run on HIP; the embedding lookup, its dropout and
-    tanh stay torch element-wise ops (their gradient is a scatter into the embedding table)."""
+    word features (one gather kernel; backward: one scatter-add kernel into the table's gradient, include/dvgr_inputs.h);
+    one BiLSTM gives the per-word dynamic embedding (zero past the question length), a second one the question embedding
+    (final states -> dropout 0.18).  `encoder_embed` is kept as the parameter holder (state_dict key, U(-1, 1) init)."""
 
     def __init__(self, vocab_size, wordvec_dim=300, rnn_dim=512, dtype: str = "fp32"):
         super().__init__()
         self.encoder_embed = nn.Embedding(vocab_size, wordvec_dim)
         self.concatRNN = _PackedRNN(wordvec_dim, rnn_dim // 2, dtype)
         self.encoder = BiLSTM(wordvec_dim, rnn_dim // 2, dtype=dtype)
-        self.embedding_dropout = nn.Dropout(p=0.15)
+        self.embedding_dropout = nn.Dropout(p=0.15)          # holds p only: the kernel's site drops with p = 0.15 or not at all
+        self.word_features = WordFeatures()
 
     def forward(self, questions, question_len):
         max_len = questions.size(1)
-        words = torch.tanh(self.embedding_dropout(self.encoder_embed(questions)))
+        # model/Preprocessing.py:112-113 as one gather kernel (and one scatter-add kernel backward), include/dvgr_inputs.h
+        if self.embedding_dropout.p not in (0.0, 0.15):
+            raise ValueError("the word-feature kernel drops with the reference's p = 0.15 (or not at all)")
+        words = self.word_features(self.encoder_embed.weight, questions, self.training and self.embedding_dropout.p > 0.0)
         output_embedding = self.concatRNN(words, question_len, max_len)
         question_embedding, _ = self.encoder.run(words, question_len, LSTM_DROP_FINAL)
         return question_embedding, words, output_embedding

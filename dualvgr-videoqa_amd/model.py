@@ -14,6 +14,7 @@ import torch.nn as nn
 from . import _lib
 from .clip import ClipEncoder, QuestionEncoder
 from .head import AnswerHead
+from .inputs import HipLinear
 from .unit import DualVGRUnit_multiple
 
 
@@ -52,7 +53,7 @@ class DualVGR(nn.Module):
         self.num_classes = len(vocab["answer_token_to_idx"])
         self.linguistic_input_unit = QuestionEncoder(vocab_size=n_q, wordvec_dim=word_dim, rnn_dim=module_dim, dtype=dtype)
         self.visual_appearance_input_unit = ClipEncoder(appearance_dim=vision_dim, module_dim=module_dim, dtype=dtype)
-        self.visual_motion_input_unit = nn.Linear(vision_dim, module_dim)
+        self.visual_motion_input_unit = HipLinear(vision_dim, module_dim, dtype=dtype)      # model/models.py:46 on the contraction engine
         self.visual_input_unit = DualVGRUnit_multiple(word_dim=word_dim, module_dim=module_dim, num_of_nodes=num_of_nodes,
                                                       appearance_graph_layers=graph_layers, motion_graph_layers=graph_layers,
                                                       graph_module=graph_module, unit_layers=unit_layers, dtype=dtype)

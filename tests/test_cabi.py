@@ -34,12 +34,14 @@ def test_library_exports_every_declared_symbol():
     from dualvgr_videoqa_amd import clip as CL
     from dualvgr_videoqa_amd import store as ST
     from dualvgr_videoqa_amd import trainer as TR
+    from dualvgr_videoqa_amd import inputs as IN
+    IN.load()
     HD.load()
     CL.load()
     ST.load()
     TR.load()
     bound = ({n for n, _, _ in L.SYMBOLS} | {n for n, _, _ in HD.HEAD_SYMBOLS} | {n for n, _, _ in CL.CLIP_SYMBOLS}
-             | {n for n, _, _ in ST.STORE_SYMBOLS} | {n for n, _, _ in TR.OPTIM_SYMBOLS})
+             | {n for n, _, _ in ST.STORE_SYMBOLS} | {n for n, _, _ in TR.OPTIM_SYMBOLS} | {n for n, _, _ in IN.INPUT_SYMBOLS})
     assert declared == bound, declared ^ bound
     for name in declared:
         assert getattr(lib, name) is not None
@@ -61,6 +63,25 @@ def test_optimizer_refuses_bad_segments_without_touching_the_gpu():
     assert lib.dvgr_optim_adam_step(segs, 1, None, 12.0, 1e-4, 0.9, 0.999, 1e-8, 0, None) == -1     # step must be >= 1
     assert lib.dvgr_optim_adam_step(segs, 1, None, 12.0, 1e-4, 1.0, 0.999, 1e-8, 1, None) == -1     # beta1 < 1
     assert lib.dvgr_optim_adam_step(segs, -1, None, 12.0, 1e-4, 0.9, 0.999, 1e-8, 1, None) == -1
+
+
+def test_input_operators_refuse_bad_arguments_without_touching_the_gpu():
+    """include/dvgr_inputs.h: argument checks come before any launch."""
+    from dualvgr_videoqa_amd import inputs as IN
+    lib = IN.load()
+    buf = (C.c_float * 64)()
+    a = C.addressof(buf)
+    a16 = (a + 15) // 16 * 16
+    assert lib.dvgr_words_forward(None, 10, 8, a16, 2, 0, 0, a16, None, None) == -2
+    assert lib.dvgr_words_forward(a16, 10, 6, a16, 2, 0, 0, a16, None, None) == -1          # wd % 4
+    assert lib.dvgr_words_forward(a16, 0, 8, a16, 2, 0, 0, a16, None, None) == -1           # empty table
+    assert lib.dvgr_words_forward(a16, 10, 8, a16, 2, 0, 0, a16 + 4, None, None) == -4      # misaligned output
+    assert lib.dvgr_words_forward(a16, 10, 8, a16, 0, 0, 0, a16, None, None) == 0           # nothing to do
+    assert lib.dvgr_words_backward(a16, a16, a16, 2, 10, 8, 0, 0, None, None) == -2
+    assert lib.dvgr_linear_forward(a16, a16, None, None, 4, 8, 8, 0, None) == -2
+    assert lib.dvgr_linear_forward(a16, a16, None, a16, 4, 6, 8, 0, None) == -1             # N % 4
+    assert lib.dvgr_linear_forward(a16, a16, None, a16, 4, 8, 8, 7, None) == -1             # unknown dtype
+    assert lib.dvgr_linear_backward(a16, a16, a16, None, None, None, 4, 8, 8, 0, None) == -2
 
 
 def test_struct_sizes_match_header():
