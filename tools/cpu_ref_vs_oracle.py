@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Build container only (needs /root/reference): times the IMPORTED reference unit (model/models.py:86-173,
+DualVGRUnit_multiple) against the oracle's op-for-op restatement (oracle/unit_torch.py, the code bench.py's cpu_baseline
+times on the GPU box) on the same CPU cores -- forward + backward, training mode, B = 8, N = 20, L = 3, T = 15, the sum of
+the visual embedding plus the two auxiliary losses as the scalar.  The reference draws its dropout masks inside the timed
+region (torch RNG), the oracle gets injected masks; everything else is the same arithmetic.
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/cpu_ref_vs_oracle.py [threads]"""
+import os
+import sys
+import time
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import torch
+
+import make_golden_model as MG                       # device-string shims + the imported reference (model.models)
+from oracle import unit_torch as O
+from dualvgr_videoqa_amd import dropout, synth
+
+threads = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+torch.set_num_threads(threads)
+B, N, L, T, D, WD = 8, 20, 3, 15, 768, 300
+
+inp = synth.unit_inputs(B, N, T, D, WD, seed=666)
+t = {k: torch.from_numpy(v) for k, v in inp.items()}
+
+ref = MG.ref_models.DualVGRUnit_multiple(word_dim=WD, module_dim=D, num_of_nodes=N, appearance_graph_layers=1, motion_graph_layers=1,
+                                         graph_module="GAT", unit_layers=L).train()
+
+
+def ref_step():
+    ref.zero_grad(set_to_none=True)
+    outs = ref(t["A"], t["M"], t["dq"], t["words"], t["qlen"])
+    O.bench_scalar_loss(outs, N).backward()
+
+
+sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in synth.xavier_state_dict(O.param_shapes(WD, D, L), seed=666).items()}
+masks = {k: torch.from_numpy(v) for k, v in dropout.site_masks(666, B, N, D, L).items()}
+
+
+def oracle_step():
+    for p in sd.values():
+        p.grad = None
+    outs = O.unit_forward(sd, t["A"], t["M"], t["dq"], t["words"], t["qlen"], L, 1, masks=masks, naive=True)
+    O.bench_scalar_loss(outs, N).backward()
+
+
+def timeit(fn, n=12):
+    fn(); fn()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    return (time.perf_counter() - t0) / n
+
+
+a = timeit(ref_step)
+b = timeit(oracle_step)
+a2 = timeit(ref_step)
+b2 = timeit(oracle_step)
+print(f"{threads} threads, B={B} N={N} L={L}: imported reference {a * 1e3:.1f} / {a2 * 1e3:.1f} ms per step, "
+      f"oracle restatement {b * 1e3:.1f} / {b2 * 1e3:.1f} ms per step, ratio {min(b, b2) / min(a, a2):.3f}")
