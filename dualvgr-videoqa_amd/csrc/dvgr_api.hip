@@ -114,6 +114,12 @@ struct PlaneMap {
   }
 };
 
+// Tensors whose ONLY readers are contractions (the dropped copies xd; backward: dpre, dWh) exist as bf16 planes alone when
+// every one of those contractions runs on the planes kernels: bf16 modes, B N a multiple of the K-tile and above the
+// batch-sized kernels' range (dvgr_small.hip reads fp32 operands for reductions <= 256 rows).  Forward and backward
+// derive the same answer from the dimensions.
+inline bool lean_planes(bool planes_on, int BN) { return planes_on && (BN % 32) == 0 && BN > 256; }
+
 // C = act(A[M,K] . B[N,K]^T + bias)                      (forward Linear)
 GemmProblem nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
                const float* bias, int M, int N, int K, int act, uint32_t drop_a = 0) {
@@ -357,6 +363,7 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
 
   const PlaneMap PM = make_plane_map(d, P, S, params, params_lp, io, saved, ws);
   int64_t plo = 0;                       // lo-plane offset of the last PM.out() lookup
+  const bool lean = lean_planes(PM.on, BN);
   if (PM.on) {                           // bf16 hi/lo planes of the caller's inputs
     SplitBatch sb{};
     sb.lo_off = S.total;
@@ -364,6 +371,14 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
     sb.j[sb.n++] = SplitJob{io->A, sv_hi + S.in_a, BND};
     sb.j[sb.n++] = SplitJob{io->M, sv_hi + S.in_m, BND};
     sb.j[sb.n++] = SplitJob{io->dq, sv_hi + S.in_dq, (int64_t)BT * D};
+    if (train && lean) { // layer 0's x-site: the planes of the two dropped copies of A and M from the same pass (no k_drop_x)
+      const Keys K0 = layer_keys(train, seed, 0);
+      for (int m = 0; m < 2; ++m)
+        for (int gi = 0; gi < 2; ++gi) {
+          sb.j[m].drop_hi[gi] = sv_hi + (S.layer_stride * 0 + S.mod_base + S.mod_stride * m + S.xd) + gi * BND;
+          sb.j[m].drop_key[gi] = K0.x[m][gi];
+        }
+    }
     DVGR_TRY(split_planes(st, sb));
   }
 
@@ -413,7 +428,9 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
     // itself carries no mask and can run on the LDS-DMA ring kernel.
     {
       GemmBatch gb{};
-      if (train && l == 0)                 // layers > 0: the previous layer's S5 kernel wrote the dropped copies
+      // the dropped copies: layers > 0 get them from the previous layer's S5 kernel; layer 0 from the split kernel above
+      // (bf16 modes: planes only, nobody reads them as fp32) or, in DVGR_F32, from k_drop_x
+      if (train && l == 0 && !lean)
         DVGR_TRY(drop_x(st, Xin[0], Xin[1], ms(l, 0) + S.xd, ms(l, 1) + S.xd, K.x, BND, PM.out(ms(l, 0) + S.xd, &plo),
                         PM.out(ms(l, 1) + S.xd, &plo), plo));
       for (int m = 0; m < 2; ++m) {
@@ -494,7 +511,7 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
         const Keys Kn = layer_keys(train, seed, l + 1);
         for (int m = 0; m < 2; ++m) {
           a.next_p[m] = ms(l + 1, m) + S.p; a.next_s[m] = ms(l + 1, m) + S.s;
-          a.next_xd[m] = train ? ms(l + 1, m) + S.xd : nullptr;
+          a.next_xd[m] = (train && !lean) ? ms(l + 1, m) + S.xd : nullptr;       // fp32 copies only where they are read
           a.next_xd_p[m] = train ? PM.out(ms(l + 1, m) + S.xd, &plo) : nullptr;
           for (int gi = 0; gi < 2; ++gi) a.next_key[m][gi] = Kn.x[m][gi];
         }
@@ -567,6 +584,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
   float* dXacc[2] = {g->gA, g->gM};     // running gradient w.r.t. the current layer boundary
   const PlaneMap PM = make_plane_map(d, P, S, params, params_lp, io, saved, ws);
   int64_t plo = 0;
+  const bool lean = lean_planes(PM.on, BN);   // dpre / dWh / xd exist as planes only (see lean_planes)
 
   // every element of gparams is written: the matrices by their contractions, everything between them (bias and vector
   // gradients, which contractions and column sums ADD into -- GemmProblem::rowsum -- and the alignment padding) is zeroed
@@ -825,7 +843,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
         const float* gs = m == 0 ? g->g_aq_fusion : g->g_mq_fusion;
         a.g_z0[m] = gc ? gc + l * BND : nullptr;
         a.g_z1[m] = gs ? gs + l * BND : nullptr;
-        a.dw[m] = ws + W.dw[set][m]; a.dpre[m] = ws + W.dpre[set][m]; a.dz[m] = ws + W.dz[m];
+        a.dw[m] = ws + W.dw[set][m]; a.dpre[m] = lean ? nullptr : ws + W.dpre[set][m]; a.dz[m] = ws + W.dz[m];
         a.dpre_p[m] = PM.out(ws + W.dpre[set][m], &plo);
       }
       a.lo_off = plo;
@@ -849,7 +867,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
         a.dz[m] = ws + W.dz[m]; a.out_c[m] = outc[m]; a.out_s[m] = outs[m];
         a.Wh[m] = ms(l, m) + S.wh; a.s[m] = ms(l, m) + S.s; a.u[m] = ms(l, m) + S.u; a.v[m] = ms(l, m) + S.v;
         a.gat_a[m] = mp(l, m) + P.gat_a; a.gat_c[m] = mp(l, m) + P.gat_c;
-        a.dWh[m] = ws + W.dWh[set][m]; a.ds_part[m] = ws + W.ds_part[set][m]; a.da_part[m] = ws + W.da_part[set][m];
+        a.dWh[m] = lean ? nullptr : ws + W.dWh[set][m]; a.ds_part[m] = ws + W.ds_part[set][m]; a.da_part[m] = ws + W.da_part[set][m];
         a.dc_part[m] = ws + W.dc_part[set][m];
         for (int h = 0; h < 8; ++h) a.key_alpha[m][h] = K.alpha[m][h];
         for (int gi = 0; gi < 2; ++gi) a.key_out[m][gi] = K.out[m][gi];
@@ -951,6 +969,8 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       // stream, which is idle by then.
       hipStream_t dws = (side && l > 0) ? hs : st;      // (layer 0's on the side stream too: no difference, 1.179 ms both)
       const Probe dprobe{O, dws};
+      // (cannot happen: lean_planes() implies the planes kernels; under it dpre / dWh have no fp32 copy for a column sum)
+      if (lean && !gemm_rowsum_supported(IC, IC, gb, prec)) return DVGR_E_DIMS;
       DVGR_TRY(dprobe.begin(DVGR_PROBE_BWD_GAT_DW, l));
       DVGR_TRY(launch_dw(dws, gb, bias, TAG_BWD_GAT_DW, cb));     // (biases the engine cannot carry join the column sums)
       DVGR_TRY(dprobe.end(DVGR_PROBE_BWD_GAT_DW, l));

@@ -31,7 +31,13 @@ int drop_x(hipStream_t st, const float* X0, const float* X1, float* out0, float*
            uint16_t* p0 = nullptr, uint16_t* p1 = nullptr, int64_t lo_off = 0);
 
 // hi/lo bf16 planes of up to 4 fp32 tensors (the unit's inputs)
-struct SplitJob { const float* src; uint16_t* hi; int64_t n; };
+struct SplitJob {
+  const float* src; uint16_t* hi; int64_t n;
+  // optional (training mode, layer 0's x-site): the planes of the two differently dropped copies of `src` as well,
+  // element index = index into src (the convention of k_drop_x / GemmOperand::drop_key); drop_hi[g] == nullptr: none
+  uint16_t* drop_hi[2];
+  uint32_t drop_key[2];
+};
 struct SplitBatch { SplitJob j[4]; int n; int64_t lo_off; };
 int split_planes(hipStream_t st, const SplitBatch& b);
 

@@ -332,7 +332,8 @@ __global__ __launch_bounds__(256) void k_sf_combine_fwd(const SfCombineArgs a) {
   float4* xo = reinterpret_cast<float4*>(a.Xout[mod] + (int64_t)row * a.D);
   float4* oo = a.o[mod] ? reinterpret_cast<float4*>(a.o[mod] + (int64_t)row * a.D) : nullptr;
   const float4* np = a.next_p[mod] ? reinterpret_cast<const float4*>(a.next_p[mod] + (int64_t)(row / a.N) * a.D) : nullptr;
-  float* nxd = a.next_xd[mod];
+  float* nxd = a.next_xd[mod];                              // fp32 copies: only where a reader wants them (DVGR_F32)
+  const bool want_xd = nxd != nullptr || a.next_xd_p[mod] != nullptr;
   const int64_t n4 = (int64_t)a.rows * D4;                  // float4s of one (B*N, D) tensor
   float gate = 0.f;
   for (int k = lane; k < D4; k += 64) {
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(256) void k_sf_combine_fwd(const SfCombineArgs a) {
     if (np) {                                               // next layer: gate logit and the two dropped copies of X'
       const float4 pv = np[k];
       gate += xn.x * pv.x + xn.y * pv.y + xn.z * pv.z + xn.w * pv.w;
-      if (nxd) {
+      if (want_xd) {
         const int64_t i = (int64_t)row * D4 + k;            // float4 index, as k_drop_x
         const uint32_t e = (uint32_t)(i * 4);
 #pragma unroll
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(256) void k_sf_combine_fwd(const SfCombineArgs a) {
           y.y = xn.y * (((h0 >> 16) >= kDropThresh16) ? kKeepScale : 0.f);
           y.z = xn.z * (((h1 & 0xFFFFu) >= kDropThresh16) ? kKeepScale : 0.f);
           y.w = xn.w * (((h1 >> 16) >= kDropThresh16) ? kKeepScale : 0.f);
-          reinterpret_cast<float4*>(nxd)[(int64_t)g * n4 + i] = y;
+          if (nxd) reinterpret_cast<float4*>(nxd)[(int64_t)g * n4 + i] = y;
           split_store4(a.next_xd_p[mod], a.next_xd_lo_off, ((int64_t)g * n4 + i) * 4, y);
         }
       }
@@ -470,8 +471,8 @@ __global__ __launch_bounds__(256) void k_sf_bwd(const SfBwdArgs a) {
   const float4* p2 = reinterpret_cast<const float4*>(a.p2[mod]);
   const float4* g0 = a.g_z0[mod] ? reinterpret_cast<const float4*>(a.g_z0[mod] + r0) : nullptr;
   const float4* g1 = a.g_z1[mod] ? reinterpret_cast<const float4*>(a.g_z1[mod] + r0) : nullptr;
-  float4* dpre0 = reinterpret_cast<float4*>(a.dpre[mod] + r0);
-  float4* dpre1 = reinterpret_cast<float4*>(a.dpre[mod] + r1);
+  float4* dpre0 = a.dpre[mod] ? reinterpret_cast<float4*>(a.dpre[mod] + r0) : nullptr;   // fp32 copy: only where it has a reader
+  float4* dpre1 = a.dpre[mod] ? reinterpret_cast<float4*>(a.dpre[mod] + r1) : nullptr;
   float4* dz0 = reinterpret_cast<float4*>(a.dz[mod] + r0);
   float4* dz1 = reinterpret_cast<float4*>(a.dz[mod] + r1);
   for (int k = lane; k < D4; k += 64) {
@@ -482,8 +483,7 @@ __global__ __launch_bounds__(256) void k_sf_bwd(const SfBwdArgs a) {
                                   dw0 * p.z * (1.f - ta.z * ta.z), dw0 * p.w * (1.f - ta.w * ta.w));
     const float4 q1 = make_float4(dw1 * p.x * (1.f - tb.x * tb.x), dw1 * p.y * (1.f - tb.y * tb.y),
                                   dw1 * p.z * (1.f - tb.z * tb.z), dw1 * p.w * (1.f - tb.w * tb.w));
-    dpre0[k] = q0;
-    dpre1[k] = q1;
+    if (dpre0) { dpre0[k] = q0; dpre1[k] = q1; }
     split_store4(a.dpre_p[mod], a.lo_off, r0 + 4 * k, q0);
     split_store4(a.dpre_p[mod], a.lo_off, r1 + 4 * k, q1);
     float4 o0 = make_float4(b0 * d.x, b0 * d.y, b0 * d.z, b0 * d.w);
@@ -674,7 +674,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
   CLK(5);
   // ---- epilogue, one wave per row j: dWh_j = s_j dZ_j + du_j a_l + dv_j a_r (fp32 + planes), ds_j = dZ_j . Wh_j,
   //      d a_l += du_j Wh_j, d a_r += dv_j Wh_j (per-wave partials in registers, then summed through LDS) ----
-  float* dWh = a.dWh[mod] + (int64_t)b * N * HF + h * F;
+  float* dWh = a.dWh[mod] ? a.dWh[mod] + (int64_t)b * N * HF + h * F : nullptr;   // fp32 copy: only where it has a reader
   float4 pal[2], par[2], gal[2], gar[2];                    // this lane's columns 4 (lane + 64 t) .. + 3, t < 2 (F <= 512)
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
         const float4 al = gal[t], ar = gar[t];
         const float4 o = make_float4(sj * z.x + duj * al.x + dvj * ar.x, sj * z.y + duj * al.y + dvj * ar.y,
                                      sj * z.z + duj * al.z + dvj * ar.z, sj * z.w + duj * al.w + dvj * ar.w);
-        *reinterpret_cast<float4*>(dWh + (int64_t)j * HF + 4 * q) = o;
+        if (dWh) *reinterpret_cast<float4*>(dWh + (int64_t)j * HF + 4 * q) = o;
         split_store4(a.dWh_p[mod], a.lo_off, (int64_t)b * N * HF + h * F + (int64_t)j * HF + 4 * q, o);
         dsp += z.x * w.x + z.y * w.y + z.z * w.z + z.w * w.w;
         pal[t].x += duj * w.x; pal[t].y += duj * w.y; pal[t].z += duj * w.z; pal[t].w += duj * w.w;
@@ -986,8 +986,24 @@ int drop_x(hipStream_t st, const float* X0, const float* X1, float* out0, float*
 __global__ __launch_bounds__(256) void k_split_planes(const SplitBatch b) {
   const SplitJob& J = b.j[blockIdx.y];
   const int64_t n4 = J.n / 4;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
-    split_store4(J.hi, b.lo_off, 4 * i, reinterpret_cast<const float4*>(J.src)[i]);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 x = reinterpret_cast<const float4*>(J.src)[i];
+    split_store4(J.hi, b.lo_off, 4 * i, x);
+    if (J.drop_hi[0]) {                                      // uniform per job
+      const uint32_t e = (uint32_t)(i * 4);
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const uint32_t h0 = mix32(((e >> 1) * 0x9E3779B1u) ^ J.drop_key[g]);
+        const uint32_t h1 = mix32((((e >> 1) + 1u) * 0x9E3779B1u) ^ J.drop_key[g]);
+        float4 y;
+        y.x = x.x * (((h0 & 0xFFFFu) >= kDropThresh16) ? kKeepScale : 0.f);
+        y.y = x.y * (((h0 >> 16) >= kDropThresh16) ? kKeepScale : 0.f);
+        y.z = x.z * (((h1 & 0xFFFFu) >= kDropThresh16) ? kKeepScale : 0.f);
+        y.w = x.w * (((h1 >> 16) >= kDropThresh16) ? kKeepScale : 0.f);
+        split_store4(J.drop_hi[g], b.lo_off, 4 * i, y);
+      }
+    }
+  }
 }
 int split_planes(hipStream_t st, const SplitBatch& b) {
   if (b.n < 1 || b.n > 4) return DVGR_E_DIMS;
