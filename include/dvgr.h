@@ -92,7 +92,9 @@ enum dvgr_saved_kind {
   DVGR_S_MFB_X1,     /* (B*N, 512) ELU(linear1(M))                                                 */
   DVGR_S_MFB_Z,      /* (B*N, 256) pair-summed product                                             */
   DVGR_S_XD,         /* (2, B*N, D) layer input after the x-site dropout of the common / specific GAT
-                        (training mode only)                                           per layer, mod */
+                        (training mode only).  In the bf16 modes with B*N % 32 == 0 and B*N > 256 only the
+                        bf16 planes of this slot are written (its readers are contractions), the fp32
+                        values are not                                                 per layer, mod */
   DVGR_S_KINDS
 };
 
