@@ -903,6 +903,20 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       cb.j[cb.n++] = ColsumJob{ws + W.da_part[set][m], nullptr, nullptr, nullptr, B, 0, kHeads * 2 * F, kHeads * 2 * F, gmp(l, m) + P.gat_a};
       cb.j[cb.n++] = ColsumJob{ws + W.dc_part[set][m], nullptr, nullptr, nullptr, B, 0, kHeads, kHeads, gmp(l, m) + P.gat_c};
     }
+    // Layer 0 with the query branch folded into the side stream (a reducer is running, DVGR_OPT_NO_QUERY_STREAM): the
+    // layer's column sums go out BEFORE the branch and get an event of their own, so that the layer block's event -- and
+    // with it the block's all-reduce -- does not wait for the query branch queued behind them (it did: both last buckets
+    // became ready together, ~100 us after the main stream's last kernel).
+    hipEvent_t colsums_done = nullptr;
+    if (l == 0 && side && qs == hs) {
+      cb.chunks = 16;
+      DVGR_TRY(colsum(hs, cb));
+      cb.n = 0;
+      colsums_done = side->next();
+      if (!colsums_done) return (int)hipErrorOutOfMemory;
+      const hipError_t e3 = hipEventRecord(colsums_done, hs);
+      if (e3 != hipSuccess) return (int)e3;
+    }
     if (l == 0) DVGR_TRY(query_branch(0, 1, L == 1 ? 1 : 0));
     // S2 backward on the critical path: dX += drop_x(dWh . Wcat)
     {
@@ -967,15 +981,14 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       // behind its short tiles -- the layers > 0 put it on the side stream (measured: 1.245 ms per step against 1.272 with
       // it on the main stream, and 1.27 merged with the dX launch); layer 0 has no next layer and keeps it on the main
       // stream, which is idle by then.
-      hipStream_t dws = (side && l > 0) ? hs : st;      // (layer 0's on the side stream too: no difference, 1.179 ms both)
+      hipStream_t dws = (side && l > 0) ? hs : st;      // (beside a reducer as well: on the main stream 1.37-1.40 against 1.32 ms)      // (layer 0's on the side stream too: no difference, 1.179 ms both)
       const Probe dprobe{O, dws};
       // (cannot happen: lean_planes() implies the planes kernels; under it dpre / dWh have no fp32 copy for a column sum)
       if (lean && !gemm_rowsum_supported(IC, IC, gb, prec)) return DVGR_E_DIMS;
       DVGR_TRY(dprobe.begin(DVGR_PROBE_BWD_GAT_DW, l));
       DVGR_TRY(launch_dw(dws, gb, bias, TAG_BWD_GAT_DW, cb));     // (biases the engine cannot carry join the column sums)
       DVGR_TRY(dprobe.end(DVGR_PROBE_BWD_GAT_DW, l));
-      cb.chunks = 16;
-      DVGR_TRY(colsum(hs, cb));
+      if (cb.n) { cb.chunks = 16; DVGR_TRY(colsum(hs, cb)); }
       if (side) {
         side_done[set] = side->next();
         if (!side_done[set]) return (int)hipErrorOutOfMemory;
@@ -985,6 +998,10 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       if (layer_done_events && layer_done_events[l]) {
         if (dws == hs || !side) {
           DVGR_TRY(layer_done(l, hs));                   // every gradient of block l was written on the side stream
+        } else if (colsums_done && !cb.n) {              // (layer 0 beside a reducer: only the column sums, see above)
+          const hipError_t e4 = hipStreamWaitEvent(st, colsums_done, 0);
+          if (e4 != hipSuccess) return (int)e4;
+          DVGR_TRY(layer_done(l, st));
         } else {                                         // block l is written on both streams: the event is recorded on the
           DVGR_TRY(to_main());                           // main stream behind the side stream's column sums
           DVGR_TRY(layer_done(l, st));
