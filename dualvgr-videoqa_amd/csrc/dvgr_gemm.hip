@@ -746,11 +746,14 @@ constexpr int kPlaneTile = RT * BK;          // bf16 elements per plane tile
 
 __device__ __forceinline__ int plane_swz_ic(int k) { return (((k & 3) | (((k >> 3) & 1) << 2)) << 1); }
 
-template <int LAYOUT>
-__device__ __forceinline__ void planes_prep(const GemmOperand& op, int idx0, int dim, int wave, int lane, uint32_t (&off)[2]) {
+// NI = DMA instructions per loader wave and plane tile: 2 for a 128-row (or 128-column) tile, 1 for the 64-row KC tile of
+// the half-height variant (256 chunks).
+template <int LAYOUT, int NI = 2>
+__device__ __forceinline__ void planes_prep(const GemmOperand& op, int idx0, int dim, int wave, int lane, uint32_t (&off)[NI]) {
+  static_assert(NI == 2 || LAYOUT == KC, "the 64-row tile exists for row-major (KC) operands only");
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {              // 512 16-byte chunks per plane tile = 4 waves x 2 instructions x 64 lanes
-    const int S = (wave * 2 + i) * 64 + lane;
+  for (int i = 0; i < NI; ++i) {             // 512 (256) 16-byte chunks per plane tile = 4 waves x NI instructions x 64 lanes
+    const int S = (wave * NI + i) * 64 + lane;
     if (LAYOUT == KC) {
       const int row = S >> 2, slot = S & 3;
       const int chunk = slot ^ ((-(row >> 2)) & 3);
@@ -767,9 +770,10 @@ __device__ __forceinline__ void planes_prep(const GemmOperand& op, int idx0, int
   }
 }
 
-template <int LAYOUT, int TERMS>
+template <int LAYOUT, int TERMS, int NI = 2>
 __device__ __forceinline__ void planes_issue(const GemmOperand& op, int k0, int kseg, int wave, int lane,
-                                             const uint32_t (&off)[2], uint16_t* lds_hi /* lo tile follows */) {
+                                             const uint32_t (&off)[NI], uint16_t* lds_hi /* lo tile follows */) {
+  constexpr int kTile = NI * 256 * 8;          // bf16 elements of this operand's plane tile
   const uint16_t* base0;
   const uint16_t* base1;
   if (LAYOUT == KC) {
@@ -780,8 +784,8 @@ __device__ __forceinline__ void planes_issue(const GemmOperand& op, int k0, int 
     base1 = op.h1 + (int64_t)(k0 - kseg) * op.ld;
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int S0 = (wave * 2 + i) * 64;
+  for (int i = 0; i < NI; ++i) {
+    const int S0 = (wave * NI + i) * 64;
     const uint16_t* base = base0;
     if (LAYOUT == IC) {
       const int krow = (S0 + lane) >> 4;
@@ -791,9 +795,11 @@ __device__ __forceinline__ void planes_issue(const GemmOperand& op, int k0, int 
                                      (__attribute__((address_space(3))) void*)(lds_hi + S0 * 8), 16, 0, 0);
     if (TERMS == 3)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + op.lo_off + off[i]),
-                                       (__attribute__((address_space(3))) void*)(lds_hi + kPlaneTile + S0 * 8), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(lds_hi + kTile + S0 * 8), 16, 0, 0);
   }
 }
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int LAYOUT>
 __device__ __forceinline__ bf16x8 planes_frag(const uint16_t* tile, int idx16, int lane) {
@@ -836,27 +842,31 @@ __device__ long long g_gemm_clk[4096 * 8];
 #define GCLK_FLUSH(base) do { } while (0)
 #endif
 
-template <int TERMS, int NS>
+template <int TERMS, int NS, int RTM = RT>
 struct PlanesLds {
   static constexpr int kPlanes = (TERMS == 3) ? 2 : 1;
-  static constexpr int kSlot = 2 * kPlanes * kPlaneTile;       // A planes, then B planes
+  static constexpr int kTileA = RTM * BK;                      // bf16 elements of one A plane tile (RTM rows)
+  static constexpr int kSlot = kPlanes * (kTileA + kPlaneTile);  // A planes, then B planes
   static constexpr int kEpi = 8 * 32 * (16 * 2 + 4) * 2;       // epilogue scratch (8 waves), in bf16-sized elements
   static constexpr int kLds = (NS * kSlot) > kEpi ? (NS * kSlot) : kEpi;
 };
 
 // one 128 x 128 output tile of problem P (the whole workgroup: 8 computing + 4 loader waves)
-template <int LA, int LB, int TERMS, int NS>
+template <int LA, int LB, int TERMS, int NS, int RTM = RT>
 __device__ __forceinline__ void planes_tile(const GemmProblem& P, uint16_t* smem) {
+  static_assert(RTM == RT || (RTM == 64 && LA == KC), "half-height tiles: row-major A only");
   int m0, n0;
-  if (!tile_coords(P.M, P.N, RT, RT, &m0, &n0)) return;
+  if (!tile_coords(P.M, P.N, RTM, RT, &m0, &n0)) return;
 
-  constexpr int kPlanes = PlanesLds<TERMS, NS>::kPlanes;
-  constexpr int kSlot = PlanesLds<TERMS, NS>::kSlot;
+  constexpr int kPlanes = PlanesLds<TERMS, NS, RTM>::kPlanes;
+  constexpr int kSlot = PlanesLds<TERMS, NS, RTM>::kSlot;
+  constexpr int kTileA = PlanesLds<TERMS, NS, RTM>::kTileA;
+  constexpr int NIA = RTM / 64;                  // DMA instructions per loader wave for one A plane tile
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave12 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool loader = wave12 >= 8;
   const int wave = loader ? wave12 - 8 : wave12;
-  constexpr int MT = 4, NT = 2;
+  constexpr int MT = RTM / 32, NT = 2;           // 8 computing waves as 2 x 4: (RTM / 2) x 32 of the tile each
 
   const int nk_all = P.K / BK;
   const int per = (nk_all + (int)gridDim.y - 1) / (int)gridDim.y;
@@ -866,40 +876,34 @@ __device__ __forceinline__ void planes_tile(const GemmProblem& P, uint16_t* smem
   const int nk = (P.dbg & 2) ? 0 : nk_real;
 
   if (loader) {
-    uint32_t offA[2], offB[2];
-    planes_prep<LA>(P.A, m0, P.M, wave, lane, offA);
+    uint32_t offA[NIA], offB[2];
+    planes_prep<LA, NIA>(P.A, m0, P.M, wave, lane, offA);
     planes_prep<LB>(P.B, n0, P.N, wave, lane, offB);
     const bool nodma = (P.dbg & 8) != 0;         // timing aid (tools/gemm_shapes.py): barriers only
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
       if (s < nk && !nodma) {
-        planes_issue<LA, TERMS>(P.A, (kbeg + s) * BK, P.kseg, wave, lane, offA, smem + s * kSlot);
-        planes_issue<LB, TERMS>(P.B, (kbeg + s) * BK, P.kseg, wave, lane, offB, smem + s * kSlot + kPlanes * kPlaneTile);
+        planes_issue<LA, TERMS, NIA>(P.A, (kbeg + s) * BK, P.kseg, wave, lane, offA, smem + s * kSlot);
+        planes_issue<LB, TERMS>(P.B, (kbeg + s) * BK, P.kseg, wave, lane, offB, smem + s * kSlot + kPlanes * kTileA);
       }
     GCLK_DECL;
     GCLK_START();
     for (int kt = 0; kt < nk; ++kt) {
-      // 4 * kPlanes DMA instructions per K-tile from this wave: keep the (up to two) younger tiles in flight
+      // kPlanes * (NIA + 2) DMA instructions per K-tile from this wave: keep the (up to two) younger tiles in flight
       const int younger = (nk - 1 - kt) < NS - 2 ? (nk - 1 - kt) : NS - 2;
       GCLK_ADD(2);                                 // DMA issue (back-pressure of the vector memory path)
-      if (TERMS == 3) {
-        if (younger >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-        else if (younger == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      } else {
-        if (younger >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+      constexpr int kPer = kPlanes * (NIA + 2);   // DMA instructions of this wave per K-tile
+      if (younger >= 3) wait_vmcnt<3 * kPer>();
+      else if (younger == 2) wait_vmcnt<2 * kPer>();
+      else if (younger == 1) wait_vmcnt<kPer>();
+      else wait_vmcnt<0>();
       GCLK_ADD(0);                                 // waiting for the DMA of tile kt
       __builtin_amdgcn_s_barrier();
       GCLK_ADD(1);                                 // waiting for the consumers at the barrier
       if (kt + NS - 1 < nk && !nodma) {
         uint16_t* dst = smem + ((kt + NS - 1) % NS) * kSlot;
-        planes_issue<LA, TERMS>(P.A, (kbeg + kt + NS - 1) * BK, P.kseg, wave, lane, offA, dst);
-        planes_issue<LB, TERMS>(P.B, (kbeg + kt + NS - 1) * BK, P.kseg, wave, lane, offB, dst + kPlanes * kPlaneTile);
+        planes_issue<LA, TERMS, NIA>(P.A, (kbeg + kt + NS - 1) * BK, P.kseg, wave, lane, offA, dst);
+        planes_issue<LB, TERMS>(P.B, (kbeg + kt + NS - 1) * BK, P.kseg, wave, lane, offB, dst + kPlanes * kTileA);
       }
     }
     __builtin_amdgcn_s_barrier();
@@ -907,7 +911,7 @@ __device__ __forceinline__ void planes_tile(const GemmProblem& P, uint16_t* smem
     return;
   }
 
-  const int wm = (wave >> 2) * 64, wn = (wave & 3) * 32;
+  const int wm = (wave >> 2) * (RTM / 2), wn = (wave & 3) * 32;
   f32x4 acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -930,12 +934,12 @@ __device__ __forceinline__ void planes_tile(const GemmProblem& P, uint16_t* smem
     GCLK_ADD(0);                                   // waiting for tile kt
     if (P.dbg & 4) continue;                       // timing aid: barriers only, no fragment reads, no MFMAs
     const uint16_t* curA = smem + (kt % NS) * kSlot;
-    const uint16_t* curB = curA + kPlanes * kPlaneTile;
+    const uint16_t* curB = curA + kPlanes * kTileA;
     bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       ah[i] = planes_frag<LA>(curA, wm + i * 16, lane);
-      if (TERMS == 3) al[i] = planes_frag<LA>(curA + kPlaneTile, wm + i * 16, lane);
+      if (TERMS == 3) al[i] = planes_frag<LA>(curA + kTileA, wm + i * 16, lane);
     }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -979,11 +983,11 @@ __device__ __forceinline__ void planes_tile(const GemmProblem& P, uint16_t* smem
   if (wave == 0) GCLK_FLUSH(0);
 }
 
-template <int LA, int LB, int TAG, int TERMS, int NS = RS>
+template <int LA, int LB, int TAG, int TERMS, int NS = RS, int RTM = RT>
 __global__ __launch_bounds__(768) void gemm_planes_kernel(const GemmBatch batch) {
-  __shared__ __attribute__((aligned(16))) uint16_t smem[PlanesLds<TERMS, NS>::kLds];
+  __shared__ __attribute__((aligned(16))) uint16_t smem[PlanesLds<TERMS, NS, RTM>::kLds];
   const GemmProblem P = batch.p[blockIdx.z];
-  planes_tile<LA, LB, TERMS, NS>(P, smem);
+  planes_tile<LA, LB, TERMS, NS, RTM>(P, smem);
 }
 
 // Problems of DIFFERENT operand layouts in one launch (GemmProblem::layout): the backward's data gradient dX += dWh . Wcat
@@ -1215,6 +1219,23 @@ static int launch_ring(hipStream_t stream, const GemmBatch& b, int prec) {
   if (split > 1) { const int ez = zero_split_outputs(stream, b); if (ez) return ez; }
   if (prec != DVGR_F32 && planes_eligible(b, LA, LB)) {
     // (2 ring slots = 64 KB would let two workgroups share a CU; measured slower alone and under the side stream)
+    if (LA == KC && split == 1 && total <= 128) {
+      // few tiles (the MFB contractions, the query branch, everything at small B N): 64-row tiles put twice as many
+      // workgroups on the chip, each with 3/4 of the DMA bytes and half the MFMAs of a full tile per K-step
+      int tiles_h = 0;
+      for (int i = 0; i < b.n; ++i) {
+        const int t = ((b.p[i].M + 63) / 64) * ((b.p[i].N + RT - 1) / RT);
+        tiles_h = t > tiles_h ? t : tiles_h;
+      }
+      static const bool no_half = []() { const char* e = getenv("DVGR_NO_HALF_TILES"); return e && e[0] == '1'; }();   // A/B timing aid
+      if (!no_half) {
+        const dim3 grid_h(8 * ((tiles_h + 7) / 8), 1, b.n);
+        constexpr int LAH = KC;                    // (the branch is dead for LA == IC; keeps the instantiation legal)
+        if (prec == DVGR_BF16X3) hipLaunchKernelGGL((gemm_planes_kernel<LAH, LB, TAG, 3, RS, 64>), grid_h, block, 0, stream, b);
+        else hipLaunchKernelGGL((gemm_planes_kernel<LAH, LB, TAG, 1, RS, 64>), grid_h, block, 0, stream, b);
+        return (int)hipGetLastError();
+      }
+    }
     if (prec == DVGR_BF16X3) hipLaunchKernelGGL((gemm_planes_kernel<LA, LB, TAG, 3>), grid, block, 0, stream, b);
     else hipLaunchKernelGGL((gemm_planes_kernel<LA, LB, TAG, 1>), grid, block, 0, stream, b);
     return (int)hipGetLastError();
