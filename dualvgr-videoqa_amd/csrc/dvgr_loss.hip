@@ -316,7 +316,10 @@ static int launch_grad_cpt(hipStream_t st, const AuxArgs& a) {
 template <int NB>
 static int launch_grad(hipStream_t st, const AuxArgs& a) {
   constexpr int kMaxCpt = NB <= 24 ? 3 : NB <= 32 ? 2 : 1;      // VGPR (CPT * NB accumulators) and LDS (CPT * N KB) budget
-  const int cpt = (a.D + 255) / 256;
+  // One column per thread (20 KB of LDS at N = 20) although three would reuse each scalar-loaded W row three times: the
+  // kernel runs beside the forward's last contractions, whose workgroups need 96-128 KB of a compute unit's 160 KB and
+  // cannot be placed next to two 61 KB workgroups of this one (measured: 1.118 -> 1.108 ms per step at C2).
+  const int cpt = 1;
   if (cpt >= 3 && kMaxCpt >= 3) return launch_grad_cpt<NB, kMaxCpt>(st, a);
   if (cpt >= 2 && kMaxCpt >= 2) return launch_grad_cpt<NB, (kMaxCpt >= 2 ? 2 : 1)>(st, a);
   return launch_grad_cpt<NB, 1>(st, a);
