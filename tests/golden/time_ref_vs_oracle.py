@@ -5,15 +5,16 @@ times on the GPU box) on the same CPU cores -- forward + backward, training mode
 the visual embedding plus the two auxiliary losses as the scalar.  The reference draws its dropout masks inside the timed
 region (torch RNG), the oracle gets injected masks; everything else is the same arithmetic.
 
-    PYTHONDONTWRITEBYTECODE=1 python tools/cpu_ref_vs_oracle.py [threads]"""
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/time_ref_vs_oracle.py [threads]"""
 import os
 import sys
 import time
 
 sys.dont_write_bytecode = True
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+sys.path.insert(0, HERE)
 import torch
 
 import make_golden_model as MG                       # device-string shims + the imported reference (model.models)
