@@ -136,7 +136,7 @@ def cpu_baseline(cfg, seconds=15.0):
             "sample": f"B={Bs} of the {cfg['B']}-pair batch, N={cfg['N']} L={cfg['L']} T={cfg['T']} fp32 TRAINING-mode "
                       f"forward+backward (keep-masks injected), naive (B,N,N,2F) form, 2 warm-up + {n} timed steps, "
                       f"{dt * 1e3:.1f} ms/step, {cores} threads on {model}; in the build container (8 cores) this port "
-                      f"takes 0.92 x the time of the imported reference itself (tests/golden/time_ref_vs_oracle.py, DESIGN.md section 6b)"}
+                      f"takes 0.92-0.96 x the time of the imported reference itself (tests/golden/time_ref_vs_oracle.py, DESIGN.md section 6b)"}
 
 
 _RESULT_FD = None
