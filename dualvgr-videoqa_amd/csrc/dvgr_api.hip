@@ -719,10 +719,25 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     gb.p[gb.n] = tn(ws + W.dp1, kMfbHidden, ms(L - 1, 1) + S.x, D, gp + P.mfb_w1, D, kMfbHidden, D, BN);
     PM.attach(gb.p[gb.n++]);
     ColsumBatch cb{};
-    DVGR_TRY(launch_mixed(st, gb, bias, TAG_GENERIC, cb));
-    if (cb.n) { cb.chunks = 16; DVGR_TRY(colsum(st, cb)); }
+    if (side && !gemm_mixed_supported(gb, prec)) {
+      // (small batches: the batch-sized kernels take the weight gradients.)  They are leaves: side stream, behind a fork
+      GemmBatch gn{}, gt{};
+      BiasOf bt[kMaxBatch] = {};
+      for (int i = 0; i < gb.n; ++i) {
+        if (gb.p[i].layout == LAYOUT_TN) { bt[gt.n] = bias[i]; gt.p[gt.n++] = gb.p[i]; }
+        else gn.p[gn.n++] = gb.p[i];
+      }
+      DVGR_TRY(side->order(st, hs));
+      DVGR_TRY(gemm_launch(st, KC, IC, gn, TAG_GENERIC, prec));
+      DVGR_TRY(launch_dw(hs, gt, bt, TAG_GENERIC, cb));
+      if (cb.n) { cb.chunks = 16; DVGR_TRY(colsum(hs, cb)); }
+      DVGR_TRY(layer_done(L, hs));
+    } else {
+      DVGR_TRY(launch_mixed(st, gb, bias, TAG_GENERIC, cb));
+      if (cb.n) { cb.chunks = 16; DVGR_TRY(colsum(st, cb)); }
+      DVGR_TRY(layer_done(L, st));
+    }
   }
-  DVGR_TRY(layer_done(L, st));
 
   // ---- query branch (S1 tail and S0 backward) of the layers [lo, hi), batched over them: d q-bar, the row kernels and
   // d(dq) form a dependent chain (query_chain); d Wq, d W1 and the bias / vector gradients of the query block are its
@@ -813,8 +828,18 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
   // Order on the query stream: chain and contractions of the layers >= 1 (issued at layer 1, they finish in the gap
   // before layer 0's d p exists), then layer 0's chain and contractions, then the leaves of ALL layers in one small
   // contraction launch and one column-sum launch.
+  hipEvent_t chain0_done = nullptr;          // small batches: layer 0's chain is done (the main stream takes its contractions)
   auto query_branch = [&](int lo, int hi, int first) -> int {
     DVGR_TRY(query_chain(lo, hi, qs, first));
+    if (lo == 0 && side && !use_qs && !(O.flags & DVGR_OPT_NO_QUERY_STREAM)) {
+      // small batch, no query stream: the branch would end as a serial tail on the side stream after the main stream has
+      // gone idle; its two contractions go to the main stream instead (issued at the end), the leaves stay here
+      chain0_done = side->next();
+      if (!chain0_done) return (int)hipErrorOutOfMemory;
+      const hipError_t e = hipEventRecord(chain0_done, qs);
+      if (e != hipSuccess) return (int)e;
+      return query_leaves(0, L, qs);
+    }
     DVGR_TRY(query_gemms(lo, hi, qs));
     return lo == 0 ? query_leaves(0, L, qs) : 0;
   };
@@ -1010,6 +1035,11 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     }
   }
 
+  if (chain0_done) {
+    const hipError_t e = hipStreamWaitEvent(st, chain0_done, 0);
+    if (e != hipSuccess) return (int)e;
+    DVGR_TRY(query_gemms(0, 1, st));
+  }
   // ---- the caller's stream sees every gradient: it waits for the side stream and the query stream
   DVGR_TRY(to_main());
   if (side && qs != hs) DVGR_TRY(side->order(qs, st));
