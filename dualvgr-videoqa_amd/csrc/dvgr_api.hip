@@ -719,8 +719,10 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     gb.p[gb.n] = tn(ws + W.dp1, kMfbHidden, ms(L - 1, 1) + S.x, D, gp + P.mfb_w1, D, kMfbHidden, D, BN);
     PM.attach(gb.p[gb.n++]);
     ColsumBatch cb{};
-    if (side && !gemm_mixed_supported(gb, prec)) {
-      // (small batches: the batch-sized kernels take the weight gradients.)  They are leaves: side stream, behind a fork
+    if (side) {
+      // The three weight gradients are leaves (40 K-steps per tile against 16 for dA / dM): side stream, behind a fork, under
+      // the last layer's S5 backward; dA / dM alone are 120 tiles and take the 64-row kernel.  (One mixed launch on the
+      // main stream: 1.115 against 1.100 ms.  Small batches: the batch-sized kernels take the weight gradients.)
       GemmBatch gn{}, gt{};
       BiasOf bt[kMaxBatch] = {};
       for (int i = 0; i < gb.n; ++i) {
