@@ -12,7 +12,7 @@ before it makes any GPU call -- launches exactly that torchrun command as a chil
 whose world size differs from --gpus fails; it never silently measures fewer GPUs.
 
 Timing: W untimed warm-up steps, then blocks of EXACTLY K steps, each bracketed by barrier + device synchronise on both
-sides and MAX-reduced over ranks; blocks repeat until >= 1 s has been timed and the line reports the MEDIAN block
+sides and MAX-reduced over ranks; blocks repeat until >= 5 s has been timed and the line reports the MEDIAN block
 (`value` = world * B * K / median block time).  Rank 0 prints ONE JSON line: whole-job QA-pairs/s, the roofline of the
 dominant kernel (the forward GAT projection contraction, timed live with HIP events on its launch stream), the optimiser
 (clip + Adam) time reported separately, and the CPU baseline (the oracle's op-for-op PyTorch-CPU restatement of the
@@ -44,7 +44,7 @@ CONFIGS = {
 }
 D, WD = 768, 300
 PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0}     # /opt/skills/guides/MI355X_MICROARCH.md, dense MFMA
-MIN_TIMED_S = 1.0
+MIN_TIMED_S = 5.0          # the driver's GPU-busy sampler has a period of ~5 s: a 1 s timed region read 0 % busy in two rounds
 MAX_BLOCKS = 200
 
 
@@ -349,19 +349,25 @@ def main():
                    "bwd_gat_dw": (L_.PROBE_BWD_GAT_DW, 8 * B * N * D * D, "dWcat = dWh^T.X (TAG_BWD_GAT_DW)"),
                    "bwd_gat_dx": (L_.PROBE_BWD_GAT_DX, 8 * B * N * D * D, "dX += dWh.Wcat (TAG_BWD_GAT_DX)")}
     site, probe_flops, probe_name = probe_sites[args.probe]
+    # second probe: the kernel that dominates the profile BY TIME, the per-layer weight-gradient launch (dP1 + dWcat of one
+    # layer with their bias gradients, 16 B N D^2 FLOP); probed on alternate probed steps, on the stream it is launched on
+    site2, probe2_flops, probe2_name = (L_.PROBE_BWD_GAT_DW, 16 * B * N * D * D,
+                                        "per-layer weight-gradient launch dP1 = dpre^T.z + dWcat = dWh^T.X (TAG_BWD_GAT_DW)")
     # layer 0's Wh contraction shares the chip with the query-side chain on the side stream; layer 1's runs alone
     probe_layer = min(1, Lr - 1)
     # timing events without the system-scope fence at their record (their documented use): closer to the kernel's own duration
     # every PROBE_EVERY-th timed step carries the pair (two event records cost the probed stream ~10 us of bubbles)
     PROBE_EVERY = 4
     pairs = [(L_.ProbeEvent(), L_.ProbeEvent()) for _ in range((args.steps + PROBE_EVERY - 1) // PROBE_EVERY)]
+    launches = {"count": 0, "steps": 0}
     for ev in (events or []):
         ev.record()          # torch creates the hipEvent lazily at the first record; the C ABI needs the handle
 
     def step(i=None):
         if i is not None:
             if i % PROBE_EVERY == 0:
-                m.set_probe(site, probe_layer, pairs[i // PROBE_EVERY][0], pairs[i // PROBE_EVERY][1])
+                k = i // PROBE_EVERY
+                m.set_probe(site if k % 2 == 0 else site2, probe_layer, pairs[k][0], pairs[k][1])
             else:
                 m.set_probe(0)
         m.zero_grad_flat()
@@ -392,7 +398,10 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    lib = L_.load()
+    n0 = lib.dvgr_dbg_launch_count()
     blocks = timed_blocks(step, args.steps, ddp, dev, args.min_seconds)
+    launches_per_step = (lib.dvgr_dbg_launch_count() - n0) / (len(blocks) * args.steps)
     m.set_probe(0)
     dt = float(np.median(blocks))
 
@@ -412,8 +421,9 @@ def main():
 
     ms_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt
-    probe_ms = float(np.mean([a.elapsed_time(b) for a, b in pairs]))
+    probe_ms = float(np.mean([a.elapsed_time(b) for a, b in pairs[0::2]]))
     achieved = probe_flops / (probe_ms * 1e-3) / 1e12
+    probe2_ms = float(np.mean([a.elapsed_time(b) for a, b in pairs[1::2]])) if len(pairs) > 1 else None
     peak = PEAK_TFLOPS[args.dtype]
     f_train = 3 * f_fwd(N, Lr, T)
     pmc = pmc_record(args.config, args.dtype, not args.eval_mode) if args.probe == "fwd_gat_gemm" else None
@@ -431,6 +441,7 @@ def main():
                            "upstream gradients of sum(vis)+common+1e-8*HSIC for all 3+4L outputs, precomputed once",
                    "timing": {"blocks": len(blocks), "steps_per_block": args.steps, "timed_s": float(sum(blocks)),
                               "ms_per_step_min_median_max": [min(blocks) / args.steps * 1e3, ms_step, max(blocks) / args.steps * 1e3]},
+                   "launches_per_step": launches_per_step,      # kernel launches of the library per timed step (dvgr_dbg_launch_count)
                    "optimizer_ms": optimizer_ms,
                    "optimizer": "clip_grad_norm_(12) + Adam over the unit's flat parameter / gradient buffers, two fused launches "
                                 "(dvgr_optim_*), OUTSIDE the timed step",
@@ -445,7 +456,12 @@ def main():
                      "mfma_pipe_busy_pmc": pmc.get("mfma_busy") if pmc else None,
                      "pmc_source": pmc.get("source") if pmc else None,
                      "kernel": probe_name, "launch_ms": probe_ms,
-                     "algorithmic_gflop_per_launch": probe_flops / 1e9, "build": build_id()},
+                     "algorithmic_gflop_per_launch": probe_flops / 1e9, "build": build_id(),
+                     # the launch that dominates the profile by time (the GAT projection above is the kernel north_star names)
+                     "dominant_by_time": None if probe2_ms is None else {
+                         "kernel": probe2_name, "launch_ms": probe2_ms, "algorithmic_gflop_per_launch": probe2_flops / 1e9,
+                         "achieved": probe2_flops / (probe2_ms * 1e-3) / 1e12, "frac": probe2_flops / (probe2_ms * 1e-3) / 1e12 / peak,
+                         "note": "runs beside the next layer's critical-path kernels on the side stream: its in-step duration"}},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)

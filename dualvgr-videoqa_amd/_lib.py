@@ -101,6 +101,7 @@ SYMBOLS += [
     ("dvgr_dbg_gemm_planes_batch", C.c_int, [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                                  C.c_int64, C.c_int64, C.c_void_p, C.c_int64] + [C.c_int] * 6 + [C.c_void_p, C.c_int, C.c_void_p]),
     ("dvgr_dbg_event_destroy", C.c_int, [C.c_void_p]),
+    ("dvgr_dbg_launch_count", C.c_longlong, []),
 ]
 
 _lib = None

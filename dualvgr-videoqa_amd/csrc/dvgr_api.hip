@@ -11,6 +11,7 @@
 using namespace dvgr;
 
 namespace dvgr {
+std::atomic<long long> g_launch_count{0};
 size_t gat_lds_bytes_max(int N, int F);
 size_t aux_ws_floats(const dvgr_dims& d);
 int aux_losses(hipStream_t st, const dvgr_dims& d, const dvgr_io* io, float alpha, float beta, float dep_scale,
@@ -1175,6 +1176,8 @@ int dvgr_dbg_event_elapsed_ms(void* begin, void* end, float* ms) {
   return (int)r;
 }
 int dvgr_dbg_event_destroy(void* event) { return event ? (int)hipEventDestroy((hipEvent_t)event) : 0; }
+
+long long dvgr_dbg_launch_count(void) { return dvgr::g_launch_count.load(std::memory_order_relaxed); }
 
 uint32_t dvgr_dbg_site_key(uint64_t seed, int layer, int mod, int gat, int which) {
   return site_key(seed, drop_site(layer, mod, gat, which));

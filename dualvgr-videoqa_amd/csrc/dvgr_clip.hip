@@ -343,9 +343,9 @@ int dvgr_lstm_forward(const dvgr_clip_dims* dp, const float* params, const dvgr_
   const int embed = (flags & DVGR_LSTM_EMBED_INPUT) ? 1 : 0;
 
   CLIP_TRY(split_weights(st, params, P, w_p, nW));
-  hipLaunchKernelGGL(k_clip_bias, dim3(blocks_for(8 * H)), dim3(256), 0, st, params + P.bih, params + P.bhh, ws + W.bias, 8 * H);
+  DVGR_LAUNCH(k_clip_bias, dim3(blocks_for(8 * H)), dim3(256), 0, st, params + P.bih, params + P.bhh, ws + W.bias, 8 * H);
   CLIP_LAUNCH_OK();
-  hipLaunchKernelGGL(k_clip_embed, dim3(blocks_for(TS * V / 4)), dim3(256), 0, st, io->x, sv + SV.e, e_p, e_lo,
+  DVGR_LAUNCH(k_clip_embed, dim3(blocks_for(TS * V / 4)), dim3(256), 0, st, io->x, sv + SV.e, e_p, e_lo,
                      clip_key(train && embed, seed, 0), S, T, V, embed);
   CLIP_LAUNCH_OK();
   {  // input contraction of every step and both directions
@@ -366,12 +366,12 @@ int dvgr_lstm_forward(const dvgr_clip_dims* dp, const float* params, const dvgr_
       }
       CLIP_TRY(gemm_launch(st, KC, KC, b, TAG_GENERIC, prec));
     }
-    hipLaunchKernelGGL(k_clip_cell_fwd, dim3(blocks_for((int64_t)S * 2 * H / 4)), dim3(256), 0, st, sv + SV.g, sv + SV.c, sv + SV.h,
+    DVGR_LAUNCH(k_clip_cell_fwd, dim3(blocks_for((int64_t)S * 2 * H / 4)), dim3(256), 0, st, sv + SV.g, sv + SV.c, sv + SV.h,
                        h_p, h_lo, S, H, t[0], t[1], k > 0 ? 1 : 0, io->lens, io->out_seq, T);
     CLIP_LAUNCH_OK();
   }
   if (io->out_final) {
-    hipLaunchKernelGGL(k_clip_out, dim3(blocks_for((int64_t)S * 2 * H)), dim3(256), 0, st, (const float*)(sv + SV.h + (int64_t)(T - 1) * S * 2 * H),
+    DVGR_LAUNCH(k_clip_out, dim3(blocks_for((int64_t)S * 2 * H)), dim3(256), 0, st, (const float*)(sv + SV.h + (int64_t)(T - 1) * S * 2 * H),
                        (const float*)(sv + SV.h), io->out_final, (float*)nullptr, (float*)nullptr,
                        clip_key(train && (flags & DVGR_LSTM_DROP_FINAL), seed, 1), S, H);
     CLIP_LAUNCH_OK();
@@ -408,12 +408,12 @@ int dvgr_lstm_backward(const dvgr_clip_dims* dp, const float* params, const dvgr
   CLIP_TRY(split_weights(st, params, P, w_p, nW));
   // dh of the last step = g_final through the output dropout (both halves: the forward direction's last step is frame
   // T-1, the reverse direction's is frame 0, and both are step T-1); dc = 0; nothing carried yet
-  hipLaunchKernelGGL(k_clip_out, dim3(blocks_for((int64_t)S * 2 * H)), dim3(256), 0, st, gr->g_final, gr->g_final, ws + W.dh, ws + W.dc,
+  DVGR_LAUNCH(k_clip_out, dim3(blocks_for((int64_t)S * 2 * H)), dim3(256), 0, st, gr->g_final, gr->g_final, ws + W.dh, ws + W.dc,
                      io->lens ? ws + W.carry : (float*)nullptr, clip_key(train && (flags & DVGR_LSTM_DROP_FINAL), seed, 1), S, H);
   CLIP_LAUNCH_OK();
   for (int k = T - 1; k >= 0; --k) {
     const int t[2] = {k, T - 1 - k};
-    hipLaunchKernelGGL(k_clip_cell_bwd, dim3(blocks_for((int64_t)S * 2 * H / 4)), dim3(256), 0, st, sv + SV.g, g_p, g_lo, sv + SV.c,
+    DVGR_LAUNCH(k_clip_cell_bwd, dim3(blocks_for((int64_t)S * 2 * H / 4)), dim3(256), 0, st, sv + SV.g, g_p, g_lo, sv + SV.c,
                        ws + W.dh, ws + W.dc, S, H, t[0], t[1], k > 0 ? 1 : 0, io->lens, ws + W.carry, gr->g_seq, T);
     CLIP_LAUNCH_OK();
     if (k > 0) {     // dh of the previous step = dG[t] Whh
@@ -463,7 +463,7 @@ int dvgr_lstm_backward(const dvgr_clip_dims* dp, const float* params, const dvgr
     b.p[b.n] = problem(opnd(sv + SV.g, 8 * H, g_p, g_lo), opnd(params + P.wih, V, w_p, nW), ws + W.de, V, nullptr, (int)TS, V, 8 * H, 1);
     b.p[b.n++].atomic_ok = 1;
     CLIP_TRY(gemm_launch(st, KC, IC, b, TAG_GENERIC, prec));
-    hipLaunchKernelGGL(k_clip_gx, dim3(blocks_for(TS * V / 4)), dim3(256), 0, st, (const float*)(ws + W.de), (const float*)(sv + SV.e), gr->g_x,
+    DVGR_LAUNCH(k_clip_gx, dim3(blocks_for(TS * V / 4)), dim3(256), 0, st, (const float*)(ws + W.de), (const float*)(sv + SV.e), gr->g_x,
                        clip_key(train && embed, seed, 0), S, T, V, embed);
     CLIP_LAUNCH_OK();
   }
@@ -493,7 +493,7 @@ int dvgr_clip_dbg_keep_mask(uint64_t seed, int site, int64_t n, float* keep, voi
   if (!keep) return DVGR_E_NULL;
   if (site < 0 || site > 1 || n < 0) return DVGR_E_DIMS;
   if (n == 0) return 0;
-  hipLaunchKernelGGL(k_clip_keep_mask, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, site_key(seed, kClipSiteBase + (uint32_t)site),
+  DVGR_LAUNCH(k_clip_keep_mask, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, site_key(seed, kClipSiteBase + (uint32_t)site),
                      n, keep, site == 0 ? kThreshIn : kThreshOut);
   return (int)hipGetLastError();
 }

@@ -4,9 +4,20 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/dvgr.h"
 
 namespace dvgr {
+
+// Every kernel launch of the library goes through DVGR_LAUNCH: one relaxed atomic increment per launch, read back by
+// dvgr_dbg_launch_count() (include/dvgr_debug.h) -- bench.py reports launches per step from it.
+extern std::atomic<long long> g_launch_count;
+#define DVGR_LAUNCH(...)                                                    \
+  do {                                                                      \
+    ::dvgr::g_launch_count.fetch_add(1, std::memory_order_relaxed);         \
+    hipLaunchKernelGGL(__VA_ARGS__);                                        \
+  } while (0)
 
 constexpr int kHeads = 8;          // 4 common-GAT heads + 4 specific-GAT heads per modality
 constexpr int kMfbHidden = 512;    // mm_dim * factor   (model/fusions/fusions.py:384-395 defaults)

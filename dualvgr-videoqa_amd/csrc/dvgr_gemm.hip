@@ -12,6 +12,15 @@
 
 namespace dvgr {
 
+// Timing aids (GemmProblem::dbg: skip the epilogue / the K loop / the MFMAs / the DMA; the DVGR_FORCE_WIDE and
+// DVGR_NO_HALF_TILES environment switches) exist only in -DDVGR_TIMING_AIDS builds (`make aids`, used by tools/ab.sh and
+// tools/gemm_shapes.py): the shipped K loops carry no debug branches and the library reads no environment variables.
+#ifdef DVGR_TIMING_AIDS
+#define DVGR_DBG(P) ((P).dbg)
+#else
+#define DVGR_DBG(P) 0
+#endif
+
 constexpr int BK = 32;  // reduction depth of one LDS stage
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -569,13 +578,13 @@ __global__ __launch_bounds__(768) void gemm_ring_kernel(const GemmBatch batch) {
   const int kbeg = (int)blockIdx.y * per;
   const int nk_real = (nk_all - kbeg) < per ? (nk_all - kbeg) : per;
   if (nk_real <= 0) return;
-  const int nk = (P.dbg & 2) ? 0 : nk_real;
+  const int nk = (DVGR_DBG(P) & 2) ? 0 : nk_real;
 
   if (loader) {
     uint32_t offA[4], offB[4];
     ring_prep<LA>(P.A, m0, P.M, wave, lane, offA);
     ring_prep<LB>(P.B, n0, P.N, wave, lane, offB);
-    const bool nodma = (P.dbg & 8) != 0;
+    const bool nodma = (DVGR_DBG(P) & 8) != 0;
 #pragma unroll
     for (int s = 0; s < RS - 1; ++s)
       if (s < nk && !nodma) {
@@ -624,7 +633,7 @@ __global__ __launch_bounds__(768) void gemm_ring_kernel(const GemmBatch batch) {
     __builtin_amdgcn_s_barrier();
     const float* curA = smem + (kt % RS) * kRingSlot;
     const float* curB = curA + kRingTile;
-    if (P.dbg & 4) continue;
+    if (DVGR_DBG(P) & 4) continue;
     if (PREC == DVGR_F32) {
       float fa[MT][8], fb[NT][8];
 #pragma unroll
@@ -723,7 +732,7 @@ __global__ __launch_bounds__(768) void gemm_ring_kernel(const GemmBatch batch) {
     }
   }
   __builtin_amdgcn_s_barrier();      // every consumer is done reading the ring; the loaders leave here
-  if (P.dbg & 1) { if (acc[0][0][0] == 12345.678f) P.C[0] = 1.f; return; }
+  if (DVGR_DBG(P) & 1) { if (acc[0][0][0] == 12345.678f) P.C[0] = 1.f; return; }
   if (do_rs) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) rs[i] += rs_total[i];
@@ -873,13 +882,13 @@ __device__ __forceinline__ void planes_tile(const GemmProblem& P, uint16_t* smem
   const int kbeg = (int)blockIdx.y * per;
   const int nk_real = (nk_all - kbeg) < per ? (nk_all - kbeg) : per;
   if (nk_real <= 0) return;
-  const int nk = (P.dbg & 2) ? 0 : nk_real;
+  const int nk = (DVGR_DBG(P) & 2) ? 0 : nk_real;
 
   if (loader) {
     uint32_t offA[NIA], offB[2];
     planes_prep<LA, NIA>(P.A, m0, P.M, wave, lane, offA);
     planes_prep<LB>(P.B, n0, P.N, wave, lane, offB);
-    const bool nodma = (P.dbg & 8) != 0;         // timing aid (tools/gemm_shapes.py): barriers only
+    const bool nodma = (DVGR_DBG(P) & 8) != 0;         // timing aid (tools/gemm_shapes.py): barriers only
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
       if (s < nk && !nodma) {
@@ -932,7 +941,7 @@ __device__ __forceinline__ void planes_tile(const GemmProblem& P, uint16_t* smem
     GCLK_ADD(1);                                   // fragment reads + MFMAs of the previous tile
     __builtin_amdgcn_s_barrier();
     GCLK_ADD(0);                                   // waiting for tile kt
-    if (P.dbg & 4) continue;                       // timing aid: barriers only, no fragment reads, no MFMAs
+    if (DVGR_DBG(P) & 4) continue;                       // timing aid: barriers only, no fragment reads, no MFMAs
     const uint16_t* curA = smem + (kt % NS) * kSlot;
     const uint16_t* curB = curA + kPlanes * kTileA;
     bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
@@ -976,7 +985,7 @@ __device__ __forceinline__ void planes_tile(const GemmProblem& P, uint16_t* smem
   }
   __builtin_amdgcn_s_barrier();
   GCLK_ADD(1);
-  if (P.dbg & 1) { if (acc[0][0][0] == 12345.678f) P.C[0] = 1.f; return; }
+  if (DVGR_DBG(P) & 1) { if (acc[0][0][0] == 12345.678f) P.C[0] = 1.f; return; }
   if (do_rs) store_rowsum<MT>(P, rs, m0 + wm, lane);
   epilogue_rows<MT, NT>(P, acc, m0 + wm, n0 + wn, lane, reinterpret_cast<float*>(smem) + wave * (32 * (16 * NT + 4)), gridDim.y > 1 || P.atomic_out);
   GCLK_ADD(2);
@@ -1126,7 +1135,9 @@ static bool planes_eligible(const GemmBatch& b, int la, int lb) {
 }
 
 static bool dbg_any(const GemmBatch& b) {
+#ifdef DVGR_TIMING_AIDS
   for (int i = 0; i < b.n; ++i) if (b.p[i].dbg) return true;
+#endif
   return false;
 }
 static bool rowsum_any(const GemmBatch& b) {
@@ -1146,7 +1157,7 @@ static int zero_split_outputs(hipStream_t stream, const GemmBatch& b) {
   bool any = false;
   for (int i = 0; i < b.n; ++i) any = any || (b.p[i].zero_on_split && !b.p[i].accumulate);
   if (!any) return 0;
-  hipLaunchKernelGGL(k_zero_outputs, dim3(128, b.n), dim3(256), 0, stream, b);
+  DVGR_LAUNCH(k_zero_outputs, dim3(128, b.n), dim3(256), 0, stream, b);
   return (int)hipGetLastError();
 }
 
@@ -1197,7 +1208,11 @@ static int launch_ring(hipStream_t stream, const GemmBatch& b, int prec) {
       total_w += t;
     }
     const bool long_k = atomic_ok && nk_min >= 256;
+#ifdef DVGR_TIMING_AIDS
     static const bool force_wide = []() { const char* e = getenv("DVGR_FORCE_WIDE"); return e && e[0] == '1'; }();   // A/B timing aid
+#else
+    constexpr bool force_wide = false;
+#endif
     if (total_w >= 480 || (long_k && total_w >= 128) || force_wide) {
       int split_w = 1;
       if (long_k) {
@@ -1210,8 +1225,8 @@ static int launch_ring(hipStream_t stream, const GemmBatch& b, int prec) {
       }
       const dim3 grid_w(8 * ((tiles_w + 7) / 8), split_w, b.n);
       if (split_w > 1) { const int ez = zero_split_outputs(stream, b); if (ez) return ez; }
-      if (prec == DVGR_BF16X3) hipLaunchKernelGGL((gemm_planes_wide_kernel<LA, LB, 3>), grid_w, dim3(768), 0, stream, b);
-      else hipLaunchKernelGGL((gemm_planes_wide_kernel<LA, LB, 1>), grid_w, dim3(768), 0, stream, b);
+      if (prec == DVGR_BF16X3) DVGR_LAUNCH((gemm_planes_wide_kernel<LA, LB, 3>), grid_w, dim3(768), 0, stream, b);
+      else DVGR_LAUNCH((gemm_planes_wide_kernel<LA, LB, 1>), grid_w, dim3(768), 0, stream, b);
       return (int)hipGetLastError();
     }
   }
@@ -1227,22 +1242,26 @@ static int launch_ring(hipStream_t stream, const GemmBatch& b, int prec) {
         const int t = ((b.p[i].M + 63) / 64) * ((b.p[i].N + RT - 1) / RT);
         tiles_h = t > tiles_h ? t : tiles_h;
       }
+#ifdef DVGR_TIMING_AIDS
       static const bool no_half = []() { const char* e = getenv("DVGR_NO_HALF_TILES"); return e && e[0] == '1'; }();   // A/B timing aid
+#else
+      constexpr bool no_half = false;
+#endif
       if (!no_half) {
         const dim3 grid_h(8 * ((tiles_h + 7) / 8), 1, b.n);
         constexpr int LAH = KC;                    // (the branch is dead for LA == IC; keeps the instantiation legal)
-        if (prec == DVGR_BF16X3) hipLaunchKernelGGL((gemm_planes_kernel<LAH, LB, TAG, 3, RS, 64>), grid_h, block, 0, stream, b);
-        else hipLaunchKernelGGL((gemm_planes_kernel<LAH, LB, TAG, 1, RS, 64>), grid_h, block, 0, stream, b);
+        if (prec == DVGR_BF16X3) DVGR_LAUNCH((gemm_planes_kernel<LAH, LB, TAG, 3, RS, 64>), grid_h, block, 0, stream, b);
+        else DVGR_LAUNCH((gemm_planes_kernel<LAH, LB, TAG, 1, RS, 64>), grid_h, block, 0, stream, b);
         return (int)hipGetLastError();
       }
     }
-    if (prec == DVGR_BF16X3) hipLaunchKernelGGL((gemm_planes_kernel<LA, LB, TAG, 3>), grid, block, 0, stream, b);
-    else hipLaunchKernelGGL((gemm_planes_kernel<LA, LB, TAG, 1>), grid, block, 0, stream, b);
+    if (prec == DVGR_BF16X3) DVGR_LAUNCH((gemm_planes_kernel<LA, LB, TAG, 3>), grid, block, 0, stream, b);
+    else DVGR_LAUNCH((gemm_planes_kernel<LA, LB, TAG, 1>), grid, block, 0, stream, b);
     return (int)hipGetLastError();
   }
-  if (prec == DVGR_BF16X3) hipLaunchKernelGGL((gemm_ring_kernel<LA, LB, TAG, DVGR_BF16X3>), grid, block, 0, stream, b);
-  else if (prec == DVGR_BF16) hipLaunchKernelGGL((gemm_ring_kernel<LA, LB, TAG, DVGR_BF16>), grid, block, 0, stream, b);
-  else hipLaunchKernelGGL((gemm_ring_kernel<LA, LB, TAG, DVGR_F32>), grid, block, 0, stream, b);
+  if (prec == DVGR_BF16X3) DVGR_LAUNCH((gemm_ring_kernel<LA, LB, TAG, DVGR_BF16X3>), grid, block, 0, stream, b);
+  else if (prec == DVGR_BF16) DVGR_LAUNCH((gemm_ring_kernel<LA, LB, TAG, DVGR_BF16>), grid, block, 0, stream, b);
+  else DVGR_LAUNCH((gemm_ring_kernel<LA, LB, TAG, DVGR_F32>), grid, block, 0, stream, b);
   return (int)hipGetLastError();
 }
 
@@ -1269,9 +1288,9 @@ static int launch_cfg(hipStream_t stream, const GemmBatch& b, int prec) {
   }
   if (tiles == 0) return 0;
   const dim3 grid(8 * ((tiles + 7) / 8), 1, b.n), block(256);
-  if (prec == DVGR_BF16X3) hipLaunchKernelGGL((gemm_lp_kernel<LA, LB, BM, BN, TAG, 3>), grid, block, 0, stream, b);
-  else if (prec == DVGR_BF16) hipLaunchKernelGGL((gemm_lp_kernel<LA, LB, BM, BN, TAG, 1>), grid, block, 0, stream, b);
-  else hipLaunchKernelGGL((gemm_kernel<LA, LB, BM, BN, TAG>), grid, block, 0, stream, b);
+  if (prec == DVGR_BF16X3) DVGR_LAUNCH((gemm_lp_kernel<LA, LB, BM, BN, TAG, 3>), grid, block, 0, stream, b);
+  else if (prec == DVGR_BF16) DVGR_LAUNCH((gemm_lp_kernel<LA, LB, BM, BN, TAG, 1>), grid, block, 0, stream, b);
+  else DVGR_LAUNCH((gemm_kernel<LA, LB, BM, BN, TAG>), grid, block, 0, stream, b);
   return (int)hipGetLastError();
 }
 
@@ -1329,11 +1348,11 @@ int gemm_launch_mixed(hipStream_t stream, const GemmBatch& b, int tag, int prec)
   if (tiles == 0) return 0;
   const dim3 grid(8 * ((tiles + 7) / 8), 1, b.n), block(768);
   if (tag == TAG_BWD_GAT_DX) {
-    if (prec == DVGR_BF16X3) hipLaunchKernelGGL((gemm_planes_mixed_kernel<TAG_BWD_GAT_DX, 3>), grid, block, 0, stream, b);
-    else hipLaunchKernelGGL((gemm_planes_mixed_kernel<TAG_BWD_GAT_DX, 1>), grid, block, 0, stream, b);
+    if (prec == DVGR_BF16X3) DVGR_LAUNCH((gemm_planes_mixed_kernel<TAG_BWD_GAT_DX, 3>), grid, block, 0, stream, b);
+    else DVGR_LAUNCH((gemm_planes_mixed_kernel<TAG_BWD_GAT_DX, 1>), grid, block, 0, stream, b);
   } else {
-    if (prec == DVGR_BF16X3) hipLaunchKernelGGL((gemm_planes_mixed_kernel<TAG_GENERIC, 3>), grid, block, 0, stream, b);
-    else hipLaunchKernelGGL((gemm_planes_mixed_kernel<TAG_GENERIC, 1>), grid, block, 0, stream, b);
+    if (prec == DVGR_BF16X3) DVGR_LAUNCH((gemm_planes_mixed_kernel<TAG_GENERIC, 3>), grid, block, 0, stream, b);
+    else DVGR_LAUNCH((gemm_planes_mixed_kernel<TAG_GENERIC, 1>), grid, block, 0, stream, b);
   }
   return (int)hipGetLastError();
 }

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void k_head_drop(const float* x, float* out, u
   out[r * ld + c] = x[r * ld + c] * drop_factor(key, (uint32_t)i);
 }
 int head_drop(hipStream_t st, const float* x, float* out, uint32_t key, int64_t rows, int cols, int64_t ld) {
-  hipLaunchKernelGGL(k_head_drop, dim3((unsigned)((rows * cols + 255) / 256)), dim3(256), 0, st, x, out, key, rows, cols, ld);
+  DVGR_LAUNCH(k_head_drop, dim3((unsigned)((rows * cols + 255) / 256)), dim3(256), 0, st, x, out, key, rows, cols, ld);
   return (int)hipGetLastError();
 }
 
@@ -324,13 +324,13 @@ int dvgr_head_forward(const dvgr_head_dims* dp, const float* params, const dvgr_
     xd = sv + S.xd;
   }
   HEAD_TRY(launch1(st, KC, KC, nt(xd, D, params + P.wv, D, sv + S.e, D, nullptr, BN, D, D, ACT_ELU), prec));
-  hipLaunchKernelGGL(k_readout_fwd, dim3(B), dim3(256), 0, st, sv + S.e, xd, params + P.wa, params + P.ba, sv + S.attn, sv + S.cat, N, D);
+  DVGR_LAUNCH(k_readout_fwd, dim3(B), dim3(256), 0, st, sv + S.e, xd, params + P.wa, params + P.ba, sv + S.attn, sv + S.cat, N, D);
   HEAD_LAUNCH_OK();
   // classifier
   HEAD_TRY(launch1(st, KC, KC, nt(io->qe, D, params + P.wq, D, sv + S.cat + D, 2 * D, params + P.bq, B, D, D, ACT_NONE), prec));
   if (drop) HEAD_TRY(head_drop(st, sv + S.cat, sv + S.cat, head_key(1, seed, 1), B, 2 * D, 2 * D));
   HEAD_TRY(launch1(st, KC, KC, nt(sv + S.cat, 2 * D, params + P.w1, 2 * D, sv + S.he, D, params + P.b1, B, D, 2 * D, ACT_ELU), prec));
-  hipLaunchKernelGGL(k_bn_fwd, dim3((D + 63) / 64), dim3(64), 0, st, sv + S.he, params + P.gamma, params + P.beta, io->run_mean,
+  DVGR_LAUNCH(k_bn_fwd, dim3((D + 63) / 64), dim3(64), 0, st, sv + S.he, params + P.gamma, params + P.beta, io->run_mean,
                      io->run_var, sv + S.mean, sv + S.istd, sv + S.yd, head_key(drop, seed, 2), B, D, bn_train);
   HEAD_LAUNCH_OK();
   HEAD_TRY(launch1(st, KC, KC, nt(sv + S.yd, D, params + P.w2, D, io->logits, C, params + P.b2, B, C, D, ACT_NONE), prec));
@@ -370,7 +370,7 @@ int dvgr_head_backward(const dvgr_head_dims* dp, const float* params, const dvgr
   cb.j[cb.n++] = ColsumJob{g->g_logits, nullptr, nullptr, nullptr, B, 0, C, C, gp + P.b2};
   HEAD_TRY(launch1(st, KC, IC, nn(g->g_logits, C, params + P.w2, D, ws + W.dyd, D, B, D, C, 0), prec));
   // dropout 2, BatchNorm1d, ELU
-  hipLaunchKernelGGL(k_bn_bwd, dim3((D + 63) / 64), dim3(64), 0, st, ws + W.dyd, sv + S.he, params + P.gamma, sv + S.mean,
+  DVGR_LAUNCH(k_bn_bwd, dim3((D + 63) / 64), dim3(64), 0, st, ws + W.dyd, sv + S.he, params + P.gamma, sv + S.mean,
                      sv + S.istd, gp + P.gamma, gp + P.beta, ws + W.dpre1, head_key(drop, seed, 2), B, D, bn_train);
   HEAD_LAUNCH_OK();
   if (side) HEAD_TRY(side->order(st, hs));                  // fork 1: gparams is zeroed, dpre1 final
@@ -384,7 +384,7 @@ int dvgr_head_backward(const dvgr_head_dims* dp, const float* params, const dvgr
   cb.j[cb.n++] = ColsumJob{ws + W.dcat + D, nullptr, nullptr, nullptr, B, 0, D, 2 * D, gp + P.bq};
   HEAD_TRY(launch1(st, KC, IC, nn(ws + W.dcat + D, 2 * D, params + P.wq, D, g->g_qe, D, B, D, D, 0), prec));
   // read-out
-  hipLaunchKernelGGL(k_readout_bwd, dim3(B), dim3(256), 0, st, ws + W.dcat, xd, sv + S.e, sv + S.attn, params + P.wa, ws + W.dl,
+  DVGR_LAUNCH(k_readout_bwd, dim3(B), dim3(256), 0, st, ws + W.dcat, xd, sv + S.e, sv + S.attn, params + P.wa, ws + W.dl,
                      g->g_vis, ws + W.dvp, N, D);
   HEAD_LAUNCH_OK();
   if (side) HEAD_TRY(side->order(st, hs));                  // fork 2: dcat, dl, dvp final
@@ -408,7 +408,7 @@ int dvgr_head_cross_entropy(const dvgr_head_dims* dp, int C_valid, const float* 
   hipStream_t st = (hipStream_t)stream;
   const hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), st);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(k_cross_entropy, dim3((dp->B + 3) / 4), dim3(256), 0, st, logits, target, loss, g_logits, dp->B, dp->C, C_valid, scale);
+  DVGR_LAUNCH(k_cross_entropy, dim3((dp->B + 3) / 4), dim3(256), 0, st, logits, target, loss, g_logits, dp->B, dp->C, C_valid, scale);
   return (int)hipGetLastError();
 }
 

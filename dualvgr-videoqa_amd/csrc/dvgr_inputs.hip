@@ -86,7 +86,7 @@ int dvgr_words_forward(const float* table, int64_t vocab, int wd, const int64_t*
   if (!aligned16(table) || !aligned16(words)) return DVGR_E_ALIGN;
   if (n == 0) return 0;
   const uint32_t key = train ? site_key(seed, kWordsSite) : 0u;
-  hipLaunchKernelGGL(k_words_fwd, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, table, vocab, wd, tokens, n, key,
+  DVGR_LAUNCH(k_words_fwd, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, table, vocab, wd, tokens, n, key,
                      words, bad_tokens);
   return (int)hipGetLastError();
 }
@@ -101,7 +101,7 @@ int dvgr_words_backward(const float* g_words, const float* words, const int64_t*
   if (e != hipSuccess) return (int)e;
   if (n == 0) return 0;
   const uint32_t key = train ? site_key(seed, kWordsSite) : 0u;
-  hipLaunchKernelGGL(k_words_bwd, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, g_words, words, tokens, n, vocab, wd, key, g_table);
+  DVGR_LAUNCH(k_words_bwd, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, g_words, words, tokens, n, vocab, wd, key, g_table);
   return (int)hipGetLastError();
 }
 
@@ -109,7 +109,7 @@ int dvgr_words_dbg_keep_mask(uint64_t seed, int64_t count, float* keep, void* st
   if (!keep) return DVGR_E_NULL;
   if (count < 0 || count >= (1ll << 32)) return DVGR_E_DIMS;
   if (count == 0) return 0;
-  hipLaunchKernelGGL(k_words_keep, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, site_key(seed, kWordsSite), count,
+  DVGR_LAUNCH(k_words_keep, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, site_key(seed, kWordsSite), count,
                      keep);
   return (int)hipGetLastError();
 }
@@ -131,7 +131,7 @@ int dvgr_linear_forward(const float* x, const float* w, const float* b, float* y
     if (b) {
       if (!aligned16(b)) return DVGR_E_ALIGN;
       const int64_t n4 = (int64_t)M * (N / 4);
-      hipLaunchKernelGGL(k_fill_bias, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, y, b, (int64_t)M, N);
+      DVGR_LAUNCH(k_fill_bias, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, y, b, (int64_t)M, N);
       const hipError_t e = hipGetLastError();
       if (e != hipSuccess) return (int)e;
       p.bias = nullptr; p.accumulate = 1; p.atomic_ok = 1;

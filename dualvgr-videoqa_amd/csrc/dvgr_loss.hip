@@ -286,7 +286,7 @@ static int launch_gram_nt(hipStream_t st, const AuxArgs& a) {
   const size_t lds = sizeof(float) * ((size_t)a.D + (NT * (NT + 1) / 2) * 256);
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_aux_gram<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_aux_gram<NT>, dim3(a.B, a.L * 4), dim3(256), lds, st, a);
+  DVGR_LAUNCH(k_aux_gram<NT>, dim3(a.B, a.L * 4), dim3(256), lds, st, a);
   return (int)hipGetLastError();
 }
 static int launch_gram(hipStream_t st, const AuxArgs& a) {
@@ -299,7 +299,7 @@ static int launch_gram(hipStream_t st, const AuxArgs& a) {
 }
 
 int sum_and_ones(hipStream_t st, const float* x, float* g_ones, int64_t n, float* out) {
-  hipLaunchKernelGGL(k_sum_and_ones, dim3(256), dim3(256), 0, st, x, g_ones, n, out);
+  DVGR_LAUNCH(k_sum_and_ones, dim3(256), dim3(256), 0, st, x, g_ones, n, out);
   return (int)hipGetLastError();
 }
 
@@ -310,7 +310,7 @@ static int launch_grad_cpt(hipStream_t st, const AuxArgs& a) {
   const size_t lds = sizeof(float) * CPT * a.N * 256;
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_aux_grad<NB, CPT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((k_aux_grad<NB, CPT>), dim3(a.B, a.L * 4), dim3(256), lds, st, a);
+  DVGR_LAUNCH((k_aux_grad<NB, CPT>), dim3(a.B, a.L * 4), dim3(256), lds, st, a);
   return (int)hipGetLastError();
 }
 template <int NB>
@@ -345,12 +345,12 @@ int aux_losses(hipStream_t st, const dvgr_dims& d, const dvgr_io* io, float alph
   hipError_t e = hipMemsetAsync(loss3, 0, 3 * sizeof(float), st);
   if (e != hipSuccess) return (int)e;
   const int64_t nv = (int64_t)d.B * d.N * d.D;
-  if (io->vis) hipLaunchKernelGGL(k_sum_and_ones, dim3(256), dim3(256), 0, st, io->vis, g_vis, nv, loss3);
+  if (io->vis) DVGR_LAUNCH(k_sum_and_ones, dim3(256), dim3(256), 0, st, io->vis, g_vis, nv, loss3);
   DVGR_TRY_HIP(launch_gram(st, a));
   const size_t lds2 = sizeof(float) * (6 * NN + 6 * d.N + 8);
   if (lds2 > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_aux_combine), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-  hipLaunchKernelGGL(k_aux_combine, dim3(d.B, d.L), dim3(256), lds2, st, a);
+  DVGR_LAUNCH(k_aux_combine, dim3(d.B, d.L), dim3(256), lds2, st, a);
   if ((e = hipGetLastError()) != hipSuccess) return (int)e;
   switch (nb_of(d.N)) {
     case 8: return launch_grad<8>(st, a);

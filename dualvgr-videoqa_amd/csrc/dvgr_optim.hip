@@ -120,7 +120,7 @@ int dvgr_optim_grad_sqnorm(const dvgr_optim_seg* segs, int nseg, float* sqnorm, 
     SegTable t{};
     const int cnt = (nseg - base) < kSegsPerLaunch ? (nseg - base) : kSegsPerLaunch;
     for (int i = 0; i < cnt; ++i) t.s[i] = segs[base + i];
-    hipLaunchKernelGGL(k_optim_sqnorm, table_grid(t, cnt), dim3(256), 0, st, t, sqnorm);
+    DVGR_LAUNCH(k_optim_sqnorm, table_grid(t, cnt), dim3(256), 0, st, t, sqnorm);
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess) return (int)le;
   }
@@ -142,7 +142,7 @@ int dvgr_optim_adam_step(const dvgr_optim_seg* segs, int nseg, const float* sqno
     SegTable t{};
     const int cnt = (nseg - base) < kSegsPerLaunch ? (nseg - base) : kSegsPerLaunch;
     for (int i = 0; i < cnt; ++i) t.s[i] = segs[base + i];
-    hipLaunchKernelGGL(k_optim_adam, table_grid(t, cnt), dim3(256), 0, st, t, a);
+    DVGR_LAUNCH(k_optim_adam, table_grid(t, cnt), dim3(256), 0, st, t, a);
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess) return (int)le;
   }

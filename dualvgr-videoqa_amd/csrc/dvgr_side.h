@@ -42,9 +42,13 @@ struct SideStream {
     st = shared_side_stream(dev, 0);
     return st ? 0 : (int)hipErrorOutOfMemory;
   }
-  // the query stream, created on first use (DVGR_OPT_NO_QUERY_STREAM / DVGR_NO_QUERY_STREAM=1: the side stream instead)
+  // the query stream, created on first use (DVGR_OPT_NO_QUERY_STREAM, or DVGR_NO_QUERY_STREAM=1 in a -DDVGR_TIMING_AIDS build: the side stream instead)
   hipStream_t query(bool allowed) {
+#ifdef DVGR_TIMING_AIDS
     static const bool env_off = []() { const char* e = getenv("DVGR_NO_QUERY_STREAM"); return e && e[0] == '1'; }();
+#else
+    constexpr bool env_off = false;
+#endif
     if (!allowed || env_off) return st;
     if (!st2) {
       int dev = 0;

@@ -232,7 +232,7 @@ bool small_eligible(const GemmBatch& b, int la, int lb) {
 int small_launch(hipStream_t st, int la, int lb, const GemmBatch& b) {
   int mx = 0, nx = 0;
   for (int i = 0; i < b.n; ++i) { mx = b.p[i].M > mx ? b.p[i].M : mx; nx = b.p[i].N > nx ? b.p[i].N : nx; }
-  if (la == KC && lb == KC) hipLaunchKernelGGL(k_small_nt, dim3((nx + 15) / 16, (mx + 63) / 64, b.n), dim3(256), 0, st, b);
+  if (la == KC && lb == KC) DVGR_LAUNCH(k_small_nt, dim3((nx + 15) / 16, (mx + 63) / 64, b.n), dim3(256), 0, st, b);
   else if (la == KC && lb == IC) {
     // few output tiles and a long reduction: split K over workgroups when every output may be added to atomically
     const int rowblocks = (mx + 63) / 64, tiles = ((nx + 15) / 16) * rowblocks * b.n;
@@ -241,9 +241,9 @@ int small_launch(hipStream_t st, int la, int lb, const GemmBatch& b) {
     for (int i = 0; i < b.n; ++i) { atomic_ok = atomic_ok && b.p[i].atomic_ok && b.p[i].accumulate; kmin = b.p[i].K < kmin ? b.p[i].K : kmin; }
     int ksplit = 1;
     if (atomic_ok && tiles < 128) { ksplit = 256 / tiles; if (ksplit > kmin / 128) ksplit = kmin / 128; if (ksplit < 1) ksplit = 1; }
-    hipLaunchKernelGGL(k_small_nn, dim3((nx + 15) / 16, rowblocks * ksplit, b.n), dim3(256), 0, st, b, rowblocks);
+    DVGR_LAUNCH(k_small_nn, dim3((nx + 15) / 16, rowblocks * ksplit, b.n), dim3(256), 0, st, b, rowblocks);
   }
-  else hipLaunchKernelGGL(k_small_tn, dim3((nx + 63) / 64, (mx + 63) / 64, b.n), dim3(256), 0, st, b);
+  else DVGR_LAUNCH(k_small_tn, dim3((nx + 63) / 64, (mx + 63) / 64, b.n), dim3(256), 0, st, b);
   return (int)hipGetLastError();
 }
 

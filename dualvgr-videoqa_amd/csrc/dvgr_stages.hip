@@ -102,8 +102,8 @@ __global__ __launch_bounds__(256) void k_qa_rows_attn(const QaRowsArgs a) {
 
 int qa_rows_fwd(hipStream_t st, const QaRowsArgs& a) {
   const int64_t rows = (int64_t)a.L * a.B * a.T;
-  hipLaunchKernelGGL(k_qa_rows_norm, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(k_qa_rows_attn, dim3(a.B, a.L), dim3(256), 0, st, a);
+  DVGR_LAUNCH(k_qa_rows_norm, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a);
+  DVGR_LAUNCH(k_qa_rows_attn, dim3(a.B, a.L), dim3(256), 0, st, a);
   DVGR_LAUNCH_CHECK();
 }
 
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_punish_fwd(const float* X0, const float
 int punish_fwd(hipStream_t st, const float* X0, const float* X1, const float* p0, const float* p1,
                float* s0, float* s1, int B, int N, int D) {
   const int rows = B * N;
-  hipLaunchKernelGGL(k_punish_fwd, dim3((rows + 3) / 4, 2), dim3(256), 0, st, X0, X1, p0, p1, s0, s1, rows, N, D);
+  DVGR_LAUNCH(k_punish_fwd, dim3((rows + 3) / 4, 2), dim3(256), 0, st, X0, X1, p0, p1, s0, s1, rows, N, D);
   DVGR_LAUNCH_CHECK();
 }
 
@@ -291,7 +291,7 @@ static int gat_attn_fwd_nt(hipStream_t st, const GatAttnArgs& a) {
   const size_t lds = gat_fwd_lds(a.N, a.D / 4);
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gat_attn_fwd<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_gat_attn_fwd<NT>, dim3(a.B, kHeads, 2), dim3(256), lds, st, a);
+  DVGR_LAUNCH(k_gat_attn_fwd<NT>, dim3(a.B, kHeads, 2), dim3(256), lds, st, a);
   DVGR_LAUNCH_CHECK();
 }
 
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void k_sf_combine_fwd(const SfCombineArgs a) {
 }
 
 int sf_combine_fwd(hipStream_t st, const SfCombineArgs& a) {
-  hipLaunchKernelGGL(k_sf_combine_fwd, dim3((a.rows + 3) / 4, 2), dim3(256), 0, st, a);
+  DVGR_LAUNCH(k_sf_combine_fwd, dim3((a.rows + 3) / 4, 2), dim3(256), 0, st, a);
   DVGR_LAUNCH_CHECK();
 }
 
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void k_mfb_pool_fwd(const float* x0, const flo
 }
 int mfb_pool_fwd(hipStream_t st, const float* x0, const float* x1, float* z, int rows, uint16_t* zp, int64_t lo_off) {
   const int64_t n = (int64_t)rows * kMfbPooled;
-  hipLaunchKernelGGL(k_mfb_pool_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x0, x1, z, n, zp, lo_off);
+  DVGR_LAUNCH(k_mfb_pool_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x0, x1, z, n, zp, lo_off);
   DVGR_LAUNCH_CHECK();
 }
 
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void k_elu_bwd(const float* g, const float* y,
 }
 int elu_bwd(hipStream_t st, const float* g, const float* y, float* out, int64_t n, uint16_t* op, int64_t lo_off) {
   const int64_t n4 = n / 4;
-  hipLaunchKernelGGL(k_elu_bwd, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, g, y, out, n4, op, lo_off);
+  DVGR_LAUNCH(k_elu_bwd, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, g, y, out, n4, op, lo_off);
   DVGR_LAUNCH_CHECK();
 }
 
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void k_mfb_pool_bwd(const float* dz, const flo
 int mfb_pool_bwd(hipStream_t st, const float* dz, const float* x0, const float* x1, float* dp0, float* dp1, int rows,
                  uint16_t* p0, uint16_t* p1, int64_t lo_off) {
   const int64_t n = (int64_t)rows * kMfbPooled;
-  hipLaunchKernelGGL(k_mfb_pool_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dz, x0, x1, dp0, dp1, n, p0, p1, lo_off);
+  DVGR_LAUNCH(k_mfb_pool_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dz, x0, x1, dp0, dp1, n, p0, p1, lo_off);
   DVGR_LAUNCH_CHECK();
 }
 
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) void k_sf_bwd(const SfBwdArgs a) {
   }
 }
 int sf_bwd(hipStream_t st, const SfBwdArgs& a) {
-  hipLaunchKernelGGL(k_sf_bwd, dim3((a.rows + 3) / 4, 2), dim3(256), 0, st, a);
+  DVGR_LAUNCH(k_sf_bwd, dim3((a.rows + 3) / 4, 2), dim3(256), 0, st, a);
   DVGR_LAUNCH_CHECK();
 }
 
@@ -737,7 +737,7 @@ static int gat_attn_bwd_nt(hipStream_t st, const GatAttnBwdArgs& a) {
   const size_t lds = gat_bwd_lds(a.N, a.D / 4);
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gat_attn_bwd<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_gat_attn_bwd<NT>, dim3(a.B, kHeads, 2), dim3(256), lds, st, a);
+  DVGR_LAUNCH(k_gat_attn_bwd<NT>, dim3(a.B, kHeads, 2), dim3(256), lds, st, a);
   DVGR_LAUNCH_CHECK();
 }
 
@@ -792,7 +792,7 @@ __global__ __launch_bounds__(256) void k_punish_bwd(const PunishBwdArgs a) {
   if (parts & 1) a.dp_cat[(int64_t)b * 2 * D + mod * D + d] = acc;
 }
 int punish_bwd(hipStream_t st, const PunishBwdArgs& a) {
-  hipLaunchKernelGGL(k_punish_bwd, dim3(a.B, 2, (a.D + 255) / 256), dim3(256), 0, st, a);
+  DVGR_LAUNCH(k_punish_bwd, dim3(a.B, 2, (a.D + 255) / 256), dim3(256), 0, st, a);
   DVGR_LAUNCH_CHECK();
 }
 
@@ -880,8 +880,8 @@ __global__ __launch_bounds__(256) void k_qa_bwd(const QaBwdArgs a) {
 }
 int qa_bwd(hipStream_t st, const QaBwdArgs& a) {
   const int64_t rows = (int64_t)a.L * a.B * a.T;
-  hipLaunchKernelGGL(k_qa_bwd_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(k_qa_bwd, dim3(a.B, kQaChunks), dim3(256), 0, st, a);
+  DVGR_LAUNCH(k_qa_bwd_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a);
+  DVGR_LAUNCH(k_qa_bwd, dim3(a.B, kQaChunks), dim3(256), 0, st, a);
   DVGR_LAUNCH_CHECK();
 }
 
@@ -948,7 +948,7 @@ int colsum(hipStream_t st, const ColsumBatch& b) {
   int maxc = 0;
   for (int i = 0; i < b.n; ++i) maxc = b.j[i].cols > maxc ? b.j[i].cols : maxc;
   const int chunks = b.chunks > 1 ? b.chunks : 1;
-  hipLaunchKernelGGL(k_colsum, dim3((maxc + 255) / 256, b.n, chunks), dim3(256), 0, st, b);
+  DVGR_LAUNCH(k_colsum, dim3((maxc + 255) / 256, b.n, chunks), dim3(256), 0, st, b);
   DVGR_LAUNCH_CHECK();
 }
 
@@ -978,7 +978,7 @@ __global__ __launch_bounds__(256) void k_drop_x(const float* X0, const float* X1
 int drop_x(hipStream_t st, const float* X0, const float* X1, float* out0, float* out1, const uint32_t (&key)[2][2], int64_t n,
            uint16_t* p0, uint16_t* p1, int64_t lo_off) {
   const int64_t n4 = n / 4;
-  hipLaunchKernelGGL(k_drop_x, dim3((unsigned)((n4 + 255) / 256), 2), dim3(256), 0, st, X0, X1, out0, out1,
+  DVGR_LAUNCH(k_drop_x, dim3((unsigned)((n4 + 255) / 256), 2), dim3(256), 0, st, X0, X1, out0, out1,
                      key[0][0], key[0][1], key[1][0], key[1][1], n4, p0, p1, lo_off);
   DVGR_LAUNCH_CHECK();
 }
@@ -1010,7 +1010,7 @@ int split_planes(hipStream_t st, const SplitBatch& b) {
   int64_t mx = 0;
   for (int i = 0; i < b.n; ++i) mx = b.j[i].n > mx ? b.j[i].n : mx;
   const int64_t blocks = (mx / 4 + 255) / 256;
-  hipLaunchKernelGGL(k_split_planes, dim3((unsigned)(blocks > 2048 ? 2048 : blocks), b.n), dim3(256), 0, st, b);
+  DVGR_LAUNCH(k_split_planes, dim3((unsigned)(blocks > 2048 ? 2048 : blocks), b.n), dim3(256), 0, st, b);
   DVGR_LAUNCH_CHECK();
 }
 
@@ -1027,7 +1027,7 @@ __global__ __launch_bounds__(256) void k_to_bf16(const float* src, uint16_t* dst
   dst[i] = (uint16_t)r;
 }
 int to_bf16(hipStream_t st, const float* src, void* dst, int64_t n) {
-  hipLaunchKernelGGL(k_to_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, (uint16_t*)dst, n);
+  DVGR_LAUNCH(k_to_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, (uint16_t*)dst, n);
   DVGR_LAUNCH_CHECK();
 }
 
@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(256) void k_keep_mask(uint32_t key, int64_t n, floa
   if (i < n) keep[i] = drop_keep(key, (uint32_t)i) ? 1.0f : 0.0f;
 }
 int keep_mask_launch(hipStream_t st, uint32_t key, int64_t n, float* keep) {
-  hipLaunchKernelGGL(k_keep_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, key, n, keep);
+  DVGR_LAUNCH(k_keep_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, key, n, keep);
   return (int)hipGetLastError();
 }
 // ---- zero a list of ranges -------------------------------------------------------------------------------------
@@ -1065,7 +1065,7 @@ int zero_ranges(hipStream_t st, const ZeroList& z) {
   for (int i = 0; i < z.count; ++i) longest = z.n[i] > longest ? z.n[i] : longest;
   int gx = (int)((longest / 4 + 255) / 256);
   gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
-  hipLaunchKernelGGL(k_zero_ranges, dim3(gx, z.count), dim3(256), 0, st, z);
+  DVGR_LAUNCH(k_zero_ranges, dim3(gx, z.count), dim3(256), 0, st, z);
   return (int)hipGetLastError();
 }
 

@@ -30,6 +30,73 @@ def layer_buckets(module) -> List[Tuple[int, int]]:
     return [module.layer_param_range(l) for l in block_order(module.layers)]
 
 
+class CollectiveIssuer:
+    """The ONE ordered place from which a process enqueues its gradient collectives on a device.
+
+    RCCL pairs collectives across ranks by issue order on a communicator, so every rank must issue the same sequence.
+    The producers are the autograd thread's hooks and the backward's host callbacks: their PROGRAM order is identical on
+    every rank (same graph, same bucket tables).  Two reducers with a helper thread each would enqueue in an order that
+    depends on thread scheduling -- the head bucket and the unit's MFB block become ready within ~100 us of each other --
+    and a mismatch pairs all-reduces of different sizes (hang or corrupt gradients).  So: one FIFO, one helper thread, one
+    communication stream per device, shared by `LayerBucketReducer` and `ParamBucketReducer`; items run in posting order."""
+
+    _by_device = {}
+    _lock = None
+
+    def __init__(self, device: torch.device):
+        import queue
+        import threading
+        self.device = device
+        # high priority: the runtime gives such a stream a hardware queue of its own; a normal-priority one was seen
+        # sharing the caller's queue, where its event waits sit in front of the backward's later launches
+        self.stream = torch.cuda.Stream(device=device, priority=-1)
+        self.q = queue.Queue()
+        self.errors = []
+        self.log = None                      # tests: list that receives a tag per item, in execution order
+
+        def worker():
+            torch.cuda.set_device(device)
+            while True:
+                item = self.q.get()
+                try:
+                    if item is None:
+                        return
+                    fn, args, tag = item
+                    if self.log is not None:
+                        self.log.append(tag)
+                    fn(*args)
+                except BaseException as e:      # surfaced by the posting reducer's finish()
+                    self.errors.append(e)
+                finally:
+                    self.q.task_done()
+
+        self.thread = threading.Thread(target=worker, daemon=True, name=f"dvgr-collectives-{device}")
+        self.thread.start()
+
+    @classmethod
+    def get(cls, device: torch.device) -> "CollectiveIssuer":
+        import threading
+        if cls._lock is None:
+            cls._lock = threading.Lock()
+        key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+        with cls._lock:
+            it = cls._by_device.get(key)
+            if it is None:
+                it = cls._by_device[key] = CollectiveIssuer(torch.device(*key))
+            return it
+
+    def post(self, fn, args=(), tag=None) -> None:
+        self.q.put((fn, args, tag))
+
+    def join(self) -> None:
+        """Every posted item has been ENQUEUED on the communication stream (not executed: that is stream-ordered)."""
+        self.q.join()
+        if self.errors:
+            err = self.errors[0]
+            self.errors.clear()
+            raise err
+
+
 class LayerBucketReducer:
     """Averages a flat gradient buffer across ranks, one all-reduce per layer bucket."""
 
@@ -38,10 +105,10 @@ class LayerBucketReducer:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.stream = None
+        self.issuer = None
         if device is not None and device.type == "cuda":
-            # high priority: the runtime gives such a stream a hardware queue of its own; a normal-priority one was seen
-            # sharing the caller's queue, where its event waits sit in front of the backward's later launches
-            self.stream = torch.cuda.Stream(device=device, priority=-1)
+            self.issuer = CollectiveIssuer.get(device)     # shared with every other reducer of this process (issue order)
+            self.stream = self.issuer.stream
 
     def _layer_order(self) -> List[int]:
         """Block index of bucket i (`layer_buckets` order: MFB = L, then L-1 .. 0, then the query block L+1)."""
@@ -84,33 +151,12 @@ class LayerBucketReducer:
     # (dvgr_opts.layer_done_cb / DualVGRUnit_multiple.set_layer_callback): the collective of a bucket enters the
     # communication stream the moment its event has been enqueued, not after the whole backward has been launched.
     def start(self, num_layers: int, threaded: bool = True) -> None:
-        """Begin one step.  threaded: the collectives are enqueued by a helper thread, so that their host cost (tens of
-        microseconds each) does not sit in the backward's launch path -- the callback only posts the bucket."""
+        """Begin one step.  threaded: the collectives are enqueued by the process's CollectiveIssuer thread, so that their
+        host cost (tens of microseconds each) does not sit in the backward's launch path -- the callback only posts the
+        bucket, and the issuer keeps ONE issue order over all reducers."""
         self._works = []
         self._bucket_of_layer = {layer: i for i, layer in enumerate(block_order(num_layers))}
-        self._error = None
-        if threaded and self.stream is not None and getattr(self, "_q", None) is None:
-            import queue
-            import threading
-            self._q = queue.Queue()
-            dev = self.stream.device
-
-            def worker():
-                torch.cuda.set_device(dev)
-                while True:
-                    item = self._q.get()
-                    try:
-                        if item is None:
-                            return
-                        self._launch_now(*item)
-                    except BaseException as e:      # surfaced by finish()
-                        self._error = e
-                    finally:
-                        self._q.task_done()
-
-            self._thread = threading.Thread(target=worker, daemon=True)
-            self._thread.start()
-        self._threaded = bool(threaded) and getattr(self, "_q", None) is not None
+        self._threaded = bool(threaded) and self.issuer is not None
 
     def _launch_now(self, layer_index: int, flat_grad: torch.Tensor, event=None, caller_stream=None) -> None:
         a, b = self.buckets[self._bucket_of_layer[layer_index]]
@@ -141,17 +187,14 @@ class LayerBucketReducer:
             return
         cur = torch.cuda.current_stream(flat_grad.device) if flat_grad.is_cuda else None
         if getattr(self, "_threaded", False) and flat_grad.is_cuda:
-            self._q.put((layer_index, flat_grad, event, cur))
+            self.issuer.post(self._launch_now, (layer_index, flat_grad, event, cur), ("unit", layer_index))
         else:
             self._launch_now(layer_index, flat_grad, event, cur)
 
     def finish(self) -> None:
         """After the backward call: scale every launched bucket and make the current stream wait for all of them."""
         if getattr(self, "_threaded", False):
-            self._q.join()
-        if getattr(self, "_error", None) is not None:
-            err, self._error = self._error, None
-            raise err
+            self.issuer.join()
         works = getattr(self, "_works", [])
         if not works:
             return
@@ -169,30 +212,44 @@ def shard_batch(n_items: int, rank: int, world: int) -> Tuple[int, int]:
 class ParamBucketReducer:
     """Averages the gradients of ordinary nn.Parameters (the encoders and the answer head around the unit) across ranks,
     one all-reduce per bucket, each launched as soon as the LAST gradient of its bucket has been accumulated -- while the
-    rest of the backward is still running (what torch's DistributedDataParallel does with its buckets; here on the same
-    helper-thread / high-priority-stream plumbing as LayerBucketReducer, and without wrapping the module).
+    rest of the backward is still running (what torch's DistributedDataParallel does with its buckets; here on the
+    process's CollectiveIssuer -- the same FIFO, helper thread and communication stream as LayerBucketReducer, so that
+    every rank issues ONE sequence of collectives -- and without wrapping the module).
+
+    Each bucket reduces a FIXED flat buffer (the numel of all its trainable parameters, zeros where a parameter received
+    no gradient this step): the element count of a collective never depends on which gradients a rank happened to get.
 
     buckets: lists of parameters, ideally in the order the backward finishes them (head first, encoders last).
     Usage per step: start(); loss.backward(); finish()."""
 
     def __init__(self, buckets: Sequence[Sequence[torch.nn.Parameter]], group=None, device: Optional[torch.device] = None):
-        self.buckets = [list(b) for b in buckets if len(b)]
+        self.buckets = [[p for p in b if p.requires_grad] for b in buckets]
+        self.buckets = [b for b in self.buckets if len(b)]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.stream = None
+        self.issuer = None
         if device is not None and device.type == "cuda":
-            self.stream = torch.cuda.Stream(device=device, priority=-1)
+            self.issuer = CollectiveIssuer.get(device)
+            self.stream = self.issuer.stream
         self._bucket_of = {}
         for bi, b in enumerate(self.buckets):
             for p in b:
                 self._bucket_of[id(p)] = bi
                 p.register_post_accumulate_grad_hook(self._hook)
+        self._flat = [None] * len(self.buckets)      # per bucket: the fixed-size buffer the collective runs on
         self._pending = None
         self._active = False
-        self._error = None
-        self._q = None
         self._events = []
+        self._launched = None
         self.force = False
+
+    def _flat_of(self, bi, like: torch.Tensor) -> torch.Tensor:
+        f = self._flat[bi]
+        n = sum(p.numel() for p in self.buckets[bi])
+        if f is None or f.device != like.device or f.numel() != n:
+            f = self._flat[bi] = torch.zeros(n, device=like.device, dtype=torch.float32)
+        return f
 
     # -- autograd thread --------------------------------------------------------------------------------------------------
     def _hook(self, p):
@@ -204,83 +261,83 @@ class ParamBucketReducer:
             self._bucket_ready(bi)
 
     def _bucket_ready(self, bi):
+        if self._launched[bi]:
+            return
+        self._launched[bi] = True
         if self.world == 1 and not self.force:
             return
-        grads = [p.grad for p in self.buckets[bi] if p.grad is not None]
-        if not grads:
-            return
-        if grads[0].is_cuda and self.stream is not None:
+        params = self.buckets[bi]
+        like = next((p.grad for p in params if p.grad is not None), params[0].data)
+        if like.is_cuda and self.issuer is not None:
             ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(grads[0].device))     # the stream this bucket's last gradient was produced on
+            ev.record(torch.cuda.current_stream(like.device))     # the stream this bucket's last gradient was produced on
             self._events.append(ev)
-            self._q.put((grads, ev))
+            self.issuer.post(self._reduce_now, (bi, ev), ("param", bi))
         else:
-            self._done_cpu.append(grads)
+            self._reduce_cpu(bi)
 
-    # -- helper thread ----------------------------------------------------------------------------------------------------
-    def _reduce_now(self, grads, ev):
+    def _pack(self, bi, flat):
+        o = 0
+        for p in self.buckets[bi]:
+            n = p.numel()
+            if p.grad is not None:
+                flat[o:o + n].copy_(p.grad.reshape(-1))
+            else:
+                flat[o:o + n].zero_()
+            o += n
+
+    def _unpack(self, bi, flat):
+        o = 0
+        for p in self.buckets[bi]:
+            n = p.numel()
+            red = flat[o:o + n].view_as(p)
+            if p.grad is not None:
+                p.grad.copy_(red)
+            elif self.world > 1:
+                p.grad = red.clone()             # another rank had a gradient for it: this rank takes the average as well
+            o += n
+
+    # -- issuer thread ----------------------------------------------------------------------------------------------------
+    def _reduce_now(self, bi, ev):
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(ev)
-            flat = torch._utils._flatten_dense_tensors(grads)
+            flat = self._flat_of(bi, self.buckets[bi][0].data)
+            self._pack(bi, flat)
             avg = dist.get_backend(self.group) == "nccl"
             w = dist.all_reduce(flat, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.group, async_op=True)
             w.wait()                                              # stream-ordered
             if not avg:
                 flat.mul_(1.0 / self.world)
-            for g, red in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
-                g.copy_(red)
-                g.record_stream(self.stream)
+            self._unpack(bi, flat)
+            for p in self.buckets[bi]:
+                if p.grad is not None:
+                    p.grad.record_stream(self.stream)
+
+    def _reduce_cpu(self, bi):
+        flat = self._flat_of(bi, self.buckets[bi][0].data)
+        self._pack(bi, flat)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        flat.mul_(1.0 / self.world)
+        self._unpack(bi, flat)
 
     def start(self) -> None:
-        self._pending = [sum(1 for p in b if p.requires_grad) for b in self.buckets]
-        self._done_cpu = []
+        self._pending = [len(b) for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
         self._events = []
-        self._error = None
         self._active = True
-        if self.stream is not None and self._q is None:
-            import queue
-            import threading
-            self._q = queue.Queue()
-            dev = self.stream.device
-
-            def worker():
-                torch.cuda.set_device(dev)
-                while True:
-                    item = self._q.get()
-                    try:
-                        if item is None:
-                            return
-                        self._reduce_now(*item)
-                    except BaseException as e:
-                        self._error = e
-                    finally:
-                        self._q.task_done()
-
-            threading.Thread(target=worker, daemon=True).start()
 
     def finish(self) -> None:
-        """After backward(): buckets whose parameters did not all receive a gradient are reduced now; then the current
-        stream waits for every collective."""
+        """After backward(): buckets whose parameters did not all receive a gradient are reduced now (in bucket order, the
+        same on every rank); then the current stream waits for every collective."""
         self._active = False
         if self.world == 1 and not self.force:
             return
-        for bi, left in enumerate(self._pending):
-            if left > 0:
-                self._pending[bi] = 0
-                self._bucket_ready(bi)
-        if self._q is not None:
-            self._q.join()
-        if self._error is not None:
-            err, self._error = self._error, None
-            raise err
-        for grads in self._done_cpu:                              # CPU / gloo path (tests): synchronous
-            flat = torch._utils._flatten_dense_tensors(grads)
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-            flat.mul_(1.0 / self.world)
-            for g, red in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
-                g.copy_(red)
-        if self.stream is not None and self._events:
-            torch.cuda.current_stream(self.stream.device).wait_stream(self.stream)
+        for bi in range(len(self.buckets)):
+            self._bucket_ready(bi)
+        if self.issuer is not None:
+            self.issuer.join()
+            if self._events:
+                torch.cuda.current_stream(self.stream.device).wait_stream(self.stream)
 
 
 def model_param_buckets(model) -> List[List[torch.nn.Parameter]]:

@@ -58,15 +58,28 @@ class ClipAdam:
     def __init__(self, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = 12.0):
         self.lr, self.betas, self.eps, self.max_norm = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(max_norm)
         self.step_count = 0
-        self._state: Dict[int, tuple] = {}          # id(param tensor storage view) -> (exp_avg, exp_avg_sq)
+        self._state: Dict[object, tuple] = {}       # segment key -> (exp_avg, exp_avg_sq), flat fp32
+        self._layouts: Dict[object, str] = {}       # segment key -> layout tag of a flat multi-parameter segment
         self._sqnorm: Optional[torch.Tensor] = None
         self._arr = None
 
+    def set_layout(self, key, tag: str) -> None:
+        """Name the element layout of a FLAT segment (the unit's buffer: a digest of its parameter table).  The tag travels
+        with state_dict(); load_state_dict() of moments recorded under another layout is refused instead of applying them
+        to the wrong parameters (an equal numel proves nothing)."""
+        self._layouts[key] = str(tag)
+
     def _moments(self, key, like: torch.Tensor):
         st = self._state.get(key)
-        if st is None or st[0].numel() != like.numel() or st[0].device != like.device:
+        if st is None:
             st = (torch.zeros(like.numel(), device=like.device, dtype=torch.float32),
                   torch.zeros(like.numel(), device=like.device, dtype=torch.float32))
+            self._state[key] = st
+        elif st[0].numel() != like.numel():
+            raise RuntimeError(f"ClipAdam: segment {key!r} has {like.numel()} elements but its stored moments have "
+                               f"{st[0].numel()} (restored from a checkpoint of another model / layout?)")
+        elif st[0].device != like.device:            # restored with map_location='cpu', or the model moved: keep the moments
+            st = (st[0].to(like.device), st[1].to(like.device))
             self._state[key] = st
         return st
 
@@ -106,13 +119,21 @@ class ClipAdam:
         return self._sqnorm
 
     def state_dict(self):
-        return {"step": self.step_count, "lr": self.lr, "betas": self.betas, "eps": self.eps, "max_norm": self.max_norm,
+        return {"format": "dvgr-clipadam-2", "step": self.step_count, "lr": self.lr, "betas": self.betas, "eps": self.eps,
+                "max_norm": self.max_norm, "layouts": dict(self._layouts),
                 "state": {k: (m.clone(), v.clone()) for k, (m, v) in self._state.items()}}
 
     def load_state_dict(self, sd):
+        for k, tag in sd.get("layouts", {}).items():
+            if k in self._layouts and self._layouts[k] != tag:
+                raise RuntimeError(f"ClipAdam: the moments of segment {k!r} were recorded under layout {tag}, this build lays the "
+                                   f"segment out as {self._layouts[k]}; restore through TrainStep.load_state_dict (per-parameter)")
+        if sd.get("format") != "dvgr-clipadam-2" and any(k in self._layouts for k in sd["state"]):
+            raise RuntimeError("ClipAdam: checkpoint without layout tags holds a flat multi-parameter segment; its element order is "
+                               "unknown -- restore through TrainStep.load_state_dict (torch.optim.Adam format) instead")
         self.step_count, self.lr = int(sd["step"]), float(sd["lr"])
         self.betas, self.eps, self.max_norm = tuple(sd["betas"]), float(sd["eps"]), float(sd["max_norm"])
-        self._state = {k: (m.clone(), v.clone()) for k, (m, v) in sd["state"].items()}
+        self._state = {k: (m.clone(), v.clone()) for k, (m, v) in sd["state"].items()}     # moved to the device at first use
 
 
 class TrainStep:
@@ -132,6 +153,9 @@ class TrainStep:
         unit_ids = {id(p) for p in self.unit.parameters()}
         self.other = [(n, p) for n, p in model.named_parameters() if id(p) not in unit_ids and p.requires_grad]
         self.timing = None                           # bench.py: {'begin': Event, 'end': Event} around clip + Adam
+        import hashlib
+        self.opt.set_layout("visual_input_unit", hashlib.sha256(repr([(n, tuple(sh), int(o)) for n, sh, o in self.unit._table])
+                                                                .encode()).hexdigest()[:16])
 
     @property
     def lr(self):
@@ -141,6 +165,85 @@ class TrainStep:
         """train.py:341-349: halve the learning rate."""
         self.opt.lr *= 0.5
         return self.opt.lr
+
+    # ---- checkpointing: train.py:360-365 saves `optimizer.state_dict()`, train.py:119 restores it -------------------------
+    def _unit_prefix(self) -> str:
+        for name, mod in self.model.named_modules():
+            if mod is self.unit:
+                return name + "."
+        raise RuntimeError("the unit is not a submodule of the model")
+
+    def state_dict(self):
+        """The optimiser state in `torch.optim.Adam.state_dict()` FORMAT over `model.parameters()` order ('state': index ->
+        {'step', 'exp_avg', 'exp_avg_sq'} shaped like the parameter; one param group): what train.py:364 stores under
+        'optimizer', independent of this package's flat layout.  Parameters that have not been stepped yet are absent,
+        as in torch."""
+        names = [n for n, _ in self.model.named_parameters()]
+        shapes = {n: tuple(p.shape) for n, p in self.model.named_parameters()}
+        pre = self._unit_prefix()
+        off = {pre + n: (int(o), tuple(sh)) for n, sh, o in self.unit._table}
+        state = {}
+        flat = self.opt._state.get("visual_input_unit")
+        for i, n in enumerate(names):
+            if n in off:
+                if flat is None:
+                    continue
+                o, sh = off[n]
+                k = 1
+                for d in sh:
+                    k *= d
+                mom = (flat[0][o:o + k].view(sh).clone(), flat[1][o:o + k].view(sh).clone())
+            else:
+                st = self.opt._state.get(n)
+                if st is None:
+                    continue
+                mom = (st[0].view(shapes[n]).clone(), st[1].view(shapes[n]).clone())
+            state[i] = {"step": torch.tensor(float(self.opt.step_count)), "exp_avg": mom[0], "exp_avg_sq": mom[1]}
+        group = {"lr": self.opt.lr, "betas": self.opt.betas, "eps": self.opt.eps, "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(names)))}
+        return {"state": state, "param_groups": [group], "max_norm": self.opt.max_norm}
+
+    def load_state_dict(self, sd):
+        """Restore from `state_dict()` or from a reference checkpoint's `optimizer` entry (torch.optim.Adam over the
+        reference model's parameters: same names, same order).  Moments may live on any device (map_location='cpu')."""
+        names = [n for n, _ in self.model.named_parameters()]
+        params = dict(self.model.named_parameters())
+        group = sd["param_groups"][0]
+        if len(group["params"]) != len(names):
+            raise RuntimeError(f"optimizer state covers {len(group['params'])} parameters, the model has {len(names)}")
+        pre = self._unit_prefix()
+        off = {pre + n: (int(o), tuple(sh)) for n, sh, o in self.unit._table}
+        flat_n = self.unit.flat_params().numel()
+        dev = self.unit.flat_params().device
+        flat = (torch.zeros(flat_n, device=dev), torch.zeros(flat_n, device=dev))
+        new_state, steps, any_unit = {}, set(), False
+        for pos, idx in enumerate(group["params"]):
+            st = sd["state"].get(idx)
+            if st is None:
+                continue
+            n = names[pos]
+            if tuple(st["exp_avg"].shape) != tuple(params[n].shape):
+                raise RuntimeError(f"optimizer state of {n}: shape {tuple(st['exp_avg'].shape)} != parameter {tuple(params[n].shape)}")
+            steps.add(int(float(st["step"])))
+            if n in off:
+                o, sh = off[n]
+                k = st["exp_avg"].numel()
+                flat[0][o:o + k] = st["exp_avg"].reshape(-1).to(dev, torch.float32)
+                flat[1][o:o + k] = st["exp_avg_sq"].reshape(-1).to(dev, torch.float32)
+                any_unit = True
+            else:
+                new_state[n] = (st["exp_avg"].reshape(-1).to(params[n].device, torch.float32).clone(),
+                                st["exp_avg_sq"].reshape(-1).to(params[n].device, torch.float32).clone())
+        if len(steps) > 1:
+            raise RuntimeError(f"per-parameter step counts differ ({sorted(steps)}): ClipAdam keeps ONE step count")
+        if any_unit:
+            new_state["visual_input_unit"] = flat
+        self.opt._state = new_state
+        self.opt.step_count = steps.pop() if steps else 0
+        self.opt.lr, self.opt.betas, self.opt.eps = float(group["lr"]), tuple(group["betas"]), float(group["eps"])
+        if "max_norm" in sd:
+            self.opt.max_norm = float(sd["max_norm"])
 
     def __call__(self, video_appearance_feat, video_motion_feat, question, question_len, answers):
         m, unit, head = self.model, self.unit, self.head

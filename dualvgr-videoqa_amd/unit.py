@@ -443,12 +443,10 @@ class DualVGRUnit_multiple(nn.Module):
         return b
 
     def flat_params(self) -> torch.Tensor:
-        # someone may have re-pointed .data (an external load that replaced tensors): .to() / load_state_dict / _apply go
-        # through _flatten themselves, so a spot check of a few parameters is enough on the per-step path
-        pl, pt = self._plist, self._ptrs
-        n = len(pl)
-        for i in (0, n // 3, (2 * n) // 3, n - 1):
-            if pl[i].data_ptr() != pt[i]:
+        # someone may have re-pointed .data (an external load that replaced tensors): every parameter must still be a view
+        # into the flat buffer (~70 L pointer compares: negligible against a step)
+        for p, ptr in zip(self._plist, self._ptrs):
+            if p.data_ptr() != ptr:
                 self._flatten()
                 break
         return self._flat
@@ -459,11 +457,10 @@ class DualVGRUnit_multiple(nn.Module):
         if self.dtype_code == L_.DVGR_F32 or self.no_planes:
             return None
         flat = self._flat
-        # every optimizer step / load_state_dict bumps the version counter of EVERY parameter it touches, so a sample of
-        # them (every 8th + the last) detects it without walking all ~70 L tensors per forward; a caller that rewrites
-        # single parameters in place behind autograd's back calls params_changed()
-        pl = self._plist
-        ver = sum(p._version for p in pl[::8]) + pl[-1]._version
+        # an in-place update (optimizer step over any SUBSET of the parameters, load_state_dict, a no_grad edit) bumps the
+        # version counter of every tensor it touches: the sum over ALL parameters detects each of them (~70 L integers per
+        # forward); a caller that rewrites the buffer behind autograd's back (a raw kernel) calls params_changed()
+        ver = sum(p._version for p in self._plist)
         if self._lowp is None or self._lowp.device != flat.device or ver != self._lowp_version:
             if self._lowp is None or self._lowp.device != flat.device:
                 self._lowp = torch.empty(2 * flat.numel(), device=flat.device, dtype=torch.bfloat16)
@@ -474,7 +471,8 @@ class DualVGRUnit_multiple(nn.Module):
 
     def lowp_planes(self):
         """The bf16 hi / lo planes tensor of the flat parameter buffer (None in fp32 mode), allocated if need be; for a
-        caller that rewrites it together with the parameters (trainer.ClipAdam) and then calls planes_written()."""
+        caller that rewrites it together with the parameters in one pass (trainer.ClipAdam: no repack follows such a step
+        because the fused kernel bumps no version counter; anyone else calls params_changed())."""
         if self.dtype_code == L_.DVGR_F32 or self.no_planes:
             return None
         self.lowp_ptr()

@@ -51,6 +51,10 @@ int dvgr_dbg_keep_mask(uint32_t key, int64_t n, float *keep, void *stream);
 /* site key of (seed, layer, mod, gat, which) exactly as the forward derives it. */
 uint32_t dvgr_dbg_site_key(uint64_t seed, int layer, int mod, int gat, int which);
 
+/* Kernel launches the library has enqueued in this process so far (every launch site counts itself: DVGR_LAUNCH in
+ * csrc/dvgr_common.h).  bench.py reports the difference over its timed steps as launches_per_step. */
+long long dvgr_dbg_launch_count(void);
+
 /* Timing events for dvgr_opts.probe_begin / probe_end, created with hipEventDisableSystemFence: the record then costs no
  * cache writeback / invalidate of its own, which is what the flag is documented for (more accurate timings of the commands
  * between two events).  bench.py times the dominant launch with them. */

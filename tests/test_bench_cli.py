@@ -24,7 +24,9 @@ def test_gpus_n_spawns_n_ranks_and_fails_loudly_without_gpus():
     r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
     assert r.returncode != 0
     assert "starting 2 ranks" in r.stderr and "--nproc-per-node=2" in r.stderr
-    assert r.stderr.count("needs a ROCm GPU") >= 2              # both ranks ran and refused to fall back to the CPU
+    # the ranks ran and refused to fall back to the CPU (torchrun terminates the sibling as soon as the first rank fails, so
+    # the second refusal may or may not make it to stderr)
+    assert r.stderr.count("needs a ROCm GPU") >= 1
     assert '"metric"' not in r.stdout                            # no result line from a failed run
 
 

@@ -5,7 +5,9 @@ the benchmark's default operand mode (bf16x3), through the C ABI:
   C4  MSRVTT-QA  num_clips = 16, unit_layers =  6, batch 256 / 8 GPUs = 32 per GPU
   C5  stress     num_clips = 64, unit_layers = 12, batch 512 / 8 GPUs = 64 per GPU
 
-(C1 / C2, num_clips = 20: tests/test_hip_parity.py.)  C3 and C4 are compared with the oracle at their full per-GPU batch,
+C1 (batch 8: the 160-row small-batch schedule with 64-row tiles) and C2 (batch 64, the headline configuration) in eval AND
+training mode as well -- training mode is what bench.py times; their golden-vector cases live in tests/test_hip_parity.py.
+C3 and C4 are compared with the oracle at their full per-GPU batch,
 eval and training mode (masks of the device RNG injected into the oracle).  C5's oracle comparison runs on a 2-sample
 batch; its full batch of 64 is then tied to that comparison through properties the path offers: samples are independent
 (rows of the full-batch outputs and input gradients equal the small-batch run's), the parameter gradient of a batch is
@@ -76,6 +78,22 @@ def _against_oracle(name, B, N, Lr, dtype, train):
     assert_flips_at_kink(stats, what)
     assert_grads(m, t, gin, gw, dbg, Lr, GTOL, what)
     return m, sd_np, t, outs
+
+
+@pytest.mark.parametrize("train", [False, True])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x3"])
+def test_c1_cpu_reference_config_at_its_own_batch(dtype, train):
+    """BASELINE.json configs[0]: B = 8 -> 160 rows at D = 768, the small-batch schedule (csrc/dvgr_api.hip: no query stream,
+    64-row planes tiles, fp32 + planes layout because B N <= 256)."""
+    _against_oracle("C1", 8, 20, 1, dtype, train)
+
+
+@pytest.mark.parametrize("train", [False, True])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x3"])
+def test_c2_headline_config_full_batch(dtype, train):
+    """BASELINE.json configs[1] at its full batch in the mode bench.py times (training, dropout masks of the device RNG
+    injected into the oracle) and in eval mode."""
+    _against_oracle("C2", 64, 20, 3, dtype, train)
 
 
 @pytest.mark.parametrize("train", [False, True])
@@ -151,6 +169,7 @@ def test_c5_stress_oracle_on_a_shard_and_properties_at_full_batch(dtype):
     assert rel_err(gfull2.cpu(), gfull.cpu()) < 2e-6
     # linearity: the parameter gradient of the batch is the sum over its shards (8 shards of 8 samples)
     acc = torch.zeros_like(gfull)
+    mag = torch.zeros_like(gfull)                # sum over shards of |shard gradient|: the scale the sums cancel from
     for s in range(0, Bf, 8):
         part = {k: v[s:s + 8].copy() for k, v in full.items()}
         tp = {k: torch.from_numpy(v).cuda() for k, v in part.items()}
@@ -160,12 +179,20 @@ def test_c5_stress_oracle_on_a_shard_and_properties_at_full_batch(dtype):
         op = m(tp["A"], tp["M"], tp["dq"], tp["words"], tp["qlen"])
         lin_upstream(op, Rf[s:s + 8].cuda()).backward()
         acc += m.last_flat_grad
+        mag += m.last_flat_grad.abs()
     torch.cuda.synchronize()
-    for l in range(Lr + 2):                      # per block of the flat buffer: one magnitude scale each
+    # A consistency property (the parity gate is the oracle comparison above).  The two sides sum the same B N = 4096 row
+    # terms in different orders, and the bias / vector gradients of the deep layers cancel to ~1e-3 of their terms, so the
+    # plain metric max|err| / max|want| measures the cancellation, not the arithmetic.  As everywhere else in this suite
+    # the error is held against the cancellation scale instead: per element, |acc - full| <= tol * (sum over shards of the
+    # shard gradients' magnitudes, floored at 1e-3 of the block's largest), tol = the operand mode's rounding x margin.
+    ctol = 2e-5 if dtype == "fp32" else 2e-4
+    for l in range(Lr + 2):                      # per block of the flat buffer
         a, b = m.layer_param_range(l)
-        # (fp32 sums over B * N = 4096 rows in two different orders; the bias gradients of the deep layers cancel heavily.
-        # This is a consistency property, not the parity gate -- that is the oracle comparison above -- so it gets 4 x GTOL
-        # in exact fp32 and a sanity bound of 40 x in bf16x3, whose 1e-5 operand rounding those cancelling sums amplify.)
-        assert rel_err(acc[a:b].cpu(), gfull[a:b].cpu()) < (4 if dtype == "fp32" else 40) * GTOL, l
+        scale = mag[a:b].clamp_min(1e-3 * float(mag[a:b].max()))
+        worst = float(((acc[a:b] - gfull[a:b]).abs() / scale).max())
+        plain = rel_err(acc[a:b].cpu(), gfull[a:b].cpu())
+        print(f"  C5 {dtype} linearity block {l}: |err| / cancellation scale {worst:.2e} (plain metric {plain:.2e})")
+        assert worst < ctol, (l, worst, plain)
     assert torch.isfinite(gfull).all() and float(gfull.abs().max()) > 0
     del g_shard0

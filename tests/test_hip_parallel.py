@@ -167,3 +167,107 @@ def test_the_reducers_streams_do_not_stall_the_step():
         assert with_reducer < 1.6 * plain, (plain, with_reducer)
     finally:
         dist.destroy_process_group()
+
+
+# ---- two ranks, BOTH reducers, one issue order ------------------------------------------------------------------------
+def _ddp_worker(rank, world, port, q):
+    """One data-parallel rank of TrainStep on GPU 0 (the box has one GPU: gloo carries the CUDA tensors, RCCL would refuse
+    two ranks on one device).  Runs (a) two steps with the threaded reducers and (b) the same two steps with gradients
+    averaged synchronously after each backward, and reports parameters of both plus the issuer's log."""
+    import numpy as np
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from test_hip_model import model_inputs
+        from dualvgr_videoqa_amd import trainer
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        V, D_, Wd, N_, Fr, L_, B_, T_, vq, va, seed = 32, 64, 32, 8, 4, 2, 8, 7, 30, 12, 77
+        vocab = {"question_token_to_idx": {str(i): i for i in range(vq)}, "answer_token_to_idx": {str(i): i for i in range(va)}}
+
+        def make():
+            torch.manual_seed(1234)              # same initial weights on every rank (as after a broadcast)
+            m = dv.DualVGR(vision_dim=V, module_dim=D_, word_dim=Wd, vocab=vocab, num_of_nodes=N_, graph_module="GAT",
+                           graph_layers=1, unit_layers=L_, dtype="fp32").to(dev).train()
+            m.set_dropout_enabled(False)
+            return m
+
+        app, mot, qq, qlen = [torch.from_numpy(x) for x in model_inputs(B_, N_, Fr, V, T_, vq, seed)]
+        ans = torch.from_numpy((synth.uniform("ddp_ans", (B_,), 0.0, float(va), seed)).astype(np.int64))
+        lo, hi = parallel.shard_batch(B_, rank, world)
+        batch = [x[lo:hi].to(dev) for x in (app, mot, qq, qlen, ans)]
+
+        # (a) the product path: both reducers on the shared issuer
+        m = make()
+        unit = m.visual_input_unit
+        events = [torch.cuda.Event() for _ in range(L_ + 2)]
+        for ev in events:
+            ev.record()
+        unit.set_layer_events(events)
+        ured = parallel.LayerBucketReducer(parallel.layer_buckets(unit), device=dev)
+        pred = parallel.ParamBucketReducer(parallel.model_param_buckets(m), device=dev)
+        assert ured.issuer is pred.issuer and ured.stream is pred.stream
+        unit.set_layer_callback(lambda idx, g: ured.launch(idx, g, events[idx]))
+        log = ured.issuer.log = []
+        ts = dv.TrainStep(m, lr=1e-3, alpha=1.0, beta=1e-3, max_norm=1e9, world=world, unit_reducer=ured, param_reducer=pred)
+        for _ in range(2):
+            ts(*batch)
+        torch.cuda.synchronize()
+        got = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu()
+
+        # (b) reference: local backward, then ONE synchronous average of every gradient, then the same optimiser
+        m2 = make()
+        ts2 = dv.TrainStep(m2, lr=1e-3, alpha=1.0, beta=1e-3, max_norm=1e9, world=world)
+        real_step = ts2.opt.step
+
+        def averaged_step(segs):
+            torch.cuda.synchronize()
+            for seg in segs:
+                g = seg[2]
+                h = g.cpu()
+                dist.all_reduce(h)
+                g.copy_((h / world).to(dev))
+            return real_step(segs)
+
+        ts2.opt.step = averaged_step
+        for _ in range(2):
+            ts2(*batch)
+        torch.cuda.synchronize()
+        want = torch.cat([p.detach().reshape(-1) for p in m2.parameters()]).cpu()
+        q.put((rank, got.numpy(), want.numpy(), list(log)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_with_both_reducers_issue_one_order_and_average_exactly():
+    """LayerBucketReducer and ParamBucketReducer used a helper thread EACH on the same process
+    group, so the order of their collectives raced.  Both now post to one CollectiveIssuer.  Two gloo ranks on this GPU run
+    TrainStep with both reducers: the issue sequence is identical on both ranks and interleaves the two reducers, both
+    ranks end with identical parameters, and those equal a step whose gradients were averaged synchronously."""
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, got, want, log = q.get(timeout=540)
+        res[r] = (got, want, log)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][2] == res[1][2], (res[0][2], res[1][2])                     # one issue order on every rank
+    kinds = [t[0] for t in res[0][2]]
+    assert "unit" in kinds and "param" in kinds
+    first_param, last_unit = kinds.index("param"), len(kinds) - 1 - kinds[::-1].index("unit")
+    assert first_param < last_unit                                            # the two reducers really interleave
+    import numpy as np
+    assert np.array_equal(res[0][0], res[1][0])                               # replicas stay identical
+    scale = float(np.abs(res[0][1]).max())
+    assert float(np.abs(res[0][0] - res[0][1]).max()) < 2e-5 * scale          # == synchronous averaging (float atomics reorder)
