@@ -206,6 +206,23 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf
 // a.b ~ hi.hi + hi.lo + lo.hi is what DVGR_BF16X3 feeds the bf16 MFMA.  Producers of GEMM operands
 // store the planes next to (or instead of) the fp32 values so the contraction kernels convert nothing.
 // ---------------------------------------------------------------------------------------------
+// Streaming stores of kernel outputs (A/B: -DDVGR_NT_STORES).  An XCD's L2 is not coherent with the other seven, so whatever
+// a kernel leaves dirty is written back at its end, in one burst the next kernel waits behind (MI355X_MICROARCH.md, row
+// `boundary`: + bytes / 6 TB/s); outputs are consumed by workgroups on arbitrary XCDs, i.e. from memory anyway.
+#ifdef DVGR_NT_STORES
+typedef float dvgr_f4v __attribute__((ext_vector_type(4)));
+typedef uint32_t dvgr_u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st4(float4* p, float4 v) {
+  __builtin_nontemporal_store(dvgr_f4v{v.x, v.y, v.z, v.w}, reinterpret_cast<dvgr_f4v*>(p));
+}
+__device__ __forceinline__ void st2u(uint2* p, uint2 v) {
+  __builtin_nontemporal_store(dvgr_u2v{v.x, v.y}, reinterpret_cast<dvgr_u2v*>(p));
+}
+#else
+__device__ __forceinline__ void st4(float4* p, float4 v) { *p = v; }
+__device__ __forceinline__ void st2u(uint2* p, uint2 v) { *p = v; }
+#endif
+
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
   bf16x2 v = {(__bf16)a, (__bf16)b};                 // v_cvt_pk_bf16_f32 (round to nearest even)
@@ -217,10 +234,10 @@ __device__ __forceinline__ float bf16_hi_as_f32(uint32_t p) { return __uint_as_f
 __device__ __forceinline__ void split_store4(uint16_t* hi, int64_t lo_off, int64_t idx, float4 v) {
   if (!hi) return;
   const uint32_t h01 = pack_bf16(v.x, v.y), h23 = pack_bf16(v.z, v.w);
-  *reinterpret_cast<uint2*>(hi + idx) = make_uint2(h01, h23);
+  st2u(reinterpret_cast<uint2*>(hi + idx), make_uint2(h01, h23));
   const uint32_t l01 = pack_bf16(v.x - bf16_lo_as_f32(h01), v.y - bf16_hi_as_f32(h01));
   const uint32_t l23 = pack_bf16(v.z - bf16_lo_as_f32(h23), v.w - bf16_hi_as_f32(h23));
-  *reinterpret_cast<uint2*>(hi + lo_off + idx) = make_uint2(l01, l23);
+  st2u(reinterpret_cast<uint2*>(hi + lo_off + idx), make_uint2(l01, l23));
 }
 __device__ __forceinline__ void split_store1(uint16_t* hi, int64_t lo_off, int64_t idx, float x) {
   if (!hi) return;

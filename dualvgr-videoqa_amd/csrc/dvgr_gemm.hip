@@ -225,7 +225,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmProblem& P, const f32x4 
             const float4 old = *reinterpret_cast<const float4*>(P.C + o);
             x[0] += old.x; x[1] += old.y; x[2] += old.z; x[3] += old.w;
           }
-          *reinterpret_cast<float4*>(P.C + o) = make_float4(x[0], x[1], x[2], x[3]);
+          st4(reinterpret_cast<float4*>(P.C + o), make_float4(x[0], x[1], x[2], x[3]));
         } else {
           for (int e = 0; e < nv; ++e) P.C[o + e] = P.accumulate ? P.C[o + e] + x[e] : x[e];
         }

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_fwd(const GatAttnArgs a) {
     y.y = elu_f(v.y) * drop_factor(ko, e0 + 1);
     y.z = elu_f(v.z) * drop_factor(ko, e0 + 2);
     y.w = elu_f(v.w) * drop_factor(ko, e0 + 3);
-    *reinterpret_cast<float4*>(out + o) = y;
+    st4(reinterpret_cast<float4*>(out + o), y);
     split_store4(zp, a.z_lo_off, (int64_t)b * N * D + hl * F + o, y);
   }
   CLK(5);
@@ -339,9 +339,9 @@ __global__ __launch_bounds__(256) void k_sf_combine_fwd(const SfCombineArgs a) {
   for (int k = lane; k < D4; k += 64) {
     const float4 u = z0[k], v = z1[k], xx = x[k];
     const float4 o = make_float4(b0 * u.x + b1 * v.x, b0 * u.y + b1 * v.y, b0 * u.z + b1 * v.z, b0 * u.w + b1 * v.w);
-    if (oo) oo[k] = o;
+    if (oo) st4(oo + k, o);
     const float4 xn = make_float4(xx.x + o.x, xx.y + o.y, xx.z + o.z, xx.w + o.w);
-    xo[k] = xn;
+    st4(xo + k, xn);
     split_store4(a.xp[mod], a.x_lo_off, (int64_t)row * a.D + 4 * k, xn);
     if (np) {                                               // next layer: gate logit and the two dropped copies of X'
       const float4 pv = np[k];
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void k_sf_combine_fwd(const SfCombineArgs a) {
           y.y = xn.y * (((h0 >> 16) >= kDropThresh16) ? kKeepScale : 0.f);
           y.z = xn.z * (((h1 & 0xFFFFu) >= kDropThresh16) ? kKeepScale : 0.f);
           y.w = xn.w * (((h1 >> 16) >= kDropThresh16) ? kKeepScale : 0.f);
-          if (nxd) reinterpret_cast<float4*>(nxd)[(int64_t)g * n4 + i] = y;
+          if (nxd) st4(reinterpret_cast<float4*>(nxd) + (int64_t)g * n4 + i, y);
           split_store4(a.next_xd_p[mod], a.next_xd_lo_off, ((int64_t)g * n4 + i) * 4, y);
         }
       }
@@ -483,15 +483,15 @@ __global__ __launch_bounds__(256) void k_sf_bwd(const SfBwdArgs a) {
                                   dw0 * p.z * (1.f - ta.z * ta.z), dw0 * p.w * (1.f - ta.w * ta.w));
     const float4 q1 = make_float4(dw1 * p.x * (1.f - tb.x * tb.x), dw1 * p.y * (1.f - tb.y * tb.y),
                                   dw1 * p.z * (1.f - tb.z * tb.z), dw1 * p.w * (1.f - tb.w * tb.w));
-    if (dpre0) { dpre0[k] = q0; dpre1[k] = q1; }
+    if (dpre0) { st4(dpre0 + k, q0); st4(dpre1 + k, q1); }
     split_store4(a.dpre_p[mod], a.lo_off, r0 + 4 * k, q0);
     split_store4(a.dpre_p[mod], a.lo_off, r1 + 4 * k, q1);
     float4 o0 = make_float4(b0 * d.x, b0 * d.y, b0 * d.z, b0 * d.w);
     float4 o1 = make_float4(b1 * d.x, b1 * d.y, b1 * d.z, b1 * d.w);
     if (g0) { const float4 e = g0[k]; o0.x += e.x; o0.y += e.y; o0.z += e.z; o0.w += e.w; }
     if (g1) { const float4 e = g1[k]; o1.x += e.x; o1.y += e.y; o1.z += e.z; o1.w += e.w; }
-    dz0[k] = o0;
-    dz1[k] = o1;
+    st4(dz0 + k, o0);
+    st4(dz1 + k, o1);
   }
 }
 int sf_bwd(hipStream_t st, const SfBwdArgs& a) {
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
         const float4 al = gal[t], ar = gar[t];
         const float4 o = make_float4(sj * z.x + duj * al.x + dvj * ar.x, sj * z.y + duj * al.y + dvj * ar.y,
                                      sj * z.z + duj * al.z + dvj * ar.z, sj * z.w + duj * al.w + dvj * ar.w);
-        if (dWh) *reinterpret_cast<float4*>(dWh + (int64_t)j * HF + 4 * q) = o;
+        if (dWh) st4(reinterpret_cast<float4*>(dWh + (int64_t)j * HF + 4 * q), o);
         split_store4(a.dWh_p[mod], a.lo_off, (int64_t)b * N * HF + h * F + (int64_t)j * HF + 4 * q, o);
         dsp += z.x * w.x + z.y * w.y + z.z * w.z + z.w * w.w;
         pal[t].x += duj * w.x; pal[t].y += duj * w.y; pal[t].z += duj * w.z; pal[t].w += duj * w.w;

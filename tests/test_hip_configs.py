@@ -184,15 +184,19 @@ def test_c5_stress_oracle_on_a_shard_and_properties_at_full_batch(dtype):
     # A consistency property (the parity gate is the oracle comparison above).  The two sides sum the same B N = 4096 row
     # terms in different orders, and the bias / vector gradients of the deep layers cancel to ~1e-3 of their terms, so the
     # plain metric max|err| / max|want| measures the cancellation, not the arithmetic.  As everywhere else in this suite
-    # the error is held against the cancellation scale instead: per element, |acc - full| <= tol * (sum over shards of the
-    # shard gradients' magnitudes, floored at 1e-3 of the block's largest), tol = the operand mode's rounding x margin.
+    # the error is held against a cancellation scale instead: per element, |acc - full| <= tol * (sum over the shards of the
+    # shard gradients' magnitudes, floored at 5 % of the block's largest: a shard's own sum over its 512 rows cancels too,
+    # so the magnitudes under-estimate the terms of an element that happens to come out small), tol = the operand mode's
+    # rounding x margin: 2e-5 (fp32) / 2e-4 (bf16x3).  (Round 2 held the plain metric to 2e-3 / 2e-2.)
     ctol = 2e-5 if dtype == "fp32" else 2e-4
+    worst_all = []
     for l in range(Lr + 2):                      # per block of the flat buffer
         a, b = m.layer_param_range(l)
-        scale = mag[a:b].clamp_min(1e-3 * float(mag[a:b].max()))
+        scale = mag[a:b].clamp_min(5e-2 * float(mag[a:b].max()))
         worst = float(((acc[a:b] - gfull[a:b]).abs() / scale).max())
         plain = rel_err(acc[a:b].cpu(), gfull[a:b].cpu())
         print(f"  C5 {dtype} linearity block {l}: |err| / cancellation scale {worst:.2e} (plain metric {plain:.2e})")
-        assert worst < ctol, (l, worst, plain)
+        worst_all.append((worst, l, plain))
+    assert max(worst_all)[0] < ctol, max(worst_all)
     assert torch.isfinite(gfull).all() and float(gfull.abs().max()) > 0
     del g_shard0
