@@ -182,21 +182,23 @@ def test_c5_stress_oracle_on_a_shard_and_properties_at_full_batch(dtype):
         mag += m.last_flat_grad.abs()
     torch.cuda.synchronize()
     # A consistency property (the parity gate is the oracle comparison above).  The two sides sum the same B N = 4096 row
-    # terms in different orders, and the bias / vector gradients of the deep layers cancel to ~1e-3 of their terms, so the
-    # plain metric max|err| / max|want| measures the cancellation, not the arithmetic.  As everywhere else in this suite
-    # the error is held against a cancellation scale instead: per element, |acc - full| <= tol * (sum over the shards of the
-    # shard gradients' magnitudes, floored at 5 % of the block's largest: a shard's own sum over its 512 rows cancels too,
-    # so the magnitudes under-estimate the terms of an element that happens to come out small), tol = the operand mode's
-    # rounding x margin: 2e-5 (fp32) / 2e-4 (bf16x3).  (Round 2 held the plain metric to 2e-3 / 2e-2.)
-    ctol = 2e-5 if dtype == "fp32" else 2e-4
+    # terms in different orders, and the gradients of the deep layers cancel to ~1e-3 of their terms (rows of a deep GAT
+    # stack share a large common component).  A cancellation scale would have to be the sum of the |row terms|, which only
+    # the oracle knows (and only at the shard size); the device can offer the sum over the shards of |shard gradient|, and
+    # a shard's own sum over its 512 rows cancels just as much -- measured against that scale the worst block reads 1.2e-2
+    # in BOTH operand modes (profiles/experiments_r03.tsv era run, gpurun_out/r3b), i.e. it measures the cancellation, not
+    # the arithmetic.  So the plain per-block metric stays, at bounds taken from the measured values with a 2 x margin:
+    # exact fp32 9.3e-4 -> 2e-3 (as before), bf16x3 2.1e-3 -> 5e-3 (round 2 allowed 2e-2); the scale-relative figure is
+    # printed beside it for the record.
+    bound = 2e-3 if dtype == "fp32" else 5e-3
     worst_all = []
     for l in range(Lr + 2):                      # per block of the flat buffer
         a, b = m.layer_param_range(l)
         scale = mag[a:b].clamp_min(5e-2 * float(mag[a:b].max()))
-        worst = float(((acc[a:b] - gfull[a:b]).abs() / scale).max())
+        rel_scale = float(((acc[a:b] - gfull[a:b]).abs() / scale).max())
         plain = rel_err(acc[a:b].cpu(), gfull[a:b].cpu())
-        print(f"  C5 {dtype} linearity block {l}: |err| / cancellation scale {worst:.2e} (plain metric {plain:.2e})")
-        worst_all.append((worst, l, plain))
-    assert max(worst_all)[0] < ctol, max(worst_all)
+        print(f"  C5 {dtype} linearity block {l}: plain metric {plain:.2e} (|err| / sum of |shard gradients| {rel_scale:.2e})")
+        worst_all.append((plain, l, rel_scale))
+    assert max(worst_all)[0] < bound, max(worst_all)
     assert torch.isfinite(gfull).all() and float(gfull.abs().max()) > 0
     del g_shard0
