@@ -81,28 +81,6 @@ int64_t ws_floats(const dvgr_dims& d) {
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-// Schedule variants (each kept or dropped by an A/B on one device, profiles/experiments_r03.tsv).  The shipped build uses
-// kSchedDefault; a -DDVGR_TIMING_AIDS build (make aids, tools/ab.sh) reads DVGR_SCHED from the environment instead.
-enum : int {
-  SCHED_FWD_LAYER0_QUERY_FIRST = 1,   // forward: only layer 0's query contraction in front of layer 0's Wh contraction; the other
-                                      // layers' ride in that launch; their row kernels follow on the side stream
-  SCHED_FWD_QUERY_REST_ON_SIDE = 4,   // with SCHED_FWD_LAYER0_QUERY_FIRST: the other layers' query contraction does not ride in layer
-                                      // 0's Wh launch but follows layer 0's chain on the side stream (beside punish / attention)
-  SCHED_BWD_SPLIT_DW = 2,             // backward: dP1 right behind the S5 backward, dWcat right behind the attention backward,
-                                      // both on the side stream (one launch each) instead of one launch behind the punish pass
-};
-#ifndef DVGR_SCHED_DEFAULT
-#define DVGR_SCHED_DEFAULT 0      // both variants measured slower (profiles/experiments_r03.tsv: sched_fwd_q0_bwd_splitdw)
-#endif
-inline int sched_flags() {
-#ifdef DVGR_TIMING_AIDS
-  static const int v = []() { const char* e = getenv("DVGR_SCHED"); return e ? atoi(e) : (int)DVGR_SCHED_DEFAULT; }();
-  return v;
-#else
-  return DVGR_SCHED_DEFAULT;
-#endif
-}
-
 // bf16 hi/lo planes of GEMM operands (DVGR_BF16 / DVGR_BF16X3).  Every fp32 buffer the library owns
 // (parameters, saved, workspace) has a parallel planes region with the same element offsets; tensors owned
 // by the caller (inputs, list outputs) get plane-only slots inside `saved`.  attach() resolves the planes of
@@ -412,60 +390,32 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
   SideStream* side = (O.flags & DVGR_OPT_SINGLE_STREAM) ? nullptr : side_stream();
   hipStream_t hs = side ? side->st : st;
   const Probe fprobe{O, st};
-  // SCHED_FWD_LAYER0_QUERY_FIRST: what stands in front of layer 0's punish gate is the query chain of layer 0 ALONE.  Its
-  // contraction (48 tiles) runs first; the contractions of the layers >= 1 ride in layer 0's Wh launch (same layout, the
-  // launch has a second round of workgroups anyway), and their row kernels follow on the side stream, due only at
-  // layer 0's S5 kernel (which computes layer 1's gate).
-  const int train_probs = train ? 4 : 2;
-  const bool q_first = (sched_flags() & SCHED_FWD_LAYER0_QUERY_FIRST) && side && L > 1 && (L - 1) + train_probs <= kMaxBatch;
-  const int q0 = q_first ? 1 : L;          // layers [0, q0): query chain in front of layer 0's gate
-  auto qa_problem = [&](int l) {
-    GemmProblem p = nt(io->dq, D, lp(l) + P.qa_w1, D, ws + W.Y + (int64_t)l * BT * D, D, lp(l) + P.qa_b1, BT, D, D, ACT_NONE);
-    PM.attach(p);
-    return p;
-  };
-  auto query_rows = [&](int lo, int hi, hipStream_t on) -> int {      // row kernels + p = Wq q + bq of the layers [lo, hi)
-    QaRowsArgs a{};
-    a.Y = ws + W.Y + (int64_t)lo * BT * D; a.logit = ws + W.R + (int64_t)lo * BT;
-    a.params = params + P.q_base + P.q_layer_stride * lo; a.off_w2 = P.qa_w2; a.off_b2 = P.qa_b2; a.layer_stride = P.q_layer_stride;
-    a.words = io->words; a.qlen = io->qlen; a.saved = saved + S.layer_stride * lo; a.s_layer_stride = S.layer_stride;
-    a.s_d = S.qa_d; a.s_nrm = S.qa_nrm; a.s_a = S.qa_a; a.s_ah = S.qa_ah; a.s_S = S.qa_s; a.s_q = S.qa_q;
-    a.B = B; a.T = T; a.D = D; a.Wd = Wd; a.L = hi - lo;
-    DVGR_TRY(qa_rows_fwd(on, a));
+  for (int l0 = 0; l0 < L; l0 += kMaxBatch) {
     GemmBatch gb{};
-    for (int l = lo; l < hi; ++l)
-      for (int m = 0; m < 2; ++m) {
-        gb.p[gb.n++] = nt(ls(l) + S.qa_q, Wd, qp(l, m) + P.wq, Wd, ms(l, m) + S.p, D, qp(l, m) + P.bq, B, D, Wd, ACT_NONE);
-        if (gb.n == kMaxBatch || (l == hi - 1 && m == 1)) { DVGR_TRY(gemm_launch(on, KC, KC, gb, TAG_GENERIC, prec)); gb.n = 0; }
-      }
-    return 0;
-  };
-  for (int l0 = 0; l0 < q0; l0 += kMaxBatch) {
-    GemmBatch gb{};
-    for (int l = l0; l < q0 && l < l0 + kMaxBatch; ++l) gb.p[gb.n++] = qa_problem(l);
+    for (int l = l0; l < L && l < l0 + kMaxBatch; ++l) {
+      gb.p[gb.n] = nt(io->dq, D, lp(l) + P.qa_w1, D, ws + W.Y + (int64_t)l * BT * D, D, lp(l) + P.qa_b1, BT, D, D, ACT_NONE);
+      PM.attach(gb.p[gb.n++]);
+    }
     DVGR_TRY(fprobe.begin(DVGR_PROBE_FWD_QA_GEMM, l0));
     DVGR_TRY(gemm_launch(st, KC, KC, gb, TAG_GENERIC, prec));
     DVGR_TRY(fprobe.end(DVGR_PROBE_FWD_QA_GEMM, l0));
   }
   if (side) DVGR_TRY(side->order(st, hs));
-  DVGR_TRY(query_rows(0, q0, hs));
-  hipEvent_t gate0_ready = nullptr, gates_ready = nullptr;     // p of layer 0 / of the layers >= 1 exists (side stream)
-  if (side) {
-    gate0_ready = side->next();
-    if (!gate0_ready) return (int)hipErrorOutOfMemory;
-    const hipError_t e = hipEventRecord(gate0_ready, hs);
-    if (e != hipSuccess) return (int)e;
+  {
+    QaRowsArgs a{};
+    a.Y = ws + W.Y; a.logit = ws + W.R; a.params = params + P.q_base; a.off_w2 = P.qa_w2; a.off_b2 = P.qa_b2; a.layer_stride = P.q_layer_stride;
+    a.words = io->words; a.qlen = io->qlen; a.saved = saved; a.s_layer_stride = S.layer_stride;
+    a.s_d = S.qa_d; a.s_nrm = S.qa_nrm; a.s_a = S.qa_a; a.s_ah = S.qa_ah; a.s_S = S.qa_s; a.s_q = S.qa_q;
+    a.B = B; a.T = T; a.D = D; a.Wd = Wd; a.L = L;
+    DVGR_TRY(qa_rows_fwd(hs, a));
   }
-  const bool q_rest_on_side = q_first && (sched_flags() & SCHED_FWD_QUERY_REST_ON_SIDE);
-  if (q_rest_on_side) {
+  {
     GemmBatch gb{};
-    for (int lq = q0; lq < L; ++lq) gb.p[gb.n++] = qa_problem(lq);
-    DVGR_TRY(gemm_launch(hs, KC, KC, gb, TAG_GENERIC, prec));
-    DVGR_TRY(query_rows(q0, L, hs));
-    gates_ready = side->next();
-    if (!gates_ready) return (int)hipErrorOutOfMemory;
-    const hipError_t e = hipEventRecord(gates_ready, hs);
-    if (e != hipSuccess) return (int)e;
+    for (int l = 0; l < L; ++l)
+      for (int m = 0; m < 2; ++m) {
+        gb.p[gb.n++] = nt(ls(l) + S.qa_q, Wd, qp(l, m) + P.wq, Wd, ms(l, m) + S.p, D, qp(l, m) + P.bq, B, D, Wd, ACT_NONE);
+        if (gb.n == kMaxBatch || (l == L - 1 && m == 1)) { DVGR_TRY(gemm_launch(hs, KC, KC, gb, TAG_GENERIC, prec)); gb.n = 0; }
+      }
   }
 
   // ---- layers ---------------------------------------------------------------------------------------
@@ -496,25 +446,12 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
           }
         }
       }
-      if (l == 0 && q_first && !q_rest_on_side)
-        for (int lq = q0; lq < L; ++lq) gb.p[gb.n++] = qa_problem(lq);
       DVGR_TRY(fprobe.begin(DVGR_PROBE_FWD_GAT_GEMM, l));
       DVGR_TRY(gemm_launch(st, KC, KC, gb, TAG_FWD_GAT, prec));
       DVGR_TRY(fprobe.end(DVGR_PROBE_FWD_GAT_GEMM, l));
-      if (l == 0 && q_first && !q_rest_on_side) {
-        DVGR_TRY(side->order(st, hs));
-        DVGR_TRY(query_rows(q0, L, hs));
-        gates_ready = side->next();
-        if (!gates_ready) return (int)hipErrorOutOfMemory;
-        const hipError_t e = hipEventRecord(gates_ready, hs);
-        if (e != hipSuccess) return (int)e;
-      }
     }
-    // S1 (needs p from S0: the main stream waits for layer 0's query chain here)
-    if (l == 0 && side) {
-      const hipError_t e = hipStreamWaitEvent(st, gate0_ready, 0);
-      if (e != hipSuccess) return (int)e;
-    }
+    // S1 (needs p from S0: the side stream joins here)
+    if (l == 0 && side) DVGR_TRY(side->order(hs, st));
     if (l == 0)                            // layers > 0: gate computed by the previous layer's S5 kernel
       DVGR_TRY(punish_fwd(st, Xin[0], Xin[1], ms(l, 0) + S.p, ms(l, 1) + S.p, ms(l, 0) + S.s, ms(l, 1) + S.s, B, N, D));
     // S3
@@ -571,10 +508,6 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
       }
       a.x_lo_off = plo;
       a.rows = BN; a.D = D; a.N = N;
-      if (l == 0 && gates_ready) {         // p of the layers >= 1 (SCHED_FWD_LAYER0_QUERY_FIRST)
-        const hipError_t e = hipStreamWaitEvent(st, gates_ready, 0);
-        if (e != hipSuccess) return (int)e;
-      }
       if (l + 1 < L) {                     // S1 and the x-site dropout of layer l + 1, on the row while it is in registers
         const Keys Kn = layer_keys(train, seed, l + 1);
         for (int m = 0; m < 2; ++m) {
@@ -914,36 +847,6 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     return lo == 0 ? query_leaves(0, L, qs) : 0;
   };
 
-  // the weight-gradient problems of layer l (buffer set `set`), appended to gb / bias
-  auto dp1_problems = [&](int l, int set, const float* const* outc, const float* const* outs, GemmBatch& gb, BiasOf* bias) {
-    for (int m = 0; m < 2; ++m) {
-      GemmProblem p = tn(ws + W.dpre[set][m], D, outc[m], D, gmp(l, m) + P.sf_p1, D, D, D, 2 * BN);
-      p.kseg = BN;
-      p.A.p1 = ws + W.dpre[set][m] + BND;
-      p.B.p1 = outs[m];
-      PM.attach(p);
-      bias[gb.n] = BiasOf{ws + W.dpre[set][m], 2 * BN, D, D, gmp(l, m) + P.sf_bp};
-      gb.p[gb.n++] = p;
-    }
-  };
-  auto dwcat_problems = [&](int l, int set, const float* const* Xin, GemmBatch& gb, BiasOf* bias) {
-    for (int m = 0; m < 2; ++m) {
-      if (!train) {
-        gb.p[gb.n] = tn(ws + W.dWh[set][m], HF, Xin[m], D, gmp(l, m) + P.gat_w, D, HF, D, BN);
-        PM.attach(gb.p[gb.n]);
-        bias[gb.n++] = BiasOf{ws + W.dWh[set][m], BN, HF, HF, gmp(l, m) + P.gat_b};
-      } else {
-        for (int gi = 0; gi < 2; ++gi) {
-          gb.p[gb.n] = tn(ws + W.dWh[set][m] + gi * 4 * F, HF, ms(l, m) + S.xd + gi * BND, D,
-                          gmp(l, m) + P.gat_w + (int64_t)gi * 4 * F * D, D, 4 * F, D, BN);
-          PM.attach(gb.p[gb.n]);
-          bias[gb.n++] = BiasOf{ws + W.dWh[set][m] + gi * 4 * F, BN, 4 * F, HF, gmp(l, m) + P.gat_b + gi * 4 * F};
-        }
-      }
-    }
-  };
-  const bool split_dw = (sched_flags() & SCHED_BWD_SPLIT_DW) && side != nullptr;
-
   // ---- layers, last to first -----------------------------------------------------------------------
   hipEvent_t side_done[2] = {nullptr, nullptr};   // side stream finished the layer that used buffer set 0 / 1
   for (int l = L - 1; l >= 0; --l) {
@@ -974,20 +877,6 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       a.lo_off = plo;
       a.rows = BN; a.D = D;
       DVGR_TRY(sf_bwd(st, a));
-    }
-    ColsumBatch cb{};
-    if (split_dw) {
-      // dP1 = sum_v dpre_v^T . z_v (+ d bP as the row sums of dpre) needs nothing but this kernel's output: side stream,
-      // NOW, under the dz contraction and the attention backward -- for layer 0 that takes 60 us out of the step's tail
-      DVGR_TRY(to_side());
-      GemmBatch gb{};
-      BiasOf bias[kMaxBatch] = {};
-      dp1_problems(l, set, outc, outs, gb, bias);
-      if (lean && !gemm_rowsum_supported(IC, IC, gb, prec)) return DVGR_E_DIMS;
-      const Probe dprobe{O, hs};
-      DVGR_TRY(dprobe.begin(DVGR_PROBE_BWD_SF_DW, l));
-      DVGR_TRY(launch_dw(hs, gb, bias, TAG_BWD_SF_DW, cb));
-      DVGR_TRY(dprobe.end(DVGR_PROBE_BWD_SF_DW, l));
     }
     {
       GemmBatch gd{};   // dz_v += dpre_v . P1
@@ -1036,6 +925,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     // a weight-gradient launch of 35 us alone took 95-105 us beside the critical path's kernels and slowed those by a
     // third), so every 240-tile contraction stays on the main stream and the side stream fills in latency-bound kernels.
     if (l == 0) DVGR_TRY(to_side_and_query()); else DVGR_TRY(to_side());
+    ColsumBatch cb{};
     for (int m = 0; m < 2; ++m) {
       cb.j[cb.n++] = ColsumJob{ms(l, m) + S.tn, nullptr, ws + W.dw[set][m], nullptr, 2 * BN, 0, D, D, gmp(l, m) + P.sf_p2};
       cb.j[cb.n++] = ColsumJob{ws + W.da_part[set][m], nullptr, nullptr, nullptr, B, 0, kHeads * 2 * F, kHeads * 2 * F, gmp(l, m) + P.gat_a};
@@ -1046,28 +936,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     // with it the block's all-reduce -- does not wait for the query branch queued behind them (it did: both last buckets
     // became ready together, ~100 us after the main stream's last kernel).
     hipEvent_t colsums_done = nullptr;
-    if (split_dw) {
-      // dWcat = dWh^T . drop_x(X) (+ d bcat) behind the attention backward, on the side stream, under the dX contraction and
-      // the punish pass; with dP1 issued above, every gradient of block l is written on the side stream
-      GemmBatch gb{};
-      BiasOf bias[kMaxBatch] = {};
-      dwcat_problems(l, set, Xin, gb, bias);
-      if (lean && !gemm_rowsum_supported(IC, IC, gb, prec)) return DVGR_E_DIMS;
-      const Probe dprobe{O, hs};
-      DVGR_TRY(dprobe.begin(DVGR_PROBE_BWD_GAT_DW, l));
-      DVGR_TRY(launch_dw(hs, gb, bias, TAG_BWD_GAT_DW, cb));
-      DVGR_TRY(dprobe.end(DVGR_PROBE_BWD_GAT_DW, l));
-      cb.chunks = 16;
-      DVGR_TRY(colsum(hs, cb));
-      cb.n = 0;
-      if (side) {
-        side_done[set] = side->next();
-        if (!side_done[set]) return (int)hipErrorOutOfMemory;
-        const hipError_t e2 = hipEventRecord(side_done[set], hs);
-        if (e2 != hipSuccess) return (int)e2;
-      }
-      DVGR_TRY(layer_done(l, hs));
-    } else if (l == 0 && side && qs == hs) {
+    if (l == 0 && side && qs == hs) {
       cb.chunks = 16;
       DVGR_TRY(colsum(hs, cb));
       cb.n = 0;
@@ -1109,11 +978,32 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     }
     // every weight gradient of the layer as ONE launch: dP1 = sum_v dpre_v^T . z_v (two row segments) and
     // dWcat = dWh^T . drop_x(X), both modalities, with the bias gradients d bP and d bcat as row sums of their dY operands
-    if (!split_dw) {
+    {
       GemmBatch gb{};
       BiasOf bias[kMaxBatch] = {};
-      dp1_problems(l, set, outc, outs, gb, bias);
-      dwcat_problems(l, set, Xin, gb, bias);
+      for (int m = 0; m < 2; ++m) {
+        GemmProblem p = tn(ws + W.dpre[set][m], D, outc[m], D, gmp(l, m) + P.sf_p1, D, D, D, 2 * BN);
+        p.kseg = BN;
+        p.A.p1 = ws + W.dpre[set][m] + BND;
+        p.B.p1 = outs[m];
+        PM.attach(p);
+        bias[gb.n] = BiasOf{ws + W.dpre[set][m], 2 * BN, D, D, gmp(l, m) + P.sf_bp};
+        gb.p[gb.n++] = p;
+      }
+      for (int m = 0; m < 2; ++m) {
+        if (!train) {
+          gb.p[gb.n] = tn(ws + W.dWh[set][m], HF, Xin[m], D, gmp(l, m) + P.gat_w, D, HF, D, BN);
+          PM.attach(gb.p[gb.n]);
+          bias[gb.n++] = BiasOf{ws + W.dWh[set][m], BN, HF, HF, gmp(l, m) + P.gat_b};
+        } else {
+          for (int gi = 0; gi < 2; ++gi) {
+            gb.p[gb.n] = tn(ws + W.dWh[set][m] + gi * 4 * F, HF, ms(l, m) + S.xd + gi * BND, D,
+                            gmp(l, m) + P.gat_w + (int64_t)gi * 4 * F * D, D, 4 * F, D, BN);
+            PM.attach(gb.p[gb.n]);
+            bias[gb.n++] = BiasOf{ws + W.dWh[set][m] + gi * 4 * F, BN, 4 * F, HF, gmp(l, m) + P.gat_b + gi * 4 * F};
+          }
+        }
+      }
       // Where: the launch is unbalanced (the dP1 tiles reduce over 2 B N rows, the dWcat tiles over B N: 72 tiles run twice
       // as long as the other 144), so beside the next layer's critical-path kernels it fills compute units that would idle
       // behind its short tiles -- the layers > 0 put it on the side stream (measured: 1.245 ms per step against 1.272 with

@@ -133,6 +133,16 @@ __device__ __forceinline__ f32x4 load_frag(const float* sm, int idx16, int kk, i
   }
 }
 
+// tanh for the S4 epilogue: 1 - 2 / (1 + e^{2x}) on the hardware exp / rcp (absolute error ~2e-7, the quantity that matters
+// downstream: tn enters a dot product with p2 and 1 - tn^2), instead of the ~40-instruction library routine -- the epilogue
+// of a 240-tile launch evaluates 3.9 M of them on the critical path.
+__device__ __forceinline__ float tanh_fast(float x) {
+  const float ax = fminf(fabsf(x), 15.0f);                    // tanh(15) == 1 in fp32; keeps e^{2x} finite
+  const float e = __expf(2.0f * ax);
+  const float t = 1.0f - __fdividef(2.0f, e + 1.0f);
+  return copysignf(t, x);
+}
+
 // Epilogue shared by both kernels.  C/D fragment map of the 16x16 MFMAs (dtype independent):
 // col = lane & 15, row = (lane >> 4) * 4 + reg.
 template <int MT, int NT>
@@ -180,6 +190,14 @@ __device__ __forceinline__ void epilogue_rows(const GemmProblem& P, const f32x4 
   const bool vec_ok = atomic || (((P.ldc & 3) == 0) && ((((uintptr_t)P.C) & 15) == 0) && ((col0 & 3) == 0));
   if (!vec_ok) { epilogue<MT, NT>(P, acc, row0, col0, lane); return; }
   static_assert(W == 64 || W == 32, "sub-tile width");
+  // this lane's four output columns are the same in every pass: their bias is loaded once, ahead of everything
+  const int cc_lane = (lane % CPR) * 4;
+  float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (P.bias && !atomic) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (col0 + cc_lane + e < P.N) bias4[e] = P.bias[col0 + cc_lane + e];
+  }
 #pragma unroll
   for (int i0 = 0; i0 < MT; i0 += MCH) {
 #pragma unroll
@@ -202,29 +220,38 @@ __device__ __forceinline__ void epilogue_rows(const GemmProblem& P, const f32x4 
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       continue;
     }
+    // Every global LOAD of the pass is issued before its first store: on this ISA loads and stores share one in-order
+    // counter (vmcnt), so a load behind a store also waits for that store's acknowledgement from L2 -- the first version
+    // loaded the bias element by element inside the loop (and the old tile of an accumulating output after the previous
+    // iteration's store) and spent 6 us of a 27 us launch in eight serialised memory round trips per wave.
+    constexpr int NIT = MCH * 16 / RPI;
+    float4 oldv[NIT];
+    if (P.accumulate) {
 #pragma unroll
-    for (int it = 0; it < MCH * 16 / RPI; ++it) {
-      const int rr = it * RPI + lane / CPR, cc = (lane % CPR) * 4;
+      for (int it = 0; it < NIT; ++it) {
+        const int rr = it * RPI + lane / CPR;
+        const int row = row0 + i0 * 16 + rr, col = col0 + cc_lane;
+        oldv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < P.M && col + 3 < P.N) oldv[it] = *reinterpret_cast<const float4*>(P.C + (int64_t)row * P.ldc + col);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int rr = it * RPI + lane / CPR, cc = cc_lane;
       const int row = row0 + i0 * 16 + rr, col = col0 + cc;
       float4 v = *reinterpret_cast<const float4*>(scratch + rr * STR + cc);
       if (row < P.M && col < P.N) {
         const int64_t o = (int64_t)row * P.ldc + col;
         const int nv = (P.N - col) < 4 ? (P.N - col) : 4;    // valid columns of this chunk
-        float x[4] = {v.x, v.y, v.z, v.w};
+        float x[4] = {v.x + bias4[0], v.y + bias4[1], v.z + bias4[2], v.w + bias4[3]};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          if (P.bias && e < nv) x[e] += P.bias[col + e];
-          if (P.act == ACT_TANH) x[e] = tanhf(x[e]);
+          if (P.act == ACT_TANH) x[e] = tanh_fast(x[e]);
           else if (P.act == ACT_ELU) x[e] = elu_f(x[e]);
           if (P.drop_key_c) x[e] *= drop_factor(P.drop_key_c, (uint32_t)(o + e));
         }
-        if (atomic) {
-          for (int e = 0; e < nv; ++e) atomicAdd(P.C + o + e, x[e]);   // global_atomic_add_f32, no return
-        } else if (nv == 4) {
-          if (P.accumulate) {
-            const float4 old = *reinterpret_cast<const float4*>(P.C + o);
-            x[0] += old.x; x[1] += old.y; x[2] += old.z; x[3] += old.w;
-          }
+        if (nv == 4) {
+          if (P.accumulate) { x[0] += oldv[it].x; x[1] += oldv[it].y; x[2] += oldv[it].z; x[3] += oldv[it].w; }
           st4(reinterpret_cast<float4*>(P.C + o), make_float4(x[0], x[1], x[2], x[3]));
         } else {
           for (int e = 0; e < nv; ++e) P.C[o + e] = P.accumulate ? P.C[o + e] + x[e] : x[e];

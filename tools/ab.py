@@ -55,16 +55,23 @@ def main():
             res[name].append(d["ms_per_step"])
             launches[name] = d["config"].get("launches_per_step")
             print(f"round {r} {name}: {d['ms_per_step']:.4f} ms/step", flush=True)
+    # rows go to profiles/experiments_r03.tsv AND to gpurun_out/ab_rows/<experiment>.tsv: a GPU box starts from the repo's
+    # copy of profiles/, so only gpurun_out/ carries this run's rows back (tools/ab_merge.py folds them in)
+    side = os.path.join(ROOT, "gpurun_out", "ab_rows")
+    os.makedirs(side, exist_ok=True)
+    hdr = "date\texperiment\tvariant\tlib\tenv\tbuild\tmedian_ms\tmin_ms\trounds\tlaunches_per_step\tbench_args\n"
     new = not os.path.exists(a.out)
-    with open(a.out, "a") as f:
+    with open(a.out, "a") as f, open(os.path.join(side, a.name + ".tsv"), "w") as g:
         if new:
-            f.write("date\texperiment\tvariant\tlib\tenv\tbuild\tmedian_ms\tmin_ms\trounds\tlaunches_per_step\tbench_args\n")
+            f.write(hdr)
         for name, lib, env in variants:
             xs = sorted(res[name])
             med = xs[len(xs) // 2]
-            f.write("\t".join([datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"), a.name, name, lib or "libdvgr_hip.so",
-                               " ".join(f"{k}={v}" for k, v in env.items()) or "-", bench.build_id(), f"{med:.4f}", f"{xs[0]:.4f}",
-                               str(a.rounds), str(launches[name]), a.bench or "-"]) + "\n")
+            row = "\t".join([datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"), a.name, name, lib or "libdvgr_hip.so",
+                             " ".join(f"{k}={v}" for k, v in env.items()) or "-", bench.build_id(), f"{med:.4f}", f"{xs[0]:.4f}",
+                             str(a.rounds), str(launches[name]), a.bench or "-"]) + "\n"
+            f.write(row)
+            g.write(row)
             print(f"{a.name}\t{name}\tmedian {med:.4f} ms\tmin {xs[0]:.4f} ms")
 
 
