@@ -233,6 +233,11 @@ def main():
                     help="with --model, A/B timing: swap tools/stock_encoders.py's nn.LSTM question encoder in")
     ap.add_argument("--appearance-encoder", default="hip", choices=["hip", "miopen"],
                     help="with --model, A/B timing: swap tools/stock_encoders.py's nn.LSTM appearance encoder in")
+    ap.add_argument("--reducer", default="auto", choices=["auto", "native", "python"],
+                    help="gradient all-reduce of the unit under --gpus N: native = enqueued by the backward call itself over the "
+                         "library's own RCCL communicator (include/dvgr_comm.h); python = parallel.LayerBucketReducer over "
+                         "torch.distributed (host callback + issuer thread); auto = both are set up, a few untimed steps of each "
+                         "are measured (MAX over ranks) and the faster one runs the timed region")
     ap.add_argument("--loss", default="fused", choices=["fused", "fused-after", "precomputed"],
                     help="fused: the scope-U loss and its gradients are computed inside every timed step by "
                          "dvgr_scope_u_loss; precomputed: fixed upstream gradients (unit kernels only)")
@@ -336,13 +341,38 @@ def main():
 
     events = None
     reducer = None
+    reducer_kind = None
+    red_native = red_python = None
     if ddp:
-        events = [torch.cuda.Event() for _ in range(Lr + 2)]
-        m.set_layer_events(events)
-        reducer = parallel.LayerBucketReducer(parallel.layer_buckets(m), device=dev)
-        reducer.force = world == 1          # self-test: run the collectives even with one rank
-        # each bucket's all-reduce is enqueued from inside the backward call, right after its event (dvgr_opts.layer_done_cb)
-        m.set_layer_callback(lambda idx, g: reducer.launch(idx, g, events[idx]))
+        if args.reducer in ("auto", "native") and args.backend == "nccl":
+            try:
+                red_native = parallel.NativeUnitReducer(dev, force_single=(world == 1))
+            except Exception as e:        # a failed communicator must not cost the whole multi-GPU measurement
+                print(f"[bench] native reducer unavailable ({e!r}); using the torch.distributed reducer", file=sys.stderr, flush=True)
+        if args.reducer in ("auto", "python") or red_native is None:
+            events = [torch.cuda.Event() for _ in range(Lr + 2)]
+            for ev in events:
+                ev.record()          # torch creates the hipEvent lazily at the first record; the C ABI needs the handle
+            red_python = parallel.LayerBucketReducer(parallel.layer_buckets(m), device=dev)
+            red_python.force = world == 1          # self-test: run the collectives even with one rank
+
+    def use_reducer(kind):
+        """Point the module at one of the two reducers (or at none)."""
+        nonlocal reducer, reducer_kind
+        m.set_comm(None)
+        m.set_layer_events(None)
+        m.set_layer_callback(None)
+        reducer, reducer_kind = None, None
+        if kind == "native":
+            m.set_comm(red_native)        # every backward call enqueues its blocks' all-reduces itself (dvgr_opts.comm)
+            reducer = red_native
+            reducer_kind = "native: RCCL all-reduce per gradient block enqueued inside dvgr_unit_backward (dvgr_opts.comm)"
+        elif kind == "python":
+            m.set_layer_events(events)
+            # each bucket's all-reduce is enqueued from inside the backward call, right after its event (dvgr_opts.layer_done_cb)
+            m.set_layer_callback(lambda idx, g: red_python.launch(idx, g, events[idx]))
+            reducer = red_python
+            reducer_kind = "python: parallel.LayerBucketReducer over torch.distributed (host callback + issuer thread)"
 
     probe_sites = {"fwd_gat_gemm": (L_.PROBE_FWD_GAT_GEMM, 8 * B * N * D * D, "S2 forward GAT projection Wh = X.Wcat^T, both modalities (TAG_FWD_GAT)"),
                    "fwd_sf_gemm": (L_.PROBE_FWD_SF_GEMM, 8 * B * N * D * D, "S4 forward tanh(z.P1^T), 2 views x 2 modalities (TAG_FWD_SF)"),
@@ -360,9 +390,6 @@ def main():
     PROBE_EVERY = 4
     pairs = [(L_.ProbeEvent(), L_.ProbeEvent()) for _ in range((args.steps + PROBE_EVERY - 1) // PROBE_EVERY)]
     launches = {"count": 0, "steps": 0}
-    for ev in (events or []):
-        ev.record()          # torch creates the hipEvent lazily at the first record; the C ABI needs the handle
-
     def step(i=None):
         if i is not None:
             if i % PROBE_EVERY == 0:
@@ -396,6 +423,30 @@ def main():
         if reducer is not None:
             reducer.finish()
 
+    reducer_trial = None
+    if ddp:
+        # Which reducer runs the timed region: a few untimed steps of each candidate, MAX over ranks, the faster one wins
+        # (the native path's speed depends on process set-up order in ways only a measurement settles: parallel.py).
+        def trial(kind, n=12):
+            use_reducer(kind)
+            for _ in range(4):
+                step()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                step()
+            torch.cuda.synchronize()
+            dt = torch.tensor([(time.perf_counter() - t0) / n * 1e3], device=dev, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            return float(dt.item())
+        cands = [k for k, r in (("native", red_native), ("python", red_python)) if r is not None]
+        reducer_trial = {k: trial(k) for k in cands}
+        best = min(reducer_trial, key=reducer_trial.get)      # identical on every rank (MAX-reduced timings)
+        use_reducer(best)
+        print(f"[bench] reducer trial ms/step {reducer_trial} -> {best}", file=sys.stderr, flush=True)
     for _ in range(args.warmup):
         step()
     lib = L_.load()
@@ -445,7 +496,7 @@ def main():
                    "optimizer_ms": optimizer_ms,
                    "optimizer": "clip_grad_norm_(12) + Adam over the unit's flat parameter / gradient buffers, two fused launches "
                                 "(dvgr_optim_*), OUTSIDE the timed step",
-                   "distributed": dist_info,
+                   "distributed": dict(dist_info, reducer=reducer_kind, reducer_trial_ms=reducer_trial) if dist_info else None,
                    "algorithmic_gflop_per_qa_train": f_train / 1e9,
                    "unit_tflops": value / world * f_train / 1e12,
                    "unit_frac_of_mfma_peak": value / world * f_train / 1e12 / peak},

@@ -22,7 +22,9 @@ DVGR_F32, DVGR_BF16, DVGR_BF16X3 = 0, 1, 2
 
 ERRORS = {-1: "DVGR_E_DIMS (unsupported dimensions)", -2: "DVGR_E_NULL (null pointer)",
           -3: "DVGR_E_WORKSPACE (saved/workspace buffer too small)", -4: "DVGR_E_ALIGN (pointer not 16-byte aligned)",
-          -5: "DVGR_E_KIND (unknown tensor kind)"}
+          -5: "DVGR_E_KIND (unknown tensor kind)",
+          -6: "DVGR_E_ORDER (create the communicator / reducer BEFORE the unit's first forward on this device: the runtime maps "
+              "streams to hardware queues in creation order, and a communication stream created last costs 3 x the step time)"}
 
 
 class Dims(C.Structure):
@@ -49,7 +51,7 @@ class Opts(C.Structure):
     _fields_ = [("train", C.c_int32), ("probe_site", C.c_int32), ("probe_layer", C.c_int32), ("flags", C.c_int32),
                 ("seed", C.c_uint64), ("probe_begin", C.c_void_p), ("probe_end", C.c_void_p),
                 ("layer_done_events", C.POINTER(C.c_void_p)), ("loss", C.POINTER(LossSpec)),
-                ("layer_done_cb", C.c_void_p), ("layer_done_user", C.c_void_p)]
+                ("layer_done_cb", C.c_void_p), ("layer_done_user", C.c_void_p), ("comm", C.c_void_p)]
 
 
 LAYER_DONE_CB = C.CFUNCTYPE(None, C.c_int32, C.c_void_p)

@@ -7,6 +7,7 @@
 #include "dvgr_gemm.h"
 #include "dvgr_side.h"
 #include "dvgr_stages.h"
+#include "../../include/dvgr_comm.h"
 
 using namespace dvgr;
 
@@ -222,7 +223,7 @@ int dvgr_streams_init(void) {
   const hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return (int)e;
   if (dev < 0 || dev >= 16) return DVGR_E_DIMS;
-  return shared_side_stream(dev, 0) ? 0 : (int)hipErrorOutOfMemory;      // (the query stream is created on first use)
+  return shared_side_stream(dev, 0) ? 0 : (int)hipErrorOutOfMemory;      // (the side, query and communication streams, in their one fixed order)
 }
 
 int dvgr_check_dims(const dvgr_dims* d) {
@@ -638,10 +639,25 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
   // (every fork costs the main stream a ~6 us bubble -- the event's barrier packet -- so there is one per layer, not one
   // per dependency: the side stream's work of a layer is enqueued behind the layer's last producer it needs)
   auto layer_done = [&](int index, hipStream_t on) -> int {
-    if (!layer_done_events || !layer_done_events[index]) return 0;
-    const hipError_t e = hipEventRecord((hipEvent_t)layer_done_events[index], on);
+    hipEvent_t ev = (layer_done_events && layer_done_events[index]) ? (hipEvent_t)layer_done_events[index] : nullptr;
+    if (!ev && !O.comm) return 0;
+    if (!ev) {                               // native all-reduce without caller events: one of the library's own
+      ev = side ? side->next() : nullptr;
+      if (!ev) {
+        static thread_local hipEvent_t own[16] = {};
+        hipEvent_t& slot = own[index & 15];
+        if (!slot && hipEventCreateWithFlags(&slot, kEventFlags) != hipSuccess) return (int)hipErrorOutOfMemory;
+        ev = slot;
+      }
+    }
+    const hipError_t e = hipEventRecord(ev, on);
     if (e != hipSuccess) return (int)e;
-    if (O.layer_done_cb) O.layer_done_cb(index, O.layer_done_user);
+    if (O.comm) {                            // the block's all-reduce enters the communication stream right here
+      int64_t first = 0, last = 0;
+      DVGR_TRY(dvgr_param_layer_range(dp, index, &first, &last));
+      DVGR_TRY(dvgr_comm_allreduce_avg((dvgr_comm*)O.comm, gp + first, last - first, (void*)ev, nullptr));
+    }
+    if (O.layer_done_cb && layer_done_events && layer_done_events[index]) O.layer_done_cb(index, O.layer_done_user);
     return 0;
   };
   // A weight gradient dW = dY^T . X carries its bias gradient dY^T . 1 along (GemmProblem::rowsum) where the engine
@@ -1023,7 +1039,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
         const hipError_t e2 = hipEventRecord(side_done[set], hs);
         if (e2 != hipSuccess) return (int)e2;
       }
-      if (layer_done_events && layer_done_events[l]) {
+      if ((layer_done_events && layer_done_events[l]) || O.comm) {
         if (dws == hs || !side) {
           DVGR_TRY(layer_done(l, hs));                   // every gradient of block l was written on the side stream
         } else if (colsums_done && !cb.n) {              // (layer 0 beside a reducer: only the column sums, see above)

@@ -18,16 +18,27 @@ namespace dvgr {
 // stream at a fixed place in the order of all the package's streams (dualvgr-videoqa_amd/_lib.py: streams()).
 // `which` = 0: the side stream proper; 1: the query stream of the unit's backward (the query branch is a chain of
 // latency-bound kernels that must not queue behind the side stream's weight-gradient contractions).
-inline hipStream_t shared_side_stream(int dev, int which = 0) {
-  static hipStream_t st[16][2] = {};
+// `which` = 2: the communication stream of the native gradient all-reduce (dvgr_comm.hip), highest priority, created by the
+// first dvgr_comm_create() on the device.
+// ORDER MATTERS and is measured, not understood: the runtime's mapping of streams onto hardware queues depends on creation
+// order in a way GPU_MAX_HW_QUEUES (4, 8, 16: no change, tools/hwq_matrix.sh) does not control.  Known-good orders, all with
+// the caller's stream first: [side, query on first use] (no communicator) and [communication, side, query] (communicator
+// created BEFORE the unit's first call).  Known-bad: a communicator created after the unit has run (its stream last: a
+// data-parallel step took 3.3 ms instead of 1.1 ms) and all three created together at dvgr_streams_init (the whole-model
+// step took 10.9 ms instead of 5.1 ms).  dvgr_comm_create() therefore refuses (DVGR_E_ORDER) once the side stream exists.
+inline hipStream_t shared_side_stream(int dev, int which = 0, bool create = true) {
+  static hipStream_t st[16][3] = {};
   static std::mutex mu;
   std::lock_guard<std::mutex> lk(mu);
-  for (int w = 0; w <= which; ++w)             // always created in the same order
-    if (!st[dev][w]) {
-      int lo = 0, hi = 0;
-      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-      if (hipStreamCreateWithPriority(&st[dev][w], hipStreamNonBlocking, lo) != hipSuccess) st[dev][w] = nullptr;
-    }
+  if (!create) return st[dev][which];
+  int lo = 0, hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+  if (which == 2) {
+    if (!st[dev][2] && hipStreamCreateWithPriority(&st[dev][2], hipStreamNonBlocking, hi) != hipSuccess) st[dev][2] = nullptr;
+    return st[dev][2];
+  }
+  for (int w = 0; w <= which; ++w)             // side before query, always
+    if (!st[dev][w] && hipStreamCreateWithPriority(&st[dev][w], hipStreamNonBlocking, lo) != hipSuccess) st[dev][w] = nullptr;
   return st[dev][which];
 }
 // The events only order streams of ONE device: no system-scope fence (host / peer visibility) at the record.

@@ -48,7 +48,9 @@ class CollectiveIssuer:
         import threading
         self.device = device
         # high priority: the runtime gives such a stream a hardware queue of its own; a normal-priority one was seen
-        # sharing the caller's queue, where its event waits sit in front of the backward's later launches
+        # sharing the caller's queue, where its event waits sit in front of the backward's later launches.  (Borrowing the
+        # library's communication stream instead -- one stream fewer -- measured 3.3 ms per step against 1.25: the runtime's
+        # stream-to-queue mapping is sensitive to creation order, csrc/dvgr_side.h.)
         self.stream = torch.cuda.Stream(device=device, priority=-1)
         self.q = queue.Queue()
         self.errors = []
@@ -200,6 +202,114 @@ class LayerBucketReducer:
             return
         torch.cuda.current_stream(works[0][3].device).wait_stream(self.stream)
         self._works = []
+
+
+COMM_SYMBOLS = None
+
+
+def _comm_lib():
+    """libdvgr_hip.so with the dvgr_comm_* entry points of include/dvgr_comm.h bound, and RCCL resolved from the copy this
+    process already uses (PyTorch's librccl.so): one RCCL per process."""
+    import ctypes as C
+    import os
+    from . import _lib as L_
+    global COMM_SYMBOLS
+    lib = L_.load()
+    if COMM_SYMBOLS is None:
+        COMM_SYMBOLS = [
+            ("dvgr_comm_load", C.c_int, [C.c_char_p]),
+            ("dvgr_comm_unique_id", C.c_int, [C.c_void_p]),
+            ("dvgr_comm_create", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+            ("dvgr_comm_destroy", C.c_int, [C.c_void_p]),
+            ("dvgr_comm_world", C.c_int, [C.c_void_p]),
+            ("dvgr_comm_allreduce_avg", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+            ("dvgr_comm_join", C.c_int, [C.c_void_p, C.c_void_p]),
+            ("dvgr_comm_device_stream", C.c_int, [C.POINTER(C.c_void_p)]),
+        ]
+        for name, restype, argtypes in COMM_SYMBOLS:
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = restype, argtypes
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        L_.check(lib.dvgr_comm_load(path.encode() if os.path.exists(path) else None), "dvgr_comm_load")
+    return lib
+
+
+class NativeUnitReducer:
+    """The unit's gradient all-reduce without the interpreter in its path (include/dvgr_comm.h): an RCCL communicator of
+    its own plus ONE communication stream, created once; `unit.set_comm(self)` makes every backward call enqueue the
+    all-reduce (mean over ranks) of each block of the flat gradient buffer right behind the block's own event -- from C,
+    inside the call -- in the order the blocks become final.  `finish()` makes the current stream wait.
+
+    The unique id travels over torch.distributed (any backend: it is 128 bytes on the host), so the job's rendezvous stays
+    where the launcher put it.  One communicator = one issue order by construction (the backward's program order, the same
+    on every rank); it shares nothing with torch's process group, whose collectives (ParamBucketReducer) keep their own."""
+
+    def __init__(self, device: torch.device, group=None, force_single: bool = False):
+        import ctypes as C
+        from . import _lib as L_
+        if device.type != "cuda":
+            raise RuntimeError("NativeUnitReducer needs a ROCm device (RCCL); CPU jobs use LayerBucketReducer over gloo")
+        self.lib = _comm_lib()
+        self.device = device
+        if dist.is_initialized():
+            self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        elif force_single:
+            self.rank, self.world = 0, 1
+        else:
+            raise RuntimeError("torch.distributed is not initialised (it carries the RCCL unique id to the ranks)")
+        # MEASURED, not understood (tools/native_order_probe.py, one rank, C2): the step with this reducer takes 1.10 ms when
+        # torch's own NCCL process group was initialised eagerly (init_process_group(..., device_id=...)) and has run a
+        # collective BEFORE this communicator is created, and 3.3 ms -- for every later step of the process, plain ones
+        # included in some orders -- when it has not (gloo rendezvous, lazily initialised NCCL group, or no collective yet).
+        # So: run that collective here.  Callers should still compare a few steps with and without the reducer (bench.py
+        # does, and falls back to LayerBucketReducer); a process whose default group is not NCCL gets a warning.
+        if dist.is_initialized() and dist.get_backend(group) == "nccl":
+            warm = torch.zeros(8, device=device, dtype=torch.float32)
+            dist.all_reduce(warm, group=group)
+            torch.cuda.synchronize(device)
+            self.warmed = True
+        else:
+            self.warmed = False
+            import warnings
+            warnings.warn("NativeUnitReducer without an eagerly initialised NCCL default group: steps with it measured 3 x "
+                          "slower in that set-up (see parallel.py); time a few steps before trusting it")
+        ident = C.create_string_buffer(128)
+        if self.rank == 0:
+            L_.check(self.lib.dvgr_comm_unique_id(ident), "dvgr_comm_unique_id")
+        if self.world > 1:
+            box = [ident.raw]
+            dist.broadcast_object_list(box, src=0, group=group)
+            ident = C.create_string_buffer(box[0], 128)
+        h = C.c_void_p()
+        with torch.cuda.device(device):     # (before the unit's first call on this device: DVGR_E_ORDER otherwise)
+            L_.check(self.lib.dvgr_comm_create(ident, self.rank, self.world, C.byref(h)), "dvgr_comm_create")
+        self.handle = h.value
+
+    def start(self, num_layers: int = 0) -> None:       # same call shape as LayerBucketReducer
+        return None
+
+    def reduce(self, flat_grad: torch.Tensor) -> None:
+        """The whole buffer in one collective, behind the current stream (a caller that does not use set_comm)."""
+        from . import _lib as L_
+        cur = torch.cuda.current_stream(self.device).cuda_stream
+        L_.check(self.lib.dvgr_comm_allreduce_avg(self.handle, flat_grad.data_ptr(), flat_grad.numel(), None, cur),
+                 "dvgr_comm_allreduce_avg")
+        self.finish()
+
+    def finish(self) -> None:
+        from . import _lib as L_
+        L_.check(self.lib.dvgr_comm_join(self.handle, torch.cuda.current_stream(self.device).cuda_stream), "dvgr_comm_join")
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.lib.dvgr_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def shard_batch(n_items: int, rank: int, world: int) -> Tuple[int, int]:

@@ -223,7 +223,7 @@ class _UnitFn(torch.autograd.Function):
         gwords = torch.empty_like(words)
         flat_mode = mod.grad_mode == "flat"
         gflat, deposit = mod._grad_target(flat) if flat_mode else (torch.empty_like(flat), None)
-        if deposit == "accumulate" and mod._layer_cb is not None:
+        if deposit == "accumulate" and (mod._layer_cb is not None or getattr(mod, "_comm", None) is not None):
             # the callback hands `gflat` to an asynchronous reducer; adding a half-reduced temporary into the live
             # buffer afterwards would race with the collectives
             raise RuntimeError("gradient accumulation into a live flat buffer cannot be combined with the layer callback: "
@@ -317,6 +317,7 @@ class DualVGRUnit_multiple(nn.Module):
         self._events_arr = None
         self._probe = None
         self._layer_cb = None
+        self._comm = None
         self._layer_cb_c = None
         self._layer_cb_error = None
         self._backward_gflat = None
@@ -525,6 +526,12 @@ class DualVGRUnit_multiple(nn.Module):
 
         self._layer_cb_c = L_.LAYER_DONE_CB(_thunk)
 
+    def set_comm(self, comm):
+        """comm: a `parallel.NativeUnitReducer` (or None).  The backward then enqueues the RCCL all-reduce of every block of
+        the flat gradient buffer itself (dvgr_opts.comm, include/dvgr_comm.h): no events, no callback, no helper thread;
+        the reducer's finish() makes the caller's stream wait for the averaged gradients."""
+        self._comm = comm
+
     def set_probe(self, site: int, layer: int = 0, begin=None, end=None):
         """Bracket one launch site (enum dvgr_probe_site) of the following calls with two
         torch.cuda.Event(enable_timing=True); site 0 disables.  Used by bench.py."""
@@ -545,6 +552,8 @@ class DualVGRUnit_multiple(nn.Module):
             if (site >= L_.PROBE_BWD_SF_DW) == backward:
                 o.probe_site, o.probe_layer = site, layer
                 o.probe_begin, o.probe_end = b.cuda_event, e.cuda_event
+        if backward and getattr(self, "_comm", None) is not None:
+            o.comm = self._comm.handle
         if backward and self._events:
             arr = (C.c_void_p * (self.layers + 2))()
             for i, ev in enumerate(self._events):

@@ -40,6 +40,7 @@ extern "C" {
 #define DVGR_E_WORKSPACE (-3) /* saved/workspace buffer too small                       */
 #define DVGR_E_ALIGN (-4)     /* a pointer is not 16-byte aligned                       */
 #define DVGR_E_KIND (-5)      /* unknown parameter / saved-tensor kind                  */
+#define DVGR_E_ORDER (-6)     /* dvgr_comm_create after the unit already ran on this device (include/dvgr_comm.h) */
 
 /* Problem dimensions.  Mirrors the constructor arguments of DualVGRUnit_multiple
  * (model/models.py:87) plus the run-time batch shape of its forward (model/models.py:121-133). */
@@ -220,6 +221,11 @@ typedef struct dvgr_opts {
                           all-reduce, so that the collectives enter their stream while the rest of the backward is still
                           being launched (after the call returns the device has usually finished the backward already) */
   void *layer_done_user;
+  void *comm;          /* backward only, nullable: a dvgr_comm* (include/dvgr_comm.h).  The backward then enqueues the RCCL
+                          all-reduce (mean over ranks, in place) of every block of `gparams` itself, on the communicator's
+                          stream, behind the block's own event, the moment the block's last kernel has been enqueued -- no host
+                          callback, no helper thread.  The caller makes its stream wait with dvgr_comm_join() before it reads
+                          the gradients.  Independent of layer_done_events / layer_done_cb (which may stay NULL). */
 } dvgr_opts;
 
 /* Forward of the whole stacked unit: replaces DualVGRUnit_multiple.forward (model/models.py:

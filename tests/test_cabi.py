@@ -35,6 +35,7 @@ def test_library_exports_every_declared_symbol():
     from dualvgr_videoqa_amd import store as ST
     from dualvgr_videoqa_amd import trainer as TR
     from dualvgr_videoqa_amd import inputs as IN
+    from dualvgr_videoqa_amd import parallel as PA
     IN.load()
     HD.load()
     CL.load()
@@ -42,6 +43,8 @@ def test_library_exports_every_declared_symbol():
     TR.load()
     bound = ({n for n, _, _ in L.SYMBOLS} | {n for n, _, _ in HD.HEAD_SYMBOLS} | {n for n, _, _ in CL.CLIP_SYMBOLS}
              | {n for n, _, _ in ST.STORE_SYMBOLS} | {n for n, _, _ in TR.OPTIM_SYMBOLS} | {n for n, _, _ in IN.INPUT_SYMBOLS})
+    PA._comm_lib()                                # resolves RCCL by dlopen (no GPU call); binds the dvgr_comm_* entry points
+    bound |= {n for n, _, _ in PA.COMM_SYMBOLS}
     assert declared == bound, declared ^ bound
     for name in declared:
         assert getattr(lib, name) is not None
