@@ -12,6 +12,9 @@
 using namespace dvgr;
 
 namespace dvgr {
+#ifdef DVGR_TIMING_AIDS
+int fwd_sf_phase_launch(hipStream_t stream, const GemmBatch& b, const SfCombineArgs& sf, int prec);   // experiment, dvgr_gemm.hip
+#endif
 std::atomic<long long> g_launch_count{0};
 size_t gat_lds_bytes_max(int N, int F);
 size_t aux_ws_floats(const dvgr_dims& d);
@@ -486,40 +489,47 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
       DVGR_TRY(aux_losses(hs, d, &lio, Q.alpha, Q.beta, Q.dep_scale, Q.loss3, nullptr, gl, ws + fwd_ws(d).total));
     }
     // S4: tn_v = tanh(z_v . P1^T + bP)
-    {
-      GemmBatch gb{};
-      for (int m = 0; m < 2; ++m) {
-        gb.p[gb.n] = nt(outc[m], D, mp(l, m) + P.sf_p1, D, ms(l, m) + S.tn, D, mp(l, m) + P.sf_bp, BN, D, D, ACT_TANH);
-        PM.attach(gb.p[gb.n++]);
-        gb.p[gb.n] = nt(outs[m], D, mp(l, m) + P.sf_p1, D, ms(l, m) + S.tn + BND, D, mp(l, m) + P.sf_bp, BN, D, D, ACT_TANH);
-        PM.attach(gb.p[gb.n++]);
-      }
-      DVGR_TRY(fprobe.begin(DVGR_PROBE_FWD_SF_GEMM, l));
-      DVGR_TRY(gemm_launch(st, KC, KC, gb, TAG_FWD_SF, prec));
-      DVGR_TRY(fprobe.end(DVGR_PROBE_FWD_SF_GEMM, l));
+    GemmBatch gb4{};
+    for (int m = 0; m < 2; ++m) {
+      gb4.p[gb4.n] = nt(outc[m], D, mp(l, m) + P.sf_p1, D, ms(l, m) + S.tn, D, mp(l, m) + P.sf_bp, BN, D, D, ACT_TANH);
+      PM.attach(gb4.p[gb4.n++]);
+      gb4.p[gb4.n] = nt(outs[m], D, mp(l, m) + P.sf_p1, D, ms(l, m) + S.tn + BND, D, mp(l, m) + P.sf_bp, BN, D, D, ACT_TANH);
+      PM.attach(gb4.p[gb4.n++]);
     }
     // S5
-    {
-      SfCombineArgs a{};
+    SfCombineArgs a5{};
+    for (int m = 0; m < 2; ++m) {
+      a5.X[m] = Xin[m]; a5.z0[m] = outc[m]; a5.z1[m] = outs[m]; a5.tn[m] = ms(l, m) + S.tn;
+      a5.p2[m] = mp(l, m) + P.sf_p2; a5.beta[m] = ms(l, m) + S.beta; a5.Xout[m] = ms(l, m) + S.x;
+      a5.o[m] = (l == L - 1) ? (m == 0 ? io->aq_embed : io->mq_embed) : nullptr;
+      a5.xp[m] = PM.out(ms(l, m) + S.x, &plo);
+    }
+    a5.x_lo_off = plo;
+    a5.rows = BN; a5.D = D; a5.N = N;
+    if (l + 1 < L) {                     // S1 and the x-site dropout of layer l + 1, on the row while it is in registers
+      const Keys Kn = layer_keys(train, seed, l + 1);
       for (int m = 0; m < 2; ++m) {
-        a.X[m] = Xin[m]; a.z0[m] = outc[m]; a.z1[m] = outs[m]; a.tn[m] = ms(l, m) + S.tn;
-        a.p2[m] = mp(l, m) + P.sf_p2; a.beta[m] = ms(l, m) + S.beta; a.Xout[m] = ms(l, m) + S.x;
-        a.o[m] = (l == L - 1) ? (m == 0 ? io->aq_embed : io->mq_embed) : nullptr;
-        a.xp[m] = PM.out(ms(l, m) + S.x, &plo);
+        a5.next_p[m] = ms(l + 1, m) + S.p; a5.next_s[m] = ms(l + 1, m) + S.s;
+        a5.next_xd[m] = (train && !lean) ? ms(l + 1, m) + S.xd : nullptr;       // fp32 copies only where they are read
+        a5.next_xd_p[m] = train ? PM.out(ms(l + 1, m) + S.xd, &plo) : nullptr;
+        for (int gi = 0; gi < 2; ++gi) a5.next_key[m][gi] = Kn.x[m][gi];
       }
-      a.x_lo_off = plo;
-      a.rows = BN; a.D = D; a.N = N;
-      if (l + 1 < L) {                     // S1 and the x-site dropout of layer l + 1, on the row while it is in registers
-        const Keys Kn = layer_keys(train, seed, l + 1);
-        for (int m = 0; m < 2; ++m) {
-          a.next_p[m] = ms(l + 1, m) + S.p; a.next_s[m] = ms(l + 1, m) + S.s;
-          a.next_xd[m] = (train && !lean) ? ms(l + 1, m) + S.xd : nullptr;       // fp32 copies only where they are read
-          a.next_xd_p[m] = train ? PM.out(ms(l + 1, m) + S.xd, &plo) : nullptr;
-          for (int gi = 0; gi < 2; ++gi) a.next_key[m][gi] = Kn.x[m][gi];
-        }
-        a.next_xd_lo_off = plo;
-      }
-      DVGR_TRY(sf_combine_fwd(st, a));
+      a5.next_xd_lo_off = plo;
+    }
+    bool phased = false;
+#ifdef DVGR_TIMING_AIDS
+    static const bool phase_on = []() { const char* e = getenv("DVGR_PHASE"); return e && e[0] == '1'; }();
+    if (phase_on) {                      // experiment: S4 and S5 as two phases of one launch behind a grid barrier
+      const int e = fwd_sf_phase_launch(st, gb4, a5, prec);
+      if (e == 0) phased = true;
+      else if (e != DVGR_E_DIMS) return e;
+    }
+#endif
+    if (!phased) {
+      DVGR_TRY(fprobe.begin(DVGR_PROBE_FWD_SF_GEMM, l));
+      DVGR_TRY(gemm_launch(st, KC, KC, gb4, TAG_FWD_SF, prec));
+      DVGR_TRY(fprobe.end(DVGR_PROBE_FWD_SF_GEMM, l));
+      DVGR_TRY(sf_combine_fwd(st, a5));
     }
   }
 

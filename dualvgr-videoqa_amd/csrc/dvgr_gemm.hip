@@ -9,6 +9,9 @@
 #include <stdlib.h>
 
 #include "dvgr_gemm.h"
+#ifdef DVGR_TIMING_AIDS
+#include "dvgr_rows.h"
+#endif
 
 namespace dvgr {
 
@@ -1018,6 +1021,82 @@ __device__ __forceinline__ void planes_tile(const GemmProblem& P, uint16_t* smem
   GCLK_ADD(2);
   if (wave == 0) GCLK_FLUSH(0);
 }
+
+#ifdef DVGR_TIMING_AIDS
+// =================================================================================================
+// EXPERIMENT (round 3, verdict item 1; -DDVGR_TIMING_AIDS builds only): the S4 contraction and the S5 row kernel of one layer
+// as TWO PHASES OF ONE LAUNCH behind an XCD-hierarchical grid barrier (MI355X_MICROARCH.md price list: barrier-xcd,
+// phase-in-launch; cdna_hip_programming.md Guideline 16 for the release / acquire around it).  256 workgroups, one per CU,
+// all resident (768 threads, 128 KB of LDS each).  Result: profiles/experiments_r03.tsv, experiment phase_s4_s5.
+// =================================================================================================
+__device__ unsigned g_phase_state[32];      // [0..7] per-partition arrival counters, [8] top counter, [16..23] generations, [31] timeout
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+__device__ __forceinline__ void grid_barrier_xcd(unsigned epoch) {
+  // every storing wave drains its stores, then the workgroup meets, then ONE lane releases at agent scope and arrives
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the fence's own wait can be dropped: Guideline 16, pitfall 12)
+    gu32* st = (gu32*)g_phase_state;
+    const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned part = lin & 7u;                             // = the XCD under round-robin placement; correctness needs no more
+    const unsigned n_part = total / 8u + ((total & 7u) > part ? 1u : 0u);
+    const unsigned old = __hip_atomic_fetch_add(st + part, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    if (old + 1u == n_part * epoch) {                           // last of its partition: carries the arrival to the top
+      __hip_atomic_fetch_add(st + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned parts = total < 8u ? total : 8u;
+      while (__hip_atomic_load(st + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < parts * epoch) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 22)) { __hip_atomic_store(st + 31, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+      __hip_atomic_store(st + 16 + part, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      while (__hip_atomic_load(st + 16 + part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 22)) { __hip_atomic_store(st + 31, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // ONE invalidate of this CU's L1 after the match
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+}
+
+template <int TERMS>
+__global__ __launch_bounds__(768) void fwd_sf_phase_kernel(const GemmBatch batch, const SfCombineArgs sf) {
+  __shared__ __attribute__((aligned(16))) uint16_t smem[PlanesLds<TERMS, RS>::kLds];
+  const GemmProblem P = batch.p[blockIdx.z];
+  planes_tile<KC, KC, TERMS, RS>(P, smem);                      // phase 1: tanh(z_v . P1^T + bP), this workgroup's tile (if any)
+  grid_barrier_xcd(1u);
+  // phase 2: S5, one wave per (modality, row)
+  const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const int w = lin * 12 + (threadIdx.x >> 6);
+  const int nw = gridDim.x * gridDim.y * gridDim.z * 12;
+  for (int item = w; item < 2 * sf.rows; item += nw) sf_combine_row(sf, item / sf.rows, item % sf.rows, threadIdx.x & 63);
+}
+
+static bool planes_eligible(const GemmBatch& b, int la, int lb);
+int fwd_sf_phase_launch(hipStream_t stream, const GemmBatch& b, const SfCombineArgs& sf, int prec) {
+  int tiles = 0;
+  for (int i = 0; i < b.n; ++i) {
+    const int t = ((b.p[i].M + RT - 1) / RT) * ((b.p[i].N + RT - 1) / RT);
+    tiles = t > tiles ? t : tiles;
+  }
+  const dim3 grid(8 * ((tiles + 7) / 8), 1, b.n), block(768);
+  if (grid.x * grid.z > 256 || prec == DVGR_F32 || !planes_eligible(b, KC, KC)) return DVGR_E_DIMS;   // every workgroup must be resident
+  void* state = nullptr;
+  hipError_t e = hipGetSymbolAddress(&state, HIP_SYMBOL(g_phase_state));
+  if (e == hipSuccess) e = hipMemsetAsync(state, 0, sizeof(unsigned) * 32, stream);
+  if (e != hipSuccess) return (int)e;
+  if (prec == DVGR_BF16X3) DVGR_LAUNCH((fwd_sf_phase_kernel<3>), grid, block, 0, stream, b, sf);
+  else DVGR_LAUNCH((fwd_sf_phase_kernel<1>), grid, block, 0, stream, b, sf);
+  return (int)hipGetLastError();
+}
+#endif  // DVGR_TIMING_AIDS
 
 template <int LA, int LB, int TAG, int TERMS, int NS = RS, int RTM = RT>
 __global__ __launch_bounds__(768) void gemm_planes_kernel(const GemmBatch batch) {
