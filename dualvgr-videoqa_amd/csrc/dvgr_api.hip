@@ -45,7 +45,7 @@ FwdWs fwd_ws(const dvgr_dims& d) {
 // twice, indexed by l & 1: the critical path may run one layer ahead of the side stream.  The query branch runs once,
 // after the last layer, for ALL layers: its inputs (d p of every layer) and intermediates are kept per layer.
 struct BwdWs {
-  int64_t dpo, dzf, dp0, dp1, dz[2], dxtmp[2];
+  int64_t dpo, dzf, dp0, dp1, dz[2], dxtmp[2], dspec[2];
   int64_t dw[2][2], dpre[2][2], dWh[2][2], ds_part[2][2], da_part[2][2], dc_part[2][2];   // [set][modality]
   int64_t dp_cat, dqbar, dr, dy, qdots, total;                                             // [L] each
 };
@@ -59,12 +59,13 @@ BwdWs bwd_ws(const dvgr_dims& d) {
   w.dp1 = o; o += round64(BN * kMfbHidden);
   for (int m = 0; m < 2; ++m) { w.dz[m] = o; o += round64(2 * BN * D); }
   for (int m = 0; m < 2; ++m) { w.dxtmp[m] = o; o += round64(BN * D); }
+  for (int m = 0; m < 2; ++m) { w.dspec[m] = o; o += d.G > 1 ? round64(BN * D) : 0; }   // graph_layers > 1: next graph layer's input grad
   for (int s = 0; s < 2; ++s) {
     for (int m = 0; m < 2; ++m) {
       w.dw[s][m] = o;      o += round64(2 * BN);
       w.dpre[s][m] = o;    o += round64(2 * BN * D);
       w.dWh[s][m] = o;     o += round64(BN * kHeads * F);
-      w.ds_part[s][m] = o; o += round64((int64_t)d.B * kHeads * d.N);
+      w.ds_part[s][m] = o; o += round64((int64_t)d.B * kHeads * d.N * (d.G > 1 ? d.G : 1));   // one block per graph layer
       w.da_part[s][m] = o; o += round64((int64_t)d.B * kHeads * 2 * F);
       w.dc_part[s][m] = o; o += round64((int64_t)d.B * kHeads);
     }
@@ -79,7 +80,9 @@ BwdWs bwd_ws(const dvgr_dims& d) {
 }
 
 int64_t ws_floats(const dvgr_dims& d) {
-  const int64_t f = fwd_ws(d).total + round64((int64_t)aux_ws_floats(d)), b = bwd_ws(d).total;   // forward may carry the loss
+  dvgr_dims dl = d;                      // the losses run over the L * G list entries
+  dl.L = d.L * (d.G > 1 ? d.G : 1);
+  const int64_t f = fwd_ws(d).total + round64((int64_t)aux_ws_floats(dl)), b = bwd_ws(d).total;   // forward may carry the loss
   return f > b ? f : b;
 }
 
@@ -123,7 +126,7 @@ struct PlaneMap {
 // every one of those contractions runs on the planes kernels: bf16 modes, B N a multiple of the K-tile and above the
 // batch-sized kernels' range (dvgr_small.hip reads fp32 operands for reductions <= 256 rows).  Forward and backward
 // derive the same answer from the dimensions.
-inline bool lean_planes(bool planes_on, int BN) { return planes_on && (BN % 32) == 0 && BN > 256; }
+inline bool lean_planes(bool planes_on, int BN, int G = 1) { return planes_on && (BN % 32) == 0 && BN > 256 && G == 1; }
 
 // C = act(A[M,K] . B[N,K]^T + bias)                      (forward Linear)
 GemmProblem nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
@@ -190,12 +193,12 @@ PlaneMap make_plane_map(const dvgr_dims& d, const ParamLayout& P, const SavedLay
   pm.add(io->A, BND, sv_hi + S.in_a, S.total);
   pm.add(io->M, BND, sv_hi + S.in_m, S.total);
   pm.add(io->dq, (int64_t)d.B * d.T * d.D, sv_hi + S.in_dq, S.total);
-  for (int l = 0; l < d.L && l < 12; ++l) {
-    const int64_t m0 = S.layer_stride * l + S.mod_base, m1 = m0 + S.mod_stride;
-    pm.add(io->com_app + l * BND, BND, sv_hi + m0 + S.zc, S.total);
-    pm.add(io->com_mot + l * BND, BND, sv_hi + m1 + S.zc, S.total);
-    pm.add(io->aq_fusion + l * BND, BND, sv_hi + m0 + S.zs, S.total);
-    pm.add(io->mq_fusion + l * BND, BND, sv_hi + m1 + S.zs, S.total);
+  for (int e = 0; e < d.L * d.G && e < 12; ++e) {      // list entry e = unit layer e / G, graph layer e % G
+    const int64_t m0 = S.layer_stride * (e / d.G) + S.mod_base + S.g_stride * (e % d.G), m1 = m0 + S.mod_stride;
+    pm.add(io->com_app + e * BND, BND, sv_hi + m0 + S.zc, S.total);
+    pm.add(io->com_mot + e * BND, BND, sv_hi + m1 + S.zc, S.total);
+    pm.add(io->aq_fusion + e * BND, BND, sv_hi + m0 + S.zs, S.total);
+    pm.add(io->mq_fusion + e * BND, BND, sv_hi + m1 + S.zs, S.total);
   }
   return pm;
 }
@@ -232,7 +235,7 @@ int dvgr_streams_init(void) {
 int dvgr_check_dims(const dvgr_dims* d) {
   if (!d) return DVGR_E_NULL;
   if (d->B < 1 || d->N < 1 || d->T < 1 || d->L < 1) return DVGR_E_DIMS;
-  if (d->G != 1) return DVGR_E_DIMS;
+  if (d->G < 1 || d->G > 4 || d->L * d->G > 48) return DVGR_E_DIMS;   // graph_layers > 1: see dvgr_unit_forward
   if (d->D < 64 || d->D % 64) return DVGR_E_DIMS;
   if (d->Wd < 4 || d->Wd % 4) return DVGR_E_DIMS;
   if (d->N > 64 || d->T > 256) return DVGR_E_DIMS;
@@ -249,8 +252,10 @@ int dvgr_param_offset(const dvgr_dims* d, int kind, int layer, int mod, int64_t*
   const ParamLayout p = param_layout(*d);
   const int64_t D = d->D, Wd = d->Wd, F = d->D / 4;
   if (kind < 0 || kind >= DVGR_P_KINDS) return DVGR_E_KIND;
-  if (kind < DVGR_P_MFB_W0 && (layer < 0 || layer >= d->L || mod < 0 || mod > 1)) return DVGR_E_KIND;
-  const int64_t mb = p.layer_stride * layer + p.mod_stride * mod;                  // layer block (GAT / SF parameters)
+  const bool gat_kind = kind >= DVGR_P_GAT_W && kind <= DVGR_P_GAT_C;              // `layer` = GAT module index, 0 .. L * G - 1
+  const int G = d->G > 1 ? d->G : 1;
+  if (kind < DVGR_P_MFB_W0 && (layer < 0 || layer >= (gat_kind ? d->L * G : d->L) || mod < 0 || mod > 1)) return DVGR_E_KIND;
+  const int64_t mb = gat_kind ? gat_set_base(p, d->L, layer, mod) : p.layer_stride * layer + p.mod_stride * mod;   // layer block
   const int64_t lb = p.q_base + p.q_layer_stride * layer;                          // query block (QueryAttn / QueryPunish)
   const int64_t qmb = lb + p.q_mod_base + p.q_mod_stride * mod;
   switch (kind) {
@@ -281,8 +286,9 @@ int dvgr_param_offset(const dvgr_dims* d, int kind, int layer, int mod, int64_t*
 int dvgr_param_layer_range(const dvgr_dims* d, int layer, int64_t* first, int64_t* last) {
   if (!d || !first || !last) return DVGR_E_NULL;
   const ParamLayout p = param_layout(*d);
-  if (layer < 0 || layer > d->L + 1) return DVGR_E_KIND;
-  if (layer == d->L + 1) { *first = p.q_base; *last = p.total; }           // query block of all layers
+  if (layer < 0 || layer > d->L + 2) return DVGR_E_KIND;
+  if (layer == d->L + 2) { *first = p.extra_base; *last = p.total; }       // extra GAT sets (graph_layers > 1; empty otherwise)
+  else if (layer == d->L + 1) { *first = p.q_base; *last = p.extra_base; } // query block of all layers
   else if (layer == d->L) { *first = p.mfb_base; *last = p.q_base; }       // MFB block
   else { *first = p.layer_stride * layer; *last = p.layer_stride * (layer + 1); }
   return 0;
@@ -295,8 +301,12 @@ int dvgr_saved_offset(const dvgr_dims* d, int kind, int layer, int mod, size_t* 
   if (!d || !offset_bytes) return DVGR_E_NULL;
   const SavedLayout s = saved_layout(*d);
   if (kind < 0 || kind >= DVGR_S_KINDS) return DVGR_E_KIND;
-  if ((kind < DVGR_S_MFB_X0 || kind == DVGR_S_XD) && (layer < 0 || layer >= d->L || mod < 0 || mod > 1)) return DVGR_E_KIND;
-  const int64_t lb = s.layer_stride * layer, mb = lb + s.mod_base + s.mod_stride * mod;
+  // per-graph-layer tensors (Wh, u, v, xd): `layer` = unit layer * G + graph layer; everything else: the unit layer
+  const int G = d->G > 1 ? d->G : 1;
+  const bool per_g = kind == DVGR_S_WH || kind == DVGR_S_U || kind == DVGR_S_V || kind == DVGR_S_XD;
+  if ((kind < DVGR_S_MFB_X0 || kind == DVGR_S_XD) && (layer < 0 || layer >= (per_g ? d->L * G : d->L) || mod < 0 || mod > 1)) return DVGR_E_KIND;
+  const int unit_layer = per_g ? layer / G : layer;
+  const int64_t lb = s.layer_stride * unit_layer, mb = lb + s.mod_base + s.mod_stride * mod + (per_g ? s.g_stride * (layer % G) : 0);
   int64_t o;
   switch (kind) {
     case DVGR_S_QA_D: o = lb + s.qa_d; break;
@@ -368,7 +378,8 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
 
   const PlaneMap PM = make_plane_map(d, P, S, params, params_lp, io, saved, ws);
   int64_t plo = 0;                       // lo-plane offset of the last PM.out() lookup
-  const bool lean = lean_planes(PM.on, BN);
+  const int G = d.G;
+  const bool lean = lean_planes(PM.on, BN, G);
   if (PM.on) {                           // bf16 hi/lo planes of the caller's inputs
     SplitBatch sb{};
     sb.lo_off = S.total;
@@ -423,29 +434,41 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
   }
 
   // ---- layers ---------------------------------------------------------------------------------------
+  // graph_layers G > 1 (model/models.py:150-160; no shipped config): unit layer l runs G GAT steps; step j uses GAT module
+  // [l + j] of each family (SHARED with every other (l', j') of the same sum -- gat_set_base), reads the previous step's
+  // SPECIFIC output (step 0: the layer input) and the layer's one punish gate, and appends its two outputs to the lists
+  // (entry l * G + j); the last step's pair feeds the SF attention.  The G > 1 path is the plain one: fp32 + planes
+  // copies everywhere (no plane-only tensors), single stream in the backward.
+  auto gp_ = [&](int k, int m) { return params + gat_set_base(P, L, k, m); };                  // GAT module k
+  auto gs_ = [&](int l, int m, int j) { return ms(l, m) + S.g_stride * j; };                   // saved block of graph layer j
   for (int l = 0; l < L; ++l) {
-    const Keys K = layer_keys(train, seed, l);
     const float* Xin[2] = {l == 0 ? io->A : ms(l - 1, 0) + S.x, l == 0 ? io->M : ms(l - 1, 1) + S.x};
-    float* outc[2] = {io->com_app + l * BND, io->com_mot + l * BND};
-    float* outs[2] = {io->aq_fusion + l * BND, io->mq_fusion + l * BND};
+    float* outc[2] = {nullptr, nullptr};
+    float* outs[2] = {nullptr, nullptr};
+    for (int j = 0; j < G; ++j) {
+    const int e = l * G + j, k = l + j;      // list entry / dropout site index, GAT module index
+    const Keys K = layer_keys(train, seed, e);
+    const float* Xj[2] = {j == 0 ? Xin[0] : outs[0], j == 0 ? Xin[1] : outs[1]};      // (outs still holds step j - 1's)
+    outc[0] = io->com_app + e * BND; outc[1] = io->com_mot + e * BND;
+    outs[0] = io->aq_fusion + e * BND; outs[1] = io->mq_fusion + e * BND;
     // S2: Wh = drop_x(X) . Wcat^T + bcat.  Training: the two GATs of a modality see differently dropped
     // copies of X, materialised once (saved: the backward needs them for dWcat) so that the contraction
     // itself carries no mask and can run on the LDS-DMA ring kernel.
     {
       GemmBatch gb{};
       // the dropped copies: layers > 0 get them from the previous layer's S5 kernel; layer 0 from the split kernel above
-      // (bf16 modes: planes only, nobody reads them as fp32) or, in DVGR_F32, from k_drop_x
-      if (train && l == 0 && !lean)
-        DVGR_TRY(drop_x(st, Xin[0], Xin[1], ms(l, 0) + S.xd, ms(l, 1) + S.xd, K.x, BND, PM.out(ms(l, 0) + S.xd, &plo),
-                        PM.out(ms(l, 1) + S.xd, &plo), plo));
+      // (bf16 modes: planes only, nobody reads them as fp32) or, in DVGR_F32, from k_drop_x; graph layers j > 0: k_drop_x
+      if (train && ((l == 0 && !lean) || j > 0))
+        DVGR_TRY(drop_x(st, Xj[0], Xj[1], gs_(l, 0, j) + S.xd, gs_(l, 1, j) + S.xd, K.x, BND, PM.out(gs_(l, 0, j) + S.xd, &plo),
+                        PM.out(gs_(l, 1, j) + S.xd, &plo), plo));
       for (int m = 0; m < 2; ++m) {
         if (!train) {
-          gb.p[gb.n] = nt(Xin[m], D, mp(l, m) + P.gat_w, D, ms(l, m) + S.wh, HF, mp(l, m) + P.gat_b, BN, HF, D, ACT_NONE);
+          gb.p[gb.n] = nt(Xj[m], D, gp_(k, m) + P.gat_w, D, gs_(l, m, j) + S.wh, HF, gp_(k, m) + P.gat_b, BN, HF, D, ACT_NONE);
           PM.attach(gb.p[gb.n++]);
         } else {
           for (int g = 0; g < 2; ++g) {
-            gb.p[gb.n] = nt(ms(l, m) + S.xd + g * BND, D, mp(l, m) + P.gat_w + (int64_t)g * 4 * F * D, D,
-                            ms(l, m) + S.wh + g * 4 * F, HF, mp(l, m) + P.gat_b + g * 4 * F, BN, 4 * F, D, ACT_NONE);
+            gb.p[gb.n] = nt(gs_(l, m, j) + S.xd + g * BND, D, gp_(k, m) + P.gat_w + (int64_t)g * 4 * F * D, D,
+                            gs_(l, m, j) + S.wh + g * 4 * F, HF, gp_(k, m) + P.gat_b + g * 4 * F, BN, 4 * F, D, ACT_NONE);
             PM.attach(gb.p[gb.n++]);
           }
         }
@@ -455,16 +478,16 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
       DVGR_TRY(fprobe.end(DVGR_PROBE_FWD_GAT_GEMM, l));
     }
     // S1 (needs p from S0: the side stream joins here)
-    if (l == 0 && side) DVGR_TRY(side->order(hs, st));
-    if (l == 0)                            // layers > 0: gate computed by the previous layer's S5 kernel
+    if (l == 0 && j == 0 && side) DVGR_TRY(side->order(hs, st));
+    if (l == 0 && j == 0)                  // layers > 0: gate computed by the previous layer's S5 kernel
       DVGR_TRY(punish_fwd(st, Xin[0], Xin[1], ms(l, 0) + S.p, ms(l, 1) + S.p, ms(l, 0) + S.s, ms(l, 1) + S.s, B, N, D));
     // S3
     {
       GatAttnArgs a{};
       for (int m = 0; m < 2; ++m) {
-        a.Wh[m] = ms(l, m) + S.wh; a.s[m] = ms(l, m) + S.s;
-        a.gat_a[m] = mp(l, m) + P.gat_a; a.gat_c[m] = mp(l, m) + P.gat_c;
-        a.u[m] = ms(l, m) + S.u; a.v[m] = ms(l, m) + S.v;
+        a.Wh[m] = gs_(l, m, j) + S.wh; a.s[m] = ms(l, m) + S.s;
+        a.gat_a[m] = gp_(k, m) + P.gat_a; a.gat_c[m] = gp_(k, m) + P.gat_c;
+        a.u[m] = gs_(l, m, j) + S.u; a.v[m] = gs_(l, m, j) + S.v;
         a.out_c[m] = outc[m]; a.out_s[m] = outs[m];
         for (int h = 0; h < 8; ++h) a.key_alpha[m][h] = K.alpha[m][h];
         for (int g = 0; g < 2; ++g) a.key_out[m][g] = K.out[m][g];
@@ -477,6 +500,7 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
       DVGR_TRY(gat_attn_fwd(st, a));
       DVGR_TRY(fprobe.end(DVGR_PROBE_FWD_GAT_ATTN, l));
     }
+    }  // graph layers
     // every list output exists now: the auxiliary losses and their gradients (VALU / HBM work) go under the
     // contractions that are still to come (S4 of this layer, MFB)
     if (l == L - 1 && O.loss) {
@@ -486,7 +510,9 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
       dvgr_io lio = *io;
       lio.vis = nullptr;                   // sum(vis) follows at the very end
       float* const gl[4] = {Q.g_com_app, Q.g_com_mot, Q.g_aq_fusion, Q.g_mq_fusion};
-      DVGR_TRY(aux_losses(hs, d, &lio, Q.alpha, Q.beta, Q.dep_scale, Q.loss3, nullptr, gl, ws + fwd_ws(d).total));
+      dvgr_dims dl = d;                    // the losses run over the list ENTRIES: L * G of them (train.py:148-154: len(list))
+      dl.L = L * G; dl.G = 1;
+      DVGR_TRY(aux_losses(hs, dl, &lio, Q.alpha, Q.beta, Q.dep_scale, Q.loss3, nullptr, gl, ws + fwd_ws(d).total));
     }
     // S4: tn_v = tanh(z_v . P1^T + bP)
     GemmBatch gb4{};
@@ -507,7 +533,7 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
     a5.x_lo_off = plo;
     a5.rows = BN; a5.D = D; a5.N = N;
     if (l + 1 < L) {                     // S1 and the x-site dropout of layer l + 1, on the row while it is in registers
-      const Keys Kn = layer_keys(train, seed, l + 1);
+      const Keys Kn = layer_keys(train, seed, (l + 1) * G);
       for (int m = 0; m < 2; ++m) {
         a5.next_p[m] = ms(l + 1, m) + S.p; a5.next_s[m] = ms(l + 1, m) + S.s;
         a5.next_xd[m] = (train && !lean) ? ms(l + 1, m) + S.xd : nullptr;       // fp32 copies only where they are read
@@ -596,7 +622,12 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
   float* dXacc[2] = {g->gA, g->gM};     // running gradient w.r.t. the current layer boundary
   const PlaneMap PM = make_plane_map(d, P, S, params, params_lp, io, saved, ws);
   int64_t plo = 0;
-  const bool lean = lean_planes(PM.on, BN);   // dpre / dWh / xd exist as planes only (see lean_planes)
+  const int G = d.G;
+  const bool lean = lean_planes(PM.on, BN, G);   // dpre / dWh / xd exist as planes only (see lean_planes)
+  if (G > 1 && (layer_done_events || O.comm)) return DVGR_E_DIMS;   // shared GAT modules: a block is final only at the very end
+  auto gpp_ = [&](int k, int m) { return params + gat_set_base(P, L, k, m); };                 // GAT module k: parameters,
+  auto ggp_ = [&](int k, int m) { return gp + gat_set_base(P, L, k, m); };                     //   gradients
+  auto gs_ = [&](int l, int m, int j) { return ms(l, m) + S.g_stride * j; };                   // saved block of graph layer j
 
   // every element of gparams is written: the matrices by their contractions, everything between them (bias and vector
   // gradients, which contractions and column sums ADD into -- GemmProblem::rowsum -- and the alignment padding) is zeroed
@@ -616,6 +647,11 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
         DVGR_TRY(add(gmp(l, m) + P.gat_b, P.sf_p1 - P.gat_b));
         DVGR_TRY(add(gmp(l, m) + P.sf_bp, P.mod_stride - P.sf_bp));
       }
+    for (int k = L; k < L * G; ++k)              // extra GAT sets: the vectors of the used ones, everything of the unused ones
+      for (int m = 0; m < 2; ++m) {
+        const bool used = k <= L + G - 2;
+        DVGR_TRY(add(ggp_(k, m) + (used ? P.gat_b : 0), P.extra_mod_stride - (used ? P.gat_b : 0)));
+      }
     DVGR_TRY(add(gp + P.mfb_b0, P.mfb_w1 - P.mfb_b0));
     DVGR_TRY(add(gp + P.mfb_b1, P.mfb_wo - P.mfb_b1));
     DVGR_TRY(add(gp + P.mfb_bo, P.q_base - P.mfb_bo));
@@ -628,7 +664,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
 
   // Two streams: `st` carries the critical path (the dX chain), `hs` every weight / bias gradient.
   // DVGR_OPT_SINGLE_STREAM (or a missing side stream) folds everything onto `st`.
-  SideStream* side = ((O.flags & DVGR_OPT_SINGLE_STREAM) || 4 * L + 16 > 256) ? nullptr : side_stream();
+  SideStream* side = ((O.flags & DVGR_OPT_SINGLE_STREAM) || 4 * L + 16 > 256 || G > 1) ? nullptr : side_stream();
   hipStream_t hs = side ? side->st : st;
   // query branch (see dvgr_side.h).  Small batches are bound by the host's enqueue rate, where a third stream only adds
   // event calls (C1, B N = 160: 0.43 ms per step without it, 0.48 ms with it).
@@ -877,10 +913,11 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
   hipEvent_t side_done[2] = {nullptr, nullptr};   // side stream finished the layer that used buffer set 0 / 1
   for (int l = L - 1; l >= 0; --l) {
     const int set = l & 1;
-    const Keys K = layer_keys(train, seed, l);
+    const int e_last = l * G + G - 1;                 // list entry of the layer's last graph layer: the pair the SF attention saw
+    const Keys K = layer_keys(train, seed, l * G);    // graph layer 0 (the part below the graph-layer loop handles j = 0)
     const float* Xin[2] = {l == 0 ? io->A : ms(l - 1, 0) + S.x, l == 0 ? io->M : ms(l - 1, 1) + S.x};
-    const float* outc[2] = {io->com_app + l * BND, io->com_mot + l * BND};
-    const float* outs[2] = {io->aq_fusion + l * BND, io->mq_fusion + l * BND};
+    const float* outc[2] = {io->com_app + e_last * BND, io->com_mot + e_last * BND};
+    const float* outs[2] = {io->aq_fusion + e_last * BND, io->mq_fusion + e_last * BND};
     if (side && side_done[set]) {      // layer l + 2 shared this buffer set
       const hipError_t e = hipStreamWaitEvent(st, side_done[set], 0);
       if (e != hipSuccess) return (int)e;
@@ -895,8 +932,8 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
         a.p2[m] = mp(l, m) + P.sf_p2;
         const float* gc = m == 0 ? g->g_com_app : g->g_com_mot;
         const float* gs = m == 0 ? g->g_aq_fusion : g->g_mq_fusion;
-        a.g_z0[m] = gc ? gc + l * BND : nullptr;
-        a.g_z1[m] = gs ? gs + l * BND : nullptr;
+        a.g_z0[m] = gc ? gc + e_last * BND : nullptr;
+        a.g_z1[m] = gs ? gs + e_last * BND : nullptr;
         a.dw[m] = ws + W.dw[set][m]; a.dpre[m] = lean ? nullptr : ws + W.dpre[set][m]; a.dz[m] = ws + W.dz[m];
         a.dpre_p[m] = PM.out(ws + W.dpre[set][m], &plo);
       }
@@ -914,25 +951,121 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_BWD_SF_DX, prec));
       DVGR_TRY(probe.end(DVGR_PROBE_BWD_SF_DX, l));
     }
-    // S3 backward
-    {
+    // S3 backward of graph layer j (list entry l * G + j, GAT module l + j)
+    auto attn_bwd = [&](int j) -> int {
+      const int e = l * G + j, k = l + j;
+      const Keys Kj = layer_keys(train, seed, e);
       GatAttnBwdArgs a{};
       for (int m = 0; m < 2; ++m) {
-        a.dz[m] = ws + W.dz[m]; a.out_c[m] = outc[m]; a.out_s[m] = outs[m];
-        a.Wh[m] = ms(l, m) + S.wh; a.s[m] = ms(l, m) + S.s; a.u[m] = ms(l, m) + S.u; a.v[m] = ms(l, m) + S.v;
-        a.gat_a[m] = mp(l, m) + P.gat_a; a.gat_c[m] = mp(l, m) + P.gat_c;
-        a.dWh[m] = lean ? nullptr : ws + W.dWh[set][m]; a.ds_part[m] = ws + W.ds_part[set][m]; a.da_part[m] = ws + W.da_part[set][m];
+        a.dz[m] = ws + W.dz[m];
+        a.out_c[m] = (m == 0 ? io->com_app : io->com_mot) + e * BND;
+        a.out_s[m] = (m == 0 ? io->aq_fusion : io->mq_fusion) + e * BND;
+        a.Wh[m] = gs_(l, m, j) + S.wh; a.s[m] = ms(l, m) + S.s; a.u[m] = gs_(l, m, j) + S.u; a.v[m] = gs_(l, m, j) + S.v;
+        a.gat_a[m] = gpp_(k, m) + P.gat_a; a.gat_c[m] = gpp_(k, m) + P.gat_c;
+        a.dWh[m] = lean ? nullptr : ws + W.dWh[set][m];
+        a.ds_part[m] = ws + W.ds_part[set][m] + (int64_t)j * B * kHeads * N;      // one block per graph layer, summed by the punish pass
+        a.da_part[m] = ws + W.da_part[set][m];
         a.dc_part[m] = ws + W.dc_part[set][m];
-        for (int h = 0; h < 8; ++h) a.key_alpha[m][h] = K.alpha[m][h];
-        for (int gi = 0; gi < 2; ++gi) a.key_out[m][gi] = K.out[m][gi];
+        for (int h = 0; h < 8; ++h) a.key_alpha[m][h] = Kj.alpha[m][h];
+        for (int gi = 0; gi < 2; ++gi) a.key_out[m][gi] = Kj.out[m][gi];
         a.dWh_p[m] = PM.out(ws + W.dWh[set][m], &plo);
       }
       a.lo_off = plo;
       a.B = B; a.N = N; a.D = D;
       DVGR_TRY(probe.begin(DVGR_PROBE_BWD_GAT_ATTN, l));
       DVGR_TRY(gat_attn_bwd(st, a));
-      DVGR_TRY(probe.end(DVGR_PROBE_BWD_GAT_ATTN, l));
+      return probe.end(DVGR_PROBE_BWD_GAT_ATTN, l);
+    };
+    // graph_layers > 1 (single stream, fp32 + planes everywhere): graph layers G - 1 .. 1 in full -- attention backward,
+    // the gradient of the graph layer's INPUT (= the previous graph layer's specific output) and the weight gradients of
+    // GAT module l + j, which other (layer, graph layer) pairs share: the first pair to touch a module overwrites, the
+    // later ones accumulate (bias / a / c gradients are added atomically into zeroed ranges either way).
+    for (int j = G - 1; j >= 1; --j) {
+      const int e = l * G + j, k = l + j;
+      const Keys Kj = layer_keys(train, seed, e);
+      if (j < G - 1) {                     // dz of this graph layer: its list gradients + what came down from graph layer j + 1
+        DzBuildArgs a{};
+        for (int m = 0; m < 2; ++m) {
+          const float* gc = m == 0 ? g->g_com_app : g->g_com_mot;
+          const float* gsx = m == 0 ? g->g_aq_fusion : g->g_mq_fusion;
+          a.g_c[m] = gc ? gc + e * BND : nullptr;
+          a.g_s[m] = gsx ? gsx + e * BND : nullptr;
+          a.in0[m] = ws + W.dspec[m];
+          a.in1[m] = train ? ws + W.dxtmp[m] : nullptr;
+          a.dz[m] = ws + W.dz[m];
+        }
+        a.n = BND;
+        DVGR_TRY(dz_build(st, a));
+      }
+      DVGR_TRY(attn_bwd(j));
+      {                                    // the small vector gradients of module k
+        ColsumBatch cbj{};
+        for (int m = 0; m < 2; ++m) {
+          cbj.j[cbj.n++] = ColsumJob{ws + W.da_part[set][m], nullptr, nullptr, nullptr, B, 0, kHeads * 2 * F, kHeads * 2 * F, ggp_(k, m) + P.gat_a};
+          cbj.j[cbj.n++] = ColsumJob{ws + W.dc_part[set][m], nullptr, nullptr, nullptr, B, 0, kHeads, kHeads, ggp_(k, m) + P.gat_c};
+        }
+        cbj.chunks = 16;
+        DVGR_TRY(colsum(st, cbj));
+      }
+      {                                    // gradient of this graph layer's input: both GATs' partials, fresh buffers
+        GemmBatch gd{};
+        if (!train) {
+          for (int m = 0; m < 2; ++m) {
+            gd.p[gd.n] = nn(ws + W.dWh[set][m], HF, gpp_(k, m) + P.gat_w, D, ws + W.dspec[m], D, BN, D, HF, 0);
+            PM.attach(gd.p[gd.n++]);
+          }
+        } else {
+          for (int gi = 0; gi < 2; ++gi)
+            for (int m = 0; m < 2; ++m) {
+              gd.p[gd.n] = nn(ws + W.dWh[set][m] + gi * 4 * F, HF, gpp_(k, m) + P.gat_w + (int64_t)gi * 4 * F * D, D,
+                              gi == 0 ? ws + W.dspec[m] : ws + W.dxtmp[m], D, BN, D, 4 * F, 0, Kj.x[m][gi]);
+              PM.attach(gd.p[gd.n++]);
+            }
+        }
+        DVGR_TRY(gemm_launch(st, KC, IC, gd, TAG_BWD_GAT_DX, prec));
+      }
+      {                                    // dWcat of module k (+ d bcat)
+        GemmBatch gb{};
+        BiasOf bias[kMaxBatch] = {};
+        const int acc = (l < L - 1) ? 1 : 0;             // layer l + 1 already wrote module k (as its graph layer j - 1)
+        const float* Xj[2] = {io->aq_fusion + (e - 1) * BND, io->mq_fusion + (e - 1) * BND};   // the graph layer's input
+        for (int m = 0; m < 2; ++m) {
+          if (!train) {
+            gb.p[gb.n] = tn(ws + W.dWh[set][m], HF, Xj[m], D, ggp_(k, m) + P.gat_w, D, HF, D, BN);
+            gb.p[gb.n].accumulate = acc;
+            PM.attach(gb.p[gb.n]);
+            bias[gb.n++] = BiasOf{ws + W.dWh[set][m], BN, HF, HF, ggp_(k, m) + P.gat_b};
+          } else {
+            for (int gi = 0; gi < 2; ++gi) {
+              gb.p[gb.n] = tn(ws + W.dWh[set][m] + gi * 4 * F, HF, gs_(l, m, j) + S.xd + gi * BND, D,
+                              ggp_(k, m) + P.gat_w + (int64_t)gi * 4 * F * D, D, 4 * F, D, BN);
+              gb.p[gb.n].accumulate = acc;
+              PM.attach(gb.p[gb.n]);
+              bias[gb.n++] = BiasOf{ws + W.dWh[set][m] + gi * 4 * F, BN, 4 * F, HF, ggp_(k, m) + P.gat_b + gi * 4 * F};
+            }
+          }
+        }
+        ColsumBatch cbw{};
+        DVGR_TRY(launch_dw(st, gb, bias, TAG_BWD_GAT_DW, cbw));
+        if (cbw.n) { cbw.chunks = 16; DVGR_TRY(colsum(st, cbw)); }
+      }
     }
+    if (G > 1) {                           // graph layer 0's dz: its list gradients + the gradient of graph layer 1's input
+      DzBuildArgs a{};
+      const int e0 = l * G;
+      for (int m = 0; m < 2; ++m) {
+        const float* gc = m == 0 ? g->g_com_app : g->g_com_mot;
+        const float* gsx = m == 0 ? g->g_aq_fusion : g->g_mq_fusion;
+        a.g_c[m] = gc ? gc + e0 * BND : nullptr;
+        a.g_s[m] = gsx ? gsx + e0 * BND : nullptr;
+        a.in0[m] = ws + W.dspec[m];
+        a.in1[m] = train ? ws + W.dxtmp[m] : nullptr;
+        a.dz[m] = ws + W.dz[m];
+      }
+      a.n = BND;
+      DVGR_TRY(dz_build(st, a));
+    }
+    DVGR_TRY(attn_bwd(0));
     auto punish = [&](int parts) -> int {   // S1 backward: bit 0 = d p (kept per layer for the query branch), bit 1 = dX
       PunishBwdArgs a{};
       for (int m = 0; m < 2; ++m) {
@@ -942,6 +1075,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       }
       a.dp_cat = ws + W.dp_cat + (int64_t)l * B * 2 * D; a.B = B; a.N = N; a.D = D; a.parts = parts;
       a.zero = (parts & 1) ? ws + W.dqbar + (int64_t)l * B * Wd : nullptr; a.zero_cols = Wd;   // dq-bar accumulates split-K partials
+      a.copies = G;
       return punish_bwd(st, a);
     };
     if (l == 0) DVGR_TRY(punish(1));        // layer 0 is the last one: its query chain must not wait for the dX chain
@@ -1035,7 +1169,12 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       // behind its short tiles -- the layers > 0 put it on the side stream (measured: 1.245 ms per step against 1.272 with
       // it on the main stream, and 1.27 merged with the dX launch); layer 0 has no next layer and keeps it on the main
       // stream, which is idle by then.
-      hipStream_t dws = (side && l > 0) ? hs : st;      // (beside a reducer as well: on the main stream 1.37-1.40 against 1.32 ms)      // (layer 0's on the side stream too: no difference, 1.179 ms both)
+#ifdef DVGR_TIMING_AIDS
+      static const bool tn_main = []() { const char* e = getenv("DVGR_TN_MAIN"); return e && e[0] == '1'; }();   // A/B aid
+#else
+      constexpr bool tn_main = false;
+#endif
+      hipStream_t dws = (side && l > 0 && !tn_main) ? hs : st;      // (beside a reducer as well: on the main stream 1.37-1.40 against 1.32 ms)      // (layer 0's on the side stream too: no difference, 1.179 ms both)
       const Probe dprobe{O, dws};
       // (cannot happen: lean_planes() implies the planes kernels; under it dpre / dWh have no fp32 copy for a column sum)
       if (lean && !gemm_rowsum_supported(IC, IC, gb, prec)) return DVGR_E_DIMS;

@@ -29,9 +29,13 @@ constexpr float kSlope = 0.01f;    // LeakyReLU slope, model/models.py:95-100
 
 // ---------------------------------------------------------------------------------------------
 // Flat parameter layout.  Every tensor starts at a multiple of 64 floats.
-//   [ layer 0 | layer 1 | ... | layer L-1 | MFB | query block ]
+//   [ layer 0 | layer 1 | ... | layer L-1 | MFB | query block | extra GAT sets (graph_layers > 1 only) ]
 //   layer block  = per modality: Wcat, bcat, a, c (the two punish-GATs, 8 heads), P1, bP, p2 (SF attention)
 //   query block  = per layer: QueryAttn W1, b1, w2, b2; per modality: QueryPunish Wq, bq
+//   extra GAT set = per modality: Wcat, bcat, a, c of GAT module index L, L+1, ..., L*G-1.  The reference builds L*G
+//                  modules per family and addresses module [i + j] in unit layer i, graph layer j (model/models.py:150-160),
+//                  so modules 0 .. L+G-2 are used (module k by every (i, j) with i + j = k: they SHARE it) and the rest only
+//                  exist in the state dict.  Module k < L lives in layer block k; the others in the extra region.
 // The query-side parameters sit in a block of their own because their gradients become final together, at the very end
 // of the backward (the query branch of ALL layers runs as one batch of launches once every layer's d p is known), while
 // a layer block is final as soon as that layer's weight-gradient contractions are: the blocks are the buckets of the
@@ -45,6 +49,7 @@ struct ParamLayout {
   int64_t q_base, q_layer_stride, q_mod_base, q_mod_stride;          // query block
   int64_t qa_w1, qa_b1, qa_w2, qa_b2;                                // offsets inside a query layer block
   int64_t wq, bq;                                                    // offsets inside a query modality block
+  int64_t extra_base, extra_stride, extra_mod_stride;                // extra GAT sets (module indices >= L), G > 1
   int64_t total;
 };
 
@@ -83,8 +88,16 @@ inline ParamLayout param_layout(const dvgr_dims& d) {
   p.bq = w; w += round64(D);
   p.q_mod_stride = w;
   p.q_layer_stride = o + 2 * w;
-  p.total = p.q_base + p.q_layer_stride * d.L;
+  p.extra_base = p.q_base + p.q_layer_stride * d.L;
+  p.extra_mod_stride = p.sf_p1;                 // Wcat, bcat, a, c: the GAT part of a modality block
+  p.extra_stride = 2 * p.extra_mod_stride;
+  const int G = d.G > 1 ? d.G : 1;
+  p.total = p.extra_base + p.extra_stride * (int64_t)d.L * (G - 1);
   return p;
+}
+// float offset of GAT module `k` (0 <= k < L*G), modality `mod`: the base its gat_w / gat_b / gat_a / gat_c offsets add to
+inline int64_t gat_set_base(const ParamLayout& p, int L, int k, int mod) {
+  return k < L ? p.layer_stride * k + p.mod_stride * mod : p.extra_base + p.extra_stride * (k - L) + p.extra_mod_stride * mod;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -93,7 +106,8 @@ inline ParamLayout param_layout(const dvgr_dims& d) {
 struct SavedLayout {
   int64_t layer_stride, mod_stride, mod_base;
   int64_t qa_d, qa_nrm, qa_a, qa_ah, qa_s, qa_q;              // inside a layer block
-  int64_t p, s, x, wh, u, v, tn, beta, xd, zc, zs;            // inside a modality block
+  int64_t p, s, x, wh, u, v, tn, beta, xd, zc, zs;            // inside a modality block (wh .. zs: graph layer 0)
+  int64_t g_stride;                                           // graph layer j > 0: the same six offsets + j * g_stride
   int64_t mfb_base, mfb_x0, mfb_x1, mfb_z, in_a, in_m, in_dq; // absolute
   int64_t total;                                              // floats; the bf16 planes region follows (2 x total x 2 bytes)
 };
@@ -113,14 +127,17 @@ inline SavedLayout saved_layout(const dvgr_dims& d) {
   s.p = m;    m += round64(B * D);
   s.s = m;    m += round64(B * N);
   s.x = m;    m += round64(B * N * D);
+  s.tn = m;   m += round64(2 * B * N * D);
+  s.beta = m; m += round64(B * N * 2);
+  const int64_t g0 = m;                      // per graph layer (G of them; every reference config has G = 1):
   s.wh = m;   m += round64(B * N * kHeads * F);
   s.u = m;    m += round64(B * kHeads * N);
   s.v = m;    m += round64(B * kHeads * N);
-  s.tn = m;   m += round64(2 * B * N * D);
-  s.beta = m; m += round64(B * N * 2);
   s.xd = m;   m += round64(2 * B * N * D);   // training mode: x * keep/(1-p) for the common / specific GAT
   s.zc = m;   m += round64(B * N * D);       // plane-only slots: bf16 hi/lo of the common / specific GAT outputs
   s.zs = m;   m += round64(B * N * D);       //   (their fp32 values live in the caller's list tensors)
+  s.g_stride = m - g0;
+  m += s.g_stride * ((d.G > 1 ? d.G : 1) - 1);
   s.mod_stride = m;
   s.layer_stride = o + 2 * m;
   s.mfb_base = s.layer_stride * d.L;

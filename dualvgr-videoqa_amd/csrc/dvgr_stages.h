@@ -149,8 +149,23 @@ struct PunishBwdArgs {
   int parts;               // bit 0: dp (needs only ds_part, s, X), bit 1: the dX update; 0 means both
   float* zero;             // nullable: a (B, zero_cols) buffer the dp part clears on its way (saves a memset launch)
   int zero_cols;
+  int copies;              // graph_layers > 1: ds_part holds `copies` consecutive (B, 8, N) blocks (one per graph layer), all
+                           // summed; 0 or 1: one block
 };
 int punish_bwd(hipStream_t st, const PunishBwdArgs& a);
+
+// graph_layers > 1, graph layer j < G - 1 of a unit layer: the gradient tile the attention backward consumes,
+//   dz[view 0] = g_c (or 0),   dz[view 1] = g_s (or 0) + in0 + in1      (all (rows, D); in0 / in1: the two partial gradients
+// of the next graph layer's input -- its specific GAT output -- through that layer's common / specific GAT; nullable)
+struct DzBuildArgs {
+  const float* g_c[2];     // per modality, nullable
+  const float* g_s[2];
+  const float* in0[2];
+  const float* in1[2];
+  float* dz[2];            // (2, rows, D)
+  int64_t n;               // rows * D
+};
+int dz_build(hipStream_t st, const DzBuildArgs& a);
 
 // S0 backward (rows), all layers, one workgroup per batch element.
 struct QaBwdArgs {

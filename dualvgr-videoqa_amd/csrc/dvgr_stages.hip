@@ -703,7 +703,9 @@ __global__ __launch_bounds__(256) void k_punish_bwd(const PunishBwdArgs a) {
   const int N = a.N, D = a.D;
   if (tid < N) {
     float ds = 0.f;
-    for (int h = 0; h < kHeads; ++h) ds += a.ds_part[mod][((int64_t)b * kHeads + h) * N + tid];
+    const int copies = a.copies > 1 ? a.copies : 1;
+    for (int c = 0; c < copies; ++c)
+      for (int h = 0; h < kHeads; ++h) ds += a.ds_part[mod][(((int64_t)c * a.B + b) * kHeads + h) * N + tid];
     const float s = a.s[mod][b * N + tid];
     shT[tid] = ds * s * (1.f - s);
   }
@@ -736,6 +738,24 @@ __global__ __launch_bounds__(256) void k_punish_bwd(const PunishBwdArgs a) {
 }
 int punish_bwd(hipStream_t st, const PunishBwdArgs& a) {
   DVGR_LAUNCH(k_punish_bwd, dim3(a.B, 2, (a.D + 255) / 256), dim3(256), 0, st, a);
+  DVGR_LAUNCH_CHECK();
+}
+
+__global__ __launch_bounds__(256) void k_dz_build(const DzBuildArgs a) {
+  const int mod = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, n4 = a.n / 4;     // float4 index
+  if (i >= n4) return;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 c = a.g_c[mod] ? reinterpret_cast<const float4*>(a.g_c[mod])[i] : z;
+  float4 s = a.g_s[mod] ? reinterpret_cast<const float4*>(a.g_s[mod])[i] : z;
+  if (a.in0[mod]) { const float4 e = reinterpret_cast<const float4*>(a.in0[mod])[i]; s.x += e.x; s.y += e.y; s.z += e.z; s.w += e.w; }
+  if (a.in1[mod]) { const float4 e = reinterpret_cast<const float4*>(a.in1[mod])[i]; s.x += e.x; s.y += e.y; s.z += e.z; s.w += e.w; }
+  reinterpret_cast<float4*>(a.dz[mod])[i] = c;
+  reinterpret_cast<float4*>(a.dz[mod])[n4 + i] = s;
+}
+int dz_build(hipStream_t st, const DzBuildArgs& a) {
+  const int64_t n4 = a.n / 4;
+  DVGR_LAUNCH(k_dz_build, dim3((unsigned)((n4 + 255) / 256), 2), dim3(256), 0, st, a);
   DVGR_LAUNCH_CHECK();
 }
 

@@ -35,16 +35,19 @@ def keep_mask(key: int, n: int) -> np.ndarray:
     return (f >= THRESH16).astype(np.float32)
 
 
-def site_masks(seed: int, B: int, N: int, D: int, L: int) -> dict:
+def site_masks(seed: int, B: int, N: int, D: int, L: int, G: int = 1) -> dict:
     """Every keep-mask of one training forward, keyed by the oracle's site names
-    (oracle/unit_torch.py: 'L{l}.G0.{family}.x', '.h{h}.alpha', '.out')."""
+    (oracle/unit_torch.py: 'L{l}.G{j}.{family}.x', '.h{h}.alpha', '.out').  The device numbers the sites of unit layer l,
+    graph layer j as "layer" l * G + j (csrc/dvgr_api.hip)."""
     out = {}
     for l in range(L):
-        for mod in range(2):
-            for gat in range(2):
-                base = f"L{l}.G0.{GAT_FAMILIES[mod][gat]}"
-                out[base + ".x"] = keep_mask(site_key(seed, drop_site(l, mod, gat, 0)), B * N * D).reshape(B, N, D)
-                out[base + ".out"] = keep_mask(site_key(seed, drop_site(l, mod, gat, 5)), B * N * D).reshape(B, N, D)
-                for h in range(4):
-                    out[f"{base}.h{h}.alpha"] = keep_mask(site_key(seed, drop_site(l, mod, gat, 1 + h)), B * N * N).reshape(B, N, N)
+        for j in range(G):
+            e = l * G + j
+            for mod in range(2):
+                for gat in range(2):
+                    base = f"L{l}.G{j}.{GAT_FAMILIES[mod][gat]}"
+                    out[base + ".x"] = keep_mask(site_key(seed, drop_site(e, mod, gat, 0)), B * N * D).reshape(B, N, D)
+                    out[base + ".out"] = keep_mask(site_key(seed, drop_site(e, mod, gat, 5)), B * N * D).reshape(B, N, D)
+                    for h in range(4):
+                        out[f"{base}.h{h}.alpha"] = keep_mask(site_key(seed, drop_site(e, mod, gat, 1 + h)), B * N * N).reshape(B, N, N)
     return out

@@ -26,7 +26,11 @@ def block_order(num_layers: int) -> List[int]:
 
 
 def layer_buckets(module) -> List[Tuple[int, int]]:
-    """[first, last) element ranges of the flat gradient buffer, in the order the backward finalises them."""
+    """[first, last) element ranges of the flat gradient buffer, in the order the backward finalises them.
+    graph_layers > 1: unit layers share GAT modules, so no block is final before the backward ends (the library refuses
+    layer events there): ONE bucket, the whole buffer, reduced after the backward (`LayerBucketReducer.reduce(flat)`)."""
+    if getattr(module, "graph_layers", 1) > 1:
+        return [(0, int(module.flat_params().numel()))]
     return [module.layer_param_range(l) for l in block_order(module.layers)]
 
 
@@ -126,12 +130,13 @@ class LayerBucketReducer:
             return
         if events is not None and len(events) != len(self.buckets):
             raise ValueError(f"expected {len(self.buckets)} block-indexed events (L + 2), got {len(events)}")
+        order = self._layer_order() if events is not None else [None] * len(self.buckets)
         if flat_grad.is_cuda and self.stream is not None:
             cur = torch.cuda.current_stream(flat_grad.device)
             works = []
             avg = dist.get_backend(self.group) == "nccl"       # RCCL averages inside the collective (ncclAvg)
             with torch.cuda.stream(self.stream):
-                for (a, b), layer in zip(self.buckets, self._layer_order()):
+                for (a, b), layer in zip(self.buckets, order):
                     ev = events[layer] if events is not None else None
                     if ev is not None:
                         self.stream.wait_event(ev)

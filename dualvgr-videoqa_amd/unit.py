@@ -14,7 +14,7 @@ the gradient is one flat buffer (one RCCL all-reduce bucket per layer for data p
 
 Deliberate deviations from the reference: the four list outputs stay on the
 device (the reference moves them to the CPU, model/models.py:153-160); no hard-coded 'cuda:1';
-graph_layers must be 1 (every reference config uses 1).
+graph_layers 1 .. 4 (every reference config uses 1; > 1 follows the reference's [i + j] module sharing, model/models.py:150-160).
 """
 from __future__ import annotations
 
@@ -50,17 +50,21 @@ def param_table(dims: L_.Dims) -> List[Tuple[str, Tuple[int, ...], int]]:
             tab.append((f"{qp}.{l}.query_weight.weight", (D, Wd), o))
             o, _, _ = L_.param_offset(dims, L_.P_BQ, l, mod)
             tab.append((f"{qp}.{l}.query_weight.bias", (D,), o))
-            ow, _, _ = L_.param_offset(dims, L_.P_GAT_W, l, mod)
-            ob, _, _ = L_.param_offset(dims, L_.P_GAT_B, l, mod)
-            oa, _, _ = L_.param_offset(dims, L_.P_GAT_A, l, mod)
-            oc, _, _ = L_.param_offset(dims, L_.P_GAT_C, l, mod)
-            for g, fam in enumerate((com, spec)):
-                for h in range(N_HEADS):
-                    hh = g * N_HEADS + h
-                    tab.append((f"{fam}.{l}.attention_{h}.W.weight", (Fh, D), ow + hh * Fh * D))
-                    tab.append((f"{fam}.{l}.attention_{h}.W.bias", (Fh,), ob + hh * Fh))
-                    tab.append((f"{fam}.{l}.attention_{h}.a.weight", (1, 2 * Fh), oa + hh * 2 * Fh))
-                    tab.append((f"{fam}.{l}.attention_{h}.a.bias", (1,), oc + hh))
+            # GAT modules: the reference builds L * G per family (model/models.py:95-100); module k < L sits in layer block
+            # k, the others in the extra region behind the query block (csrc/dvgr_common.h)
+            G = max(int(dims.G), 1)
+            for k in ([l] if l < L - 1 else [l] + list(range(L, L * G))):
+                ow, _, _ = L_.param_offset(dims, L_.P_GAT_W, k, mod)
+                ob, _, _ = L_.param_offset(dims, L_.P_GAT_B, k, mod)
+                oa, _, _ = L_.param_offset(dims, L_.P_GAT_A, k, mod)
+                oc, _, _ = L_.param_offset(dims, L_.P_GAT_C, k, mod)
+                for g, fam in enumerate((com, spec)):
+                    for h in range(N_HEADS):
+                        hh = g * N_HEADS + h
+                        tab.append((f"{fam}.{k}.attention_{h}.W.weight", (Fh, D), ow + hh * Fh * D))
+                        tab.append((f"{fam}.{k}.attention_{h}.W.bias", (Fh,), ob + hh * Fh))
+                        tab.append((f"{fam}.{k}.attention_{h}.a.weight", (1, 2 * Fh), oa + hh * 2 * Fh))
+                        tab.append((f"{fam}.{k}.attention_{h}.a.bias", (1,), oc + hh))
             o, _, _ = L_.param_offset(dims, L_.P_SF_P1, l, mod)
             tab.append((f"{att}.{l}.project.0.weight", (D, D), o))
             o, _, _ = L_.param_offset(dims, L_.P_SF_BP, l, mod)
@@ -157,7 +161,7 @@ class _UnitFn(torch.autograd.Function):
         st_ = mod._shape_state(B, N, T, dev)       # dims (checked once), buffer sizes, reusable buffers of this shape
         dims = st_["dims"]
         flat = mod.flat_params()
-        Lr = mod.layers
+        Lr = mod.layers * mod.graph_layers          # list entries: one per (unit layer, graph layer)
         if mod.reuse_buffers:
             vis, aqe, mqe, lists, saved = mod._shape_buffers(st_, "fwd", lambda: (
                 torch.empty((B, N, D), device=dev, dtype=torch.float32), torch.empty((B, N, D), device=dev, dtype=torch.float32),
@@ -272,8 +276,9 @@ class DualVGRUnit_multiple(nn.Module):
         if graph_module != 'GAT':
             # the reference builds no GNN lists for any other value and then fails in forward
             raise ValueError("graph_module must be 'GAT' (model/models.py:94)")
-        if appearance_graph_layers != 1 or motion_graph_layers != 1:
-            raise NotImplementedError("graph_layers > 1 is not supported by the HIP path (all reference configs use 1)")
+        if appearance_graph_layers != motion_graph_layers or not 1 <= appearance_graph_layers <= 4:
+            # (DualVGR passes ONE graph_layers to both, model/models.py:44-45; the kernels batch the two modalities)
+            raise NotImplementedError("appearance_graph_layers and motion_graph_layers must be equal and between 1 and 4")
         if module_dim % 64 or word_dim % 4:
             raise ValueError("module_dim must be a multiple of 64 and word_dim a multiple of 4")
         self.layers = unit_layers
@@ -284,13 +289,14 @@ class DualVGRUnit_multiple(nn.Module):
         self.num_of_motion_graph_layers = motion_graph_layers
         self.dtype_code = {'fp32': L_.DVGR_F32, 'bf16': L_.DVGR_BF16, 'bf16x3': L_.DVGR_BF16X3}[dtype]
         D, Wd, Fh, Lr = module_dim, word_dim, module_dim // 4, unit_layers
+        G = self.graph_layers = appearance_graph_layers
         self.queryAttn = nn.ModuleList([_QueryAttn(D) for _ in range(Lr)])
         self.queryPunish_appear = nn.ModuleList([_QueryPunish(Wd, D) for _ in range(Lr)])
         self.queryPunish_motion = nn.ModuleList([_QueryPunish(Wd, D) for _ in range(Lr)])
-        self.appearance_GCN = nn.ModuleList([_GAT(D, Fh) for _ in range(Lr)])
-        self.motion_GCN = nn.ModuleList([_GAT(D, Fh) for _ in range(Lr)])
-        self.acGCN = nn.ModuleList([_GAT(D, Fh) for _ in range(Lr)])
-        self.mcGCN = nn.ModuleList([_GAT(D, Fh) for _ in range(Lr)])
+        self.appearance_GCN = nn.ModuleList([_GAT(D, Fh) for _ in range(Lr * G)])
+        self.motion_GCN = nn.ModuleList([_GAT(D, Fh) for _ in range(Lr * G)])
+        self.acGCN = nn.ModuleList([_GAT(D, Fh) for _ in range(Lr * G)])
+        self.mcGCN = nn.ModuleList([_GAT(D, Fh) for _ in range(Lr * G)])
         self.attention_appearance = nn.ModuleList([_SFAttn(D) for _ in range(Lr)])
         self.attention_motion = nn.ModuleList([_SFAttn(D) for _ in range(Lr)])
         self.visualfusion = _MFB(D)
@@ -301,7 +307,7 @@ class DualVGRUnit_multiple(nn.Module):
         self.appearance_adj = adj
         self.motion_adj = adj.clone()
 
-        self._dims0 = L_.make_dims(1, num_of_nodes, 1, D, Wd, Lr, 1, self.dtype_code)
+        self._dims0 = L_.make_dims(1, num_of_nodes, 1, D, Wd, Lr, G, self.dtype_code)
         L_.load()       # raises with the build instructions when libdvgr_hip.so is missing
         self._table = param_table(self._dims0)
         named = dict(self.named_parameters())
@@ -427,7 +433,7 @@ class DualVGRUnit_multiple(nn.Module):
         st_ = self._shapes.get(key)
         if st_ is None:
             lib = L_.load()
-            dims = L_.make_dims(B, N, T, self.module_dim, self.word_dim, self.layers, 1, self.dtype_code)
+            dims = L_.make_dims(B, N, T, self.module_dim, self.word_dim, self.layers, self.graph_layers, self.dtype_code)
             L_.check(lib.dvgr_check_dims(C.byref(dims)), "dvgr_check_dims")
             st_ = {"dims": dims, "saved_bytes": lib.dvgr_saved_bytes(C.byref(dims)), "ws_bytes": lib.dvgr_workspace_bytes(C.byref(dims)),
                    "buf": {}}

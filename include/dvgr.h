@@ -51,7 +51,10 @@ typedef struct dvgr_dims {
   int32_t D;     /* module_dim (768); multiple of 64                                 */
   int32_t Wd;    /* word_dim (300); multiple of 4                                    */
   int32_t L;     /* unit_layers                                                      */
-  int32_t G;     /* graph_layers; only 1 is supported (all reference configs use 1)  */
+  int32_t G;     /* graph_layers, 1 .. 4 (all reference configs use 1).  G > 1 follows model/models.py:150-160: unit layer i,
+                    graph layer j uses GAT module [i + j] of each family (shared between unit layers; modules > L + G - 2 exist
+                    in the state dict only), every list output has L * G entries (entry i * G + j), the backward runs on the
+                    caller's stream alone and refuses layer_done_events / comm (no block is final before the end) */
   int32_t dtype; /* DVGR_F32, DVGR_BF16 or DVGR_BF16X3 (precision of the MFMA operands) */
 } dvgr_dims;
 
@@ -109,16 +112,16 @@ typedef struct dvgr_io {
   float *vis;           /* visual_feature              (B, N, D)  */
   float *aq_embed;      /* last layer's fused appearance embedding (B, N, D) */
   float *mq_embed;      /* last layer's fused motion embedding     (B, N, D) */
-  float *com_app;       /* com_app_list    as one (L, B, N, D) tensor */
-  float *com_mot;       /* com_motion_list as one (L, B, N, D) tensor */
-  float *aq_fusion;     /* aq_fusion_list  as one (L, B, N, D) tensor */
-  float *mq_fusion;     /* mq_fusion_list  as one (L, B, N, D) tensor */
+  float *com_app;       /* com_app_list    as one (L * G, B, N, D) tensor */
+  float *com_mot;       /* com_motion_list as one (L * G, B, N, D) tensor */
+  float *aq_fusion;     /* aq_fusion_list  as one (L * G, B, N, D) tensor */
+  float *mq_fusion;     /* mq_fusion_list  as one (L * G, B, N, D) tensor */
 } dvgr_io;
 
 /* Upstream gradients (any may be NULL = zero) and gradient outputs of the backward pass. */
 typedef struct dvgr_grads {
   const float *g_vis, *g_aq_embed, *g_mq_embed;                 /* (B, N, D)    */
-  const float *g_com_app, *g_com_mot, *g_aq_fusion, *g_mq_fusion; /* (L, B, N, D) */
+  const float *g_com_app, *g_com_mot, *g_aq_fusion, *g_mq_fusion; /* (L * G, B, N, D) */
   float *gA, *gM;       /* (B, N, D)  */
   float *gdq;           /* (B, T, D)  */
   float *gwords;        /* (B, T, Wd) */
@@ -133,7 +136,7 @@ const char *dvgr_version(void);
  * its own (copy streams, encoder streams) calls this at a fixed place in that order (see _lib.py: streams()). */
 int dvgr_streams_init(void);
 
-/* 0 when `d` is supported: B,N,T,L >= 1, G == 1, D % 64 == 0, Wd % 4 == 0, N <= 64, T <= 256. */
+/* 0 when `d` is supported: B,N,T,L >= 1, 1 <= G <= 4, D % 64 == 0, Wd % 4 == 0, N <= 64, T <= 256. */
 int dvgr_check_dims(const dvgr_dims *d);
 
 /* Number of fp32 elements of the flat parameter buffer (replaces the nn.ModuleList storage built

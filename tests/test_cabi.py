@@ -93,7 +93,7 @@ def test_struct_sizes_match_header():
     assert C.sizeof(L.Grads) == 12 * 8
 
 
-@pytest.mark.parametrize("bad", [dict(G=2), dict(D=100), dict(Wd=301), dict(N=65), dict(T=257), dict(B=0), dict(dtype=7)])
+@pytest.mark.parametrize("bad", [dict(G=5), dict(G=0), dict(D=100), dict(Wd=301), dict(N=65), dict(T=257), dict(B=0), dict(dtype=7)])
 def test_check_dims_rejects(bad):
     lib = L.load()
     kw = dict(B=4, N=20, T=15, D=768, Wd=300, L=3, G=1, dtype=0)
@@ -113,12 +113,12 @@ def test_null_and_small_buffers_are_refused_without_touching_the_gpu():
     assert lib.dvgr_unit_forward(C.byref(d), p, None, C.byref(io), p, 16, p, 16, None, None) == -3
 
 
-@pytest.mark.parametrize("D,Wd,Lr", [(64, 32, 2), (768, 300, 1), (768, 300, 3)])
-def test_param_layout_is_disjoint_and_aligned(D, Wd, Lr):
-    d = L.make_dims(1, 8, 1, D, Wd, Lr)
+@pytest.mark.parametrize("D,Wd,Lr,G", [(64, 32, 2, 1), (768, 300, 1, 1), (768, 300, 3, 1), (64, 32, 2, 2), (64, 32, 3, 3)])
+def test_param_layout_is_disjoint_and_aligned(D, Wd, Lr, G):
+    d = L.make_dims(1, 8, 1, D, Wd, Lr, G)
     total = L.load().dvgr_param_count(C.byref(d))
     tab = dv.param_table(d)
-    shapes = O.param_shapes(Wd, D, Lr)
+    shapes = O.param_shapes(Wd, D, Lr, G)
     assert {n for n, _, _ in tab} == set(shapes)
     used = np.zeros(total, dtype=np.int8)
     for name, shape, off in tab:
@@ -138,12 +138,14 @@ def test_param_layout_is_disjoint_and_aligned(D, Wd, Lr):
         assert lib.dvgr_param_layer_range(C.byref(d), l, C.byref(a), C.byref(b)) == 0
         assert a.value == prev and b.value > a.value
         prev = b.value
-    assert prev == total
+    # block L + 2: the GAT modules L .. L * G - 1 of graph_layers > 1 (empty at G = 1)
     a, b = C.c_int64(), C.c_int64()
-    assert lib.dvgr_param_layer_range(C.byref(d), Lr + 2, C.byref(a), C.byref(b)) == -5
+    assert lib.dvgr_param_layer_range(C.byref(d), Lr + 2, C.byref(a), C.byref(b)) == 0
+    assert a.value == prev and b.value == total and (b.value > a.value) == (G > 1)
+    assert lib.dvgr_param_layer_range(C.byref(d), Lr + 3, C.byref(a), C.byref(b)) == -5
     # which parameter lives in which block
     rng = {}
-    for l in range(Lr + 2):
+    for l in range(Lr + 3):
         assert lib.dvgr_param_layer_range(C.byref(d), l, C.byref(a), C.byref(b)) == 0
         rng[l] = (a.value, b.value)
     for name, shape, off in tab:
@@ -153,7 +155,8 @@ def test_param_layout_is_disjoint_and_aligned(D, Wd, Lr):
         elif name.startswith("visualfusion."):
             assert blk == Lr, name
         else:
-            assert blk == int(name.split(".")[1]), name
+            idx = int(name.split(".")[1])                  # GAT module index (or SF-attention layer): modules >= L: extra block
+            assert blk == (idx if idx < Lr else Lr + 2), name
     n_real = sum(int(np.prod(s)) for s in shapes.values())
     assert int(used.sum()) == n_real
 
@@ -201,8 +204,10 @@ def test_module_refuses_cpu_tensors():
 def test_constructor_mirrors_reference_errors():
     with pytest.raises(ValueError):
         dv.DualVGRUnit_multiple(graph_module="GCN")        # reference builds no GNN lists then fails in forward
-    with pytest.raises(NotImplementedError):
-        dv.DualVGRUnit_multiple(module_dim=64, word_dim=32, appearance_graph_layers=2, motion_graph_layers=2)
+    with pytest.raises(NotImplementedError):               # the two modalities are batched: one graph_layers for both
+        dv.DualVGRUnit_multiple(module_dim=64, word_dim=32, appearance_graph_layers=2, motion_graph_layers=1)
+    m = dv.DualVGRUnit_multiple(module_dim=64, word_dim=32, appearance_graph_layers=2, motion_graph_layers=2, unit_layers=2)
+    assert len(m.acGCN) == 4 and len(m.motion_GCN) == 4   # L * G modules per family, as the reference builds them
 
 
 def test_dropout_replica_statistics_and_site_keys():

@@ -447,3 +447,112 @@ def test_train_mode_mask_injected_other_sizes(N, D, Lr, B, T):
     werr = max(float((p.grad.cpu() - sd[k].grad).abs().max()) / max(float(sd[k].grad.abs().max()), 1e-3)
                for k, p in m.named_parameters() if not k.endswith(".fc.bias") and not k.endswith(".a.bias"))
     assert werr < GTOL, werr
+
+
+# ---- graph_layers > 1 (model/models.py:150-160: GAT module [i + j], shared between unit layers) ------------------------------
+def _build_g(case, train=False, dtype="fp32"):
+    m = dv.DualVGRUnit_multiple(word_dim=case.Wd, module_dim=case.D, num_of_nodes=case.N, appearance_graph_layers=case.G,
+                                motion_graph_layers=case.G, unit_layers=case.L, dtype=dtype)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in case.sd_np.items()}, strict=True)   # all L * G modules per family
+    m = m.cuda()
+    m.train(train)
+    m.keep_saved = True
+    return m
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x3"])
+def test_graph_layers_2_golden_forward_backward(dtype):
+    """tests/golden/g_quirk_g2.npz: the imported reference with graph_layers = 2 (its `[i + j]` indexing makes unit layers
+    share GAT modules and leaves the last modules unused).  Every list entry (L * G per list), the loss, every input and
+    parameter gradient -- shared modules accumulate over the pairs that use them, unused ones get exact zeros."""
+    case = GoldenCase("g_quirk_g2")
+    assert case.G == 2
+    z = case.z
+    m = _build_g(case, dtype=dtype)
+    t, outs, loss, com, dep = run_hip(case, m)
+    vis, aqe, mqe, ca, cm, aq, mq = outs
+    assert len(ca) == len(cm) == len(aq) == len(mq) == case.L * case.G
+    errs = {"vis": rel_err(vis.detach().cpu(), z["out/vis"]), "aq_embed": rel_err(aqe.detach().cpu(), z["out/aq_embed"]),
+            "mq_embed": rel_err(mqe.detach().cpu(), z["out/mq_embed"])}
+    for e in range(case.L * case.G):
+        errs[f"com_app{e}"] = rel_err(ca[e].detach().cpu(), z[f"out/com_app{e}"])
+        errs[f"com_motion{e}"] = rel_err(cm[e].detach().cpu(), z[f"out/com_motion{e}"])
+        errs[f"aq_fusion{e}"] = rel_err(aq[e].detach().cpu(), z[f"out/aq_fusion{e}"])
+        errs[f"mq_fusion{e}"] = rel_err(mq[e].detach().cpu(), z[f"out/mq_fusion{e}"])
+    print("  forward:", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert max(errs.values()) < TOL, errs
+    assert abs(float(loss) - float(z["loss"])) < 1e-3 * max(1.0, abs(float(z["loss"])))
+    gerrs = {k: rel_err(t[k].grad.cpu(), z["gin/" + k]) for k in ("A", "M", "dq", "words")}
+    print("  input grads:", {k: f"{v:.2e}" for k, v in gerrs.items()})
+    assert max(gerrs.values()) < GTOL, gerrs
+    werrs, unused = {}, 0
+    last_used = case.L + case.G - 2
+    big = sorted(set(z["gwbig_names"].tolist())) if "gwbig_names" in z.files else []
+    for k, p in m.named_parameters():
+        g = p.grad.cpu().numpy()
+        if k.endswith(".fc.bias"):
+            continue
+        if k in big:                                                   # large matrices: their first 64 elements are recorded
+            head = z["gwbig_head"][big.index(k)]
+            werrs[k] = float(np.abs(g.ravel()[:64] - head).max()) / (float(np.abs(head).max()) + 1e-2)
+            continue
+        want = z["gw/" + k]
+        fam = k.split(".")[0]
+        if fam in ("acGCN", "appearance_GCN", "mcGCN", "motion_GCN") and int(k.split(".")[1]) > last_used:
+            assert float(np.abs(g).max()) == 0.0 and float(np.abs(want).max()) == 0.0, k     # never touched by the reference
+            unused += 1
+            continue
+        werrs[k] = float(np.abs(g - want).max()) / max(float(np.abs(want).max()), 1e-3)
+    worst = sorted(werrs.items(), key=lambda kv: -kv[1])[:6]
+    print("  worst weight grads:", [(k, f"{v:.2e}") for k, v in worst], "unused tensors:", unused)
+    assert unused > 0
+    assert worst[0][1] < (GTOL if dtype == "fp32" else 4 * GTOL), worst
+
+
+@pytest.mark.parametrize("G", [2, 3])
+def test_graph_layers_training_mode_against_the_oracle(G):
+    """Training mode with G graph layers: the device's keep-masks of every (unit layer, graph layer) site injected into
+    the autograd oracle (oracle/unit_torch.py restates the [i + j] loop), forward and every gradient."""
+    Wd, D, N, Lr, B, T = 32, 64, 6, 3, 5, 7
+    sd_np = synth.xavier_state_dict(O.param_shapes(Wd, D, Lr, G), seed=17, bias_range=0.1)
+    inp = synth.unit_inputs(B, N, T, D, Wd, seed=17)
+    m = dv.DualVGRUnit_multiple(word_dim=Wd, module_dim=D, num_of_nodes=N, appearance_graph_layers=G, motion_graph_layers=G,
+                                unit_layers=Lr, dtype="fp32")
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()}, strict=True)
+    m = m.cuda().train()
+    m.forced_seed = 424242
+    t = {k: torch.from_numpy(v.copy()).cuda() for k, v in inp.items()}
+    for k in ("A", "M", "dq", "words"):
+        t[k].requires_grad_(True)
+    outs = m(t["A"], t["M"], t["dq"], t["words"], t["qlen"])
+    R = torch.from_numpy(synth.normal("Rg", (B, N, D), 1.0, 17))
+
+    def upstream(o, Rr):
+        c, d_ = O.aux_losses(o, N)
+        return (o[0] * Rr).sum() + 0.3 * (o[1] * Rr).sum() + sum(((x * Rr).sum() * (0.1 + 0.05 * i)) for i, x in enumerate(o[3] + o[5])) \
+            + sum((x * Rr).sum() * 0.07 for x in o[4] + o[6]) + c + 1e-3 * d_
+
+    upstream(outs, R.cuda()).backward()
+    torch.cuda.synchronize()
+    from dualvgr_videoqa_amd import dropout
+    masks = {k: torch.from_numpy(v) for k, v in dropout.site_masks(424242, B, N, D, Lr, G).items()}
+    sd = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in sd_np.items()}
+    ti = {k: torch.from_numpy(v.copy()) for k, v in inp.items()}
+    for k in ("A", "M", "dq", "words"):
+        ti[k].requires_grad_(True)
+    oo = O.unit_forward(sd, ti["A"], ti["M"], ti["dq"], ti["words"], ti["qlen"], Lr, G, masks=masks, naive=False)
+    upstream(oo, R).backward()
+    flat_h = [outs[0], outs[1], outs[2]] + outs[3] + outs[4] + outs[5] + outs[6]
+    flat_o = [oo[0], oo[1], oo[2]] + list(oo[3]) + list(oo[4]) + list(oo[5]) + list(oo[6])
+    assert len(flat_h) == len(flat_o) == 3 + 4 * Lr * G
+    ferr = max(rel_err(h.detach().cpu(), o.detach()) for h, o in zip(flat_h, flat_o))
+    gerr = max(rel_err(t[k].grad.cpu(), ti[k].grad) for k in ("A", "M", "dq", "words"))
+    werrs = {}
+    for k, p in m.named_parameters():
+        if k.endswith(".fc.bias"):
+            continue
+        want = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
+        werrs[k] = float((p.grad.cpu() - want).abs().max()) / max(float(want.abs().max()), 1e-3)
+    worst = sorted(werrs.items(), key=lambda kv: -kv[1])[:5]
+    print(f"  G={G}: forward {ferr:.2e}, input grads {gerr:.2e}, worst weight grads {[(k, f'{v:.2e}') for k, v in worst]}")
+    assert ferr < TOL and gerr < GTOL and worst[0][1] < GTOL, (ferr, gerr, worst)

@@ -151,7 +151,13 @@ def test_moments_restored_on_the_host_are_moved_not_reset():
     pb = pa.clone()
     a.step([("w", pa, grads[2].clone())])
     b.step([("w", pb, grads[2].clone())])
-    assert b.step_count == 3 and torch.equal(pa, pb)
+    # (the gradient norm is summed with float atomics: the clip coefficient may differ in its last bit between two launches)
+    assert b.step_count == 3 and float((pa - pb).abs().max()) <= 1e-6 * float(pa.abs().max())
+    zero = trainer.ClipAdam(lr=1e-2)             # what round 2 did: moments silently reset -> a visibly different step
+    pz = p0.clone()
+    zero.step_count = 2
+    zero.step([("w", pz, grads[2].clone())])
+    assert float((pz - (pa - 0)).abs().max()) > 1e-4
     with pytest.raises(RuntimeError, match="elements"):
         b.step([("w", torch.zeros(5, device="cuda"), torch.zeros(5, device="cuda"))])
 
