@@ -214,6 +214,20 @@ __device__ __forceinline__ float wave_max(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float elu_f(float x) { return x > 0.0f ? x : expm1f(x); }
+// ELU on the hardware exponential (absolute error ~1e-7: the attention epilogues evaluate one per output element on a
+// VALU-bound path, where the library expm1f costs ~4 x as many instructions)
+__device__ __forceinline__ float elu_fast(float x) { return x > 0.0f ? x : __expf(x) - 1.0f; }
+// keep factors (1/(1-p) or 0; all 1 for key == 0) of FOUR consecutive elements e0 .. e0+3, e0 a multiple of 4: two hashes
+// (a hash serves the two elements of an even / odd pair) instead of the four drop_factor() would compute
+__device__ __forceinline__ void drop_factor4(uint32_t key, uint32_t e0, float (&f)[4]) {
+  if (key == 0u) { f[0] = f[1] = f[2] = f[3] = 1.0f; return; }
+  const uint32_t h0 = mix32(((e0 >> 1) * 0x9E3779B1u) ^ key);
+  const uint32_t h1 = mix32((((e0 >> 1) + 1u) * 0x9E3779B1u) ^ key);
+  f[0] = (h0 & 0xFFFFu) >= kDropThresh16 ? kKeepScale : 0.f;
+  f[1] = (h0 >> 16) >= kDropThresh16 ? kKeepScale : 0.f;
+  f[2] = (h1 & 0xFFFFu) >= kDropThresh16 ? kKeepScale : 0.f;
+  f[3] = (h1 >> 16) >= kDropThresh16 ? kKeepScale : 0.f;
+}
 // d ELU(P)/dP from the output value O = ELU(P)
 __device__ __forceinline__ float elu_grad_from_out(float o) { return o > 0.0f ? 1.0f : o + 1.0f; }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }

@@ -164,25 +164,13 @@ __global__ __launch_bounds__(256) void k_gat_attn_fwd(const GatAttnArgs a) {
   float* shV = shU + N;            // [N]
   const float* Wh = a.Wh[mod] + (int64_t)b * N * HF + h * F;
   CLK(0);
-  {                                                         // the tile as float4s, four independent loads in flight
-    const int F4 = F / 4, total = ZR * F4;                  // rows N .. ZR-1 are zero padding
-    for (int base = 0; base < total; base += 1024) {
-      float4 v[4];
-      int dst[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int idx = base + r * 256 + tid;
-        dst[r] = -1;
-        if (idx < total) {
-          const int j = idx / F4, q = idx - j * F4;
-          v[r] = j < N ? *reinterpret_cast<const float4*>(Wh + (int64_t)j * HF + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-          dst[r] = j * FS + 4 * q;
-        }
+  {                                                         // the tile as float4s: a wave per row, a lane per float4 column
+    const int F4 = F / 4;                                   // (no index division on this VALU-bound path); rows N .. ZR-1: zeros
+    for (int j = wave; j < ZR; j += 4)
+      for (int q = lane; q < F4; q += 64) {
+        const float4 v = j < N ? *reinterpret_cast<const float4*>(Wh + (int64_t)j * HF + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(shZ + j * FS + 4 * q) = v;
       }
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (dst[r] >= 0) *reinterpret_cast<float4*>(shZ + dst[r]) = v[r];
-    }
   }
   for (int e = tid; e < 16 * NT * NP; e += 256) shA[e] = 0.f;
   for (int f = tid; f < F; f += 256) {
@@ -220,13 +208,14 @@ __global__ __launch_bounds__(256) void k_gat_attn_fwd(const GatAttnArgs a) {
       if (lane < N) shA[i * NP + lane] = pe / sum * drop_factor(key, (uint32_t)((b * N + i) * N + lane));
     }
   }
-  for (int e = tid; e < N * (F / 4); e += 256) {            // punish AFTER the logits (GraphNN.py:102-104)
-    const int j = e / (F / 4), q = e - j * (F / 4);
-    float4* p = reinterpret_cast<float4*>(shZ + j * FS + 4 * q);
+  for (int j = wave; j < N; j += 4) {                       // punish AFTER the logits (GraphNN.py:102-104)
     const float sj = shS[j];
-    float4 v = *p;
-    v.x *= sj; v.y *= sj; v.z *= sj; v.w *= sj;
-    *p = v;
+    for (int q = lane; q < F / 4; q += 64) {
+      float4* p = reinterpret_cast<float4*>(shZ + j * FS + 4 * q);
+      float4 v = *p;
+      v.x *= sj; v.y *= sj; v.z *= sj; v.w *= sj;
+      *p = v;
+    }
   }
   __syncthreads();
   CLK(3);
@@ -264,19 +253,21 @@ __global__ __launch_bounds__(256) void k_gat_attn_fwd(const GatAttnArgs a) {
   float* out = (g ? a.out_s[mod] : a.out_c[mod]) + (int64_t)b * N * D + hl * F;
   const uint32_t ko = a.key_out[mod][g];
   uint16_t* zp = g ? a.zp_s[mod] : a.zp_c[mod];
-  for (int e = tid; e < N * (F / 4); e += 256) {            // ELU, dropout, fp32 + planes, 16 bytes per lane
-    const int i = e / (F / 4), q = e - i * (F / 4);
-    const float4 v = *reinterpret_cast<const float4*>(shZ + i * FS + 4 * q);
-    const int64_t o = (int64_t)i * D + 4 * q;
-    const uint32_t e0 = (uint32_t)(((int64_t)b * N) * D + hl * F + o);
-    float4 y;
-    y.x = elu_f(v.x) * drop_factor(ko, e0 + 0);
-    y.y = elu_f(v.y) * drop_factor(ko, e0 + 1);
-    y.z = elu_f(v.z) * drop_factor(ko, e0 + 2);
-    y.w = elu_f(v.w) * drop_factor(ko, e0 + 3);
-    st4(reinterpret_cast<float4*>(out + o), y);
-    split_store4(zp, a.z_lo_off, (int64_t)b * N * D + hl * F + o, y);
-  }
+  for (int i = wave; i < N; i += 4)                          // ELU, dropout, fp32 + planes, 16 bytes per lane
+    for (int q = lane; q < F / 4; q += 64) {
+      const float4 v = *reinterpret_cast<const float4*>(shZ + i * FS + 4 * q);
+      const int64_t o = (int64_t)i * D + 4 * q;
+      const uint32_t e0 = (uint32_t)(((int64_t)b * N) * D + hl * F + o);
+      float kf[4];
+      drop_factor4(ko, e0, kf);
+      float4 y;
+      y.x = elu_fast(v.x) * kf[0];
+      y.y = elu_fast(v.y) * kf[1];
+      y.z = elu_fast(v.z) * kf[2];
+      y.w = elu_fast(v.w) * kf[3];
+      st4(reinterpret_cast<float4*>(out + o), y);
+      split_store4(zp, a.z_lo_off, (int64_t)b * N * D + hl * F + o, y);
+    }
   CLK(5);
 }
 
@@ -478,42 +469,25 @@ __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
   const uint32_t ko = a.key_out[mod][g];
   const uint32_t ka = a.key_alpha[mod][h];
   CLK(0);
-  {                                                         // three tiles as float4s, independent loads in flight
-    const int total = (N + 1) * F4;                         // row N is the zero row
-    for (int base = 0; base < total; base += 512) {
-      float4 w[2], z[2], y[2];
-      int row[2], col[2];
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int idx = base + r * 256 + tid;
-        row[r] = -1;
-        if (idx < total) {
-          const int i = idx / F4, q = idx - i * F4;
-          row[r] = i; col[r] = 4 * q;
-          if (i < N) {
-            w[r] = *reinterpret_cast<const float4*>(Wh + (int64_t)i * HF + 4 * q);
-            z[r] = *reinterpret_cast<const float4*>(dz + (int64_t)i * D + 4 * q);
-            y[r] = *reinterpret_cast<const float4*>(outp + (int64_t)i * D + 4 * q);
-          }
+  {                                                         // three tiles as float4s: a wave per row, a lane per float4 column
+    const float sc = ko ? (1.0f - kDropP) : 1.0f;           // un-dropped ELU output where kept
+    for (int i = wave; i <= N; i += 4)                      // row N is the zero row
+      for (int q = lane; q < F4; q += 64) {
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f), wv = p;
+        if (i < N) {
+          wv = *reinterpret_cast<const float4*>(Wh + (int64_t)i * HF + 4 * q);
+          const float4 z = *reinterpret_cast<const float4*>(dz + (int64_t)i * D + 4 * q);
+          const float4 y = *reinterpret_cast<const float4*>(outp + (int64_t)i * D + 4 * q);
+          float kf[4];
+          drop_factor4(ko, (uint32_t)(((int64_t)b * N + i) * D + hl * F + 4 * q), kf);
+          p.x = z.x * kf[0] * elu_grad_from_out(y.x * sc);
+          p.y = z.y * kf[1] * elu_grad_from_out(y.y * sc);
+          p.z = z.z * kf[2] * elu_grad_from_out(y.z * sc);
+          p.w = z.w * kf[3] * elu_grad_from_out(y.w * sc);
         }
+        *reinterpret_cast<float4*>(shW + i * FS + 4 * q) = wv;
+        *reinterpret_cast<float4*>(shP + i * FS + 4 * q) = p;
       }
-#pragma unroll
-      for (int r = 0; r < 2; ++r)
-        if (row[r] >= 0) {
-          float4 p = make_float4(0.f, 0.f, 0.f, 0.f), wv = p;
-          if (row[r] < N) {
-            wv = w[r];
-            const uint32_t e0 = (uint32_t)(((int64_t)b * N + row[r]) * D + hl * F + col[r]);
-            const float sc = ko ? (1.0f - kDropP) : 1.0f;   // un-dropped ELU output where kept
-            p.x = z[r].x * drop_factor(ko, e0 + 0) * elu_grad_from_out(y[r].x * sc);
-            p.y = z[r].y * drop_factor(ko, e0 + 1) * elu_grad_from_out(y[r].y * sc);
-            p.z = z[r].z * drop_factor(ko, e0 + 2) * elu_grad_from_out(y[r].z * sc);
-            p.w = z[r].w * drop_factor(ko, e0 + 3) * elu_grad_from_out(y[r].w * sc);
-          }
-          *reinterpret_cast<float4*>(shW + row[r] * FS + col[r]) = wv;
-          *reinterpret_cast<float4*>(shP + row[r] * FS + col[r]) = p;
-        }
-    }
   }
   for (int e = tid; e < (N + 1) * NP; e += 256) shAd[e] = 0.f;
   if (tid < N) {
