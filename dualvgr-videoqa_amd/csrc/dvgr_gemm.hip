@@ -1357,7 +1357,12 @@ static int launch_ring(hipStream_t stream, const GemmBatch& b, int prec) {
 #else
     constexpr bool force_wide = false;
 #endif
-    if (total_w >= 480 || (long_k && total_w >= 128) || force_wide) {
+#ifdef DVGR_TIMING_AIDS
+    static const long wide_min = []() { const char* e = getenv("DVGR_WIDE_MIN"); return e ? atol(e) : 384L; }();    // A/B timing aid
+#else
+    constexpr long wide_min = 384;       // (480 until round 3: C5's 384-tile launches 11.46 -> 10.90 ms per step on the wide tiles)
+#endif
+    if (total_w >= wide_min || (long_k && total_w >= 128) || force_wide) {
       int split_w = 1;
       if (long_k) {
         long best = ((total_w + 255) / 256) * (long)(2 * nk_min + 6);

@@ -148,8 +148,11 @@ int punish_fwd(hipStream_t st, const float* X0, const float* X1, const float* p0
 // The result tile goes back through LDS so that the ELU / dropout / planes epilogue stores whole 16-byte vectors.
 typedef float gat_f32x4 __attribute__((ext_vector_type(4)));
 
-template <int NT>
-__global__ __launch_bounds__(256) void k_gat_attn_fwd(const GatAttnArgs a) {
+// NW = waves per workgroup (8 since round 3; 4 before).  At N > 48 the LDS images allow two (forward) / one (backward)
+// workgroups per CU, and four or eight waves per CU cannot hide a phase's latencies: C5 10.72 -> 9.71 ms per step with 8 waves
+// (12 and 16 measure the same); at N <= 48 it is worth 0.4 % (C2) to 1.9 % (C4).  profiles/experiments_r03.tsv: *_wave_count.
+template <int NT, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void k_gat_attn_fwd(const GatAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int b = blockIdx.x, h = blockIdx.y, mod = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -166,21 +169,21 @@ __global__ __launch_bounds__(256) void k_gat_attn_fwd(const GatAttnArgs a) {
   CLK(0);
   {                                                         // the tile as float4s: a wave per row, a lane per float4 column
     const int F4 = F / 4;                                   // (no index division on this VALU-bound path); rows N .. ZR-1: zeros
-    for (int j = wave; j < ZR; j += 4)
+    for (int j = wave; j < ZR; j += NW)
       for (int q = lane; q < F4; q += 64) {
         const float4 v = j < N ? *reinterpret_cast<const float4*>(Wh + (int64_t)j * HF + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<float4*>(shZ + j * FS + 4 * q) = v;
       }
   }
-  for (int e = tid; e < 16 * NT * NP; e += 256) shA[e] = 0.f;
-  for (int f = tid; f < F; f += 256) {
+  for (int e = tid; e < 16 * NT * NP; e += 64 * NW) shA[e] = 0.f;
+  for (int f = tid; f < F; f += 64 * NW) {
     shAl[f] = a.gat_a[mod][h * 2 * F + f];
     shAr[f] = a.gat_a[mod][h * 2 * F + F + f];
   }
   if (tid < N) shS[tid] = a.s[mod][b * N + tid];
   __syncthreads();
   CLK(1);
-  for (int i = wave; i < N; i += 4) {                       // u_i = a_l . Wh_i, v_i = a_r . Wh_i
+  for (int i = wave; i < N; i += NW) {                      // u_i = a_l . Wh_i, v_i = a_r . Wh_i
     float pu = 0.f, pv = 0.f;
     for (int f = lane; f < F; f += 64) {
       const float w = shZ[i * FS + f];
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_fwd(const GatAttnArgs a) {
   {                                                         // softmax over j of LeakyReLU(u_i + v_j + c): one wave per row
     const float c = a.gat_c[mod][h];
     const uint32_t key = a.key_alpha[mod][h];
-    for (int i = wave; i < N; i += 4) {
+    for (int i = wave; i < N; i += NW) {
       float e = -INFINITY;
       if (lane < N) { e = shU[i] + shV[lane] + c; e = e > 0.f ? e : kSlope * e; }
       const float mx = wave_max(e);
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_fwd(const GatAttnArgs a) {
       if (lane < N) shA[i * NP + lane] = pe / sum * drop_factor(key, (uint32_t)((b * N + i) * N + lane));
     }
   }
-  for (int j = wave; j < N; j += 4) {                       // punish AFTER the logits (GraphNN.py:102-104)
+  for (int j = wave; j < N; j += NW) {                      // punish AFTER the logits (GraphNN.py:102-104)
     const float sj = shS[j];
     for (int q = lane; q < F / 4; q += 64) {
       float4* p = reinterpret_cast<float4*>(shZ + j * FS + 4 * q);
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_fwd(const GatAttnArgs a) {
   for (int I = 0; I < NT; ++I)
 #pragma unroll
     for (int s4 = 0; s4 < 4 * NT; ++s4) af[I][s4] = s4 < S ? shA[(16 * I + r16) * NP + 4 * s4 + kq] : 0.f;
-  for (int J = wave; J < JT; J += 4) {
+  for (int J = wave; J < JT; J += NW) {
     gat_f32x4 acc[NT];
 #pragma unroll
     for (int I = 0; I < NT; ++I) acc[I] = gat_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_fwd(const GatAttnArgs a) {
   float* out = (g ? a.out_s[mod] : a.out_c[mod]) + (int64_t)b * N * D + hl * F;
   const uint32_t ko = a.key_out[mod][g];
   uint16_t* zp = g ? a.zp_s[mod] : a.zp_c[mod];
-  for (int i = wave; i < N; i += 4)                          // ELU, dropout, fp32 + planes, 16 bytes per lane
+  for (int i = wave; i < N; i += NW)                         // ELU, dropout, fp32 + planes, 16 bytes per lane
     for (int q = lane; q < F / 4; q += 64) {
       const float4 v = *reinterpret_cast<const float4*>(shZ + i * FS + 4 * q);
       const int64_t o = (int64_t)i * D + 4 * q;
@@ -272,6 +275,14 @@ __global__ __launch_bounds__(256) void k_gat_attn_fwd(const GatAttnArgs a) {
 }
 
 static int gat_nt(int N) { return (N + 15) / 16; }
+#ifndef DVGR_ATTN_WAVES_WIDE
+#define DVGR_ATTN_WAVES_WIDE 8
+#endif
+constexpr int kAttnWavesWide = DVGR_ATTN_WAVES_WIDE;   // waves per workgroup of the NT = 4 (N > 48) attention kernels
+#ifndef DVGR_ATTN_WAVES_SMALL
+#define DVGR_ATTN_WAVES_SMALL 8
+#endif
+constexpr int kAttnWavesSmall = DVGR_ATTN_WAVES_SMALL; // ... of the NT <= 3 ones
 static size_t gat_fwd_lds(int N, int F) {
   const size_t S = (N + 3) / 4, NT = gat_nt(N);
   return sizeof(float) * (4 * S * (F + 16) + 16 * NT * (4 * S + 1) + 2 * F + 3 * N + 16);
@@ -280,10 +291,11 @@ static int gat_nb(int N) { return N <= 8 ? 8 : N <= 16 ? 16 : N <= 24 ? 24 : N <
 
 template <int NT>
 static int gat_attn_fwd_nt(hipStream_t st, const GatAttnArgs& a) {
+  constexpr int NW = NT == 4 ? kAttnWavesWide : kAttnWavesSmall;
   const size_t lds = gat_fwd_lds(a.N, a.D / 4);
   if (lds > 48 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gat_attn_fwd<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  DVGR_LAUNCH(k_gat_attn_fwd<NT>, dim3(a.B, kHeads, 2), dim3(256), lds, st, a);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gat_attn_fwd<NT, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  DVGR_LAUNCH((k_gat_attn_fwd<NT, NW>), dim3(a.B, kHeads, 2), dim3(64 * NW), lds, st, a);
   DVGR_LAUNCH_CHECK();
 }
 
@@ -441,8 +453,8 @@ int sf_bwd(hipStream_t st, const SfBwdArgs& a) {
 //   dZ[j][f] = sum_i alpha_d[i][j] dP[i][f]   A = alpha_d^T (registers), B = dP; a wave owns whole 16-column strips of f,
 //              so it overwrites its strip of shP with dZ without a barrier (only the owner reads those columns)
 // LDS images are zero padded to 16 NT rows (shW, shP) / 4 S rows and 16 NT columns (shAd) so fragments need no guards.
-template <int NT>
-__global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
+template <int NT, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int b = blockIdx.x, h = blockIdx.y, mod = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, kq = lane >> 4;
@@ -450,7 +462,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
   const int S = (N + 3) / 4, NP = N + 1;                    // k-steps over the nodes; row stride of the N x N images
   // Fragment rows / columns beyond N are redirected to one all-zero row (index N) / column (index N) instead of padding
   // every image to 16 NT rows: at N = 20 that is 39 KB of LDS per workgroup (4 per CU) instead of 62 KB (2 per CU).
-  const int WR = ((N + 1) * FS > 8 * F) ? (N + 1) * FS : 8 * F;   // shW doubles as the d a_l / d a_r partial buffer at the end
+  const int WR = ((N + 1) * FS > 2 * NW * F) ? (N + 1) * FS : 2 * NW * F;   // shW doubles as the d a_l / d a_r partial buffer at the end
   const int g = h >> 2, hl = h & 3;
   float* shW = sm;                 // [N + 1][FS] Wh (unscaled); row N = 0
   float* shP = shW + WR;           // [N + 1][FS] dP, later dZ; row N = 0
@@ -462,7 +474,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
   float* shV = shU + N;            // [N]
   float* shDu = shV + N;           // [N]
   float* shDv = shDu + N;          // [N]
-  float* shRed = shDv + N;         // [4]
+  float* shRed = shDv + N;         // [NW <= 16]
   const float* Wh = a.Wh[mod] + (int64_t)b * N * HF + h * F;
   const float* dz = a.dz[mod] + (int64_t)g * a.B * N * D + (int64_t)b * N * D + hl * F;   // view g of (2, B*N, D)
   const float* outp = (g ? a.out_s[mod] : a.out_c[mod]) + (int64_t)b * N * D + hl * F;
@@ -471,7 +483,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
   CLK(0);
   {                                                         // three tiles as float4s: a wave per row, a lane per float4 column
     const float sc = ko ? (1.0f - kDropP) : 1.0f;           // un-dropped ELU output where kept
-    for (int i = wave; i <= N; i += 4)                      // row N is the zero row
+    for (int i = wave; i <= N; i += NW)                      // row N is the zero row
       for (int q = lane; q < F4; q += 64) {
         float4 p = make_float4(0.f, 0.f, 0.f, 0.f), wv = p;
         if (i < N) {
@@ -489,7 +501,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
         *reinterpret_cast<float4*>(shP + i * FS + 4 * q) = p;
       }
   }
-  for (int e = tid; e < (N + 1) * NP; e += 256) shAd[e] = 0.f;
+  for (int e = tid; e < (N + 1) * NP; e += 64 * NW) shAd[e] = 0.f;
   if (tid < N) {
     shS[tid] = a.s[mod][b * N + tid];
     shU[tid] = a.u[mod][((int64_t)b * kHeads + h) * N + tid];
@@ -498,7 +510,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
   __syncthreads();
   CLK(1);
   const float c = a.gat_c[mod][h];
-  for (int i = wave; i < N; i += 4) {                       // recompute alpha and alpha * keep: one wave per row
+  for (int i = wave; i < N; i += NW) {                      // recompute alpha and alpha * keep: one wave per row
     float e = -INFINITY;
     if (lane < N) { e = shU[i] + shV[lane] + c; e = e > 0.f ? e : kSlope * e; }
     const float mx = wave_max(e);
@@ -512,7 +524,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
   }
   CLK(2);
   // ---- dalpha_ij = keep_ij * s_j * (dP_i . Wh_j): NT x NT tiles dealt round-robin to the waves ----
-  for (int tile = wave; tile < NT * NT; tile += 4) {
+  for (int tile = wave; tile < NT * NT; tile += NW) {
     const int I = tile / NT, J = tile - I * NT;
     gat_f32x4 acc = gat_f32x4{0.f, 0.f, 0.f, 0.f};
     const int ra = 16 * I + r16, rb = 16 * J + r16;
@@ -535,7 +547,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
   __syncthreads();
   CLK(3);
   float dc_w = 0.f;
-  for (int i = wave; i < N; i += 4) {                       // softmax and LeakyReLU backward, du_i: one wave per row
+  for (int i = wave; i < N; i += NW) {                      // softmax and LeakyReLU backward, du_i: one wave per row
     const float al = lane < N ? shA[i * NP + lane] : 0.f;
     const float da = lane < N ? shG[i * NP + lane] : 0.f;
     const float rowdot = wave_sum(al * da);
@@ -553,7 +565,12 @@ __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
     for (int i = 0; i < N; ++i) dv += shG[i * NP + tid];
     shDv[tid] = dv;
   }
-  if (tid == 0) a.dc_part[mod][b * kHeads + h] = shRed[0] + shRed[1] + shRed[2] + shRed[3];
+  if (tid == 0) {
+    float dc = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) dc += shRed[w];
+    a.dc_part[mod][b * kHeads + h] = dc;
+  }
   CLK(4);
   // ---- dZ = alpha_d^T . dP: wave w owns the column strips Ft = w, w + 4, ... and overwrites them in shP ----
   {
@@ -565,7 +582,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
         const int i = 4 * s4 + kq, j = 16 * Jt + r16;
         af[Jt][s4] = s4 < S ? shAd[(i < N ? i : N) * NP + (j < N ? j : N)] : 0.f;
       }
-    for (int Ft = wave; Ft < F / 16; Ft += 4) {
+    for (int Ft = wave; Ft < F / 16; Ft += NW) {
       gat_f32x4 acc[NT];
 #pragma unroll
       for (int Jt = 0; Jt < NT; ++Jt) acc[Jt] = gat_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -602,7 +619,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
       gar[t] = *reinterpret_cast<const float4*>(a.gat_a[mod] + h * 2 * F + F + 4 * q);
     }
   }
-  for (int j = wave; j < N; j += 4) {
+  for (int j = wave; j < N; j += NW) {
     const float sj = shS[j], duj = shDu[j], dvj = shDv[j];
     float dsp = 0.f;
 #pragma unroll
@@ -624,7 +641,7 @@ __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
     if (lane == 0) a.ds_part[mod][((int64_t)b * kHeads + h) * N + j] = dsp;
   }
   __syncthreads();                                          // every wave is done with shW: it now holds the partials
-  float* shDa = shW;                                        // [4][2 F]
+  float* shDa = shW;                                        // [NW][2 F]
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int q = lane + 64 * t;
@@ -634,15 +651,20 @@ __global__ __launch_bounds__(256) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
     }
   }
   __syncthreads();
-  for (int f = tid; f < 2 * F; f += 256)
-    a.da_part[mod][((int64_t)b * kHeads + h) * 2 * F + f] = (shDa[f] + shDa[2 * F + f]) + (shDa[4 * F + f] + shDa[6 * F + f]);
+  for (int f = tid; f < 2 * F; f += 64 * NW) {
+    float acc = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; w += 2) acc += shDa[w * 2 * F + f] + shDa[(w + 1) * 2 * F + f];
+    a.da_part[mod][((int64_t)b * kHeads + h) * 2 * F + f] = acc;
+  }
   CLK(6);
 }
 
 static size_t gat_bwd_lds(int N, int F) {
   const size_t NP = N + 1, FS = F + 4;
-  const size_t WR = ((N + 1) * FS > 8 * (size_t)F) ? (N + 1) * FS : 8 * (size_t)F;
-  return sizeof(float) * (WR + (N + 1) * FS + (3 * (size_t)N + 1) * NP + 5 * N + 8);
+  const size_t NW = gat_nt(N) == 4 ? kAttnWavesWide : kAttnWavesSmall;
+  const size_t WR = ((N + 1) * FS > 2 * NW * (size_t)F) ? (N + 1) * FS : 2 * NW * (size_t)F;
+  return sizeof(float) * (WR + (N + 1) * FS + (3 * (size_t)N + 1) * NP + 5 * N + 16);
 }
 size_t gat_lds_bytes_max(int N, int F) {
   const size_t f = gat_fwd_lds(N, F), b = gat_bwd_lds(N, F);
@@ -651,10 +673,11 @@ size_t gat_lds_bytes_max(int N, int F) {
 
 template <int NT>
 static int gat_attn_bwd_nt(hipStream_t st, const GatAttnBwdArgs& a) {
+  constexpr int NW = NT == 4 ? kAttnWavesWide : kAttnWavesSmall;
   const size_t lds = gat_bwd_lds(a.N, a.D / 4);
   if (lds > 48 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gat_attn_bwd<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  DVGR_LAUNCH(k_gat_attn_bwd<NT>, dim3(a.B, kHeads, 2), dim3(256), lds, st, a);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gat_attn_bwd<NT, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  DVGR_LAUNCH((k_gat_attn_bwd<NT, NW>), dim3(a.B, kHeads, 2), dim3(64 * NW), lds, st, a);
   DVGR_LAUNCH_CHECK();
 }
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-phase timing of the attention kernels from the phase-clock debug build (make -C dualvgr-videoqa_amd/csrc clk).
-usage: DVGR_LIB=dualvgr-videoqa_amd/libdvgr_hip_clk.so python tools/phase_clocks.py [fwd|bwd]"""
+usage: DVGR_LIB=dualvgr-videoqa_amd/libdvgr_hip_clk.so python tools/phase_clocks.py [fwd|bwd] [num_clips=20]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,7 +9,7 @@ import dualvgr_videoqa_amd as dv
 from dualvgr_videoqa_amd import _lib as L_, synth
 
 which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
-B, N, Lr, T, D, WD = 64, 20, 1, 20, 768, 300
+B, N, Lr, T, D, WD = 64, (int(sys.argv[2]) if len(sys.argv) > 2 else 20), 1, 20, 768, 300
 m = dv.DualVGRUnit_multiple(word_dim=WD, module_dim=D, num_of_nodes=N, unit_layers=Lr, dtype="bf16x3").cuda()
 m.single_stream = True
 inp = synth.unit_inputs(B, N, T, D, WD, seed=1)
