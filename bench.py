@@ -181,6 +181,9 @@ def spawn_ranks(n):
     return 0
 
 
+HOST_ENQUEUE_MS = []     # per block: host time to enqueue the K steps (before the closing synchronise) / K, in ms
+
+
 def timed_blocks(step, K, ddp, dev, min_seconds=MIN_TIMED_S):
     """Blocks of exactly K steps, barrier + synchronise on both sides, MAX over ranks; repeated until min_seconds."""
     import torch
@@ -194,6 +197,7 @@ def timed_blocks(step, K, ddp, dev, min_seconds=MIN_TIMED_S):
         t0 = time.perf_counter()
         for i in range(K):
             step(i)
+        HOST_ENQUEUE_MS.append((time.perf_counter() - t0) / K * 1e3)
         torch.cuda.synchronize()
         if ddp:
             dist.barrier()
@@ -493,6 +497,7 @@ def main():
                    "timing": {"blocks": len(blocks), "steps_per_block": args.steps, "timed_s": float(sum(blocks)),
                               "ms_per_step_min_median_max": [min(blocks) / args.steps * 1e3, ms_step, max(blocks) / args.steps * 1e3]},
                    "launches_per_step": launches_per_step,      # kernel launches of the library per timed step (dvgr_dbg_launch_count)
+                   "host_enqueue_ms_per_step": float(np.median(HOST_ENQUEUE_MS)),   # host time to enqueue a step (< ms_per_step: not launch-bound)
                    "optimizer_ms": optimizer_ms,
                    "optimizer": "clip_grad_norm_(12) + Adam over the unit's flat parameter / gradient buffers, two fused launches "
                                 "(dvgr_optim_*), OUTSIDE the timed step",
@@ -583,6 +588,7 @@ def bench_model(args, dev, rank, world, cfg, ddp, dist_info):
                                   f"T={T}, vocab {VQ}/{VA}; appearance encoder on {args.appearance_encoder}, question encoder on "
                                   f"{args.question_encoder}, unit + head on hip",
                       "optimizer_ms": optimizer_ms, "forward_backward_ms": dt / args.steps * 1e3 - optimizer_ms,
+                      "host_enqueue_ms_per_step": float(np.median(HOST_ENQUEUE_MS)),
                       "timing": {"blocks": len(blocks), "steps_per_block": args.steps, "timed_s": float(sum(blocks))},
                       "distributed": dist_info, "global_batch": world * B, "parallelism": f"dp{world}"}}
     if rank == 0:

@@ -213,58 +213,80 @@ __global__ __launch_bounds__(256) void k_aux_combine(const AuxArgs a) {
   }
 }
 
-// ---- pass 3: g_t = W_t^T c_t, one feature column per thread; W rows are wave-uniform -> scalar loads ---------------
-template <int NB, int CPT>
+// ---- pass 3: g_t = W_t^T c_t on the fp32 MFMA (v_mfma_f32_16x16x4_f32: exact fp32 products) ------------------------
+// One workgroup per (b, l, tensor); a wave takes 64-column chunks of D.  A = W^T (rows i, reduction index j) is loaded ONCE
+// per wave as fragments (lane (r, q): W[4 ks + q][16 I + r]); B = the centred rows c[j][d].  The four column blocks of a
+// chunk are INTERLEAVED -- block e holds the columns 4 r + e -- so a lane's B operands of one k-step are ONE float4 load
+// (16 lanes x 16 B = a whole 256-byte row piece) and its four results of an output row are ONE float4 store.  The column
+// means come from the loaded fragments themselves (in-lane sum over the k-steps, then over the four lane groups), and the
+// rows are centred BEFORE the products (test_fused_loss_rows_with_a_large_shared_component).
+// (Until round 3 this pass ran on the VALU, one column per thread with scalar-loaded W rows: 28 us at N = 20, 650 us at
+// N = 64, where it left the main stream idle at the end of the forward.)
+template <int NT>
 __global__ __launch_bounds__(256) void k_aux_grad(const AuxArgs a) {
-  extern __shared__ float cs_all[];                   // [CPT][N][256]: each thread's centred columns (one bank per lane)
-  const int b = blockIdx.x, l = blockIdx.y >> 2, t = blockIdx.y & 3, tid = threadIdx.x;
-  const int N = a.N, D = a.D;
+  const int b = blockIdx.x, l = blockIdx.y >> 2, t = blockIdx.y & 3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = a.N, D = a.D, NB = a.NBP;
   const int64_t bl = (int64_t)l * a.B + b;
-  // constant address space + wave-uniform index = s_load (the matrix was written by the previous kernel); each fetched
-  // row is used for CPT columns per thread
-  typedef const float __attribute__((address_space(4))) * ConstPtr;
-  ConstPtr W = (ConstPtr)(uintptr_t)(a.wt + (bl * 4 + t) * N * NB);
+  const float* __restrict__ W = a.wt + (bl * 4 + t) * N * NB;
   const float* __restrict__ E = a.t[t] + bl * N * D;
   float* __restrict__ g = a.g[t] + bl * N * D;
-  float* cs = cs_all + tid;
-  for (int d0 = tid; d0 < D; d0 += 256 * CPT) {
+  const int r = lane & 15, kq = lane >> 4;
+  constexpr int KS = NT * 4;                          // k-steps of four rows j: 16 NT >= N
+  const int ksn = (N + 3) >> 2;
+  // W^T fragments come from an LDS image of W (zero padded to 16 NT x 16 NT; row stride = 16 mod 32 floats: the four lane
+  // groups of a fragment read hit different banks); in registers they cost 16 NT VGPRs = the second wave per SIMD at N = 64
+  constexpr int NBS = (NT & 1) ? 16 * NT : 16 * NT + 16;
+  __shared__ float Wl[16 * NT * NBS];
+  for (int e = tid; e < 16 * NT * 16 * NT; e += 256) {
+    const int j = e / (16 * NT), i = e - j * (16 * NT);
+    Wl[j * NBS + i] = (j < N && i < NB) ? W[j * NB + i] : 0.f;
+  }
+  __syncthreads();
+  const float inv_n = 1.0f / (float)N;
+  for (int c = wave; c < D / 64; c += 4) {
+    const int d0 = c * 64 + 4 * r;
+    float4 bf[KS];
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int q = 0; q < CPT; ++q) {
-      const int d = d0 + 256 * q;
-      float c[NB];
-      float mu = 0.f;
-#pragma unroll
-      for (int i = 0; i < NB; ++i) { c[i] = (i < N && d < D) ? E[i * D + d] : 0.f; mu += c[i]; }
-      mu /= (float)N;
-#pragma unroll
-      for (int i = 0; i < NB; ++i)
-        if (i < N) cs[(q * N + i) * 256] = c[i] - mu;
+    for (int ks = 0; ks < KS; ++ks) {
+      const int j = 4 * ks + kq;
+      bf[ks] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ks < ksn && j < N) bf[ks] = *reinterpret_cast<const float4*>(E + (int64_t)j * D + d0);
+      s.x += bf[ks].x; s.y += bf[ks].y; s.z += bf[ks].z; s.w += bf[ks].w;
     }
-    float o[CPT][NB];
+    s.x += __shfl_xor(s.x, 16); s.y += __shfl_xor(s.y, 16); s.z += __shfl_xor(s.z, 16); s.w += __shfl_xor(s.w, 16);
+    s.x += __shfl_xor(s.x, 32); s.y += __shfl_xor(s.y, 32); s.z += __shfl_xor(s.z, 32); s.w += __shfl_xor(s.w, 32);
+    s.x *= inv_n; s.y *= inv_n; s.z *= inv_n; s.w *= inv_n;
+    floatx4 acc[NT][4];
 #pragma unroll
-    for (int q = 0; q < CPT; ++q)
+    for (int I = 0; I < NT; ++I)
 #pragma unroll
-      for (int i = 0; i < NB; ++i) o[q][i] = 0.f;
-    ConstPtr Wj = W;
-#pragma unroll 2
-    for (int j = 0; j < N; ++j, Wj += NB) {
-      float cj[CPT];
+      for (int e = 0; e < 4; ++e) acc[I][e] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int q = 0; q < CPT; ++q) cj[q] = cs[(q * N + j) * 256];
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks < ksn) {                                   // (wave-uniform)
+        const bool in = 4 * ks + kq < N;
+        const float b0 = in ? bf[ks].x - s.x : 0.f, b1 = in ? bf[ks].y - s.y : 0.f;
+        const float b2 = in ? bf[ks].z - s.z : 0.f, b3 = in ? bf[ks].w - s.w : 0.f;
 #pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const float w = Wj[i];
-#pragma unroll
-        for (int q = 0; q < CPT; ++q) o[q][i] += w * cj[q];
+        for (int I = 0; I < NT; ++I) {
+          const float af = Wl[(4 * ks + kq) * NBS + 16 * I + r];
+          acc[I][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, b0, acc[I][0], 0, 0, 0);
+          acc[I][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, b1, acc[I][1], 0, 0, 0);
+          acc[I][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, b2, acc[I][2], 0, 0, 0);
+          acc[I][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, b3, acc[I][3], 0, 0, 0);
+        }
       }
     }
 #pragma unroll
-    for (int q = 0; q < CPT; ++q) {
-      const int d = d0 + 256 * q;
+    for (int I = 0; I < NT; ++I)
 #pragma unroll
-      for (int i = 0; i < NB; ++i)
-        if (i < N && d < D) g[i * D + d] = o[q][i];
-    }
+      for (int q = 0; q < 4; ++q) {
+        const int i = 16 * I + 4 * kq + q;
+        if (i < N)
+          *reinterpret_cast<float4*>(g + (int64_t)i * D + d0) = make_float4(acc[I][0][q], acc[I][1][q], acc[I][2][q], acc[I][3][q]);
+      }
   }
 }
 
@@ -305,24 +327,10 @@ int sum_and_ones(hipStream_t st, const float* x, float* g_ones, int64_t n, float
 
 static int nb_of(int N) { return N <= 8 ? 8 : N <= 16 ? 16 : N <= 24 ? 24 : N <= 32 ? 32 : 64; }
 
-template <int NB, int CPT>
-static int launch_grad_cpt(hipStream_t st, const AuxArgs& a) {
-  const size_t lds = sizeof(float) * CPT * a.N * 256;
-  if (lds > 48 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_aux_grad<NB, CPT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  DVGR_LAUNCH((k_aux_grad<NB, CPT>), dim3(a.B, a.L * 4), dim3(256), lds, st, a);
-  return (int)hipGetLastError();
-}
-template <int NB>
+template <int NT>
 static int launch_grad(hipStream_t st, const AuxArgs& a) {
-  constexpr int kMaxCpt = NB <= 24 ? 3 : NB <= 32 ? 2 : 1;      // VGPR (CPT * NB accumulators) and LDS (CPT * N KB) budget
-  // One column per thread (20 KB of LDS at N = 20) although three would reuse each scalar-loaded W row three times: the
-  // kernel runs beside the forward's last contractions, whose workgroups need 96-128 KB of a compute unit's 160 KB and
-  // cannot be placed next to two 61 KB workgroups of this one (measured: 1.118 -> 1.108 ms per step at C2).
-  const int cpt = 1;
-  if (cpt >= 3 && kMaxCpt >= 3) return launch_grad_cpt<NB, kMaxCpt>(st, a);
-  if (cpt >= 2 && kMaxCpt >= 2) return launch_grad_cpt<NB, (kMaxCpt >= 2 ? 2 : 1)>(st, a);
-  return launch_grad_cpt<NB, 1>(st, a);
+  DVGR_LAUNCH(k_aux_grad<NT>, dim3(a.B, a.L * 4), dim3(256), 0, st, a);
+  return (int)hipGetLastError();
 }
 
 size_t aux_ws_floats(const dvgr_dims& d) {
@@ -352,12 +360,13 @@ int aux_losses(hipStream_t st, const dvgr_dims& d, const dvgr_io* io, float alph
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_aux_combine), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
   DVGR_LAUNCH(k_aux_combine, dim3(d.B, d.L), dim3(256), lds2, st, a);
   if ((e = hipGetLastError()) != hipSuccess) return (int)e;
-  switch (nb_of(d.N)) {
-    case 8: return launch_grad<8>(st, a);
-    case 16: return launch_grad<16>(st, a);
-    case 24: return launch_grad<24>(st, a);
-    case 32: return launch_grad<32>(st, a);
-    default: return launch_grad<64>(st, a);
+  // (sending the entries out in groups of unit layers as they come into existence, each group under the layers that
+  // follow, changes nothing at C2 or C5: profiles/experiments_r03.tsv, c5_aux_groups)
+  switch ((d.N + 15) / 16) {
+    case 1: return launch_grad<1>(st, a);
+    case 2: return launch_grad<2>(st, a);
+    case 3: return launch_grad<3>(st, a);
+    default: return launch_grad<4>(st, a);
   }
 }
 
