@@ -29,4 +29,5 @@ done
 python tools/pmc_collect.py $O/c2 c2 bf16x3 auto $O/pmc_fetch.csv $O/pmc_write.csv $O/pmc_sq.csv > $O/pmc_collect.log 2>&1 || { tail -5 $O/pmc_collect.log; exit 1; }
 cp profiles/pmc_c2_bf16x3.json $O/pmc_c2_bf16x3.json
 rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_fetch.csv $O/pmc_write.csv $O/pmc_sq.csv
+BENCH_ARGS="--config c5" bash tools/kstats.sh $O c5=dualvgr-videoqa_amd/libdvgr_hip.so || exit 1      # summary_c5.txt, timeline_c5.txt
 for f in $O/bench_*.json; do echo "$(basename $f) $(python -c "import json,sys; d=json.load(open('$f')); print(round(d['value'],1), d['unit'], round(d['ms_per_step'],4), 'ms')")"; done
