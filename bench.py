@@ -353,6 +353,11 @@ def main():
                 red_native = parallel.NativeUnitReducer(dev, force_single=(world == 1))
             except Exception as e:        # a failed communicator must not cost the whole multi-GPU measurement
                 print(f"[bench] native reducer unavailable ({e!r}); using the torch.distributed reducer", file=sys.stderr, flush=True)
+        if world > 1:                     # every rank must hold the same candidates, or the trial's collectives deadlock
+            ok = torch.tensor([1 if red_native is not None else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                red_native = None
         if args.reducer in ("auto", "python") or red_native is None:
             events = [torch.cuda.Event() for _ in range(Lr + 2)]
             for ev in events:

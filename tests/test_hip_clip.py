@@ -166,6 +166,41 @@ def test_packed_bilstm_matches_oracle(shape, train):
         assert rel_err(p.grad.cpu().numpy(), sd[k].grad.numpy()) < GTOL, k
 
 
+@pytest.mark.parametrize("shape", [(256, 5, 32, 64), (512, 4, 32, 384), (256, 3, 64, 128), (1280, 3, 32, 384)])
+@pytest.mark.parametrize("with_lens", [False, True])
+def test_bilstm_bf16x3_at_bench_scale_matches_oracle(shape, with_lens):
+    """(S, T, V, H) at the row counts the bench runs (the last shape: the appearance encoder's 1280 sequences x 384 units) in the
+    bench's dtype: both outputs, the input gradient and every parameter gradient against the packed-LSTM oracle, with and
+    without lengths.  (These are also the shapes the one-launch recurrence experiment of round 3 takes -- S a multiple of 256,
+    H in {64, 128, 256, 384}: profiles/patches/r03_one_launch_recurrence.patch was held to this test.)"""
+    from dualvgr_videoqa_amd import synth
+    S, T, V, H = shape
+    sd_np = synth.xavier_state_dict(CT.lstm_shapes("", V, H), seed=47, bias_range=0.1)
+    x_np = synth.normal("rl_x", (S, T, V), 0.6, 47)
+    lens_np = (1 + (synth.uniform("rl_len", (S,), 0.0, 1.0, 47) * T).astype(np.int64)).clip(1, T)
+    lens_np[0] = T
+    if not with_lens:
+        lens_np[:] = T
+    Rf, Rs = synth.normal("rl_Rf", (S, 2 * H), 1.0, 47), synth.normal("rl_Rs", (S, T, 2 * H), 1.0, 47)
+    m = CL.BiLSTM(V, H, dtype="bf16x3")
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()}, strict=True)
+    m = m.cuda().eval()
+    x = torch.from_numpy(x_np.copy()).cuda().requires_grad_(True)
+    lens = torch.from_numpy(lens_np).cuda() if with_lens else None
+    final, seq = m.run(x, lens, 0, want_final=True, want_seq=True)
+    ((final * torch.from_numpy(Rf).cuda()).sum() + (seq * torch.from_numpy(Rs).cuda()).sum()).backward()
+    torch.cuda.synchronize()
+    sd = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in sd_np.items()}
+    xo = torch.from_numpy(x_np.copy()).requires_grad_(True)
+    of, os_ = CT.packed_bilstm(sd, "", xo, torch.from_numpy(lens_np))
+    ((of * torch.from_numpy(Rf)).sum() + (os_ * torch.from_numpy(Rs)).sum()).backward()
+    assert rel_err(final.detach().cpu().numpy(), of.detach().numpy()) < TOL
+    assert rel_err(seq.detach().cpu().numpy(), os_.detach().numpy()) < TOL
+    assert rel_err(x.grad.cpu().numpy(), xo.grad.numpy()) < 2e-3
+    for k, p in m.named_parameters():
+        assert rel_err(p.grad.cpu().numpy(), sd[k].grad.numpy()) < 2e-3, k
+
+
 def test_bilstm_single_output_variants():
     """Only the final states / only the per-step states requested: same values, gradients flow through the one asked for."""
     from dualvgr_videoqa_amd import synth
