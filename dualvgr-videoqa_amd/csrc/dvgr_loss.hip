@@ -26,13 +26,117 @@ struct AuxArgs {
 };
 
 // ---- pass 1: centred Gram of one tensor of one (b, l) ---------------------------------------------------
-// c c^T on the fp32 MFMA (v_mfma_f32_16x16x4_f32: exact fp32 products).  A lane holds c[16 I + lane%16][k0 + 4 (lane/16)
-// .. +3]; the same fragment serves as the A operand of row block I and the B operand of column block J, so the four k-steps
-// of one float4 are four MFMAs per (I, J >= I).  The four waves split D and their partial tiles are summed through LDS.
+// c c^T on the fp32 MFMA (v_mfma_f32_16x16x4_f32: exact fp32 products).  The four waves split D; a wave walks its columns
+// in chunks of 64: the chunk of all N rows is loaded ONCE with whole 256-byte row pieces per instruction (16 lanes x 16 B per
+// row, four rows per instruction), centred on the way (the column means of a chunk come from the loaded values themselves:
+// in-lane over the row groups, then across the four lanes that hold a column) and staged in the wave's own LDS tile, from which
+// the MFMA fragments are read (lane (r, q): row 16 I + r, columns 4 q .. 4 q + 3 of a 16-column k-step; the same fragment is
+// the A operand of row block I and the B operand of column block J >= I).  The waves' partial tiles are summed through LDS.
+// (Until round 3 the fragments came straight from global memory -- 16 rows x 64 bytes per instruction -- behind a separate
+// pass over the rows for the means: 356 us at N = 64, 1.7 TB/s.)
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+// chunk width CW: 64 columns at N > 32; 32 at N <= 32, where the kernel runs beside the forward's last contractions and its
+// LDS (4 waves x 16 NT rows x (CW + 4) floats + the partial tiles) has to fit next to their 128 KB on a compute unit
+template <int NT> struct GramCfg { static constexpr int CW = NT >= 3 ? 64 : 32, STR = CW + 4; };
 
 template <int NT>
 __global__ __launch_bounds__(256) void k_aux_gram(const AuxArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int b = blockIdx.x, l = blockIdx.y >> 2, t = blockIdx.y & 3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = a.N, D = a.D;
+  constexpr int NR = 16 * NT;                         // staged rows (rows >= N are zero)
+  constexpr int CW = GramCfg<NT>::CW, STR = GramCfg<NT>::STR, LPR = CW / 4, RPI = 64 / LPR;   // lanes per row piece, rows per instruction
+  float* stage = sm + wave * NR * STR;                // [NR][CW + 4] per wave
+  float* red = sm + 4 * NR * STR;                     // [NT (NT + 1) / 2][256]
+  const float* E = a.t[t] + ((int64_t)l * a.B + b) * N * D;
+  const int r16 = lane & 15, kq = lane >> 4;
+  floatx4 acc[NT][NT];
+#pragma unroll
+  for (int I = 0; I < NT; ++I)
+#pragma unroll
+    for (int J = 0; J < NT; ++J) acc[I][J] = floatx4{0.f, 0.f, 0.f, 0.f};
+  const int kw = D / 4;                               // D % 256 == 0 or the tail chunk is narrower: handled by `cols`
+  const float inv_n = 1.0f / (float)N;
+  const int lc = lane % LPR, lr = lane / LPR;          // load lane: columns 4 lc .. 4 lc + 3 of the rows lr, lr + RPI, ...
+  for (int c0 = wave * kw; c0 < (wave + 1) * kw; c0 += CW) {
+    const int cols = ((wave + 1) * kw - c0) < CW ? ((wave + 1) * kw - c0) : CW;      // multiple of 16 (D % 64 == 0)
+    const bool cin = 4 * lc < cols;
+    float4 v[NR / RPI];
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < NR / RPI; ++i) {
+      const int row = RPI * i + lr;
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (cin && row < N) v[i] = *reinterpret_cast<const float4*>(E + (int64_t)row * D + c0 + 4 * lc);
+      sum.x += v[i].x; sum.y += v[i].y; sum.z += v[i].z; sum.w += v[i].w;
+    }
+#pragma unroll
+    for (int m = LPR; m < 64; m <<= 1) {              // over the lanes that hold the same columns
+      sum.x += __shfl_xor(sum.x, m); sum.y += __shfl_xor(sum.y, m); sum.z += __shfl_xor(sum.z, m); sum.w += __shfl_xor(sum.w, m);
+    }
+    sum.x *= inv_n; sum.y *= inv_n; sum.z *= inv_n; sum.w *= inv_n;
+#pragma unroll
+    for (int i = 0; i < NR / RPI; ++i) {
+      const int row = RPI * i + lr;
+      float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (cin && row < N) c = make_float4(v[i].x - sum.x, v[i].y - sum.y, v[i].z - sum.z, v[i].w - sum.w);
+      *reinterpret_cast<float4*>(stage + row * STR + 4 * lc) = c;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the tile is wave-private: LDS ops of one wave execute in order
+    for (int ks = 0; ks < cols / 16; ++ks) {
+      float4 f[NT];
+#pragma unroll
+      for (int I = 0; I < NT; ++I) f[I] = *reinterpret_cast<const float4*>(stage + (16 * I + r16) * STR + 16 * ks + 4 * kq);
+#pragma unroll
+      for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int J = I; J < NT; ++J) {
+          acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[I].x, f[J].x, acc[I][J], 0, 0, 0);
+          acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[I].y, f[J].y, acc[I][J], 0, 0, 0);
+          acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[I].z, f[J].z, acc[I][J], 0, 0, 0);
+          acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[I].w, f[J].w, acc[I][J], 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  }
+  // the four waves add their partial tiles into one LDS image in a fixed order (deterministic)
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+      int tix = 0;
+#pragma unroll
+      for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int J = I; J < NT; ++J, ++tix)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* p = red + tix * 256 + r * 64 + lane;
+            *p = (w == 0) ? acc[I][J][r] : *p + acc[I][J][r];
+          }
+    }
+    __syncthreads();
+  }
+  float* G = a.gram + (((int64_t)l * a.B + b) * 4 + t) * N * N;
+  const int r = tid >> 6;
+  {
+    int tix = 0;
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+      for (int J = I; J < NT; ++J, ++tix) {
+        const float v = red[tix * 256 + tid];
+        const int row = 16 * I + 4 * (lane >> 4) + r, col = 16 * J + (lane & 15);
+        if (row < N && col < N) { G[row * N + col] = v; G[col * N + row] = v; }
+      }
+  }
+}
+
+// The same pass with the fragments read straight from global memory (16 rows x 64 bytes per instruction) behind a separate
+// pass over the rows for the column means: 13 KB of LDS instead of 21.  Kept for N <= 32, where it runs beside the forward's
+// last contractions and measures 0.6 % of a C2 step FASTER than the staged form (aux_gram_staged_c2); at N = 64 the staged form
+// is worth 1.2 % of a C5 step (aux_gram_staged_c5).
+template <int NT>
+__global__ __launch_bounds__(256) void k_aux_gram_direct(const AuxArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int b = blockIdx.x, l = blockIdx.y >> 2, t = blockIdx.y & 3;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -175,9 +279,9 @@ __global__ __launch_bounds__(256) void k_aux_combine(const AuxArgs a) {
   if (tid < 2 * N) {                                  // s_i = sum_j Mc_ij C_ij
     const int t = tid / N, i = tid - t * N;
     float s = 0.f;
-    for (int j = 0; j < N; ++j) {
-      const float c = G[t * NN + i * N + j] * (inv[t * N + i] * inv[t * N + j]);
-      s += (t ? -A1[i * N + j] : A1[i * N + j]) * c;
+    for (int j = 0; j < N; ++j) {                     // (G and Mc are symmetric: [j][i] puts consecutive threads on consecutive banks --
+      const float c = G[t * NN + j * N + i] * (inv[t * N + i] * inv[t * N + j]);   //  [i][j] is a stride of N floats, a 32-way conflict at N = 64)
+      s += (t ? -A1[j * N + i] : A1[j * N + i]) * c;
     }
     srow[tid] = s;
   }
@@ -193,7 +297,7 @@ __global__ __launch_bounds__(256) void k_aux_combine(const AuxArgs a) {
     const int t = tid / N, j = tid - t * N;
     const float* A = t ? A2 : A1;
     float s = 0.f;
-    for (int i = 0; i < N; ++i) s += A[j * N + i];
+    for (int i = 0; i < N; ++i) s += A[i * N + j];      // (symmetric as well)
     rmean[tid] = s / (float)N;
   }
   __syncthreads();
@@ -305,7 +409,14 @@ __global__ __launch_bounds__(256) void k_sum_and_ones(const float* x, float* g_o
 
 template <int NT>
 static int launch_gram_nt(hipStream_t st, const AuxArgs& a) {
-  const size_t lds = sizeof(float) * ((size_t)a.D + (NT * (NT + 1) / 2) * 256);
+  if (NT <= 2) {
+    const size_t lds = sizeof(float) * ((size_t)a.D + (NT * (NT + 1) / 2) * 256);
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_aux_gram_direct<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    DVGR_LAUNCH(k_aux_gram_direct<NT>, dim3(a.B, a.L * 4), dim3(256), lds, st, a);
+    return (int)hipGetLastError();
+  }
+  const size_t lds = sizeof(float) * ((size_t)4 * 16 * NT * GramCfg<NT>::STR + (NT * (NT + 1) / 2) * 256);
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_aux_gram<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   DVGR_LAUNCH(k_aux_gram<NT>, dim3(a.B, a.L * 4), dim3(256), lds, st, a);
