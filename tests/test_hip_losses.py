@@ -38,7 +38,8 @@ def random_lists(Lr, B, N, D, seed, corr=0.0):
 
 
 @pytest.mark.parametrize("Lr,B,N,D", [(3, 8, 20, 768), (2, 3, 8, 128), (1, 2, 33, 64), (2, 2, 64, 128), (1, 3, 16, 256),
-                                      (1, 2, 1, 64), (1, 2, 2, 64), (4, 5, 24, 192)])
+                                      (1, 2, 1, 64), (1, 2, 2, 64), (4, 5, 24, 192),
+                                      (2, 2, 64, 768), (1, 3, 48, 320), (1, 2, 40, 1024)])   # N > 32: the staged Gram pass, full and partial 64-column chunks
 def test_fused_loss_against_float64_oracle(Lr, B, N, D):
     lists, vis = random_lists(Lr, B, N, D, seed=11 + N)
     alpha, beta, scale = 0.7, 3e-3, 2.0
