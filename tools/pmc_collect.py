@@ -63,6 +63,8 @@ def main():
     print("\n".join(lines[-12:]))
     # the probed kernel: the forward GAT projection contraction (template TAG 1 of the KC x KC engine)
     probe = [r for r in rows if "TAG" not in r[0] and ("<0, 0, 1," in r[0] or "fwd_gat" in r[0].lower())]
+    if not probe:       # from 384 tiles per launch up (C5) S2 runs on the 128 x 256-tile kernel, one symbol for S2 and S4 (same shape)
+        probe = [r for r in rows if "gemm_planes_wide_kernel<0, 0," in r[0]]
     rec = {"build": bench.build_id(), "config": config, "dtype": dtype, "train": True,
            "source": os.path.relpath(prefix + "_pmc_hbm.txt", ROOT), "fabric_bytes_per_step": total}
     if probe:
