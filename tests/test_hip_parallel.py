@@ -81,20 +81,20 @@ def test_accumulation_with_the_layer_callback_is_refused():
     torch.cuda.synchronize()
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+def _rendezvous():
+    """A fresh file:// rendezvous (no TCP port: a port probed as free can be taken again before the store binds it --
+    EADDRINUSE once in a while under the full suite)."""
+    import tempfile
+    fd, path = tempfile.mkstemp(prefix="dvgr_pg_")
+    os.close(fd)
+    os.unlink(path)              # the FileStore creates it
+    return "file://" + path
 
 
 def test_reducer_gates_each_bucket_on_its_own_layers_event():
     """One rank over RCCL (the collectives really run): reduce() takes the LAYER-indexed event list of set_layer_events and
     must wait for events[L], events[L-1], ..., events[0] in its bucket order; the averaged buffer equals the input."""
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(_free_port())
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    dist.init_process_group("nccl", init_method=_rendezvous(), rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         m, t = _module(train=False)
         events = [torch.cuda.Event() for _ in range(Lr + 2)]
@@ -128,10 +128,8 @@ def test_reducer_gates_each_bucket_on_its_own_layers_event():
 
 def _stall_child(q):
     import time
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(_free_port())
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    dist.init_process_group("nccl", init_method=_rendezvous(), rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         # the reducer (and with it the communication stream) BEFORE the unit's first call: the runtime maps streams to hardware
         # queues in creation order, and a reducer created after the unit had run measured 2.4 ms per step instead of 1.25
@@ -191,15 +189,13 @@ def test_the_reducers_streams_do_not_stall_the_step():
 
 
 # ---- two ranks, BOTH reducers, one issue order ------------------------------------------------------------------------
-def _ddp_worker(rank, world, port, q):
+def _ddp_worker(rank, world, rendezvous, q):
     """One data-parallel rank of TrainStep on GPU 0 (the box has one GPU: gloo carries the CUDA tensors, RCCL would refuse
     two ranks on one device).  Runs (a) two steps with the threaded reducers and (b) the same two steps with gradients
     averaged synchronously after each backward, and reports parameters of both plus the issuer's log."""
     import numpy as np
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=rendezvous, rank=rank, world_size=world)
     try:
         from test_hip_model import model_inputs
         from dualvgr_videoqa_amd import trainer
@@ -277,8 +273,8 @@ def test_two_ranks_with_both_reducers_issue_one_order_and_average_exactly():
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q)) for r in range(world)]
+    rendezvous = _rendezvous()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, rendezvous, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
@@ -307,12 +303,10 @@ def test_two_ranks_with_both_reducers_issue_one_order_and_average_exactly():
 # has long run the unit by now: each native test body runs in a fresh child process.
 def _native_child(which, q):
     import time
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(_free_port())
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # torch's NCCL group, initialised eagerly: it carries the unique id, and its first collective (run by the reducer's
     # constructor) is what keeps the step fast (parallel.NativeUnitReducer)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    dist.init_process_group("nccl", init_method=_rendezvous(), rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         red = parallel.NativeUnitReducer(torch.device("cuda", 0))
         assert red.world == 1 and red.handle and red.warmed
@@ -415,9 +409,7 @@ def test_a_communicator_created_after_the_unit_ran_is_refused():
     m.zero_grad_flat()
     _step(m, t)
     torch.cuda.synchronize()
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(_free_port())
-    dist.init_process_group("gloo", rank=0, world_size=1)
+    dist.init_process_group("gloo", init_method=_rendezvous(), rank=0, world_size=1)
     try:
         with pytest.raises(RuntimeError, match="DVGR_E_ORDER"):
             parallel.NativeUnitReducer(torch.device("cuda", 0))

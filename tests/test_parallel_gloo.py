@@ -21,11 +21,13 @@ WD, D, N, LR, T, B = 32, 64, 5, 2, 6, 6
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    """A fresh file:// rendezvous (kept under its old name): a TCP port probed as free can be taken again before the store
+    binds it."""
+    import tempfile
+    fd, path = tempfile.mkstemp(prefix="dvgr_pg_")
+    os.close(fd)
+    os.unlink(path)              # the FileStore creates it
+    return "file://" + path
 
 
 def _grads(sd_np, inp, lo, hi, world):
@@ -40,9 +42,7 @@ def _grads(sd_np, inp, lo, hi, world):
 
 
 def _worker(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=port, rank=rank, world_size=world)
     try:
         torch.set_num_threads(2)
         sd_np = synth.xavier_state_dict(O.param_shapes(WD, D, LR), seed=5, bias_range=0.1)
@@ -104,9 +104,7 @@ def test_two_rank_gradient_average_equals_full_batch():
 
 
 def _worker_params(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=port, rank=rank, world_size=world)
     try:
         torch.manual_seed(0)
         net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
