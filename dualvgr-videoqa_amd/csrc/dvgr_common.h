@@ -5,6 +5,10 @@
 #include <stdint.h>
 
 #include <atomic>
+#ifdef DVGR_TIMING_AIDS
+#include <stdlib.h>
+#include <string.h>
+#endif
 
 #include "../../include/dvgr.h"
 
@@ -13,11 +17,36 @@ namespace dvgr {
 // Every kernel launch of the library goes through DVGR_LAUNCH: one relaxed atomic increment per launch, read back by
 // dvgr_dbg_launch_count() (include/dvgr_debug.h) -- bench.py reports launches per step from it.
 extern std::atomic<long long> g_launch_count;
+#ifdef DVGR_TIMING_AIDS
+// knock-out timing aid (tools/knockout.sh): DVGR_SKIP=<substring>[,<substring>...] -- launches whose kernel expression contains
+// one of them are not enqueued (results are garbage; the step's time without a kernel is that kernel's cost IN the step)
+inline bool launch_skipped(const char* what) {
+  static const char* env = getenv("DVGR_SKIP");
+  if (!env || !*env) return false;
+  const char* p = env;
+  while (*p) {
+    const char* q = p;
+    while (*q && *q != ',') ++q;
+    const size_t n = (size_t)(q - p);
+    if (n) for (const char* w = what; *w; ++w) if (!strncmp(w, p, n)) return true;
+    p = *q ? q + 1 : q;
+  }
+  return false;
+}
+#define DVGR_LAUNCH_FIRST(first, ...) #first
+#define DVGR_LAUNCH(...)                                                    \
+  do {                                                                      \
+    if (::dvgr::launch_skipped(DVGR_LAUNCH_FIRST(__VA_ARGS__))) break;      \
+    ::dvgr::g_launch_count.fetch_add(1, std::memory_order_relaxed);         \
+    hipLaunchKernelGGL(__VA_ARGS__);                                        \
+  } while (0)
+#else
 #define DVGR_LAUNCH(...)                                                    \
   do {                                                                      \
     ::dvgr::g_launch_count.fetch_add(1, std::memory_order_relaxed);         \
     hipLaunchKernelGGL(__VA_ARGS__);                                        \
   } while (0)
+#endif
 
 constexpr int kHeads = 8;          // 4 common-GAT heads + 4 specific-GAT heads per modality
 constexpr int kMfbHidden = 512;    // mm_dim * factor   (model/fusions/fusions.py:384-395 defaults)

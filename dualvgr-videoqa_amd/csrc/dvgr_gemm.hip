@@ -1313,6 +1313,12 @@ static int launch_ring(hipStream_t stream, const GemmBatch& b, int prec) {
     tiles = t > tiles ? t : tiles;
   }
   if (tiles == 0) return 0;
+#ifdef DVGR_TIMING_AIDS
+  {                                        // knock-out timing aid: DVGR_SKIP_TAGS = bit mask of launch-site tags that are not enqueued
+    static const int skip_tags = []() { const char* e = getenv("DVGR_SKIP_TAGS"); return e ? atoi(e) : 0; }();
+    if (skip_tags & (1 << TAG)) return 0;
+  }
+#endif
   // split-K (float atomics into a pre-zeroed / accumulating output) when the launch would leave most CUs
   // idle: aim at ~1-2 workgroups per CU, at least 4 K-tiles per split
   int split = 1;
