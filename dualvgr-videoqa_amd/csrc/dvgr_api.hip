@@ -440,6 +440,10 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
   // (entry l * G + j); the last step's pair feeds the SF attention.  The G > 1 path is the plain one: fp32 + planes
   // copies everywhere (no plane-only tensors), single stream in the backward.
   auto gp_ = [&](int k, int m) { return params + gat_set_base(P, L, k, m); };                  // GAT module k
+  // S2 + S3 as one launch (dvgr_gatf.hip) where the shape allows it.  Layer 0 beside the side stream keeps two launches: its
+  // gate needs the query chain S0, which runs on the side stream UNDER the separate projection.
+  const bool fuse_ok = PM.on && !(O.flags & DVGR_OPT_NO_FUSED_GAT) && gat_fused_supported(B, N, D, prec);
+  auto fuse_gat = [&](int l, int j) { return fuse_ok && !(side && l == 0 && j == 0); };
   auto gs_ = [&](int l, int m, int j) { return ms(l, m) + S.g_stride * j; };                   // saved block of graph layer j
   for (int l = 0; l < L; ++l) {
     const float* Xin[2] = {l == 0 ? io->A : ms(l - 1, 0) + S.x, l == 0 ? io->M : ms(l - 1, 1) + S.x};
@@ -454,13 +458,49 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
     // S2: Wh = drop_x(X) . Wcat^T + bcat.  Training: the two GATs of a modality see differently dropped
     // copies of X, materialised once (saved: the backward needs them for dWcat) so that the contraction
     // itself carries no mask and can run on the LDS-DMA ring kernel.
-    {
+    // the dropped copies: layers > 0 get them from the previous layer's S5 kernel; layer 0 from the split kernel above
+    // (bf16 modes: planes only, nobody reads them as fp32) or, in DVGR_F32, from k_drop_x; graph layers j > 0: k_drop_x
+    if (train && ((l == 0 && !lean) || j > 0))
+      DVGR_TRY(drop_x(st, Xj[0], Xj[1], gs_(l, 0, j) + S.xd, gs_(l, 1, j) + S.xd, K.x, BND, PM.out(gs_(l, 0, j) + S.xd, &plo),
+                      PM.out(gs_(l, 1, j) + S.xd, &plo), plo));
+    if (fuse_gat(l, j)) {
+      // S2 + S3 as one launch (dvgr_gatf.hip).  The gate s must exist: layer 0 takes this branch only without a side stream,
+      // i.e. with S0 in front of it on this stream; later layers got theirs from the previous layer's S5 kernel.
+      if (l == 0 && j == 0)
+        DVGR_TRY(punish_fwd(st, Xin[0], Xin[1], ms(l, 0) + S.p, ms(l, 1) + S.p, ms(l, 0) + S.s, ms(l, 1) + S.s, B, N, D));
+      GatFusedArgs fa{};
+      GatAttnArgs& a = fa.at;
+      int64_t xlo = -1, wlo = -1, lo1 = 0;
+      bool ok = true;
+      for (int m = 0; m < 2 && ok; ++m) {
+        a.s[m] = ms(l, m) + S.s;
+        a.gat_a[m] = gp_(k, m) + P.gat_a; a.gat_c[m] = gp_(k, m) + P.gat_c;
+        a.u[m] = gs_(l, m, j) + S.u; a.v[m] = gs_(l, m, j) + S.v;
+        a.out_c[m] = outc[m]; a.out_s[m] = outs[m];
+        for (int h = 0; h < 8; ++h) a.key_alpha[m][h] = K.alpha[m][h];
+        for (int g = 0; g < 2; ++g) a.key_out[m][g] = K.out[m][g];
+        a.zp_c[m] = PM.out(outc[m], &plo);
+        a.zp_s[m] = PM.out(outs[m], &plo);
+        for (int g = 0; g < 2; ++g) {
+          fa.xh[m][g] = PM.find(train ? gs_(l, m, j) + S.xd + g * BND : Xj[m], &lo1);
+          ok = ok && fa.xh[m][g] && (xlo < 0 || xlo == lo1);
+          xlo = lo1;
+        }
+        fa.wh[m] = PM.find(gp_(k, m) + P.gat_w, &lo1);
+        ok = ok && fa.wh[m] && (wlo < 0 || wlo == lo1);
+        wlo = lo1;
+        fa.bias[m] = gp_(k, m) + P.gat_b;
+        fa.Wh_out[m] = gs_(l, m, j) + S.wh;
+      }
+      if (!ok) return DVGR_E_DIMS;          // (cannot happen: fuse_gat() implies planes of every operand)
+      a.z_lo_off = plo;
+      fa.x_lo_off = xlo; fa.w_lo_off = wlo;
+      a.B = B; a.N = N; a.D = D;
+      DVGR_TRY(fprobe.begin(DVGR_PROBE_FWD_GAT_GEMM, l));
+      DVGR_TRY(gat_fused_fwd(st, fa, prec));
+      DVGR_TRY(fprobe.end(DVGR_PROBE_FWD_GAT_GEMM, l));
+    } else {
       GemmBatch gb{};
-      // the dropped copies: layers > 0 get them from the previous layer's S5 kernel; layer 0 from the split kernel above
-      // (bf16 modes: planes only, nobody reads them as fp32) or, in DVGR_F32, from k_drop_x; graph layers j > 0: k_drop_x
-      if (train && ((l == 0 && !lean) || j > 0))
-        DVGR_TRY(drop_x(st, Xj[0], Xj[1], gs_(l, 0, j) + S.xd, gs_(l, 1, j) + S.xd, K.x, BND, PM.out(gs_(l, 0, j) + S.xd, &plo),
-                        PM.out(gs_(l, 1, j) + S.xd, &plo), plo));
       for (int m = 0; m < 2; ++m) {
         if (!train) {
           gb.p[gb.n] = nt(Xj[m], D, gp_(k, m) + P.gat_w, D, gs_(l, m, j) + S.wh, HF, gp_(k, m) + P.gat_b, BN, HF, D, ACT_NONE);
@@ -479,10 +519,10 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
     }
     // S1 (needs p from S0: the side stream joins here)
     if (l == 0 && j == 0 && side) DVGR_TRY(side->order(hs, st));
-    if (l == 0 && j == 0)                  // layers > 0: gate computed by the previous layer's S5 kernel
+    if (l == 0 && j == 0 && !fuse_gat(l, j))   // layers > 0: gate computed by the previous layer's S5 kernel
       DVGR_TRY(punish_fwd(st, Xin[0], Xin[1], ms(l, 0) + S.p, ms(l, 1) + S.p, ms(l, 0) + S.s, ms(l, 1) + S.s, B, N, D));
     // S3
-    {
+    if (!fuse_gat(l, j)) {
       GatAttnArgs a{};
       for (int m = 0; m < 2; ++m) {
         a.Wh[m] = gs_(l, m, j) + S.wh; a.s[m] = ms(l, m) + S.s;

@@ -26,6 +26,7 @@ struct Api {
 std::mutex api_mu;
 
 inline int nccl_rc(int r) { return r == 0 ? 0 : 1000 + r; }
+inline bool api_loaded() { std::lock_guard<std::mutex> lk(api_mu); return api.handle != nullptr; }
 
 }  // namespace
 
@@ -64,7 +65,7 @@ int dvgr_comm_load(const char* path) {
 
 int dvgr_comm_unique_id(void* id_out) {
   if (!id_out) return DVGR_E_NULL;
-  if (!api.handle) { const int e = dvgr_comm_load(nullptr); if (e) return e; }
+  if (!api_loaded()) { const int e = dvgr_comm_load(nullptr); if (e) return e; }
   ncclUniqueId id;
   const int r = api.GetUniqueId(&id);
   if (r) return nccl_rc(r);
@@ -75,7 +76,7 @@ int dvgr_comm_unique_id(void* id_out) {
 int dvgr_comm_create(const void* id, int rank, int world, dvgr_comm** out) {
   if (!id || !out) return DVGR_E_NULL;
   if (world < 1 || rank < 0 || rank >= world) return DVGR_E_DIMS;
-  if (!api.handle) { const int e = dvgr_comm_load(nullptr); if (e) return e; }
+  if (!api_loaded()) { const int e = dvgr_comm_load(nullptr); if (e) return e; }
   dvgr_comm* c = new dvgr_comm();
   c->world = world;
   hipError_t e = hipGetDevice(&c->device);

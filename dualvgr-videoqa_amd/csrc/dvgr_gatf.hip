@@ -1,0 +1,395 @@
+// dvgr_gatf.hip -- the fused GAT-view kernel (SURVEY.md section 7.2, K2 `gat_pair`): projection, attention logits, softmax
+// over the clips, punish-scaled aggregation, ELU and both dropout sites of ONE head of ONE modality for a tile of WHOLE
+// samples, in one launch.  Reference: model/GraphNN.py:95-111 (PunishGraphAttentionLayer.forward, factorised logits as in
+// SURVEY.md Appendix A.3) and :174-178 (punishGAT: x-site dropout -- the dropped copies arrive pre-materialised as bf16
+// planes -- heads concatenated on dim 2, out-site dropout).
+//
+// Why one kernel: as two launches (gemm_planes_kernel<TAG_FWD_GAT> then k_gat_attn_fwd) the projection Wh (B N x 8F fp32,
+// 15.7 MB at C2) is written by the contraction's generic epilogue, re-read by 1024 attention workgroups through L2 / HBM, and
+// the two launches pay two ramps, two drains and a boundary.  The seam is TILE-LOCAL: head h of sample b needs only that
+// sample's N rows x that head's F columns of Wh, so with an output tile of SPT whole samples x one head (16 MTILES rows x F
+// columns) the attention is the contraction's epilogue and needs no grid-wide synchronisation.
+//
+// Work decomposition (C2: B = 64, N = 20, F = 192): SPT = 4 samples = 80 rows per tile -> 16 row tiles x 8 heads x 2
+// modalities = 256 workgroups = one per compute unit.  12 waves per workgroup:
+//   waves 8-11  loaders: LDS-DMA (global_load_lds_dwordx4) of the bf16 hi / lo planes of a 32-deep K-tile -- A = 16 MTILES
+//               rows of the (dropped) layer input, B = the head's F rows of Wcat -- into an NS-slot ring, counted vmcnt, one
+//               raw s_barrier per K-tile (the structure of gemm_planes_kernel, dvgr_gemm.hip);
+//   waves 0-7   MFMA (v_mfma_f32_16x16x32_bf16, bf16x3 = hi.hi + hi.lo + lo.hi): wave w owns the F / 4 columns of column
+//               group w & 3 and the row tiles of row group w >> 2 (ceil / floor halves of MTILES: waves w and w + 4 share a
+//               SIMD, so every SIMD carries one larger and one smaller block).
+// Epilogue, all 12 waves, in the ring's (now idle) LDS:
+//   E1  accumulators + bias -> shZ [rows][F + 16] (fp32); the loaders fetch a_l, a_r, the punish gates s and clear shA
+//   E2  Wh tile -> global (saved for the backward) as whole 16-byte row pieces; u_i = a_l . Wh_i, v_i = a_r . Wh_i (a wave per row)
+//   E3  softmax_j LeakyReLU(u_i + v_j + c) (a wave per row), alpha-site dropout, times s_j -> shA  (punish AFTER the
+//       logits, GraphNN.py:102-104: alpha . (s * Wh) = (alpha * s^T) . Wh)
+//   E4  aggregation on the fp32 MFMA (v_mfma_f32_16x16x4_f32, exact fp32): one (sample, 16-column strip) per wave at a time;
+//       the wave overwrites its strip of shZ with the result (nobody else reads those columns of that sample)
+//   E5  ELU, out-site dropout, fp32 + bf16 planes as 16-byte vectors into the list output (common heads -> com_*, specific
+//       heads -> *_fusion)
+// What it saves per launch pair at C2: the generic epilogue's transposition, 15.7 MB of Wh re-read, one launch boundary
+// and the attention kernel's load phase.  Layer 0 keeps the two-launch form when the side stream is in use: its punish gate
+// depends on the query chain (S0), which the separate Wh contraction hides.
+#include "dvgr_planes.h"
+#include "dvgr_stages.h"
+
+#define DVGR_LAUNCH_CHECK() return (int)hipGetLastError()
+
+namespace dvgr {
+
+typedef float gatf_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int TERMS, int MTILES, int NTC>
+struct GatfCfg {
+  static constexpr int kPlanes = TERMS == 3 ? 2 : 1;
+  static constexpr int RP = 16 * MTILES;                  // rows of the A tile
+  static constexpr int F = 64 * NTC;                      // columns of the tile = width of one head
+  static constexpr int FS = F + 16;                       // shZ row stride (floats): 16 banks mod 64, the fp32 B fragment is conflict free
+  static constexpr int kTileA = RP * BK;                  // bf16 elements of one A plane tile
+  static constexpr int kTileB = F * BK;
+  static constexpr int kSlot = kPlanes * (kTileA + kTileB);
+  static constexpr int NS = (4 * kSlot * 2 <= 150 * 1024) ? 4 : 3;   // ring slots
+  static constexpr int IA = MTILES;                       // DMA instructions per plane and K-tile: A tile (64 chunks of 16 bytes each)
+  static constexpr int IB = F / 16;                       //   B tile
+  static constexpr int ITOT = IA + IB;
+  static constexpr int IHI = (ITOT + 3) / 4;              // instructions of loader wave w: IHI for w < ITOT % 4 (all of them when
+  static constexpr int ILO = ITOT / 4;                    //   ITOT % 4 == 0), ILO otherwise
+  static constexpr int MT0 = (MTILES + 1) / 2;            // row tiles of the row group 0 waves, MTILES - MT0 of the others
+  static constexpr int kRingBytes = NS * kSlot * 2;
+};
+
+// ---- loader waves -------------------------------------------------------------------------------------------------
+template <class C, int TERMS, int CNT>
+__device__ __forceinline__ void gatf_loader(const GatFusedArgs& a, uint16_t* smem, int mod, int h, int g, int m0, int BN,
+                                            int D, int nk, int wave, int lane) {
+  // instruction k of this wave is instruction i = wave + 4 k of the K-tile: i < IA -> rows 16 i .. 16 i + 15 of the A tile,
+  // else rows 16 (i - IA) .. of the B tile.  Per-lane element offsets are computed once (the K loop moves a uniform base).
+  uint32_t off[CNT];
+  bool is_a[CNT];
+  int dst[CNT];                                            // element offset of the instruction's 1 KB piece inside the slot (hi plane)
+#pragma unroll
+  for (int k = 0; k < CNT; ++k) {
+    const int i = wave + 4 * k;
+    is_a[k] = i < C::IA;
+    const int j = is_a[k] ? i : i - C::IA;
+    const int S = j * 64 + lane;
+    const int row = S >> 2, slot = S & 3;
+    const int chunk = slot ^ ((-(row >> 2)) & 3);
+    if (is_a[k]) {
+      int gi = m0 + row;
+      gi = gi < BN ? gi : BN - 1;                          // rows past the matrix: any valid row (never stored)
+      off[k] = (uint32_t)gi * (uint32_t)D + (uint32_t)(chunk * 8);
+      dst[k] = j * 512;
+    } else {
+      off[k] = (uint32_t)(h * C::F + row) * (uint32_t)D + (uint32_t)(chunk * 8);
+      dst[k] = C::kPlanes * C::kTileA + j * 512;
+    }
+  }
+  const uint16_t* xa = a.xh[mod][g];
+  const uint16_t* wb = a.wh[mod];
+  auto issue = [&](int kt, uint16_t* slot_base) {
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int k = 0; k < CNT; ++k) {
+      const uint16_t* base = (is_a[k] ? xa : wb) + k0;
+      const int64_t lo = is_a[k] ? a.x_lo_off : a.w_lo_off;
+      const int ptile = is_a[k] ? C::kTileA : C::kTileB;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off[k]),
+                                       (__attribute__((address_space(3))) void*)(slot_base + dst[k]), 16, 0, 0);
+      if (TERMS == 3)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + lo + off[k]),
+                                         (__attribute__((address_space(3))) void*)(slot_base + dst[k] + ptile), 16, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int s = 0; s < C::NS - 1; ++s)
+    if (s < nk) issue(s, smem + s * C::kSlot);
+  constexpr int kPer = C::kPlanes * CNT;                   // DMA instructions of this wave per K-tile
+  for (int kt = 0; kt < nk; ++kt) {
+    const int younger = (nk - 1 - kt) < C::NS - 2 ? (nk - 1 - kt) : C::NS - 2;
+    if (younger >= 2) wait_vmcnt<2 * kPer>();
+    else if (younger == 1) wait_vmcnt<kPer>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                          // publishes tile kt, frees slot (kt - 1) % NS
+    if (kt + C::NS - 1 < nk) issue(kt + C::NS - 1, smem + ((kt + C::NS - 1) % C::NS) * C::kSlot);
+  }
+}
+
+// ---- computing waves ----------------------------------------------------------------------------------------------
+template <class C, int TERMS, int MTW, int NTC>
+__device__ __forceinline__ void gatf_compute(const uint16_t* smem, int nk, int row0, int col0, int lane, f32x4 (&acc)[4][NTC]) {
+#pragma unroll
+  for (int i = 0; i < MTW; ++i)
+#pragma unroll
+    for (int j = 0; j < NTC; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int kt = 0; kt < nk; ++kt) {
+    __builtin_amdgcn_s_barrier();
+    const uint16_t* curA = smem + (kt % C::NS) * C::kSlot;
+    const uint16_t* curB = curA + C::kPlanes * C::kTileA;
+    bf16x8 ah[MTW], al[MTW], bh[NTC], bl[NTC];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+      ah[i] = planes_frag<KC>(curA, row0 + i * 16, lane);
+      if (TERMS == 3) al[i] = planes_frag<KC>(curA + C::kTileA, row0 + i * 16, lane);
+    }
+#pragma unroll
+    for (int j = 0; j < NTC; ++j) {
+      bh[j] = planes_frag<KC>(curB, col0 + j * 16, lane);
+      if (TERMS == 3) bl[j] = planes_frag<KC>(curB + C::kTileB, col0 + j * 16, lane);
+    }
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+      for (int j = 0; j < NTC; ++j) {
+        if (TERMS == 3) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        }
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      }
+  }
+}
+
+// grid: 8 * ceil(total / 8) workgroups, total = mtiles * 8 heads * 2 modalities.  Workgroups b and b + 8 share an XCD
+// (round-robin placement: speed only), so XCD x takes the contiguous chunk x of the (modality, head, row tile) list: with 256
+// workgroups that is 2 heads x all row tiles, i.e. two B panels and one modality's A panels per L2.
+template <int TERMS, int MTILES, int NT, int NTC>
+__global__ __launch_bounds__(768) void k_gat_fused_fwd(const GatFusedArgs a) {
+  using C = GatfCfg<TERMS, MTILES, NTC>;
+  extern __shared__ __attribute__((aligned(16))) uint16_t gatf_smem[];
+  uint16_t* smem = gatf_smem;
+  const int N = a.at.N, D = a.at.D, B = a.at.B, BN = B * N;
+  constexpr int F = C::F, FS = C::FS, RP = C::RP, F4 = F / 4, JT = F / 16;
+  const int HF = kHeads * F;
+  const int SPT = a.spt;                                   // samples per tile (SPT * N <= RP)
+  const int mtiles = (B + SPT - 1) / SPT;
+  const int total = mtiles * kHeads * 2;
+  const int chunk = (int)gridDim.x >> 3;
+  const int idx = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+  if (idx >= total) return;                                // uniform per workgroup, before any barrier
+  const int mod = idx / (mtiles * kHeads);
+  const int rem = idx - mod * mtiles * kHeads;
+  const int h = rem / mtiles, mt = rem - h * mtiles;
+  const int g = h >> 2, hl = h & 3;
+  const int b0 = mt * SPT;                                 // first sample of the tile
+  const int m0 = b0 * N;                                   // first row
+  const int spt_valid = (B - b0) < SPT ? (B - b0) : SPT;
+  const int rows_valid = spt_valid * N;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave12 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave12 >= 8;
+  const int nk = D / BK;
+
+  f32x4 acc[4][NTC];                                       // (row group 0 uses MT0 of the 4 row slots, row group 1 MTILES - MT0)
+  int row0 = 0, col0 = 0;
+  if (loader) {
+    const int w = wave12 - 8;
+    // waves w < ITOT % 4 carry IHI instructions per plane, the others ILO (equal when ITOT % 4 == 0)
+    if (C::IHI == C::ILO || w < (C::ITOT & 3)) gatf_loader<C, TERMS, C::IHI>(a, smem, mod, h, g, m0, BN, D, nk, w, lane);
+    else gatf_loader<C, TERMS, (C::ILO > 0 ? C::ILO : 1)>(a, smem, mod, h, g, m0, BN, D, nk, w, lane);
+  } else {
+    const int rg = wave12 >> 2, cg = wave12 & 3;
+    col0 = cg * 16 * NTC;
+    if (rg == 0) { row0 = 0; gatf_compute<C, TERMS, C::MT0, NTC>(smem, nk, row0, col0, lane, acc); }
+    else { row0 = 16 * C::MT0; gatf_compute<C, TERMS, (MTILES - C::MT0 > 0 ? MTILES - C::MT0 : 1), NTC>(smem, nk, row0, col0, lane, acc); }
+  }
+  __builtin_amdgcn_s_barrier();                            // every fragment read of the ring is done: its LDS is free
+
+  // ---- epilogue images (floats) -------------------------------------------------------------------------------------
+  const int S = (N + 3) >> 2, NP = 4 * S + 1;
+  float* shZ = reinterpret_cast<float*>(smem);             // [RP + 4][FS]  Wh tile (+ 4 zero rows), later the output tile
+  float* shA = shZ + (RP + 4) * FS;                        // [SPT][16 NT][NP]  alpha_d[i][j] * s_j per sample
+  float* shAl = shA + SPT * 16 * NT * NP;                  // [F]
+  float* shAr = shAl + F;                                  // [F]
+  float* shS = shAr + F;                                   // [RP]
+  float* shU = shS + RP;                                   // [RP]
+  float* shV = shU + RP;                                   // [RP]
+  // E1
+  if (!loader) {
+    const int mtw = (wave12 >> 2) == 0 ? C::MT0 : MTILES - C::MT0;
+    const float* bias = a.bias[mod] + h * F;
+#pragma unroll
+    for (int j = 0; j < NTC; ++j) {
+      const int col = col0 + 16 * j + (lane & 15);
+      const float bv = bias[col];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i < mtw) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) shZ[(row0 + 16 * i + 4 * (lane >> 4) + r) * FS + col] = acc[i][j][r] + bv;
+        }
+      }
+    }
+  } else {
+    const int tl = tid - 512;                              // 0 .. 255
+    for (int e = tl; e < SPT * 16 * NT * NP; e += 256) shA[e] = 0.f;
+    for (int e = tl; e < 4 * FS; e += 256) shZ[RP * FS + e] = 0.f;
+    const float* ga = a.at.gat_a[mod] + h * 2 * F;
+    for (int f = tl; f < F; f += 256) { shAl[f] = ga[f]; shAr[f] = ga[F + f]; }
+    for (int r = tl; r < RP; r += 256) shS[r] = r < rows_valid ? a.at.s[mod][m0 + r] : 0.f;
+  }
+  __syncthreads();
+  // E2: the projection is saved for the backward (fp32, whole row pieces), and the two halves of the logits
+  {
+    float* Wg = a.Wh_out[mod] + (int64_t)m0 * HF + h * F;
+    for (int e = tid; e < rows_valid * F4; e += 768) {
+      const int r = e / F4, q = e - r * F4;
+      st4(reinterpret_cast<float4*>(Wg + (int64_t)r * HF + 4 * q), *reinterpret_cast<const float4*>(shZ + r * FS + 4 * q));
+    }
+    int sidx = wave12 / N, i = wave12 - sidx * N;          // row r = sidx * N + i
+    for (int r = wave12; r < rows_valid; r += 12) {
+      float pu = 0.f, pv = 0.f;
+      for (int f = lane; f < F; f += 64) {
+        const float w = shZ[r * FS + f];
+        pu += w * shAl[f];
+        pv += w * shAr[f];
+      }
+      pu = wave_sum(pu); pv = wave_sum(pv);
+      if (lane == 0) {
+        shU[r] = pu; shV[r] = pv;
+        const int64_t o = ((int64_t)(b0 + sidx) * kHeads + h) * N + i;
+        a.at.u[mod][o] = pu;
+        a.at.v[mod][o] = pv;
+      }
+      i += 12;
+      while (i >= N) { i -= N; ++sidx; }
+    }
+  }
+  __syncthreads();
+  // E3: softmax over j of LeakyReLU(u_i + v_j + c), one wave per row; alpha-site dropout; the punish gate of column j
+  {
+    const float c = a.at.gat_c[mod][h];
+    const uint32_t key = a.at.key_alpha[mod][h];
+    int sidx = wave12 / N, i = wave12 - sidx * N;
+    for (int r = wave12; r < rows_valid; r += 12) {
+      float e = -INFINITY;
+      if (lane < N) { e = shU[r] + shV[sidx * N + lane] + c; e = e > 0.f ? e : kSlope * e; }
+      const float mx = wave_max(e);
+      const float pe = lane < N ? expf(e - mx) : 0.f;
+      const float sum = wave_sum(pe);
+      if (lane < N)
+        shA[(sidx * 16 * NT + i) * NP + lane] =
+            pe / sum * drop_factor(key, (uint32_t)(((b0 + sidx) * N + i) * N + lane)) * shS[sidx * N + lane];
+      i += 12;
+      while (i >= N) { i -= N; ++sidx; }
+    }
+  }
+  __syncthreads();
+  // E4: P = (alpha_d * s^T) . Wh on the fp32 MFMA.  A = shA (rows i, reduction j), B = the sample's rows of shZ (reduction
+  // j, columns f); reduction steps past the sample's N rows read the zero rows RP .. RP + 3 (their A entries are zero too).
+  {
+    const int r16 = lane & 15, kq = lane >> 4;
+    for (int item = wave12; item < spt_valid * JT; item += 12) {
+      const int sidx = item / JT, J = item - sidx * JT;
+      const float* A_ = shA + sidx * 16 * NT * NP;
+      float* Z_ = shZ + sidx * N * FS + 16 * J;
+      gatf_f32x4 pacc[NT];
+#pragma unroll
+      for (int I = 0; I < NT; ++I) pacc[I] = gatf_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s4 = 0; s4 < 4 * NT; ++s4) {
+        if (s4 < S) {
+          const int jr = 4 * s4 + kq;
+          const float bf = jr < N ? Z_[jr * FS + r16] : 0.f;
+#pragma unroll
+          for (int I = 0; I < NT; ++I)
+            pacc[I] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_[(16 * I + r16) * NP + jr], bf, pacc[I], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * I + 4 * kq + r;
+          if (row < N) Z_[row * FS + r16] = pacc[I][r];
+        }
+    }
+  }
+  __syncthreads();
+  // E5: ELU, out-site dropout, fp32 + planes, 16 bytes per lane
+  {
+    float* out = (g ? a.at.out_s[mod] : a.at.out_c[mod]) + (int64_t)m0 * D + hl * F;
+    uint16_t* zp = g ? a.at.zp_s[mod] : a.at.zp_c[mod];
+    const uint32_t ko = a.at.key_out[mod][g];
+    for (int e = tid; e < rows_valid * F4; e += 768) {
+      const int r = e / F4, q = e - r * F4;
+      const float4 v = *reinterpret_cast<const float4*>(shZ + r * FS + 4 * q);
+      const int64_t o = (int64_t)r * D + 4 * q;
+      const int64_t eg = (int64_t)m0 * D + hl * F + o;     // element index inside the (B, N, D) output
+      float kf[4];
+      drop_factor4(ko, (uint32_t)eg, kf);
+      float4 y;
+      y.x = elu_fast(v.x) * kf[0];
+      y.y = elu_fast(v.y) * kf[1];
+      y.z = elu_fast(v.z) * kf[2];
+      y.w = elu_fast(v.w) * kf[3];
+      st4(reinterpret_cast<float4*>(out + o), y);
+      split_store4(zp, a.at.z_lo_off, eg, y);
+    }
+  }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------
+struct GatfShape { int mtiles16, nt, spt; };
+static bool gatf_shape(int B, int N, GatfShape* s) {
+  if (N < 1 || N > 64) return false;
+  if (N <= 16) { s->mtiles16 = 4; s->nt = 1; s->spt = 64 / N; }
+  else if (N <= 20) { s->mtiles16 = 5; s->nt = 2; s->spt = 80 / N; }
+  else if (N <= 32) { s->mtiles16 = 6; s->nt = 2; s->spt = 96 / N; }
+  else if (N <= 48) { s->mtiles16 = 6; s->nt = 3; s->spt = 96 / N; }
+  else { s->mtiles16 = 8; s->nt = 4; s->spt = 128 / N; }
+  if (s->spt > B) s->spt = B;
+  return s->spt >= 1;
+}
+
+bool gat_fused_supported(int B, int N, int D, int prec) {
+  GatfShape s;
+  return prec != DVGR_F32 && D == 768 && gatf_shape(B, N, &s) && (int64_t)B * N * D < (1ll << 31);
+}
+
+template <int TERMS, int MTILES, int NT>
+static int gatf_launch(hipStream_t st, const GatFusedArgs& a) {
+  constexpr int NTC = 3;
+  using C = GatfCfg<TERMS, MTILES, NTC>;
+  const int N = a.at.N, S = (N + 3) / 4, NP = 4 * S + 1;
+  const size_t epi = sizeof(float) * ((size_t)(C::RP + 4) * C::FS + (size_t)a.spt * 16 * NT * NP + 2 * C::F + 3 * C::RP);
+  const size_t lds = (epi > (size_t)C::kRingBytes ? epi : (size_t)C::kRingBytes) + 16;
+  if (lds > 160 * 1024) return DVGR_E_DIMS;
+  static bool attr_set = false;                            // (benign race: the attribute is idempotent)
+  if (!attr_set) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gat_fused_fwd<TERMS, MTILES, NT, NTC>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int mtiles = (a.at.B + a.spt - 1) / a.spt;
+  const int total = mtiles * kHeads * 2;
+  DVGR_LAUNCH((k_gat_fused_fwd<TERMS, MTILES, NT, NTC>), dim3(8 * ((total + 7) / 8)), dim3(768), lds, st, a);
+  DVGR_LAUNCH_CHECK();
+}
+
+template <int TERMS>
+static int gatf_dispatch(hipStream_t st, const GatFusedArgs& a, const GatfShape& s) {
+  if (s.mtiles16 == 4 && s.nt == 1) return gatf_launch<TERMS, 4, 1>(st, a);
+  if (s.mtiles16 == 5 && s.nt == 2) return gatf_launch<TERMS, 5, 2>(st, a);
+  if (s.mtiles16 == 6 && s.nt == 2) return gatf_launch<TERMS, 6, 2>(st, a);
+  if (s.mtiles16 == 6 && s.nt == 3) return gatf_launch<TERMS, 6, 3>(st, a);
+  if (s.mtiles16 == 8 && s.nt == 4) return gatf_launch<TERMS, 8, 4>(st, a);
+  return DVGR_E_DIMS;
+}
+
+int gat_fused_fwd(hipStream_t st, const GatFusedArgs& a_in, int prec) {
+  GatFusedArgs a = a_in;
+  GatfShape s;
+  if (!gat_fused_supported(a.at.B, a.at.N, a.at.D, prec) || !gatf_shape(a.at.B, a.at.N, &s)) return DVGR_E_DIMS;
+  for (int m = 0; m < 2; ++m) {
+    if (!a.wh[m] || !a.xh[m][0] || !a.xh[m][1] || !a.bias[m] || !a.Wh_out[m]) return DVGR_E_NULL;
+    if (((uintptr_t)a.wh[m] | (uintptr_t)a.xh[m][0] | (uintptr_t)a.xh[m][1]) & 15) return DVGR_E_ALIGN;
+  }
+  if ((a.x_lo_off & 7) || (a.w_lo_off & 7)) return DVGR_E_ALIGN;
+  a.spt = s.spt;
+  return prec == DVGR_BF16X3 ? gatf_dispatch<3>(st, a, s) : gatf_dispatch<1>(st, a, s);
+}
+
+}  // namespace dvgr

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 
 #include "dvgr_gemm.h"
+#include "dvgr_planes.h"
 #ifdef DVGR_TIMING_AIDS
 #include "dvgr_rows.h"
 #endif
@@ -24,10 +25,6 @@ namespace dvgr {
 #define DVGR_DBG(P) 0
 #endif
 
-constexpr int BK = 32;  // reduction depth of one LDS stage
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 // XCD-aware workgroup -> output-tile map.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and
 // b + 8 share an L2), and each XCD's L2 is only 4 MiB: give every XCD a CONTIGUOUS chunk of the tile list,
@@ -143,7 +140,7 @@ __device__ __forceinline__ float tanh_fast(float x) {
   const float ax = fminf(fabsf(x), 15.0f);                    // tanh(15) == 1 in fp32; keeps e^{2x} finite
   const float e = __expf(2.0f * ax);
   const float t = 1.0f - __fdividef(2.0f, e + 1.0f);
-  return copysignf(t, x);
+  return (x != x) ? x : copysignf(t, x);                      // fminf(|NaN|, 15) is 15: a NaN must stay a NaN (as tanhf's does)
 }
 
 // Epilogue shared by both kernels.  C/D fragment map of the 16x16 MFMAs (dtype independent):
@@ -532,7 +529,6 @@ __global__ __launch_bounds__(256) void gemm_lp_kernel(const GemmBatch batch) {
 #endif
 constexpr int RS = DVGR_NS;                 // ring slots (A/B experiments: -DDVGR_NS=5 = all 160 KB of LDS)
 static_assert(RS >= 3 && RS <= 5, "the counted vmcnt waits cover at most three younger tiles");
-constexpr int RT = 128;                     // tile extent (M and N)
 constexpr int kRingTile = RT * BK;          // floats per operand tile (16 KB)
 constexpr int kRingSlot = 2 * kRingTile;    // A tile + B tile
 
@@ -821,7 +817,6 @@ __global__ __launch_bounds__(768) void gemm_ring_kernel(const GemmBatch batch) {
 // =================================================================================================
 constexpr int kPlaneTile = RT * BK;          // bf16 elements per plane tile
 
-__device__ __forceinline__ int plane_swz_ic(int k) { return (((k & 3) | (((k >> 3) & 1) << 2)) << 1); }
 
 // NI = DMA instructions per loader wave and plane tile: 2 for a 128-row (or 128-column) tile, 1 for the 64-row KC tile of
 // the half-height variant (256 chunks).
@@ -875,31 +870,6 @@ __device__ __forceinline__ void planes_issue(const GemmOperand& op, int k0, int 
                                        (__attribute__((address_space(3))) void*)(lds_hi + kTile + S0 * 8), 16, 0, 0);
   }
 }
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-template <int LAYOUT>
-__device__ __forceinline__ bf16x8 planes_frag(const uint16_t* tile, int idx16, int lane) {
-  const int r = lane & 15, g = lane >> 4;
-  if (LAYOUT == KC) {
-    const int row = idx16 + r;
-    const int slot = g ^ ((-(row >> 2)) & 3);
-    return *reinterpret_cast<const bf16x8*>(tile + row * BK + slot * 8);
-  } else {
-    const int q = r >> 2, p = r & 3;
-    const int k = 8 * g + q;
-    const int c = (idx16 >> 3) + (p >> 1);
-    typedef __attribute__((address_space(3))) s16x4* lds_ptr;
-    const uint16_t* a0 = tile + k * RT + ((c ^ plane_swz_ic(k)) << 3) + 4 * (p & 1);
-    const uint16_t* a1 = a0 + 4 * RT;            // rows k + 4: same swizzle value
-    const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a0));
-    const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a1));
-    typedef short s16x8 __attribute__((ext_vector_type(8)));
-    const s16x8 t = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
-    return __builtin_bit_cast(bf16x8, t);
-  }
-}
-
 // Phase clocks (debug builds only, `make clk`; read back by tools/gemm_clocks.py): where the first loader wave and the
 // first computing wave of every workgroup spend their time.
 #ifdef DVGR_CLK

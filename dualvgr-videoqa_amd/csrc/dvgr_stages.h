@@ -60,6 +60,21 @@ struct GatAttnArgs {
 };
 int gat_attn_fwd(hipStream_t st, const GatAttnArgs& a);
 
+// S2 + S3 in one launch (dvgr_gatf.hip): the projection Wh = xd . Wcat^T + bcat of one head for a tile of whole samples, with
+// the attention of GatAttnArgs as its epilogue.  bf16 modes with pre-split planes of both operands only.
+struct GatFusedArgs {
+  GatAttnArgs at;              // at.Wh is not read (the projection is produced here); everything else as for gat_attn_fwd
+  const uint16_t* xh[2][2];    // [mod][gat] hi plane of the GAT's input (B*N, D): the dropped copy (training) or X itself
+  int64_t x_lo_off;            // lo plane = hi plane + x_lo_off elements
+  const uint16_t* wh[2];       // [mod] hi plane of Wcat (8F, D)
+  int64_t w_lo_off;
+  const float* bias[2];        // bcat (8F)
+  float* Wh_out[2];            // (B*N, 8F) fp32, saved for the backward
+  int spt;                     // samples per tile (set by the launcher)
+};
+bool gat_fused_supported(int B, int N, int D, int prec);
+int gat_fused_fwd(hipStream_t st, const GatFusedArgs& a, int prec);
+
 // S5: w_v = tn_v . p2; beta = softmax over the two views; o = sum_v beta_v z_v; X' = X + o.
 struct SfCombineArgs {
   const float* X[2];     // layer input (B*N, D)

@@ -278,9 +278,28 @@ class NativeUnitReducer:
             import warnings
             warnings.warn("NativeUnitReducer without an eagerly initialised NCCL default group: steps with it measured 3 x "
                           "slower in that set-up (see parallel.py); time a few steps before trusting it")
+        # Everything that can fail on ONE rank only -- resolving RCCL (done above), the stream-order rule (DVGR_E_ORDER), the
+        # unique id on rank 0 -- happens BEFORE the first collective of the set-up, and the ranks agree on the outcome (MAX of
+        # a failure flag) so that they raise together: a rank that failed alone would leave its peers blocked in the id
+        # broadcast or in ncclCommInitRank while it moves on to a different collective.
         ident = C.create_string_buffer(128)
-        if self.rank == 0:
-            L_.check(self.lib.dvgr_comm_unique_id(ident), "dvgr_comm_unique_id")
+        failure = None
+        try:
+            s_ = C.c_void_p()
+            with torch.cuda.device(device):
+                L_.check(self.lib.dvgr_comm_device_stream(C.byref(s_)), "dvgr_comm_device_stream")   # order rule; creates the stream
+            if self.rank == 0:
+                L_.check(self.lib.dvgr_comm_unique_id(ident), "dvgr_comm_unique_id")
+        except Exception as e:                       # noqa: BLE001 -- reported on every rank below
+            failure = e
+        if self.world > 1:
+            on_dev = dist.get_backend(group) == "nccl"
+            flag = torch.tensor([1 if failure is not None else 0], dtype=torch.int32, device=device if on_dev else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+            if int(flag.item()) and failure is None:
+                failure = RuntimeError("NativeUnitReducer: the set-up failed on another rank")
+        if failure is not None:
+            raise RuntimeError(f"NativeUnitReducer set-up failed (rank {self.rank}): {failure}") from failure
         if self.world > 1:
             box = [ident.raw]
             dist.broadcast_object_list(box, src=0, group=group)
@@ -376,6 +395,16 @@ class ParamBucketReducer:
             self._bucket_ready(bi)
 
     def _bucket_ready(self, bi):
+        """Bucket bi has all its gradients (or finish() declares it complete).  Collectives are POSTED STRICTLY IN BUCKET-INDEX
+        ORDER: a ready bucket waits until every lower-index bucket has been posted.  Which gradients a rank received (and
+        therefore which buckets complete from a hook and which only in finish()) may differ between ranks; the index order
+        does not, so every rank issues the same sequence on the shared CollectiveIssuer."""
+        self._ready[bi] = True
+        while self._next < len(self.buckets) and self._ready[self._next]:
+            self._post_bucket(self._next)
+            self._next += 1
+
+    def _post_bucket(self, bi):
         if self._launched[bi]:
             return
         self._launched[bi] = True
@@ -438,6 +467,8 @@ class ParamBucketReducer:
     def start(self) -> None:
         self._pending = [len(b) for b in self.buckets]
         self._launched = [False] * len(self.buckets)
+        self._ready = [False] * len(self.buckets)
+        self._next = 0                               # lowest bucket index not posted yet
         self._events = []
         self._active = True
 

@@ -148,6 +148,14 @@ class TrainStep:
         self.alpha, self.beta, self.world = float(alpha), float(beta), int(world)
         self.opt = ClipAdam(lr=lr, betas=betas, eps=eps, max_norm=max_norm)
         self.unit_reducer, self.param_reducer = unit_reducer, param_reducer
+        self._unit_shared = getattr(self.unit, "graph_layers", 1) > 1
+        if self._unit_shared and unit_reducer is not None:
+            if not hasattr(unit_reducer, "reduce"):
+                raise ValueError("graph_layers > 1 needs a reducer with a whole-buffer reduce(flat) (LayerBucketReducer / NativeUnitReducer)")
+            # per-block events / callbacks / an in-call communicator cannot be honoured (DVGR_E_DIMS): the step reduces afterwards
+            self.unit.set_layer_events(None)
+            self.unit.set_layer_callback(None)
+            self.unit.set_comm(None)
         if self.unit.grad_mode != "flat":
             raise ValueError("TrainStep needs the unit's flat gradient buffer (grad_mode='flat')")
         unit_ids = {id(p) for p in self.unit.parameters()}
@@ -262,10 +270,16 @@ class TrainStep:
         terms, g = unit.last_loss                                            # {0, mean_l common, mean_l dependence}, upstream grads
         raw = m.last_raw                                                     # (L, B, N, D) list tensors as the kernels wrote them
         torch.autograd.backward([logits, raw[3], raw[4], raw[5], raw[6]], [g_logits, g[3], g[4], g[5], g[6]])
-        if self.unit_reducer is not None:
+        if self.unit_reducer is not None and not self._unit_shared:
             self.unit_reducer.finish()
         if self.param_reducer is not None:
             self.param_reducer.finish()
+        if self.unit_reducer is not None and self._unit_shared:
+            # graph_layers > 1: GAT modules are shared between unit layers, no block of the flat buffer is final before the
+            # backward ends (the library refuses layer events / an in-call communicator there): ONE whole-buffer all-reduce
+            # behind the backward, before clip + Adam -- issued from this thread AFTER the parameter buckets have all been
+            # enqueued by the issuer thread (finish() above joins it), so every rank issues the same sequence
+            self.unit_reducer.reduce(unit.last_flat_grad)
         # clip_grad_norm_(model.parameters(), 12) + Adam (train.py:158-159)
         segs = [("visual_input_unit", unit.flat_params(), unit.last_flat_grad, unit.lowp_planes())]
         for name, p in self.other:

@@ -192,6 +192,11 @@ enum dvgr_probe_site {
  * runtime then spends the time on the host between launches; dualvgr-videoqa_amd/unit.py sets it whenever layer events
  * are installed).  The environment variable DVGR_NO_QUERY_STREAM=1 has the same effect for every call. */
 #define DVGR_OPT_NO_QUERY_STREAM 2
+/* Forward: the GAT projection (S2) and the attention (S3) of a layer run as ONE launch (csrc/dvgr_gatf.hip: the attention is
+ * the contraction's epilogue on a tile of whole samples x one head) wherever the shape allows it -- bf16 modes, D = 768 --
+ * and the punish gate does not depend on work the separate projection would hide (layer 0 beside the side stream keeps two
+ * launches).  DVGR_OPT_NO_FUSED_GAT forces the two-launch form everywhere (A/B timing, parity of the two forms). */
+#define DVGR_OPT_NO_FUSED_GAT 4
 
 /* Scope-U loss evaluated by the forward itself (dvgr_opts.loss): the same arithmetic and outputs as
  * dvgr_scope_u_loss below, but the kernels are enqueued as soon as the last layer's list outputs exist and run on the

@@ -105,6 +105,25 @@ def test_gemm_strided_views_bias_activation_accumulate():
     assert float((wide[:, N:] - (A.double() @ W.double().T).float()).abs().max()) < 2e-4 * float(ref.abs().max())
 
 
+def test_tanh_epilogue_keeps_a_nan_a_nan():
+    """the hardware-exp tanh of the S4 epilogue clamps |x| with fminf, which would turn a NaN pre-activation
+    into +-1 and hide a diverged run; the reference's tanh propagates it (model/Attention.py:16)."""
+    torch.manual_seed(1)
+    M, N, K = 128, 128, 64
+    A = torch.randn(M, K, device="cuda")
+    W = torch.randn(N, K, device="cuda")
+    A[5, 7] = float("nan")
+    A[9, 0] = float("inf")
+    W[:, 0] = W[:, 0].abs() + 0.1          # +inf * positive = +inf -> tanh = 1 (the correct limit)
+    for prec in (0, 2):                    # DVGR_F32, DVGR_BF16X3
+        got = _gemm(0, A, W, M, N, K, act=1, prec=prec)
+        assert torch.isnan(got[5]).all(), prec
+        assert torch.all(got[9] == 1.0), prec
+        ok = torch.ones(M, dtype=torch.bool, device="cuda")
+        ok[5] = ok[9] = False
+        assert torch.isfinite(got[ok]).all()
+
+
 def test_keep_mask_device_equals_numpy_replica():
     lib = L.load()
     n = 300_001

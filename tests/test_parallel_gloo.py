@@ -149,6 +149,56 @@ def test_param_bucket_reducer_averages_ordinary_parameters():
         assert np.allclose(g, w.numpy(), rtol=1e-6, atol=1e-7)
 
 
+def _worker_order(rank, world, port, q):
+    """Gradient presence differs between the ranks: on rank 1 one parameter of bucket 0 receives no gradient, so bucket 0
+    completes from a hook on rank 0 and only in finish() on rank 1, while buckets 1 and 2 complete from hooks on both."""
+    dist.init_process_group("gloo", init_method=port, rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        a = torch.nn.Linear(4, 3)
+        b = torch.nn.Linear(3, 2)
+        side = torch.nn.Parameter(torch.ones(3))                    # bucket 0 member, used on rank 0 only
+        c = torch.nn.Linear(2, 2)
+        buckets = [list(c.parameters()) + [side], list(b.parameters()), list(a.parameters())]   # backward order: c, b, a
+        red = parallel.ParamBucketReducer(buckets)
+        order = []
+        real_cpu = red._reduce_cpu
+        red._reduce_cpu = lambda bi: (order.append(bi), real_cpu(bi))[1]
+        x = torch.arange(8, dtype=torch.float32).reshape(2, 4) / 5 + rank
+        red.start()
+        h = b(torch.tanh(a(x)))
+        y = c(h) + ((h[:, :1] * side[:1]).sum() if rank == 0 else 0.0)
+        y.pow(2).mean().backward()
+        red.finish()
+        q.put((rank, order, [None if p.grad is None else p.grad.numpy().copy() for bk in buckets for p in bk]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_param_buckets_are_issued_in_index_order_whatever_gradients_a_rank_received():
+    """the size of each collective was rank-invariant but the ISSUE ORDER followed which buckets completed
+    from a hook.  Every rank must post bucket 0, 1, 2 in that order; a parameter without a local gradient takes the average."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_order, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, order, grads = q.get(timeout=240)
+        res[r] = (order, grads)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][0] == res[1][0] == [0, 1, 2], (res[0][0], res[1][0])
+    for g0, g1 in zip(res[0][1], res[1][1]):
+        assert g0 is not None and g1 is not None
+        assert np.allclose(g0, g1, rtol=1e-6, atol=1e-7)            # both ranks hold the same averaged gradients
+
+
 def test_shard_batch_partitions():
     for n in (1, 7, 64, 512):
         for w in (1, 2, 3, 8):
