@@ -11,6 +11,14 @@ RANK / LOCAL_RANK / WORLD_SIZE from the environment; started plainly (`python be
 before it makes any GPU call -- launches exactly that torchrun command as a child and relays rank 0's JSON line.  A run
 whose world size differs from --gpus fails; it never silently measures fewer GPUs.
 
+Which gradient reducer runs the timed region (--reducer auto) is settled BEFORE this process touches the GPU: every rank
+starts three short child processes, one after the other -- the plain step (no collectives), the step with ONLY the native
+reducer set up, the step with ONLY the torch.distributed reducer set up -- each child of a rank meeting the same child of
+the other ranks in a process group of its own.  (Both reducers in one process slow each other down 3 x, and the native
+path's speed depends on the order in which streams and RCCL are set up: DESIGN.md section 5.)  The timed process then sets
+up the winner alone.  If neither candidate stays within 1.3 x (one rank) / 2.5 x (several ranks: real all-reduces) of the
+plain step, the run exits non-zero instead of printing a line that measures a broken set-up.
+
 Timing: W untimed warm-up steps, then blocks of EXACTLY K steps, each bracketed by barrier + device synchronise on both
 sides and MAX-reduced over ranks; blocks repeat until >= 5 s has been timed and the line reports the MEDIAN block
 (`value` = world * B * K / median block time).  Rank 0 prints ONE JSON line: whole-job QA-pairs/s, the roofline of the
@@ -181,6 +189,81 @@ def spawn_ranks(n):
     return 0
 
 
+TRIAL_KINDS = ("plain", "native", "python")
+SLOW_FACTOR_ONE_RANK, SLOW_FACTOR_RANKS = 1.3, 2.5
+
+
+def run_trial_children(args):
+    """Called by every rank BEFORE it makes a GPU call: one short child process per candidate (`--trial KIND`), sequentially.
+    A child inherits RANK / LOCAL_RANK / WORLD_SIZE and meets the same child of the other ranks on MASTER_PORT + 1 + index
+    (torchrun's agent store is not used: the rank-0 child creates the store).  Returns {kind: parsed JSON or None}."""
+    base_port = int(os.environ.get("MASTER_PORT", "29533"))
+    out = {}
+    argv = [a for a in sys.argv[1:]]
+    for idx, kind in enumerate(TRIAL_KINDS):
+        if kind == "native" and args.backend != "nccl":
+            out[kind] = None
+            continue
+        env = dict(os.environ)
+        env["MASTER_PORT"] = str(base_port + 1 + idx)
+        env.setdefault("MASTER_ADDR", "127.0.0.1")
+        env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+        env["DVGR_BENCH_TRIAL_CHILD"] = "1"
+        if kind != "plain":
+            # what RCCL chose (channels, algorithm, protocol) is read from its INFO log; the log goes to a file of the child's own
+            env.setdefault("NCCL_DEBUG", "INFO")
+            env.setdefault("NCCL_DEBUG_SUBSYS", "INIT,TUNING")
+            env["NCCL_DEBUG_FILE"] = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"dvgr_rccl_{kind}_{os.getpid()}_%p.log")
+        cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--trial", kind]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
+            line = next((l for l in r.stdout.splitlines() if l.startswith("{") and '"trial"' in l), None)
+            out[kind] = json.loads(line) if (r.returncode == 0 and line) else None
+            if out[kind] is None:
+                tail = (r.stderr or "").strip().splitlines()[-6:]
+                print(f"[bench] trial child '{kind}' failed (rc {r.returncode}): " + " | ".join(tail), file=sys.stderr, flush=True)
+        except subprocess.TimeoutExpired:
+            out[kind] = None
+            print(f"[bench] trial child '{kind}' timed out", file=sys.stderr, flush=True)
+        print(f"[bench] trial child '{kind}': {out[kind] and out[kind].get('ms')} ms/step ({time.perf_counter() - t0:.0f} s)",
+              file=sys.stderr, flush=True)
+    return out
+
+
+def rccl_info_from_log(pattern_prefix):
+    """Channel count / algorithm / protocol lines of RCCL's INFO log of THIS process (NCCL_DEBUG_FILE), best effort."""
+    import glob
+    import re
+    path = os.environ.get("NCCL_DEBUG_FILE", "")
+    if not path:
+        return None
+    files = glob.glob(path.replace("%p", str(os.getpid())).replace("%h", "*"))
+    info = {"channels": None, "allreduce_tuning": []}
+    algo = {0: "Tree", 1: "Ring", 2: "CollNetDirect", 3: "CollNetChain", 4: "NVLS", 5: "NVLSTree"}
+    proto = {0: "LL", 1: "LL128", 2: "Simple"}
+    seen = set()
+    for fn in files:
+        try:
+            text = open(fn, errors="replace").read()
+        except OSError:
+            continue
+        m = re.search(r"(\d+) coll channels, (\d+) collnet channels, (\d+) nvls channels, (\d+) p2p channels", text)
+        if m:
+            info["channels"] = {"coll": int(m.group(1)), "p2p": int(m.group(4))}
+        for m in re.finditer(r"AllReduce: (\d+) Bytes -> Algo (\d+) proto (\d+) time ([0-9.]+)", text):
+            key = (int(m.group(1)), int(m.group(2)), int(m.group(3)))
+            if key not in seen and len(seen) < 8:
+                seen.add(key)
+                info["allreduce_tuning"].append({"bytes": key[0], "algo": algo.get(key[1], key[1]), "proto": proto.get(key[2], key[2]),
+                                                 "model_time_us": float(m.group(4))})
+        try:
+            os.unlink(fn)
+        except OSError:
+            pass
+    return info
+
+
 HOST_ENQUEUE_MS = []     # per block: host time to enqueue the K steps (before the closing synchronise) / K, in ms
 
 
@@ -242,6 +325,9 @@ def main():
                          "library's own RCCL communicator (include/dvgr_comm.h); python = parallel.LayerBucketReducer over "
                          "torch.distributed (host callback + issuer thread); auto = both are set up, a few untimed steps of each "
                          "are measured (MAX over ranks) and the faster one runs the timed region")
+    ap.add_argument("--trial", default=None, choices=list(TRIAL_KINDS),
+                    help="internal: a short untimed measurement of the step with ONE reducer set up (plain = none), printed as one "
+                         "JSON line; started by --reducer auto as a child process before the timed process touches the GPU")
     ap.add_argument("--loss", default="fused", choices=["fused", "fused-after", "precomputed"],
                     help="fused: the scope-U loss and its gradients are computed inside every timed step by "
                          "dvgr_scope_u_loss; precomputed: fixed upstream gradients (unit kernels only)")
@@ -251,6 +337,10 @@ def main():
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return spawn_ranks(args.gpus)            # nothing above touched the GPU
+    want_ddp = int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("DVGR_DDP_SELFTEST", "0") == "1"
+    trials = None
+    if want_ddp and args.trial is None and args.reducer == "auto" and os.environ.get("DVGR_BENCH_TRIAL_CHILD") != "1":
+        trials = run_trial_children(args)        # nothing above touched the GPU; the children are gone when this returns
     # stdout carries exactly ONE line, the result: whatever libraries print there (RCCL's version banner at init) goes to
     # stderr instead -- file descriptor 1 is pointed at stderr for the run and the JSON line is written to the saved one
     global _RESULT_FD
@@ -276,18 +366,20 @@ def main():
     dev = torch.device("cuda", local)
     # DVGR_DDP_SELFTEST=1: run the data-parallel plumbing (process group, per-layer buckets gated by the library's events,
     # communication stream) with a single rank, to check it on a one-GPU box
-    ddp = world > 1 or os.environ.get("DVGR_DDP_SELFTEST", "0") == "1"
+    ddp = (world > 1 or os.environ.get("DVGR_DDP_SELFTEST", "0") == "1") and args.trial != "plain"
     dist_info = None
     if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        import datetime
+        pg_timeout = datetime.timedelta(seconds=180 if args.trial else 600)
         if args.backend == "nccl":
             opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)   # RCCL's own stream on a queue of its own as well
-            dist.init_process_group("nccl", device_id=dev, pg_options=opts)
+            dist.init_process_group("nccl", device_id=dev, pg_options=opts, timeout=pg_timeout)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=pg_timeout)
         if dist.get_world_size() != args.gpus and world > 1:
             raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
         ver = None
@@ -303,8 +395,38 @@ def main():
 
     cfg = CONFIGS[args.config]
     B, N, Lr, T = cfg["B"], cfg["N"], cfg["L"], cfg["T"]
+    # ---- which reducer: the children's verdict (identical on every rank after the agreement below), or the command line
+    choice = args.trial if args.trial in ("native", "python") else (args.reducer if args.reducer != "auto" else None)
+    trial_report = None
+    if ddp and trials is not None:
+        ms = {k: (trials[k]["ms"] if trials.get(k) else float("inf")) for k in TRIAL_KINDS}
+        if world > 1:                    # a child may have failed on one rank only: agree on MAX (inf = unavailable anywhere)
+            tt = torch.tensor([min(ms[k], 1e9) for k in TRIAL_KINDS], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ms = {k: (float(v) if float(v) < 1e9 else float("inf")) for k, v in zip(TRIAL_KINDS, tt.tolist())}
+        cands = {k: ms[k] for k in ("native", "python") if ms[k] != float("inf")}
+        trial_report = {"ms_per_step": {k: (None if v == float("inf") else v) for k, v in ms.items()},
+                        "how": "one child process per candidate and rank, before the timed process touched the GPU (MAX over ranks)",
+                        "rccl": {k: trials[k].get("rccl") for k in ("native", "python") if trials.get(k)}}
+        if not cands:
+            raise SystemExit("bench.py: neither gradient reducer could be set up in its trial process; no measurement")
+        choice = min(cands, key=cands.get)
+        limit = SLOW_FACTOR_ONE_RANK if world == 1 else SLOW_FACTOR_RANKS
+        if ms["plain"] != float("inf") and cands[choice] > limit * ms["plain"] and os.environ.get("DVGR_BENCH_ALLOW_SLOW", "0") != "1":
+            print(f"[bench] reducer trials {ms}: the best candidate is more than {limit} x the plain step -- this measures a broken "
+                  f"set-up (DESIGN.md section 5), not the path; refusing to print a result (DVGR_BENCH_ALLOW_SLOW=1 overrides)",
+                  file=sys.stderr, flush=True)
+            if ddp:
+                dist.destroy_process_group()
+            raise SystemExit(3)
+        print(f"[bench] reducer trials ms/step {ms} -> {choice}", file=sys.stderr, flush=True)
+    elif ddp and choice is None:
+        choice = "native" if args.backend == "nccl" else "python"
+    if ddp and choice == "native" and args.backend != "nccl":
+        choice = "python"
+
     if args.model:
-        bench_model(args, dev, rank, world, cfg, ddp, dist_info)
+        bench_model(args, dev, rank, world, cfg, ddp, dist_info, choice, trial_report)
         if ddp:
             dist.destroy_process_group()
         return 0
@@ -346,41 +468,26 @@ def main():
     events = None
     reducer = None
     reducer_kind = None
-    red_native = red_python = None
     if ddp:
-        if args.reducer in ("auto", "native") and args.backend == "nccl":
+        if choice == "native":
             try:
-                red_native = parallel.NativeUnitReducer(dev, force_single=(world == 1))
-            except Exception as e:        # a failed communicator must not cost the whole multi-GPU measurement
+                red = parallel.NativeUnitReducer(dev, force_single=(world == 1))
+                m.set_comm(red)               # every backward call enqueues its blocks' all-reduces itself (dvgr_opts.comm)
+                reducer = red
+                reducer_kind = "native: RCCL all-reduce per gradient block enqueued inside dvgr_unit_backward (dvgr_opts.comm)"
+            except Exception as e:            # raised on EVERY rank together (parallel.NativeUnitReducer agrees before it raises)
                 print(f"[bench] native reducer unavailable ({e!r}); using the torch.distributed reducer", file=sys.stderr, flush=True)
-        if world > 1:                     # every rank must hold the same candidates, or the trial's collectives deadlock
-            ok = torch.tensor([1 if red_native is not None else 0], device=dev, dtype=torch.int32)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0:
-                red_native = None
-        if args.reducer in ("auto", "python") or red_native is None:
+                choice = "python"
+        if choice == "python":
             events = [torch.cuda.Event() for _ in range(Lr + 2)]
             for ev in events:
                 ev.record()          # torch creates the hipEvent lazily at the first record; the C ABI needs the handle
-            red_python = parallel.LayerBucketReducer(parallel.layer_buckets(m), device=dev)
-            red_python.force = world == 1          # self-test: run the collectives even with one rank
-
-    def use_reducer(kind):
-        """Point the module at one of the two reducers (or at none)."""
-        nonlocal reducer, reducer_kind
-        m.set_comm(None)
-        m.set_layer_events(None)
-        m.set_layer_callback(None)
-        reducer, reducer_kind = None, None
-        if kind == "native":
-            m.set_comm(red_native)        # every backward call enqueues its blocks' all-reduces itself (dvgr_opts.comm)
-            reducer = red_native
-            reducer_kind = "native: RCCL all-reduce per gradient block enqueued inside dvgr_unit_backward (dvgr_opts.comm)"
-        elif kind == "python":
+            red = parallel.LayerBucketReducer(parallel.layer_buckets(m), device=dev)
+            red.force = world == 1            # self-test: run the collectives even with one rank
             m.set_layer_events(events)
             # each bucket's all-reduce is enqueued from inside the backward call, right after its event (dvgr_opts.layer_done_cb)
-            m.set_layer_callback(lambda idx, g: red_python.launch(idx, g, events[idx]))
-            reducer = red_python
+            m.set_layer_callback(lambda idx, g: red.launch(idx, g, events[idx]))
+            reducer = red
             reducer_kind = "python: parallel.LayerBucketReducer over torch.distributed (host callback + issuer thread)"
 
     probe_sites = {"fwd_gat_gemm": (L_.PROBE_FWD_GAT_GEMM, 8 * B * N * D * D, "S2 forward GAT projection Wh = X.Wcat^T, both modalities (TAG_FWD_GAT)"),
@@ -432,30 +539,24 @@ def main():
         if reducer is not None:
             reducer.finish()
 
-    reducer_trial = None
-    if ddp:
-        # Which reducer runs the timed region: a few untimed steps of each candidate, MAX over ranks, the faster one wins
-        # (the native path's speed depends on process set-up order in ways only a measurement settles: parallel.py).
-        def trial(kind, n=12):
-            use_reducer(kind)
-            for _ in range(4):
-                step()
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-            t0 = time.perf_counter()
-            for _ in range(n):
-                step()
-            torch.cuda.synchronize()
-            dt = torch.tensor([(time.perf_counter() - t0) / n * 1e3], device=dev, dtype=torch.float64)
-            if world > 1:
-                dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-            return float(dt.item())
-        cands = [k for k, r in (("native", red_native), ("python", red_python)) if r is not None]
-        reducer_trial = {k: trial(k) for k in cands}
-        best = min(reducer_trial, key=reducer_trial.get)      # identical on every rank (MAX-reduced timings)
-        use_reducer(best)
-        print(f"[bench] reducer trial ms/step {reducer_trial} -> {best}", file=sys.stderr, flush=True)
+    if args.trial is not None:
+        # a trial child: 6 warm-up + 16 measured steps of this ONE set-up, MAX over ranks, one JSON line, done
+        for _ in range(6):
+            step()
+        torch.cuda.synchronize()
+        if ddp and world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(16):
+            step()
+        torch.cuda.synchronize()
+        dtt = torch.tensor([(time.perf_counter() - t0) / 16 * 1e3], device=dev, dtype=torch.float64)
+        if ddp and world > 1:
+            dist.all_reduce(dtt, op=dist.ReduceOp.MAX)
+        if ddp:
+            dist.destroy_process_group()
+        emit({"trial": args.trial, "ms": float(dtt.item()), "rccl": rccl_info_from_log(args.trial) if args.trial != "plain" else None})
+        return 0
     for _ in range(args.warmup):
         step()
     lib = L_.load()
@@ -502,11 +603,17 @@ def main():
                    "timing": {"blocks": len(blocks), "steps_per_block": args.steps, "timed_s": float(sum(blocks)),
                               "ms_per_step_min_median_max": [min(blocks) / args.steps * 1e3, ms_step, max(blocks) / args.steps * 1e3]},
                    "launches_per_step": launches_per_step,      # kernel launches of the library per timed step (dvgr_dbg_launch_count)
-                   "host_enqueue_ms_per_step": float(np.median(HOST_ENQUEUE_MS)),   # host time to enqueue a step (< ms_per_step: not launch-bound)
+                   # host time to enqueue a step, measured at THIS batch: the runtime's queue fills up ~15 steps ahead of the
+                   # device, so the figure includes back-pressure and approaches ms_per_step; the launch path's own cost is what
+                   # tools/host_time.py reads at B = 1 (0.55 ms for the 64 launches of a C2 step)
+                   "host_enqueue_ms_per_step": float(np.median(HOST_ENQUEUE_MS)),
                    "optimizer_ms": optimizer_ms,
                    "optimizer": "clip_grad_norm_(12) + Adam over the unit's flat parameter / gradient buffers, two fused launches "
                                 "(dvgr_optim_*), OUTSIDE the timed step",
-                   "distributed": dict(dist_info, reducer=reducer_kind, reducer_trial_ms=reducer_trial) if dist_info else None,
+                   "distributed": dict(dist_info, reducer=reducer_kind, reducer_trial=trial_report,
+                                       allreduce_bytes_per_block={str(l): 4 * (b - a) for l, (a, b) in
+                                                                  ((l, m.layer_param_range(l)) for l in parallel.block_order(Lr))},
+                                       allreduce_bytes_per_step=4 * int(m.flat_params().numel())) if dist_info else None,
                    "algorithmic_gflop_per_qa_train": f_train / 1e9,
                    "unit_tflops": value / world * f_train / 1e12,
                    "unit_frac_of_mfma_peak": value / world * f_train / 1e12 / peak},
@@ -533,7 +640,7 @@ def main():
     return 0
 
 
-def bench_model(args, dev, rank, world, cfg, ddp, dist_info):
+def bench_model(args, dev, rank, world, cfg, ddp, dist_info, choice=None, trial_report=None):
     """Scope M: the whole training step at the DualVGR.forward boundary: trainer.TrainStep =
     train.py:139-159 (forward, CE + auxiliary losses, backward, gradient averaging, clip 12, Adam)."""
     import torch
@@ -561,7 +668,27 @@ def bench_model(args, dev, rank, world, cfg, ddp, dist_info):
     answers = torch.from_numpy((synth.uniform("b_ans", (B,), 0.0, float(VA), 666 + rank)).astype(np.int64)).to(dev)
 
     unit_red = param_red = None
-    if ddp:
+    reducer_kind = None
+    if ddp and choice == "native":
+        # every gradient of the model on the library's own RCCL communicator: the unit's blocks enqueued by its backward call
+        # (dvgr_opts.comm), the flat gradient buffers of the four BiLSTMs and of the answer head by theirs (grad_sink), the
+        # embedding table and the motion projection from their accumulate hooks -- one issue order, no interpreter thread
+        try:
+            from dualvgr_videoqa_amd.clip import BiLSTM
+            unit_red = parallel.NativeUnitReducer(dev, force_single=(world == 1))
+            unit.set_comm(unit_red)
+            flat_mods = [m._head] + [x for x in m.modules() if isinstance(x, BiLSTM)]
+            unit_ids = {id(p) for p in unit.parameters()}
+            rest = [p for p in m.parameters() if id(p) not in unit_ids]
+            param_red = parallel.NativeParamReducer(unit_red, flat_mods, rest)
+            reducer_kind = ("native: one RCCL communicator of the library's own; unit blocks enqueued inside dvgr_unit_backward, "
+                            f"{len(flat_mods)} flat module buffers + {len(param_red.params)} tensors from their backward calls / hooks")
+        except Exception as e:
+            print(f"[bench] native reducers unavailable ({e!r}); using the torch.distributed reducers", file=sys.stderr, flush=True)
+            unit_red = param_red = None
+            unit.set_comm(None)
+            choice = "python"
+    if ddp and choice == "python":
         # the unit's gradients: per-layer buckets launched from the backward's host callback; everything else: buckets of
         # ordinary parameters launched from autograd's post-accumulate hooks -- both overlap the remaining backward
         events = [torch.cuda.Event() for _ in range(Lr + 2)]
@@ -572,6 +699,7 @@ def bench_model(args, dev, rank, world, cfg, ddp, dist_info):
         param_red = parallel.ParamBucketReducer(parallel.model_param_buckets(m), device=dev)
         unit_red.force = param_red.force = world == 1
         unit.set_layer_callback(lambda idx, g: unit_red.launch(idx, g, events[idx]))
+        reducer_kind = "python: parallel.LayerBucketReducer + ParamBucketReducer over torch.distributed (one issuer thread)"
     ts = dv.TrainStep(m, lr=1e-4, alpha=1.0, beta=1e-8, max_norm=12.0, world=world, unit_reducer=unit_red, param_reducer=param_red)
     opt_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
@@ -579,6 +707,23 @@ def bench_model(args, dev, rank, world, cfg, ddp, dist_info):
         ts.timing = {"begin": opt_ev[i][0], "end": opt_ev[i][1]} if i is not None else None
         ts(app, mot, q, qlen, answers)
 
+    if args.trial is not None:
+        import torch.distributed as dist
+        for _ in range(4):
+            step()
+        torch.cuda.synchronize()
+        if ddp and world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
+        dtt = torch.tensor([(time.perf_counter() - t0) / 10 * 1e3], device=dev, dtype=torch.float64)
+        if ddp and world > 1:
+            dist.all_reduce(dtt, op=dist.ReduceOp.MAX)
+        if rank == 0 or True:            # every rank's parent reads its own child
+            emit({"trial": args.trial, "ms": float(dtt.item()), "rccl": rccl_info_from_log(args.trial) if args.trial != "plain" else None})
+        return
     for _ in range(args.warmup):
         step()
     blocks = timed_blocks(step, args.steps, ddp, dev, args.min_seconds)
@@ -595,7 +740,9 @@ def bench_model(args, dev, rank, world, cfg, ddp, dist_info):
                       "optimizer_ms": optimizer_ms, "forward_backward_ms": dt / args.steps * 1e3 - optimizer_ms,
                       "host_enqueue_ms_per_step": float(np.median(HOST_ENQUEUE_MS)),
                       "timing": {"blocks": len(blocks), "steps_per_block": args.steps, "timed_s": float(sum(blocks))},
-                      "distributed": dist_info, "global_batch": world * B, "parallelism": f"dp{world}"}}
+                      "distributed": dict(dist_info, reducer=reducer_kind, reducer_trial=trial_report,
+                                          collectives_per_step=(getattr(param_red, "count", None))) if dist_info else None,
+                      "global_batch": world * B, "parallelism": f"dp{world}"}}
     if rank == 0:
         emit(out)
 

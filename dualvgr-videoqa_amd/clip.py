@@ -134,6 +134,8 @@ class _LstmFn(torch.autograd.Function):
         L_.check(lib.dvgr_lstm_backward(C.byref(dims), flat.data_ptr(), C.byref(io), C.byref(gr), ctx.flags, saved.data_ptr(),
                                         saved.numel(), ws.data_ptr(), ws.numel(), int(ctx.train), ctx.seed, stream),
                  "dvgr_lstm_backward")
+        if mod.grad_sink is not None:             # data parallel: the flat gradient buffer goes to the reducer right here
+            mod.grad_sink(mod, gflat)             # (parallel.NativeParamReducer: one in-place all-reduce, enqueued behind this call)
         pgrads = [gflat[o:o + p.numel()].view(p.shape) for p, o in zip(mod._plist, mod._table)]
         return (None, g_x, None, None, None, None, *pgrads)
 
@@ -154,6 +156,7 @@ class BiLSTM(nn.Module):
         self.forced_seed = None
         self.dropout_enabled = True   # False: training mode without the dropout sites (deterministic step comparisons)
         self.last_seed = 0
+        self.grad_sink = None         # callable(module, flat_gradient) or None: see _LstmFn.backward
         self._plist = [getattr(self, n) for n in CP_NAMES]
         self._table = None
         self._flat = None

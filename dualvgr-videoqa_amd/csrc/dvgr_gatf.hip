@@ -39,6 +39,17 @@ namespace dvgr {
 
 typedef float gatf_f32x4 __attribute__((ext_vector_type(4)));
 
+// Phase clocks (debug builds only, `make clk`; tools/gatf_clocks.py): wave 0 of every workgroup stamps the 100 MHz wall clock
+#ifdef DVGR_CLK
+__device__ long long g_gatf_clk[1024 * 8];
+#define GFCLK(k)                                                                                              \
+  do {                                                                                                        \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_gatf_clk[blockIdx.x * 8 + (k)] = wall_clock64();            \
+  } while (0)
+#else
+#define GFCLK(k) do { } while (0)
+#endif
+
 template <int TERMS, int MTILES, int NTC>
 struct GatfCfg {
   static constexpr int kPlanes = TERMS == 3 ? 2 : 1;
@@ -183,6 +194,7 @@ __global__ __launch_bounds__(768) void k_gat_fused_fwd(const GatFusedArgs a) {
 
   f32x4 acc[4][NTC];                                       // (row group 0 uses MT0 of the 4 row slots, row group 1 MTILES - MT0)
   int row0 = 0, col0 = 0;
+  GFCLK(0);
   if (loader) {
     const int w = wave12 - 8;
     // waves w < ITOT % 4 carry IHI instructions per plane, the others ILO (equal when ITOT % 4 == 0)
@@ -195,6 +207,7 @@ __global__ __launch_bounds__(768) void k_gat_fused_fwd(const GatFusedArgs a) {
     else { row0 = 16 * C::MT0; gatf_compute<C, TERMS, (MTILES - C::MT0 > 0 ? MTILES - C::MT0 : 1), NTC>(smem, nk, row0, col0, lane, acc); }
   }
   __builtin_amdgcn_s_barrier();                            // every fragment read of the ring is done: its LDS is free
+  GFCLK(1);
 
   // ---- epilogue images (floats) -------------------------------------------------------------------------------------
   const int S = (N + 3) >> 2, NP = 4 * S + 1;
@@ -230,6 +243,7 @@ __global__ __launch_bounds__(768) void k_gat_fused_fwd(const GatFusedArgs a) {
     for (int r = tl; r < RP; r += 256) shS[r] = r < rows_valid ? a.at.s[mod][m0 + r] : 0.f;
   }
   __syncthreads();
+  GFCLK(2);
   // E2: the projection is saved for the backward (fp32, whole row pieces), and the two halves of the logits
   {
     float* Wg = a.Wh_out[mod] + (int64_t)m0 * HF + h * F;
@@ -257,6 +271,7 @@ __global__ __launch_bounds__(768) void k_gat_fused_fwd(const GatFusedArgs a) {
     }
   }
   __syncthreads();
+  GFCLK(3);
   // E3: softmax over j of LeakyReLU(u_i + v_j + c), one wave per row; alpha-site dropout; the punish gate of column j
   {
     const float c = a.at.gat_c[mod][h];
@@ -276,6 +291,7 @@ __global__ __launch_bounds__(768) void k_gat_fused_fwd(const GatFusedArgs a) {
     }
   }
   __syncthreads();
+  GFCLK(4);
   // E4: P = (alpha_d * s^T) . Wh on the fp32 MFMA.  A = shA (rows i, reduction j), B = the sample's rows of shZ (reduction
   // j, columns f); reduction steps past the sample's N rows read the zero rows RP .. RP + 3 (their A entries are zero too).
   {
@@ -307,6 +323,7 @@ __global__ __launch_bounds__(768) void k_gat_fused_fwd(const GatFusedArgs a) {
     }
   }
   __syncthreads();
+  GFCLK(5);
   // E5: ELU, out-site dropout, fp32 + planes, 16 bytes per lane
   {
     float* out = (g ? a.at.out_s[mod] : a.at.out_c[mod]) + (int64_t)m0 * D + hl * F;
@@ -328,7 +345,15 @@ __global__ __launch_bounds__(768) void k_gat_fused_fwd(const GatFusedArgs a) {
       split_store4(zp, a.at.z_lo_off, eg, y);
     }
   }
+  GFCLK(6);
 }
+
+#ifdef DVGR_CLK
+extern "C" int dvgr_dbg_gatf_clocks(long long* host_out, int n) {
+  if (n > 1024 * 8) n = 1024 * 8;
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gatf_clk), sizeof(long long) * n, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 // ---- host side ----------------------------------------------------------------------------------------------------
 struct GatfShape { int mtiles16, nt, spt; };

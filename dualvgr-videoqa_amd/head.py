@@ -146,6 +146,8 @@ class _HeadFn(torch.autograd.Function):
         stream = torch.cuda.current_stream(dev).cuda_stream
         L_.check(lib.dvgr_head_backward(C.byref(dims), flat.data_ptr(), C.byref(io), C.byref(gr), saved.data_ptr(), saved.numel(),
                                         ws.data_ptr(), ws.numel(), int(ctx.train), ctx.seed, stream), "dvgr_head_backward")
+        if mod.grad_sink is not None:             # data parallel: see clip._LstmFn.backward
+            mod.grad_sink(mod, gflat)
         pgrads = []
         for (o, n, shape, rows_used) in mod.param_slices:
             gview = gflat[o:o + n].view(shape)
@@ -167,6 +169,7 @@ class AnswerHead(nn.Module):
         self.forced_seed = None
         self.dropout_enabled = True    # False: training-mode BatchNorm with the dropout sites off (DVGR_HEAD_TRAIN_NO_DROPOUT)
         self.last_logits_padded = None
+        self.grad_sink = None          # callable(module, flat_gradient) or None (parallel.NativeParamReducer)
         cl = self.output_unit.classifier
         self._plist = [self.feature_aggregation.v_proj.weight, self.feature_aggregation.attn.weight,
                        self.feature_aggregation.attn.bias, self.output_unit.question_proj.weight,

@@ -55,7 +55,7 @@ def _run(m, inp, R, N, seed=None):
     return t, outs
 
 
-def _against_oracle(name, B, N, Lr, dtype, train):
+def _against_oracle(name, B, N, Lr, dtype, train, scale_tol=None):
     sd_np = synth.xavier_state_dict(O.param_shapes(WD, D, Lr), seed=31, bias_range=0.05)
     inp = synth.unit_inputs(B, N, T, D, WD, seed=31)
     R = torch.from_numpy(synth.normal("Rcfg", (B, N, D), 1.0, 31))
@@ -76,7 +76,7 @@ def _against_oracle(name, B, N, Lr, dtype, train):
     print(f"  {what}: forward (all {len(flat_h)} outputs) {ferr:.2e}")
     assert ferr < TOL, ferr
     assert_flips_at_kink(stats, what)
-    assert_grads(m, t, gin, gw, dbg, Lr, GTOL, what)
+    assert_grads(m, t, gin, gw, dbg, Lr, GTOL, what, scale_tol=scale_tol)
     return m, sd_np, t, outs
 
 
@@ -137,7 +137,10 @@ def test_c5_stress_oracle_on_a_shard_and_properties_at_full_batch(dtype):
     print(f"  C5 shard B={Bs} {dtype}: forward (all {len(flat_h)} outputs) {ferr:.2e}")
     assert ferr < TOL, ferr
     assert_flips_at_kink(stats, f"C5 shard {dtype}")
-    assert_grads(m, t0, gin, gw, dbg, Lr, GTOL, f"C5 shard {dtype}")
+    # (bias gradients against their cancellation scale: 5e-5 is the 3-layer bound of bf16x3; through 12 layers, with the
+    # projection on bf16x3 planes since round 4 -- the fused GAT-view kernel; the 128-row shard used to take the exact-fp32
+    # batch-sized kernels there -- the worst one measures 6.3e-5)
+    assert_grads(m, t0, gin, gw, dbg, Lr, GTOL, f"C5 shard {dtype}", scale_tol=None if dtype == "fp32" else 1.5e-4)
     g_shard0 = m.last_flat_grad.clone()
     out0_keep = [x.detach().clone() for x in (outs0[0], outs0[3][-1], outs0[6][-1])]
     gin0_keep = {k: t0[k].grad.clone() for k in ("A", "M", "dq", "words")}
@@ -202,3 +205,31 @@ def test_c5_stress_oracle_on_a_shard_and_properties_at_full_batch(dtype):
     assert max(worst_all)[0] < bound, max(worst_all)
     assert torch.isfinite(gfull).all() and float(gfull.abs().max()) > 0
     del g_shard0
+
+
+def test_c5_training_mode_shard_on_the_kernels_the_full_batch_runs():
+    """Round-3 review: C5's oracle comparison ran in eval mode on a 2-sample shard (128 rows: the batch-sized exact-fp32
+    contractions), while bench.py --config c5 times TRAINING mode on the ring / wide / 8-wave N = 64 kernels.  Here: N = 64,
+    L = 12, D = 768 (F = 192 per head), bf16x3, training mode, on a 5-sample shard = 320 rows -- above the batch-sized
+    kernels' range and inside the plane-only layout (csrc/dvgr_api.hip: lean_planes), so the contractions, the fused GAT-view
+    kernel (8 row tiles x 2 samples), the attention backward <4, 8> and the staged loss Gram are the ones the full batch
+    takes -- against the oracle with the device's 24 x 12 dropout masks injected, forward and every gradient.  Then the
+    full per-GPU batch of 64 in training mode with the same seed: the dropout counters of a sample's elements do not depend
+    on the batch size, so the first five samples of the full run must reproduce the shard run."""
+    N, Lr, Bs, Bf, dtype = 64, 12, 5, 64, "bf16x3"
+    m, sd_np, t0, outs0 = _against_oracle("C5-shard", Bs, N, Lr, dtype, True, scale_tol=1.5e-4)   # (12 layers deep: see the eval-mode shard)
+    seed = 0x5EED_0000 + N
+    keep = [x.detach().clone() for x in (outs0[0], outs0[3][-1], outs0[6][-1], outs0[4][0])]
+    full = synth.unit_inputs(Bf, N, T, D, WD, seed=31)
+    shard = synth.unit_inputs(Bs, N, T, D, WD, seed=31)
+    if not all(np.array_equal(full[k][:Bs], shard[k]) for k in full):
+        pytest.skip("synthetic inputs of the shard are not a prefix of the full batch's")
+    tf = {k: torch.from_numpy(v.copy()).cuda() for k, v in full.items()}
+    m.forced_seed = seed
+    with torch.no_grad():
+        outsf = m(tf["A"], tf["M"], tf["dq"], tf["words"], tf["qlen"])
+    torch.cuda.synchronize()
+    for a, b in zip(keep, (outsf[0], outsf[3][-1], outsf[6][-1], outsf[4][0])):
+        e = rel_err(b[:Bs].detach().cpu(), a.cpu())
+        assert e < 5e-5, e
+    assert float((outsf[3][0] == 0).float().mean()) > 0.1          # dropout ran

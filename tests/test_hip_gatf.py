@@ -143,13 +143,22 @@ def test_graph_layers_2_fused_equals_two_launch_form():
 
 
 def test_plain_bf16_mode_takes_the_fused_kernel_too():
+    """DVGR_BF16 (one plane per operand): layer 0's projection is bit-identical in both forms; downstream, an fp32-rounding
+    difference in the attention can flip the bf16 rounding of a later operand element (2^-9 relative), so the outputs are held
+    to the mode's own tolerance class, not to fp32 rounding."""
     B, N, Lr = 7, 20, 2
     sd_np = synth.xavier_state_dict(O.param_shapes(WD, D, Lr), seed=45, bias_range=0.05)
     inp = synth.unit_inputs(B, N, T, D, WD, seed=45)
-    a = _forward(_module(N, Lr, "bf16", sd_np, True, True, single=True), inp, 5)
-    b = _forward(_module(N, Lr, "bf16", sd_np, True, False, single=True), inp, 5)
+    dims = L.make_dims(B, N, T, D, WD, Lr)
+    ma = _module(N, Lr, "bf16", sd_np, True, True, single=True)
+    a = _forward(ma, inp, 5)
+    wa = [_saved(ma, dims, L.S_WH, 0, mi, (B, N, 8 * (D // 4))) for mi in range(2)]
+    mb = _module(N, Lr, "bf16", sd_np, True, False, single=True)
+    b = _forward(mb, inp, 5)
+    wb = [_saved(mb, dims, L.S_WH, 0, mi, (B, N, 8 * (D // 4))) for mi in range(2)]
+    assert torch.equal(wa[0], wb[0]) and torch.equal(wa[1], wb[1])
     worst = max(rel_err(x.cpu(), y.cpu()) for x, y in zip([a[0]] + list(a[3]) + list(a[6]), [b[0]] + list(b[3]) + list(b[6])))
-    assert worst < 1e-5, worst
+    assert worst < 5e-3, worst
 
 
 def test_launch_count_drops_by_one_per_fused_layer():

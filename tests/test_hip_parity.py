@@ -378,8 +378,9 @@ def test_other_graph_sizes_against_oracle(N, D, Lr, B, T, dtype):
     assert_grads(m, t, gin, gw, dbg, Lr, GTOL, f"N={N} D={D} L={Lr} {dtype}")
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("train", [False, True])
-def test_side_stream_schedule_equals_single_stream(train):
+def test_side_stream_schedule_equals_single_stream(train, fused):
     """The two-stream schedules (forward: query chain + loss on the side stream; backward: weight gradients and the query
     branch) against DVGR_OPT_SINGLE_STREAM on the full-size problem, several times in a row: any missing dependency edge
     shows up as a mismatch.  Tolerance covers only the order of float atomics in split-K / column-sum accumulation."""
@@ -394,6 +395,10 @@ def test_side_stream_schedule_equals_single_stream(train):
         m = m.cuda().train(train)
         m.forced_seed = 4242
         m.single_stream = single
+        # fused = False: both schedules launch the same kernels, only the order of float atomics may differ (2e-6).  fused =
+        # True (the default): the single-stream schedule takes the fused GAT-view kernel at layer 0 as well, the two-stream
+        # one keeps two launches there (csrc/dvgr_api.hip) -- equal to fp32 rounding of the attention's operand order (1e-5).
+        m.fused_gat = fused
         m.loss_in_forward = (1.0, 1e-3, 1.0)
         t = {k: torch.from_numpy(v.copy()).cuda() for k, v in inp.items()}
         for k in ("A", "M", "dq", "words"):
@@ -411,7 +416,7 @@ def test_side_stream_schedule_equals_single_stream(train):
     ref = results[0]
     for other in results[1:]:
         for a, b in zip(ref, other):
-            assert rel_err(b, a) < 2e-6
+            assert rel_err(b, a) < (1e-5 if fused else 2e-6)
 
 
 @pytest.mark.parametrize("N,D,Lr,B,T", [(20, 128, 3, 3, 6), (33, 64, 2, 2, 4), (64, 64, 1, 2, 3), (16, 256, 2, 70, 5)])
