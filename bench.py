@@ -239,7 +239,7 @@ def rccl_info_from_log(pattern_prefix):
     if not path:
         return None
     files = glob.glob(path.replace("%p", str(os.getpid())).replace("%h", "*"))
-    info = {"channels": None, "allreduce_tuning": []}
+    info = {"channels": None, "allreduce_tuning": [], "log_files": len(files)}
     algo = {0: "Tree", 1: "Ring", 2: "CollNetDirect", 3: "CollNetChain", 4: "NVLS", 5: "NVLSTree"}
     proto = {0: "LL", 1: "LL128", 2: "Simple"}
     seen = set()

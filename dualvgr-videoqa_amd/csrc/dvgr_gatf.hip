@@ -30,6 +30,8 @@
 // What it saves per launch pair at C2: the generic epilogue's transposition, 15.7 MB of Wh re-read, one launch boundary
 // and the attention kernel's load phase.  Layer 0 keeps the two-launch form when the side stream is in use: its punish gate
 // depends on the query chain (S0), which the separate Wh contraction hides.
+#include <type_traits>
+
 #include "dvgr_planes.h"
 #include "dvgr_stages.h"
 
@@ -193,16 +195,31 @@ __global__ __launch_bounds__(768) void k_gat_fused_fwd(const GatFusedArgs a) {
   const int nk = D / BK;
 
   f32x4 acc[4][NTC];                                       // (row group 0 uses MT0 of the 4 row slots, row group 1 MTILES - MT0)
-  int row0 = 0, col0 = 0;
+  int row0 = 0;
+  const int col0 = (wave12 & 3) * 16 * NTC;
+  // what the epilogue needs from global memory is fetched BEFORE the K loop (it lands under it): the computing waves' bias
+  // elements, and by the loader threads one element each of a_l, a_r and of the punish gates
+  float bv[NTC], pre_al = 0.f, pre_ar = 0.f, pre_s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NTC; ++j) bv[j] = 0.f;
   GFCLK(0);
   if (loader) {
+    const int tl = tid - 512;                              // 0 .. 255
+    const float* ga = a.at.gat_a[mod] + h * 2 * F;
+    // (unconditional loads at clamped indices: a load under a branch makes the compiler wait for it where the branch
+    // ends -- in front of the ring's first DMA -- instead of at its use behind the K loop)
+    const int ta = tl < F ? tl : F - 1, ts = tl < rows_valid ? tl : rows_valid - 1;
+    pre_al = ga[ta]; pre_ar = ga[F + ta];
+    pre_s = a.at.s[mod][m0 + ts];
     const int w = wave12 - 8;
     // waves w < ITOT % 4 carry IHI instructions per plane, the others ILO (equal when ITOT % 4 == 0)
     if (C::IHI == C::ILO || w < (C::ITOT & 3)) gatf_loader<C, TERMS, C::IHI>(a, smem, mod, h, g, m0, BN, D, nk, w, lane);
     else gatf_loader<C, TERMS, (C::ILO > 0 ? C::ILO : 1)>(a, smem, mod, h, g, m0, BN, D, nk, w, lane);
   } else {
-    const int rg = wave12 >> 2, cg = wave12 & 3;
-    col0 = cg * 16 * NTC;
+    const int rg = wave12 >> 2;
+    const float* bias = a.bias[mod] + h * F;
+#pragma unroll
+    for (int j = 0; j < NTC; ++j) bv[j] = bias[col0 + 16 * j + (lane & 15)];
     if (rg == 0) { row0 = 0; gatf_compute<C, TERMS, C::MT0, NTC>(smem, nk, row0, col0, lane, acc); }
     else { row0 = 16 * C::MT0; gatf_compute<C, TERMS, (MTILES - C::MT0 > 0 ? MTILES - C::MT0 : 1), NTC>(smem, nk, row0, col0, lane, acc); }
   }
@@ -210,6 +227,10 @@ __global__ __launch_bounds__(768) void k_gat_fused_fwd(const GatFusedArgs a) {
   GFCLK(1);
 
   // ---- epilogue images (floats) -------------------------------------------------------------------------------------
+  // Barriers here are raw s_barrier behind an LDS-only wait (lgk_barrier): __syncthreads() also waits for every outstanding
+  // global store (vmcnt(0)), which made each phase boundary wait for the 61 KB of Wh stores of phase E2 to be acknowledged
+  // by L2 (phase clocks: E2 5.9 us of a 16 us epilogue).  Nothing after E1 loads from global memory, so stores simply drain
+  // under the later phases.
   const int S = (N + 3) >> 2, NP = 4 * S + 1;
   float* shZ = reinterpret_cast<float*>(smem);             // [RP + 4][FS]  Wh tile (+ 4 zero rows), later the output tile
   float* shA = shZ + (RP + 4) * FS;                        // [SPT][16 NT][NP]  alpha_d[i][j] * s_j per sample
@@ -218,19 +239,22 @@ __global__ __launch_bounds__(768) void k_gat_fused_fwd(const GatFusedArgs a) {
   float* shS = shAr + F;                                   // [RP]
   float* shU = shS + RP;                                   // [RP]
   float* shV = shU + RP;                                   // [RP]
+  auto lgk_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
   // E1
   if (!loader) {
     const int mtw = (wave12 >> 2) == 0 ? C::MT0 : MTILES - C::MT0;
-    const float* bias = a.bias[mod] + h * F;
 #pragma unroll
     for (int j = 0; j < NTC; ++j) {
       const int col = col0 + 16 * j + (lane & 15);
-      const float bv = bias[col];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (i < mtw) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) shZ[(row0 + 16 * i + 4 * (lane >> 4) + r) * FS + col] = acc[i][j][r] + bv;
+          for (int r = 0; r < 4; ++r) shZ[(row0 + 16 * i + 4 * (lane >> 4) + r) * FS + col] = acc[i][j][r] + bv[j];
         }
       }
     }
@@ -238,91 +262,175 @@ __global__ __launch_bounds__(768) void k_gat_fused_fwd(const GatFusedArgs a) {
     const int tl = tid - 512;                              // 0 .. 255
     for (int e = tl; e < SPT * 16 * NT * NP; e += 256) shA[e] = 0.f;
     for (int e = tl; e < 4 * FS; e += 256) shZ[RP * FS + e] = 0.f;
-    const float* ga = a.at.gat_a[mod] + h * 2 * F;
-    for (int f = tl; f < F; f += 256) { shAl[f] = ga[f]; shAr[f] = ga[F + f]; }
-    for (int r = tl; r < RP; r += 256) shS[r] = r < rows_valid ? a.at.s[mod][m0 + r] : 0.f;
+    static_assert(F <= 256 && RP <= 256, "one prefetched element per loader thread");
+    if (tl < F) { shAl[tl] = pre_al; shAr[tl] = pre_ar; }
+    if (tl < RP) shS[tl] = tl < rows_valid ? pre_s : 0.f;
   }
-  __syncthreads();
+  lgk_barrier();
   GFCLK(2);
-  // E2: the projection is saved for the backward (fp32, whole row pieces), and the two halves of the logits
-  {
-    float* Wg = a.Wh_out[mod] + (int64_t)m0 * HF + h * F;
-    for (int e = tid; e < rows_valid * F4; e += 768) {
+  const int rsub = lane >> 4, c16 = lane & 15;             // the row phases: 4 rows per wave pass, 16 lanes per row
+  const float inv_n = 1.0f / (float)N;
+  // E2: the projection is saved for the backward (fp32, whole row pieces), and the two halves of the logits:
+  // u_i = a_l . Wh_i, v_i = a_r . Wh_i.  Lane (rsub, c16) takes the columns 4 c16 + 64 k .. + 3 (k < NTC) of row 4 pass + rsub;
+  // the 16 partial sums of a row meet by DPP rotations inside the 16-lane row (every lane ends with the total).
+  // The Wh tile leaves for global memory from REGISTERS, a piece per phase: 61 KB per workgroup issued in one burst took the
+  // whole chip's store bandwidth for 3.5 us while nothing else could proceed (phase clocks: E2 4.3 us), whereas E3 / E4 leave
+  // the memory system idle.  (E4 overwrites the image, so the values are read here.)
+  constexpr int WV = (RP * F4 + 767) / 768;                // float4 pieces per thread
+  float4 wv[WV];
+  float* Wg = a.Wh_out[mod] + (int64_t)m0 * HF + h * F;
+  auto wh_store = [&](int k) {
+    const int e = tid + 768 * k;
+    if (e < rows_valid * F4) {
       const int r = e / F4, q = e - r * F4;
-      st4(reinterpret_cast<float4*>(Wg + (int64_t)r * HF + 4 * q), *reinterpret_cast<const float4*>(shZ + r * FS + 4 * q));
+      st4(reinterpret_cast<float4*>(Wg + (int64_t)r * HF + 4 * q), wv[k]);
     }
-    int sidx = wave12 / N, i = wave12 - sidx * N;          // row r = sidx * N + i
-    for (int r = wave12; r < rows_valid; r += 12) {
+  };
+  {
+#pragma unroll
+    for (int k = 0; k < WV; ++k) {
+      const int e = tid + 768 * k;
+      const int r = e / F4, q = e - r * F4;
+      wv[k] = e < RP * F4 ? *reinterpret_cast<const float4*>(shZ + r * FS + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < WV; k += 3) wh_store(k);
+    float4 al4[NTC], ar4[NTC];
+#pragma unroll
+    for (int k = 0; k < NTC; ++k) {
+      al4[k] = *reinterpret_cast<const float4*>(shAl + 4 * c16 + 64 * k);
+      ar4[k] = *reinterpret_cast<const float4*>(shAr + 4 * c16 + 64 * k);
+    }
+    for (int pass = wave12; 4 * pass < rows_valid; pass += 12) {
+      const int r = 4 * pass + rsub;                       // < RP: the image has that many rows (rows >= rows_valid: unused values)
       float pu = 0.f, pv = 0.f;
-      for (int f = lane; f < F; f += 64) {
-        const float w = shZ[r * FS + f];
-        pu += w * shAl[f];
-        pv += w * shAr[f];
+#pragma unroll
+      for (int k = 0; k < NTC; ++k) {
+        const float4 w = *reinterpret_cast<const float4*>(shZ + r * FS + 4 * c16 + 64 * k);
+        pu += w.x * al4[k].x + w.y * al4[k].y + w.z * al4[k].z + w.w * al4[k].w;
+        pv += w.x * ar4[k].x + w.y * ar4[k].y + w.z * ar4[k].z + w.w * ar4[k].w;
       }
-      pu = wave_sum(pu); pv = wave_sum(pv);
-      if (lane == 0) {
+      pu += dpp_move<0xb1, 0xf>(0.f, pu); pv += dpp_move<0xb1, 0xf>(0.f, pv);     // quad_perm [1,0,3,2]
+      pu += dpp_move<0x4e, 0xf>(0.f, pu); pv += dpp_move<0x4e, 0xf>(0.f, pv);     // quad_perm [2,3,0,1]
+      pu += dpp_move<0x124, 0xf>(0.f, pu); pv += dpp_move<0x124, 0xf>(0.f, pv);   // row_ror 4
+      pu += dpp_move<0x128, 0xf>(0.f, pu); pv += dpp_move<0x128, 0xf>(0.f, pv);   // row_ror 8
+      if (c16 == 0 && r < rows_valid) {
         shU[r] = pu; shV[r] = pv;
+        const int sidx = (int)(((float)r + 0.5f) * inv_n), i = r - sidx * N;      // r / N, exact for these small integers
         const int64_t o = ((int64_t)(b0 + sidx) * kHeads + h) * N + i;
         a.at.u[mod][o] = pu;
         a.at.v[mod][o] = pv;
       }
-      i += 12;
-      while (i >= N) { i -= N; ++sidx; }
     }
   }
-  __syncthreads();
+  lgk_barrier();
   GFCLK(3);
-  // E3: softmax over j of LeakyReLU(u_i + v_j + c), one wave per row; alpha-site dropout; the punish gate of column j
+  // E3: softmax over j of LeakyReLU(u_i + v_j + c); alpha-site dropout; the punish gate of column j.  Lane (rsub, c16) takes
+  // j = c16 + 16 t (t < NT) of row 4 pass + rsub; row maximum and row sum by DPP rotations inside the 16-lane row.
   {
-    const float c = a.at.gat_c[mod][h];
+#pragma unroll
+    for (int k = 1; k < WV; k += 3) wh_store(k);
+    const float cc = a.at.gat_c[mod][h];
     const uint32_t key = a.at.key_alpha[mod][h];
-    int sidx = wave12 / N, i = wave12 - sidx * N;
-    for (int r = wave12; r < rows_valid; r += 12) {
-      float e = -INFINITY;
-      if (lane < N) { e = shU[r] + shV[sidx * N + lane] + c; e = e > 0.f ? e : kSlope * e; }
-      const float mx = wave_max(e);
-      const float pe = lane < N ? expf(e - mx) : 0.f;
-      const float sum = wave_sum(pe);
-      if (lane < N)
-        shA[(sidx * 16 * NT + i) * NP + lane] =
-            pe / sum * drop_factor(key, (uint32_t)(((b0 + sidx) * N + i) * N + lane)) * shS[sidx * N + lane];
-      i += 12;
-      while (i >= N) { i -= N; ++sidx; }
-    }
-  }
-  __syncthreads();
-  GFCLK(4);
-  // E4: P = (alpha_d * s^T) . Wh on the fp32 MFMA.  A = shA (rows i, reduction j), B = the sample's rows of shZ (reduction
-  // j, columns f); reduction steps past the sample's N rows read the zero rows RP .. RP + 3 (their A entries are zero too).
-  {
-    const int r16 = lane & 15, kq = lane >> 4;
-    for (int item = wave12; item < spt_valid * JT; item += 12) {
-      const int sidx = item / JT, J = item - sidx * JT;
-      const float* A_ = shA + sidx * 16 * NT * NP;
-      float* Z_ = shZ + sidx * N * FS + 16 * J;
-      gatf_f32x4 pacc[NT];
+    for (int pass = wave12; 4 * pass < rows_valid; pass += 12) {
+      const int r = 4 * pass + rsub;
+      const bool valid = r < rows_valid;
+      const int sidx = valid ? (int)(((float)r + 0.5f) * inv_n) : 0, i = valid ? r - sidx * N : 0;
+      const float ui = shU[valid ? r : 0];
+      float e[NT];
+      float mx = -INFINITY;
 #pragma unroll
-      for (int I = 0; I < NT; ++I) pacc[I] = gatf_f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < NT; ++t) {
+        const int j = c16 + 16 * t;
+        e[t] = -INFINITY;
+        if (j < N) { const float x = ui + shV[sidx * N + j] + cc; e[t] = x > 0.f ? x : kSlope * x; }
+        mx = fmaxf(mx, e[t]);
+      }
+      mx = fmaxf(mx, dpp_move<0xb1, 0xf>(-INFINITY, mx));
+      mx = fmaxf(mx, dpp_move<0x4e, 0xf>(-INFINITY, mx));
+      mx = fmaxf(mx, dpp_move<0x124, 0xf>(-INFINITY, mx));
+      mx = fmaxf(mx, dpp_move<0x128, 0xf>(-INFINITY, mx));
+      float sum = 0.f;
 #pragma unroll
-      for (int s4 = 0; s4 < 4 * NT; ++s4) {
-        if (s4 < S) {
-          const int jr = 4 * s4 + kq;
-          const float bf = jr < N ? Z_[jr * FS + r16] : 0.f;
+      for (int t = 0; t < NT; ++t) { e[t] = (c16 + 16 * t) < N ? expf(e[t] - mx) : 0.f; sum += e[t]; }
+      sum += dpp_move<0xb1, 0xf>(0.f, sum);
+      sum += dpp_move<0x4e, 0xf>(0.f, sum);
+      sum += dpp_move<0x124, 0xf>(0.f, sum);
+      sum += dpp_move<0x128, 0xf>(0.f, sum);
+      if (valid) {
 #pragma unroll
-          for (int I = 0; I < NT; ++I)
-            pacc[I] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_[(16 * I + r16) * NP + jr], bf, pacc[I], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) {
+          const int j = c16 + 16 * t;
+          if (j < N)
+            shA[(sidx * 16 * NT + i) * NP + j] =
+                e[t] / sum * drop_factor(key, (uint32_t)(((b0 + sidx) * N + i) * N + j)) * shS[sidx * N + j];
         }
       }
-#pragma unroll
-      for (int I = 0; I < NT; ++I)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * I + 4 * kq + r;
-          if (row < N) Z_[row * FS + r16] = pacc[I][r];
-        }
     }
   }
-  __syncthreads();
+  lgk_barrier();
+  GFCLK(4);
+  // E4: P = (alpha_d * s^T) . Wh on the fp32 MFMA.  A = shA (rows i, reduction j), B = the sample's rows of shZ (reduction
+  // j, columns f); reduction steps past the sample's N rows read zero (their A entries are zero too).  Items = (sample,
+  // 16-column strip); a wave takes a contiguous run of them, so its A fragments change only when the sample does.  Every load
+  // of an item is issued ahead of its MFMAs; the wave then overwrites its strip of shZ with the result (only the owner of a
+  // strip ever reads those columns of that sample).
+  {
+#pragma unroll
+    for (int k = 2; k < WV; k += 3) wh_store(k);
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int items = spt_valid * JT, per = (items + 11) / 12;
+    const int it0 = wave12 * per, it1 = (it0 + per) < items ? (it0 + per) : items;
+    // SC = the number of reduction steps as a compile-time constant where it is one of the shipped clip counts' (a uniform
+    // branch per step between dependent MFMAs cost as much as the MFMAs), 0 = the run-time bound
+    auto run = [&](auto sc_tag) {
+      constexpr int SC = decltype(sc_tag)::value;
+      constexpr int KS = SC ? SC : 4 * NT;
+      float af[NT][KS];
+      int cur = -1;
+      for (int item = it0; item < it1; ++item) {
+        const int sidx = item / JT, J = item - sidx * JT;
+        if (sidx != cur) {
+          cur = sidx;
+          const float* A_ = shA + sidx * 16 * NT * NP;
+#pragma unroll
+          for (int I = 0; I < NT; ++I)
+#pragma unroll
+            for (int s4 = 0; s4 < KS; ++s4) af[I][s4] = (SC || s4 < S) ? A_[(16 * I + r16) * NP + 4 * s4 + kq] : 0.f;
+        }
+        float* Z_ = shZ + sidx * N * FS + 16 * J;
+        float bf[KS];
+#pragma unroll
+        for (int s4 = 0; s4 < KS; ++s4) {
+          const int jr = 4 * s4 + kq;
+          bf[s4] = ((SC || s4 < S) && jr < N) ? Z_[jr * FS + r16] : 0.f;
+        }
+        gatf_f32x4 pacc[NT];
+#pragma unroll
+        for (int I = 0; I < NT; ++I) pacc[I] = gatf_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s4 = 0; s4 < KS; ++s4) {
+          if (SC || s4 < S) {
+#pragma unroll
+            for (int I = 0; I < NT; ++I) pacc[I] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[I][s4], bf[s4], pacc[I], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int I = 0; I < NT; ++I)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * I + 4 * kq + r;
+            if (row < N) Z_[row * FS + r16] = pacc[I][r];
+          }
+      }
+    };
+    if (S == 4 * NT) run(std::integral_constant<int, 4 * NT>{});                      // N = 16 NT - 3 .. 16 NT (8 -> NT 1: S = 2 below)
+    else if (NT == 2 && S == 5) run(std::integral_constant<int, NT == 2 ? 5 : 1>{});  // N = 17 .. 20
+    else if (NT == 1 && S == 2) run(std::integral_constant<int, NT == 1 ? 2 : 1>{});  // N = 5 .. 8
+    else if (NT == 2 && S == 6) run(std::integral_constant<int, NT == 2 ? 6 : 1>{});  // N = 21 .. 24
+    else run(std::integral_constant<int, 0>{});
+  }
+  lgk_barrier();
   GFCLK(5);
   // E5: ELU, out-site dropout, fp32 + planes, 16 bytes per lane
   {
