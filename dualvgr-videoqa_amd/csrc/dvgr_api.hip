@@ -19,7 +19,7 @@ std::atomic<long long> g_launch_count{0};
 size_t gat_lds_bytes_max(int N, int F);
 size_t aux_ws_floats(const dvgr_dims& d);
 int aux_losses(hipStream_t st, const dvgr_dims& d, const dvgr_io* io, float alpha, float beta, float dep_scale,
-               float* loss3, float* g_vis, float* const g[4], float* ws);
+               float* loss3, float* g_vis, float* const g[4], float* ws, bool zero_loss3 = true, int first = 0, int count = -1);
 int sum_and_ones(hipStream_t st, const float* x, float* g_ones, int64_t n, float* out);
 }
 
@@ -380,6 +380,7 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
   int64_t plo = 0;                       // lo-plane offset of the last PM.out() lookup
   const int G = d.G;
   const bool lean = lean_planes(PM.on, BN, G);
+  bool loss3_cleared = false;            // the loss scalars were zeroed by the input split kernel (else: a memset of aux_losses)
   if (PM.on) {                           // bf16 hi/lo planes of the caller's inputs
     SplitBatch sb{};
     sb.lo_off = S.total;
@@ -395,6 +396,7 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
           sb.j[m].drop_key[gi] = K0.x[m][gi];
         }
     }
+    if (O.loss && O.loss->loss3) { sb.zero3 = O.loss->loss3; loss3_cleared = true; }   // before anything adds into them
     DVGR_TRY(split_planes(st, sb));
   }
 
@@ -445,6 +447,7 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
   const bool fuse_ok = PM.on && !(O.flags & DVGR_OPT_NO_FUSED_GAT) && gat_fused_supported(B, N, D, prec);
   auto fuse_gat = [&](int l, int j) { return fuse_ok && !(side && l == 0 && j == 0); };
   auto gs_ = [&](int l, int m, int j) { return ms(l, m) + S.g_stride * j; };                   // saved block of graph layer j
+  int aux_done = 0;                      // unit layers whose list entries have gone to the auxiliary-loss kernels
   for (int l = 0; l < L; ++l) {
     const float* Xin[2] = {l == 0 ? io->A : ms(l - 1, 0) + S.x, l == 0 ? io->M : ms(l - 1, 1) + S.x};
     float* outc[2] = {nullptr, nullptr};
@@ -541,9 +544,18 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
       DVGR_TRY(fprobe.end(DVGR_PROBE_FWD_GAT_ATTN, l));
     }
     }  // graph layers
-    // every list output exists now: the auxiliary losses and their gradients (VALU / HBM work) go under the
-    // contractions that are still to come (S4 of this layer, MFB)
-    if (l == L - 1 && O.loss) {
+    // The auxiliary losses and their gradients (VALU / HBM work on one (sample, list entry) at a time, means over all
+    // entries) go to the side stream in groups of unit layers as the entries come into existence, each group under the
+    // contractions that follow.  Round 3 measured no difference between group sizes (the forward's tail was the main stream's);
+    // with S6 as one launch and sum(vis) inside the out contraction the tail is the loss chain (80 us at C2 for all three
+    // layers at once, starting 12 us behind the last GAT kernel): one layer per group up to three layers, three beyond.
+#ifdef DVGR_TIMING_AIDS
+    static const int aux_group_env = []() { const char* e = getenv("DVGR_AUX_GROUP"); return e ? atoi(e) : 0; }();   // A/B timing aid
+    const int aux_group = aux_group_env > 0 ? aux_group_env : (L <= 3 ? 1 : 3);
+#else
+    const int aux_group = L <= 3 ? 1 : 3;
+#endif
+    if (O.loss && ((l + 1) % aux_group == 0 || l == L - 1)) {
       const dvgr_loss_spec& Q = *O.loss;
       if (!Q.loss3 || !Q.g_com_app || !Q.g_com_mot || !Q.g_aq_fusion || !Q.g_mq_fusion) return DVGR_E_NULL;
       if (side) DVGR_TRY(side->order(st, hs));
@@ -552,7 +564,10 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
       float* const gl[4] = {Q.g_com_app, Q.g_com_mot, Q.g_aq_fusion, Q.g_mq_fusion};
       dvgr_dims dl = d;                    // the losses run over the list ENTRIES: L * G of them (train.py:148-154: len(list))
       dl.L = L * G; dl.G = 1;
-      DVGR_TRY(aux_losses(hs, dl, &lio, Q.alpha, Q.beta, Q.dep_scale, Q.loss3, nullptr, gl, ws + fwd_ws(d).total));
+      const int e0 = aux_done * G, e1 = (l + 1) * G;
+      DVGR_TRY(aux_losses(hs, dl, &lio, Q.alpha, Q.beta, Q.dep_scale, Q.loss3, nullptr, gl, ws + fwd_ws(d).total,
+                          !loss3_cleared && aux_done == 0, e0, e1 - e0));
+      aux_done = l + 1;
     }
     // S4: tn_v = tanh(z_v . P1^T + bP)
     GemmBatch gb4{};
@@ -600,7 +615,28 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
   }
 
   // ---- S6: MFB ------------------------------------------------------------------------------------------
+  bool vis_sum_fused = false;
   {
+    // linear0 / linear1 + ELU + the pooled product as ONE launch on the planes path (k_mfb_fwd, dvgr_gemm.hip); otherwise the
+    // two-problem contraction followed by k_mfb_pool_fwd
+    MfbFwdArgs fa{};
+    int64_t lx0 = 0, lx1 = 0, lw0 = 0, lw1 = 0;
+    bool fused6 = PM.on && !(O.flags & DVGR_OPT_NO_FUSED_GAT) && BN > 128 && mfb_fwd_supported(BN, D, kMfbHidden, prec);
+    if (fused6) {
+      fa.xa = PM.find(ms(L - 1, 0) + S.x, &lx0); fa.xm = PM.find(ms(L - 1, 1) + S.x, &lx1);
+      fa.w0 = PM.find(params + P.mfb_w0, &lw0); fa.w1 = PM.find(params + P.mfb_w1, &lw1);
+      fused6 = fa.xa && fa.xm && fa.w0 && fa.w1 && lx0 == lx1 && lw0 == lw1;
+    }
+    if (fused6) {
+      fa.x_lo = lx0; fa.w_lo = lw0;
+      fa.b0 = params + P.mfb_b0; fa.b1 = params + P.mfb_b1;
+      fa.x0 = saved + S.mfb_x0; fa.x1 = saved + S.mfb_x1; fa.z = saved + S.mfb_z;
+      fa.zp = PM.out(saved + S.mfb_z, &plo); fa.z_lo = plo;
+      fa.rows = BN; fa.K = D; fa.hidden = kMfbHidden;
+      DVGR_TRY(fprobe.begin(DVGR_PROBE_FWD_MFB_GEMM, 0));
+      DVGR_TRY(mfb_fwd_launch(st, fa, prec));
+      DVGR_TRY(fprobe.end(DVGR_PROBE_FWD_MFB_GEMM, 0));
+    } else {
     GemmBatch gb{};
     gb.p[gb.n] = nt(ms(L - 1, 0) + S.x, D, params + P.mfb_w0, D, saved + S.mfb_x0, kMfbHidden, params + P.mfb_b0, BN, kMfbHidden, D, ACT_ELU);
     PM.attach(gb.p[gb.n++]);
@@ -611,14 +647,23 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
     DVGR_TRY(fprobe.end(DVGR_PROBE_FWD_MFB_GEMM, 0));
     uint16_t* zfp = PM.out(saved + S.mfb_z, &plo);
     DVGR_TRY(mfb_pool_fwd(st, saved + S.mfb_x0, saved + S.mfb_x1, saved + S.mfb_z, BN, zfp, plo));
+    }
     GemmBatch go{};
     go.p[go.n] = nt(saved + S.mfb_z, kMfbPooled, params + P.mfb_wo, kMfbPooled, io->vis, D, params + P.mfb_bo, BN, D, kMfbPooled, ACT_ELU);
     PM.attach(go.p[go.n++]);
+    // sum(vis) and d sum(vis) / d vis = 1 of the scope-U loss ride in this contraction's epilogue where it runs on the planes
+    // kernels (one float atomic per workgroup into loss3[0], cleared at the head of the forward): no k_sum_and_ones launch
+    if (O.loss && O.loss->g_vis && loss3_cleared) {
+      go.p[0].sum_out = O.loss->loss3;
+      go.p[0].ones_out = O.loss->g_vis;
+      if (gemm_sum_supported(KC, KC, go, prec)) vis_sum_fused = true;
+      else { go.p[0].sum_out = nullptr; go.p[0].ones_out = nullptr; }
+    }
     DVGR_TRY(gemm_launch(st, KC, KC, go, TAG_GENERIC, prec));
   }
   if (O.loss) {
     if (side) DVGR_TRY(side->order(hs, st));
-    if (O.loss->g_vis) DVGR_TRY(sum_and_ones(st, io->vis, O.loss->g_vis, BND, O.loss->loss3));
+    if (O.loss->g_vis && !vis_sum_fused) DVGR_TRY(sum_and_ones(st, io->vis, O.loss->g_vis, BND, O.loss->loss3));
   }
   return 0;
 }
@@ -699,7 +744,9 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       DVGR_TRY(add(glp(l) + P.qa_b1, P.q_mod_base - P.qa_b1));
       for (int m = 0; m < 2; ++m) DVGR_TRY(add(gqp(l, m) + P.bq, P.q_mod_stride - P.bq));
     }
-    DVGR_TRY(zero_ranges(st, z));
+    // the last batch of ranges goes out together with the first element-wise kernel of the backward (S6: the ELU derivative)
+    uint16_t* dpop = PM.out(ws + W.dpo, &plo);
+    DVGR_TRY(bwd_head(st, z, g->g_vis, io->vis, ws + W.dpo, BND, dpop, plo));
   }
 
   // Two streams: `st` carries the critical path (the dX chain), `hs` every weight / bias gradient.
@@ -790,11 +837,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     return 0;
   };
 
-  // ---- S6 backward ------------------------------------------------------------------------------------
-  {
-    uint16_t* dpop = PM.out(ws + W.dpo, &plo);
-    DVGR_TRY(elu_bwd(st, g->g_vis, io->vis, ws + W.dpo, BND, dpop, plo));
-  }
+  // ---- S6 backward (its ELU derivative went out with the zero list above) ---------------------------------
   {
     GemmBatch gd{};   // dz = dpo . Wo
     gd.p[gd.n] = nn(ws + W.dpo, D, params + P.mfb_wo, kMfbPooled, ws + W.dzf, kMfbPooled, BN, kMfbPooled, D, 0);

@@ -129,17 +129,21 @@ __device__ __forceinline__ void gatf_loader(const GatFusedArgs& a, uint16_t* sme
 }
 
 // ---- computing waves ----------------------------------------------------------------------------------------------
-template <class C, int TERMS, int MTW, int NTC>
+#ifdef DVGR_STAGGER
+constexpr bool kGatfStagger = true;
+#else
+constexpr bool kGatfStagger = false;
+#endif
+template <class C, int TERMS, int MTW, int NTC, bool LATE = false>
 __device__ __forceinline__ void gatf_compute(const uint16_t* smem, int nk, int row0, int col0, int lane, f32x4 (&acc)[4][NTC]) {
 #pragma unroll
   for (int i = 0; i < MTW; ++i)
 #pragma unroll
     for (int j = 0; j < NTC; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int kt = 0; kt < nk; ++kt) {
-    __builtin_amdgcn_s_barrier();
+  bf16x8 ah[MTW], al[MTW], bh[NTC], bl[NTC];
+  auto read_frags = [&](int kt) {
     const uint16_t* curA = smem + (kt % C::NS) * C::kSlot;
     const uint16_t* curB = curA + C::kPlanes * C::kTileA;
-    bf16x8 ah[MTW], al[MTW], bh[NTC], bl[NTC];
 #pragma unroll
     for (int i = 0; i < MTW; ++i) {
       ah[i] = planes_frag<KC>(curA, row0 + i * 16, lane);
@@ -150,6 +154,8 @@ __device__ __forceinline__ void gatf_compute(const uint16_t* smem, int nk, int r
       bh[j] = planes_frag<KC>(curB, col0 + j * 16, lane);
       if (TERMS == 3) bl[j] = planes_frag<KC>(curB + C::kTileB, col0 + j * 16, lane);
     }
+  };
+  auto mma_tile = [&]() {
 #pragma unroll
     for (int i = 0; i < MTW; ++i)
 #pragma unroll
@@ -160,6 +166,23 @@ __device__ __forceinline__ void gatf_compute(const uint16_t* smem, int nk, int r
         }
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
       }
+  };
+  if (!LATE) {
+    for (int kt = 0; kt < nk; ++kt) {
+      __builtin_amdgcn_s_barrier();
+      read_frags(kt);
+      mma_tile();
+    }
+  } else {
+    // the second row group's waves share their SIMDs with the first's: they run half a K-tile behind (see planes_tile,
+    // dvgr_gemm.hip): multiply tile kt - 1 from registers while the partner reads tile kt, then read tile kt
+    if (nk > 0) { __builtin_amdgcn_s_barrier(); read_frags(0); }
+    for (int kt = 1; kt < nk; ++kt) {
+      __builtin_amdgcn_s_barrier();
+      mma_tile();
+      read_frags(kt);
+    }
+    if (nk > 0) mma_tile();
   }
 }
 
@@ -221,7 +244,7 @@ __global__ __launch_bounds__(768) void k_gat_fused_fwd(const GatFusedArgs a) {
 #pragma unroll
     for (int j = 0; j < NTC; ++j) bv[j] = bias[col0 + 16 * j + (lane & 15)];
     if (rg == 0) { row0 = 0; gatf_compute<C, TERMS, C::MT0, NTC>(smem, nk, row0, col0, lane, acc); }
-    else { row0 = 16 * C::MT0; gatf_compute<C, TERMS, (MTILES - C::MT0 > 0 ? MTILES - C::MT0 : 1), NTC>(smem, nk, row0, col0, lane, acc); }
+    else { row0 = 16 * C::MT0; gatf_compute<C, TERMS, (MTILES - C::MT0 > 0 ? MTILES - C::MT0 : 1), NTC, kGatfStagger>(smem, nk, row0, col0, lane, acc); }
   }
   __builtin_amdgcn_s_barrier();                            // every fragment read of the ring is done: its LDS is free
   GFCLK(1);

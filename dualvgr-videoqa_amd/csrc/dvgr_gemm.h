@@ -51,6 +51,10 @@ struct GemmProblem {
   int zero_on_split;   // atomic_ok with an output that is NOT pre-zeroed: a launch that does split K zeroes it first (own launch)
   int atomic_out;      // several problems of one batch ADD into this same (pre-zeroed) output: every tile is added with
                        // float atomics whether or not K is split
+  float* ones_out;     // nullable: a tensor of C's shape and leading dimension that receives 1.0 wherever C is written, and
+  float* sum_out;      // nullable: *sum_out += the sum of every value stored to C (one float atomic per workgroup) -- the forward's
+                       // last contraction carries sum(vis) and d sum(vis) / d vis = 1 of the scope-U loss this way instead of a
+                       // k_sum_and_ones launch behind it.  Honoured by the planes kernels only: gemm_sum_supported().
   float* rowsum;       // nullable, TN only (A = dY[k][m]): rowsum[m] += sum_k A[k][m], i.e. the bias gradient dY^T . 1 that
                        // belongs to the weight gradient C = dY^T . X, taken from the A fragments the kernel already holds
                        // (one extra MFMA against a ones fragment per A fragment, in the workgroups of output column 0).
@@ -70,6 +74,8 @@ enum : int { TAG_GENERIC = 0, TAG_FWD_GAT = 1, TAG_FWD_SF = 2, TAG_BWD_GAT_DW = 
 // True when gemm_launch will honour GemmProblem::rowsum for this batch (the LDS-DMA ring kernels do; the register-staged
 // fallbacks for odd shapes and the batch-sized kernels do not: their callers use a column-sum job instead).
 bool gemm_rowsum_supported(int la, int lb, const GemmBatch& batch, int prec);
+// True when gemm_launch will honour GemmProblem::ones_out / sum_out for this batch (NT problems on the planes kernels).
+bool gemm_sum_supported(int la, int lb, const GemmBatch& batch, int prec);
 
 // Problems of different layouts (GemmProblem::layout) in ONE launch where every problem qualifies for the planes kernel
 // (bf16 modes, pre-split operands, K % 32 == 0, not batch-sized); otherwise one gemm_launch per layout.  rowsum is honoured
@@ -79,6 +85,20 @@ int gemm_launch_mixed(hipStream_t stream, const GemmBatch& batch, int tag = TAG_
 
 // Enqueue the batch on `stream`.  la / lb in {KC, IC}.  Returns hipError_t as int.
 int gemm_launch(hipStream_t stream, int la, int lb, const GemmBatch& batch, int tag = TAG_GENERIC, int prec = DVGR_F32);
+
+// S6 of the forward as ONE launch (model/fusions/fusions.py:426-440): x0 = ELU(A . W0^T + b0), x1 = ELU(M . W1^T + b1) on the
+// same tile coordinates of one workgroup and, in its epilogue, the pooled product z[r][k] = x0[r][2k] x1[r][2k] +
+// x0[r][2k+1] x1[r][2k+1] (fp32 + bf16 planes).  bf16 modes, pre-split planes of all four operands, K % 32 == 0.
+struct MfbFwdArgs {
+  const uint16_t* xa; const uint16_t* xm; int64_t x_lo;     // hi planes of the two layer outputs (rows, K); lo = hi + x_lo
+  const uint16_t* w0; const uint16_t* w1; int64_t w_lo;     // hi planes of linear0 / linear1 weights (hidden, K)
+  const float* b0; const float* b1;                         // (hidden)
+  float* x0; float* x1;                                     // (rows, hidden) fp32, saved for the backward
+  float* z; uint16_t* zp; int64_t z_lo;                     // (rows, hidden / 2) fp32 + planes (zp nullable)
+  int rows, K, hidden;
+};
+bool mfb_fwd_supported(int rows, int K, int hidden, int prec);
+int mfb_fwd_launch(hipStream_t stream, const MfbFwdArgs& a, int prec);
 
 inline GemmOperand operand(const float* p, int64_t ld, uint32_t drop_key = 0) {
   GemmOperand o; o.p0 = p; o.p1 = p; o.ld = ld; o.drop_key = drop_key; o.h0 = nullptr; o.h1 = nullptr; o.lo_off = 0; return o;

@@ -181,7 +181,8 @@ __device__ __forceinline__ void epilogue(const GemmProblem& P, const f32x4 (&acc
 template <int MT, int NT>
 __device__ __forceinline__ void epilogue_rows(const GemmProblem& P, const f32x4 (&acc)[MT][NT], int row0, int col0,
                                               int lane, float* scratch /* wave-private, >= 32 * (16*NT + 4) floats */,
-                                              bool atomic = false /* split-K partial tile: add with float atomics */) {
+                                              bool atomic = false /* split-K partial tile: add with float atomics */,
+                                              float* lsum = nullptr /* GemmProblem::sum_out: this lane's share of the sum */) {
   constexpr int W = NT * 16, STR = W + 4;          // sub-tile width, padded LDS row stride (floats)
   constexpr int MCH = MT < 2 ? MT : 2;             // tile bands per pass
   constexpr int CPR = W / 4;                       // float4 chunks per row
@@ -260,6 +261,8 @@ __device__ __forceinline__ void epilogue_rows(const GemmProblem& P, const f32x4 
         if (P.accumulate) { x[0] += oldv[it].x; x[1] += oldv[it].y; x[2] += oldv[it].z; x[3] += oldv[it].w; }
         if ((DVGR_DBG(P) & 16) && x[0] != 12345.678f) continue;              // timing aid: everything but the global store
         st4(reinterpret_cast<float4*>(cp + it * rstep), make_float4(x[0], x[1], x[2], x[3]));
+        if (lsum) *lsum += (x[0] + x[1]) + (x[2] + x[3]);
+        if (P.ones_out) st4(reinterpret_cast<float4*>(P.ones_out + (cp - P.C) + it * rstep), make_float4(1.f, 1.f, 1.f, 1.f));
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       continue;
@@ -291,8 +294,15 @@ __device__ __forceinline__ void epilogue_rows(const GemmProblem& P, const f32x4 
         if (nv == 4) {
           if (P.accumulate) { x[0] += oldv[it].x; x[1] += oldv[it].y; x[2] += oldv[it].z; x[3] += oldv[it].w; }
           st4(reinterpret_cast<float4*>(P.C + o), make_float4(x[0], x[1], x[2], x[3]));
+          if (lsum) *lsum += (x[0] + x[1]) + (x[2] + x[3]);
+          if (P.ones_out) st4(reinterpret_cast<float4*>(P.ones_out + o), make_float4(1.f, 1.f, 1.f, 1.f));
         } else {
-          for (int e = 0; e < nv; ++e) P.C[o + e] = P.accumulate ? P.C[o + e] + x[e] : x[e];
+          for (int e = 0; e < nv; ++e) {
+            const float y = P.accumulate ? P.C[o + e] + x[e] : x[e];
+            P.C[o + e] = y;
+            if (lsum) *lsum += y;
+            if (P.ones_out) P.ones_out[o + e] = 1.f;
+          }
         }
       }
     }
@@ -312,6 +322,17 @@ __device__ __forceinline__ void store_rowsum(const GemmProblem& P, const f32x4 (
       const int row = row0 + i * 16 + (lane >> 4) * 4 + r;
       if (row < P.M) atomicAdd(P.rowsum + row, rs[i][r]);
     }
+}
+
+// GemmProblem::sum_out: the eight computing waves of a workgroup (the loaders have left) meet once more, and ONE float atomic
+// per workgroup adds the tile's sum (a same-address atomic per wave serialises at the memory side: ~12 ns each).
+__device__ __forceinline__ void tile_sum_out(const GemmProblem& P, float lsum, float* red /* 8 floats of LDS past the epilogue scratch */,
+                                             int wave, int lane) {
+  lsum = wave_sum(lsum);
+  if (lane == 0) red[wave] = lsum;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wave == 0 && lane == 0) atomicAdd(P.sum_out, ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7])));
 }
 
 // =================================================================================================
@@ -975,14 +996,10 @@ __device__ __forceinline__ void planes_tile(const GemmProblem& P, uint16_t* smem
 
   GCLK_DECL;
   GCLK_START();
-  for (int kt = 0; kt < nk; ++kt) {
-    GCLK_ADD(1);                                   // fragment reads + MFMAs of the previous tile
-    __builtin_amdgcn_s_barrier();
-    GCLK_ADD(0);                                   // waiting for tile kt
-    if (DVGR_DBG(P) & 4) continue;                       // timing aid: barriers only, no fragment reads, no MFMAs
+  bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
+  auto read_frags = [&](int kt) {
     const uint16_t* curA = smem + (kt % NS) * kSlot;
     const uint16_t* curB = curA + kPlanes * kTileA;
-    bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       ah[i] = planes_frag<LA>(curA, wm + i * 16, lane);
@@ -993,6 +1010,8 @@ __device__ __forceinline__ void planes_tile(const GemmProblem& P, uint16_t* smem
       bh[j] = planes_frag<LB>(curB, wn + j * 16, lane);
       if (TERMS == 3) bl[j] = planes_frag<LB>(curB + kPlaneTile, wn + j * 16, lane);
     }
+  };
+  auto mma_tile = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -1016,6 +1035,34 @@ __device__ __forceinline__ void planes_tile(const GemmProblem& P, uint16_t* smem
         for (int i = 0; i < MT; ++i) { rs_total[i] += rs[i]; rs[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
       }
     }
+  };
+#ifdef DVGR_STAGGER
+  // Waves 4-7 run half a K-tile behind waves 0-3 (MI355X_MICROARCH.md, two waves per SIMD, item 9): waves w and w + 4 share a
+  // SIMD, and with one barrier per K-tile both would read their fragments at the same time and then queue for the MFMA pipe.
+  // The late half multiplies tile kt - 1 (fragments kept in registers across the barrier) while the early half reads tile kt,
+  // then reads tile kt while the early half multiplies.  Every wave still reads tile kt between barrier kt and barrier
+  // kt + 1, so the ring's slot rule is unchanged, and every wave executes nk + 1 barriers.
+  const bool late = wave >= 4 && !(DVGR_DBG(P) & 4);
+#else
+  constexpr bool late = false;
+#endif
+  if (!late) {
+    for (int kt = 0; kt < nk; ++kt) {
+      GCLK_ADD(1);                                 // fragment reads + MFMAs of the previous tile
+      __builtin_amdgcn_s_barrier();
+      GCLK_ADD(0);                                 // waiting for tile kt
+      if (DVGR_DBG(P) & 4) continue;                     // timing aid: barriers only, no fragment reads, no MFMAs
+      read_frags(kt);
+      mma_tile(kt);
+    }
+  } else {
+    if (nk > 0) { __builtin_amdgcn_s_barrier(); read_frags(0); }
+    for (int kt = 1; kt < nk; ++kt) {
+      __builtin_amdgcn_s_barrier();
+      mma_tile(kt - 1);
+      read_frags(kt);
+    }
+    if (nk > 0) mma_tile(nk - 1);
   }
   if (do_rs) {
 #pragma unroll
@@ -1025,9 +1072,154 @@ __device__ __forceinline__ void planes_tile(const GemmProblem& P, uint16_t* smem
   GCLK_ADD(1);
   if (DVGR_DBG(P) & 1) { if (acc[0][0][0] == 12345.678f) P.C[0] = 1.f; return; }
   if (do_rs) store_rowsum<MT>(P, rs, m0 + wm, lane);
-  epilogue_rows<MT, NT>(P, acc, m0 + wm, n0 + wn, lane, reinterpret_cast<float*>(smem) + wave * (32 * (16 * NT + 4)), gridDim.y > 1 || P.atomic_out);
+  float lsum = 0.f;
+  epilogue_rows<MT, NT>(P, acc, m0 + wm, n0 + wn, lane, reinterpret_cast<float*>(smem) + wave * (32 * (16 * NT + 4)), gridDim.y > 1 || P.atomic_out,
+                        P.sum_out ? &lsum : nullptr);
+  if (P.sum_out) tile_sum_out(P, lsum, reinterpret_cast<float*>(smem) + 8 * (32 * (16 * NT + 4)), wave, lane);
   GCLK_ADD(2);
   if (wave == 0) GCLK_FLUSH(0);
+}
+
+// =================================================================================================
+// S6 forward in one launch (MfbFwdArgs, dvgr_gemm.h).  Tile = 64 rows x 64 hidden columns of BOTH products: the LDS slot
+// holds four 64 x 32 operand tiles [A0 | A1 | B0 | B1] (hi, lo planes each) = the 32 KB of a 128 x 128 tile's K-step, the
+// eight computing waves are 2 row groups x 4 column groups, column groups 0, 1 on (A0, B0) = x0 and 2, 3 on (A1, B1) = x1.
+// Epilogue: ELU(acc + bias) of both products into one LDS image [64][128 + 4]; then whole-row stores of x0, x1 (the backward
+// needs them) and the pooled z as 16-byte vectors (fp32 + planes).  Replaces the 120-tile contraction + k_mfb_pool_fwd
+// (16 us beside the loss kernels, a launch boundary and a 7.9 MB round trip of x0, x1).
+// =================================================================================================
+template <int TERMS>
+__global__ __launch_bounds__(768) void k_mfb_fwd(const MfbFwdArgs a) {
+  constexpr int kPlanes = (TERMS == 3) ? 2 : 1;
+  constexpr int kT = 64 * BK;                       // bf16 elements of one 64-row plane tile
+  constexpr int kSlot = 4 * kPlanes * kT;           // A0, A1, B0, B1
+  constexpr int NS = 4;
+  __shared__ __attribute__((aligned(16))) uint16_t smem[NS * kSlot];
+  const int tiles_m = (a.rows + 63) / 64, tiles_n = a.hidden / 64, tiles = tiles_m * tiles_n;
+  const int chunk = (int)gridDim.x >> 3;
+  const int idx = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+  if (idx >= tiles) return;
+  const int mt = idx / tiles_n, ct = idx - mt * tiles_n;
+  const int m0 = mt * 64, n0 = ct * 64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave12 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave12 >= 8;
+  const int nk = a.K / BK;
+  GemmOperand op[4];
+  for (int i = 0; i < 4; ++i) { op[i].p0 = op[i].p1 = nullptr; op[i].ld = a.K; op[i].drop_key = 0; }
+  op[0].h0 = op[0].h1 = a.xa; op[1].h0 = op[1].h1 = a.xm; op[0].lo_off = op[1].lo_off = a.x_lo;
+  op[2].h0 = op[2].h1 = a.w0; op[3].h0 = op[3].h1 = a.w1; op[2].lo_off = op[3].lo_off = a.w_lo;
+  if (loader) {
+    const int wave = wave12 - 8;
+    uint32_t off[4][1];
+    planes_prep<KC, 1>(op[0], m0, a.rows, wave, lane, off[0]);
+    planes_prep<KC, 1>(op[1], m0, a.rows, wave, lane, off[1]);
+    planes_prep<KC, 1>(op[2], n0, a.hidden, wave, lane, off[2]);
+    planes_prep<KC, 1>(op[3], n0, a.hidden, wave, lane, off[3]);
+    auto issue = [&](int kt, uint16_t* slot) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) planes_issue<KC, TERMS, 1>(op[i], kt * BK, a.K, wave, lane, off[i], slot + i * kPlanes * kT);
+    };
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+      if (s < nk) issue(s, smem + s * kSlot);
+    constexpr int kPer = 4 * kPlanes;               // DMA instructions of this wave per K-tile
+    for (int kt = 0; kt < nk; ++kt) {
+      const int younger = (nk - 1 - kt) < NS - 2 ? (nk - 1 - kt) : NS - 2;
+      if (younger >= 2) wait_vmcnt<2 * kPer>();
+      else if (younger == 1) wait_vmcnt<kPer>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (kt + NS - 1 < nk) issue(kt + NS - 1, smem + ((kt + NS - 1) % NS) * kSlot);
+    }
+    __builtin_amdgcn_s_barrier();
+    return;
+  }
+  const int wave = wave12, rg = wave >> 2, cg = wave & 3, prod = cg >> 1;      // prod 0: x0 = A0 . B0^T, 1: x1 = A1 . B1^T
+  const int wm = rg * 32, wn = (cg & 1) * 32;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* bias = (prod ? a.b1 : a.b0) + n0 + wn;
+  float bv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) bv[j] = bias[16 * j + (lane & 15)];
+  for (int kt = 0; kt < nk; ++kt) {
+    __builtin_amdgcn_s_barrier();
+    const uint16_t* curA = smem + (kt % NS) * kSlot + prod * kPlanes * kT;
+    const uint16_t* curB = smem + (kt % NS) * kSlot + (2 + prod) * kPlanes * kT;
+    bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ah[i] = planes_frag<KC>(curA, wm + i * 16, lane);
+      if (TERMS == 3) al[i] = planes_frag<KC>(curA + kT, wm + i * 16, lane);
+      bh[i] = planes_frag<KC>(curB, wn + i * 16, lane);
+      if (TERMS == 3) bl[i] = planes_frag<KC>(curB + kT, wn + i * 16, lane);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (TERMS == 3) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        }
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      }
+  }
+  __builtin_amdgcn_s_barrier();                      // the ring is free; the loaders leave
+  constexpr int XS = 128 + 4;                        // image row stride (floats)
+  float* shX = reinterpret_cast<float*>(smem);       // [64][XS]: columns 0..63 = x0 tile, 64..127 = x1 tile
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        shX[(wm + 16 * i + 4 * (lane >> 4) + r) * XS + 64 * prod + wn + 16 * j + (lane & 15)] = elu_f(acc[i][j][r] + bv[j]);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                      // (the eight computing waves)
+  const int t = tid;                                 // 0 .. 511
+  // x0, x1: 64 rows x 2 x 16 float4
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = t + 512 * k, r = e >> 5, q = e & 31, p = q >> 4, c4 = (q & 15) * 4;
+    if (m0 + r < a.rows)
+      st4(reinterpret_cast<float4*>((p ? a.x1 : a.x0) + (int64_t)(m0 + r) * a.hidden + n0 + c4),
+          *reinterpret_cast<const float4*>(shX + r * XS + 64 * p + c4));
+  }
+  // z: 64 rows x 8 float4 (4 pooled values each from 8 + 8 inputs)
+  {
+    const int r = t >> 3, q = t & 7;
+    if (m0 + r < a.rows) {
+      const float4 u0 = *reinterpret_cast<const float4*>(shX + r * XS + 8 * q), u1 = *reinterpret_cast<const float4*>(shX + r * XS + 8 * q + 4);
+      const float4 v0 = *reinterpret_cast<const float4*>(shX + r * XS + 64 + 8 * q), v1 = *reinterpret_cast<const float4*>(shX + r * XS + 64 + 8 * q + 4);
+      const float4 zz = make_float4(u0.x * v0.x + u0.y * v0.y, u0.z * v0.z + u0.w * v0.w, u1.x * v1.x + u1.y * v1.y, u1.z * v1.z + u1.w * v1.w);
+      const int64_t o = (int64_t)(m0 + r) * (a.hidden / 2) + n0 / 2 + 4 * q;
+      st4(reinterpret_cast<float4*>(a.z + o), zz);
+      split_store4(a.zp, a.z_lo, o, zz);
+    }
+  }
+}
+
+bool mfb_fwd_supported(int rows, int K, int hidden, int prec) {
+  return prec != DVGR_F32 && rows >= 1 && K >= BK && (K % BK) == 0 && hidden >= 64 && (hidden % 64) == 0 &&
+         (int64_t)rows * K < (1ll << 31) && (int64_t)hidden * K < (1ll << 31);
+}
+
+int mfb_fwd_launch(hipStream_t stream, const MfbFwdArgs& a, int prec) {
+  if (!mfb_fwd_supported(a.rows, a.K, a.hidden, prec)) return DVGR_E_DIMS;
+  if (!a.xa || !a.xm || !a.w0 || !a.w1 || !a.b0 || !a.b1 || !a.x0 || !a.x1 || !a.z) return DVGR_E_NULL;
+  if ((((uintptr_t)a.xa | (uintptr_t)a.xm | (uintptr_t)a.w0 | (uintptr_t)a.w1 | (uintptr_t)a.x0 | (uintptr_t)a.x1 | (uintptr_t)a.z) & 15) ||
+      (a.x_lo & 7) || (a.w_lo & 7) || (a.z_lo & 3))
+    return DVGR_E_ALIGN;
+  const int tiles = ((a.rows + 63) / 64) * (a.hidden / 64);
+  const dim3 grid(8 * ((tiles + 7) / 8)), block(768);
+  if (prec == DVGR_BF16X3) DVGR_LAUNCH((k_mfb_fwd<3>), grid, block, 0, stream, a);
+  else DVGR_LAUNCH((k_mfb_fwd<1>), grid, block, 0, stream, a);
+  return (int)hipGetLastError();
 }
 
 #ifdef DVGR_TIMING_AIDS
@@ -1225,7 +1417,10 @@ __global__ __launch_bounds__(768) void gemm_planes_wide_kernel(const GemmBatch b
       }
   }
   __builtin_amdgcn_s_barrier();
-  epilogue_rows<MT, NT>(P, acc, m0 + wm, n0 + wn, lane, reinterpret_cast<float*>(smem) + wave * (32 * (16 * NT + 4)), gridDim.y > 1 || P.atomic_out);
+  float lsum = 0.f;
+  epilogue_rows<MT, NT>(P, acc, m0 + wm, n0 + wn, lane, reinterpret_cast<float*>(smem) + wave * (32 * (16 * NT + 4)), gridDim.y > 1 || P.atomic_out,
+                        P.sum_out ? &lsum : nullptr);
+  if (P.sum_out) tile_sum_out(P, lsum, reinterpret_cast<float*>(smem) + 8 * (32 * (16 * NT + 4)), wave, lane);
 }
 
 #ifdef DVGR_CLK
@@ -1482,6 +1677,16 @@ int gemm_launch_mixed(hipStream_t stream, const GemmBatch& b, int tag, int prec)
   return (int)hipGetLastError();
 }
 
+bool gemm_sum_supported(int la, int lb, const GemmBatch& b, int prec) {
+  if (la != KC || lb != KC || prec == DVGR_F32) return false;
+  if (small_eligible(b, la, lb) || !ring_eligible(b) || !planes_eligible(b, la, lb) || dbg_any(b)) return false;
+  for (int i = 0; i < b.n; ++i) {
+    if (b.p[i].atomic_ok || b.p[i].atomic_out) return false;      // (a split-K partial tile is not the value stored)
+    if ((b.p[i].ldc & 3) || (((uintptr_t)b.p[i].C | (uintptr_t)b.p[i].ones_out) & 15)) return false;   // the row epilogue's vector path
+  }
+  return true;
+}
+
 bool gemm_rowsum_supported(int la, int lb, const GemmBatch& b, int prec) {
   if (la != IC || lb != IC) return false;
   if (small_eligible(b, la, lb) || !ring_eligible(b)) return false;
@@ -1499,6 +1704,8 @@ int gemm_launch(hipStream_t stream, int la, int lb, const GemmBatch& b, int tag,
     if (lb == KC && (p.K & 3)) return DVGR_E_DIMS;
     if (lb == IC && (p.N & 3)) return DVGR_E_DIMS;
   }
+  for (int i = 0; i < b.n; ++i)
+    if ((b.p[i].sum_out || b.p[i].ones_out) && !gemm_sum_supported(la, lb, b, prec)) return DVGR_E_DIMS;
   if (small_eligible(b, la, lb)) return small_launch(stream, la, lb, b);     // batch-sized problems: dvgr_small.hip
   if (la == KC && lb == KC) {
     if (tag == TAG_FWD_GAT) return launch_layout<KC, KC, TAG_FWD_GAT>(stream, b, prec);

@@ -22,7 +22,8 @@ struct AuxArgs {
   float* wt;             // [L][B][4][N][NBP] gradient matrices: g_t[i] = sum_j wt_t[j][i] c_t[j]
   float* loss;           // [3]: sum(vis), mean_l common_l, mean_l dep_l
   float wc, wh;          // alpha / (L B N^2), beta * dep_scale / L
-  int B, N, D, L, NBP;
+  int B, N, D, L, NBP;   // L = the list entries THIS call works on (a group of them: aux_losses' first / count)
+  int Ltot;              // all list entries of the step: the means are over these
 };
 
 // ---- pass 1: centred Gram of one tensor of one (b, l) ---------------------------------------------------
@@ -312,8 +313,8 @@ __global__ __launch_bounds__(256) void k_aux_combine(const AuxArgs a) {
     W[(3 * N + j) * NBP + i] = in ? 2.f * a.wh * G[NN + q] : 0.f;                               // mq      <- com_mot
   }
   if (tid == 0) {
-    atomicAdd(a.loss + 1, (red[0] + red[1] + red[2] + red[3]) / ((float)a.B * N * N * a.L));
-    atomicAdd(a.loss + 2, (red[4] + red[5] + red[6] + red[7]) / (float)a.L);
+    atomicAdd(a.loss + 1, (red[0] + red[1] + red[2] + red[3]) / ((float)a.B * N * N * a.Ltot));
+    atomicAdd(a.loss + 2, (red[4] + red[5] + red[6] + red[7]) / (float)a.Ltot);
   }
 }
 
@@ -449,27 +450,37 @@ size_t aux_ws_floats(const dvgr_dims& d) {
   return LB * 4 * NN + LB * 4 * (size_t)d.N * nb_of(d.N) + 64;
 }
 
+// first / count: the list entries [first, first + count) only (count < 0: all d.L of them).  The losses are means over ALL d.L
+// entries and every kernel works on one (sample, entry) at a time, so the forward sends the entries out in groups as they come
+// into existence; the values add up in loss3, the gradients of different entries are different tensors.
 int aux_losses(hipStream_t st, const dvgr_dims& d, const dvgr_io* io, float alpha, float beta, float dep_scale,
-               float* loss3, float* g_vis, float* const g[4], float* ws) {
+               float* loss3, float* g_vis, float* const g[4], float* ws, bool zero_loss3, int first, int count) {
+  if (count < 0) { first = 0; count = d.L; }
+  if (first < 0 || count < 1 || first + count > d.L) return DVGR_E_DIMS;
   AuxArgs a{};
-  a.t[0] = io->com_app; a.t[1] = io->com_mot; a.t[2] = io->aq_fusion; a.t[3] = io->mq_fusion;
-  for (int i = 0; i < 4; ++i) a.g[i] = g[i];
+  const int64_t e_off = (int64_t)first * d.B * d.N * d.D;
+  a.t[0] = io->com_app + e_off; a.t[1] = io->com_mot + e_off; a.t[2] = io->aq_fusion + e_off; a.t[3] = io->mq_fusion + e_off;
+  for (int i = 0; i < 4; ++i) a.g[i] = g[i] + e_off;
   const size_t LB = (size_t)d.L * d.B, NN = (size_t)d.N * d.N;
-  a.gram = ws; a.wt = a.gram + round64((int64_t)(LB * 4 * NN));
   a.NBP = nb_of(d.N);
+  a.gram = ws + (size_t)first * d.B * 4 * NN;
+  a.wt = ws + round64((int64_t)(LB * 4 * NN)) + (size_t)first * d.B * 4 * d.N * a.NBP;
   a.loss = loss3;
   a.wc = alpha / ((float)d.L * d.B * d.N * d.N);
   a.wh = beta * dep_scale / (float)d.L;
-  a.B = d.B; a.N = d.N; a.D = d.D; a.L = d.L;
-  hipError_t e = hipMemsetAsync(loss3, 0, 3 * sizeof(float), st);
-  if (e != hipSuccess) return (int)e;
+  a.B = d.B; a.N = d.N; a.D = d.D; a.L = count; a.Ltot = d.L;
+  hipError_t e = hipSuccess;
+  if (zero_loss3) {                        // (the forward clears the three scalars itself, on the way of its first kernel)
+    e = hipMemsetAsync(loss3, 0, 3 * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+  }
   const int64_t nv = (int64_t)d.B * d.N * d.D;
   if (io->vis) DVGR_LAUNCH(k_sum_and_ones, dim3(256), dim3(256), 0, st, io->vis, g_vis, nv, loss3);
   DVGR_TRY_HIP(launch_gram(st, a));
   const size_t lds2 = sizeof(float) * (6 * NN + 6 * d.N + 8);
   if (lds2 > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_aux_combine), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-  DVGR_LAUNCH(k_aux_combine, dim3(d.B, d.L), dim3(256), lds2, st, a);
+  DVGR_LAUNCH(k_aux_combine, dim3(a.B, a.L), dim3(256), lds2, st, a);
   if ((e = hipGetLastError()) != hipSuccess) return (int)e;
   // (sending the entries out in groups of unit layers as they come into existence, each group under the layers that
   // follow, changes nothing at C2 or C5: profiles/experiments_r03.tsv, c5_aux_groups)

@@ -38,7 +38,7 @@ struct SplitJob {
   uint16_t* drop_hi[2];
   uint32_t drop_key[2];
 };
-struct SplitBatch { SplitJob j[4]; int n; int64_t lo_off; };
+struct SplitBatch { SplitJob j[4]; int n; int64_t lo_off; float* zero3; /* nullable: three floats cleared on the way */ };
 int split_planes(hipStream_t st, const SplitBatch& b);
 
 // S3: per (b, head, mod): logits, softmax over j, punish-scaled aggregation, ELU, dropout.
@@ -219,6 +219,9 @@ int colsum(hipStream_t st, const ColsumBatch& b);
 constexpr int kMaxZeroSegs = 40;
 struct ZeroList { float* p[kMaxZeroSegs]; int64_t n[kMaxZeroSegs]; int count; };
 int zero_ranges(hipStream_t st, const ZeroList& z);
+// zero_ranges(z) and elu_bwd(g, y, out, n, op, lo_off) as one launch (the head of the backward)
+int bwd_head(hipStream_t st, const ZeroList& z, const float* g, const float* y, float* out, int64_t n, uint16_t* op = nullptr,
+             int64_t lo_off = 0);
 
 // fp32 -> bf16 shadow copy (round to nearest even)
 int to_bf16(hipStream_t st, const float* src, void* dst, int64_t n);

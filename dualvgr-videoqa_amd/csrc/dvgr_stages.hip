@@ -972,6 +972,7 @@ int drop_x(hipStream_t st, const float* X0, const float* X1, float* out0, float*
 }
 
 __global__ __launch_bounds__(256) void k_split_planes(const SplitBatch b) {
+  if (b.zero3 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 3) b.zero3[threadIdx.x] = 0.f;   // (the forward's loss scalars)
   const SplitJob& J = b.j[blockIdx.y];
   const int64_t n4 = J.n / 4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
@@ -1044,6 +1045,50 @@ __global__ __launch_bounds__(256) void k_zero_ranges(const ZeroList z) {
   } else {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] = 0.f;
   }
+}
+
+// The head of the backward as ONE launch: the zero list (k_zero_ranges) and the ELU derivative of the MFB output
+// (k_elu_bwd) -- two 6 us launches on an idle chip whose cost was their two boundaries.  Blocks [0, nb_elu) take one float4 of
+// the element-wise job each, the rest walk the zero list as k_zero_ranges does (gx blocks per range).
+__global__ __launch_bounds__(256) void k_bwd_head(const ZeroList z, int gx, int nb_elu, const float* g, const float* y, float* out,
+                                                  int64_t n4, uint16_t* op, int64_t lo_off) {
+  if ((int)blockIdx.x < nb_elu) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // float4 index
+    if (i >= n4) return;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g) {
+      const float4 gg = reinterpret_cast<const float4*>(g)[i], yy = reinterpret_cast<const float4*>(y)[i];
+      v = make_float4(gg.x * elu_grad_from_out(yy.x), gg.y * elu_grad_from_out(yy.y), gg.z * elu_grad_from_out(yy.z),
+                      gg.w * elu_grad_from_out(yy.w));
+    }
+    reinterpret_cast<float4*>(out)[i] = v;
+    split_store4(op, lo_off, 4 * i, v);
+    return;
+  }
+  const int b = (int)blockIdx.x - nb_elu, seg = b / gx, bx = b - seg * gx;
+  float* p = z.p[seg];
+  const int64_t n = z.n[seg];
+  const int64_t stride = (int64_t)gx * 256;
+  if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+    const int64_t n4z = n >> 2;
+    for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < n4z; i += stride)
+      reinterpret_cast<float4*>(p)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t i = (n4z << 2) + (int64_t)bx * 256 + threadIdx.x; i < n; i += stride) p[i] = 0.f;
+  } else {
+    for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < n; i += stride) p[i] = 0.f;
+  }
+}
+
+int bwd_head(hipStream_t st, const ZeroList& z, const float* g, const float* y, float* out, int64_t n, uint16_t* op, int64_t lo_off) {
+  if (z.count > kMaxZeroSegs || (n & 3)) return DVGR_E_DIMS;
+  int64_t longest = 0;
+  for (int i = 0; i < z.count; ++i) longest = z.n[i] > longest ? z.n[i] : longest;
+  int gx = (int)((longest / 4 + 255) / 256);
+  gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+  const int64_t n4 = n / 4;
+  const int nb_elu = (int)((n4 + 255) / 256);
+  DVGR_LAUNCH(k_bwd_head, dim3((unsigned)(nb_elu + gx * (z.count > 0 ? z.count : 0))), dim3(256), 0, st, z, gx, nb_elu, g, y, out, n4, op, lo_off);
+  return (int)hipGetLastError();
 }
 
 int zero_ranges(hipStream_t st, const ZeroList& z) {

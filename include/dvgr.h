@@ -197,6 +197,8 @@ enum dvgr_probe_site {
  * and the punish gate does not depend on work the separate projection would hide (layer 0 beside the side stream keeps two
  * launches).  DVGR_OPT_NO_FUSED_GAT forces the two-launch form everywhere (A/B timing, parity of the two forms). */
 #define DVGR_OPT_NO_FUSED_GAT 4
+/* (The same bit also keeps S6 -- linear0 / linear1 + ELU + the pooled product, one launch on the planes path, k_mfb_fwd --
+ * in its two-launch form: the flag means "no fused forward kernels".) */
 
 /* Scope-U loss evaluated by the forward itself (dvgr_opts.loss): the same arithmetic and outputs as
  * dvgr_scope_u_loss below, but the kernels are enqueued as soon as the last layer's list outputs exist and run on the

@@ -173,5 +173,6 @@ def test_launch_count_drops_by_one_per_fused_layer():
         n0 = lib.dvgr_dbg_launch_count()
         _forward(m, inp, 3)
         counts[fused] = lib.dvgr_dbg_launch_count() - n0
-    # two-stream mode: layer 0 keeps two launches (its gate waits for the query chain), layers 1 .. L - 1 are fused
-    assert counts[False] - counts[True] == Lr - 1, counts
+    # two-stream mode: layer 0 keeps two launches (its gate waits for the query chain), layers 1 .. L - 1 are fused; the same
+    # flag also selects S6 as one launch (k_mfb_fwd: linear0 / linear1 + ELU + pooling) instead of contraction + pooling kernel
+    assert counts[False] - counts[True] == (Lr - 1) + 1, counts

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Fold the A/B rows a GPU call brought back (gpurun_out/ab_rows/*.tsv, written by tools/ab.py) into
-profiles/experiments_r03.tsv; rows already present (same experiment, variant, build, numbers) are skipped."""
+profiles/experiments_r04.tsv; rows already present (same experiment, variant, build, numbers) are skipped."""
 import glob
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out = os.path.join(ROOT, "profiles", "experiments_r03.tsv")
+out = os.path.join(ROOT, "profiles", "experiments_r04.tsv")
 lines = open(out).read().splitlines(True)
 seen = {tuple(l.split("\t")[1:3] + l.split("\t")[5:8]) for l in lines[1:]}
 for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "ab_rows", "*.tsv"))):
