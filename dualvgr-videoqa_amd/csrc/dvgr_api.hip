@@ -548,12 +548,13 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
     // entries) go to the side stream in groups of unit layers as the entries come into existence, each group under the
     // contractions that follow.  Round 3 measured no difference between group sizes (the forward's tail was the main stream's);
     // with S6 as one launch and sum(vis) inside the out contraction the tail is the loss chain (80 us at C2 for all three
-    // layers at once, starting 12 us behind the last GAT kernel): one layer per group up to three layers, three beyond.
+    // layers at once, starting 12 us behind the last GAT kernel): one layer per group (experiments_r04.tsv, aux_groups_*:
+    // C2 1.0065 ms against 1.0085 for one group of three; C5 9.177 against 9.205 in threes and 9.237 for all twelve at once).
 #ifdef DVGR_TIMING_AIDS
     static const int aux_group_env = []() { const char* e = getenv("DVGR_AUX_GROUP"); return e ? atoi(e) : 0; }();   // A/B timing aid
-    const int aux_group = aux_group_env > 0 ? aux_group_env : (L <= 3 ? 1 : 3);
+    const int aux_group = aux_group_env > 0 ? aux_group_env : 1;
 #else
-    const int aux_group = L <= 3 ? 1 : 3;
+    constexpr int aux_group = 1;
 #endif
     if (O.loss && ((l + 1) % aux_group == 0 || l == L - 1)) {
       const dvgr_loss_spec& Q = *O.loss;

@@ -129,12 +129,7 @@ __device__ __forceinline__ void gatf_loader(const GatFusedArgs& a, uint16_t* sme
 }
 
 // ---- computing waves ----------------------------------------------------------------------------------------------
-#ifdef DVGR_STAGGER
-constexpr bool kGatfStagger = true;
-#else
-constexpr bool kGatfStagger = false;
-#endif
-template <class C, int TERMS, int MTW, int NTC, bool LATE = false>
+template <class C, int TERMS, int MTW, int NTC>
 __device__ __forceinline__ void gatf_compute(const uint16_t* smem, int nk, int row0, int col0, int lane, f32x4 (&acc)[4][NTC]) {
 #pragma unroll
   for (int i = 0; i < MTW; ++i)
@@ -167,22 +162,10 @@ __device__ __forceinline__ void gatf_compute(const uint16_t* smem, int nk, int r
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
       }
   };
-  if (!LATE) {
-    for (int kt = 0; kt < nk; ++kt) {
-      __builtin_amdgcn_s_barrier();
-      read_frags(kt);
-      mma_tile();
-    }
-  } else {
-    // the second row group's waves share their SIMDs with the first's: they run half a K-tile behind (see planes_tile,
-    // dvgr_gemm.hip): multiply tile kt - 1 from registers while the partner reads tile kt, then read tile kt
-    if (nk > 0) { __builtin_amdgcn_s_barrier(); read_frags(0); }
-    for (int kt = 1; kt < nk; ++kt) {
-      __builtin_amdgcn_s_barrier();
-      mma_tile();
-      read_frags(kt);
-    }
-    if (nk > 0) mma_tile();
+  for (int kt = 0; kt < nk; ++kt) {
+    __builtin_amdgcn_s_barrier();
+    read_frags(kt);
+    mma_tile();
   }
 }
 
@@ -244,7 +227,7 @@ __global__ __launch_bounds__(768) void k_gat_fused_fwd(const GatFusedArgs a) {
 #pragma unroll
     for (int j = 0; j < NTC; ++j) bv[j] = bias[col0 + 16 * j + (lane & 15)];
     if (rg == 0) { row0 = 0; gatf_compute<C, TERMS, C::MT0, NTC>(smem, nk, row0, col0, lane, acc); }
-    else { row0 = 16 * C::MT0; gatf_compute<C, TERMS, (MTILES - C::MT0 > 0 ? MTILES - C::MT0 : 1), NTC, kGatfStagger>(smem, nk, row0, col0, lane, acc); }
+    else { row0 = 16 * C::MT0; gatf_compute<C, TERMS, (MTILES - C::MT0 > 0 ? MTILES - C::MT0 : 1), NTC>(smem, nk, row0, col0, lane, acc); }
   }
   __builtin_amdgcn_s_barrier();                            // every fragment read of the ring is done: its LDS is free
   GFCLK(1);

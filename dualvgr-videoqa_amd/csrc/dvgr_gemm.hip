@@ -1036,33 +1036,15 @@ __device__ __forceinline__ void planes_tile(const GemmProblem& P, uint16_t* smem
       }
     }
   };
-#ifdef DVGR_STAGGER
-  // Waves 4-7 run half a K-tile behind waves 0-3 (MI355X_MICROARCH.md, two waves per SIMD, item 9): waves w and w + 4 share a
-  // SIMD, and with one barrier per K-tile both would read their fragments at the same time and then queue for the MFMA pipe.
-  // The late half multiplies tile kt - 1 (fragments kept in registers across the barrier) while the early half reads tile kt,
-  // then reads tile kt while the early half multiplies.  Every wave still reads tile kt between barrier kt and barrier
-  // kt + 1, so the ring's slot rule is unchanged, and every wave executes nk + 1 barriers.
-  const bool late = wave >= 4 && !(DVGR_DBG(P) & 4);
-#else
-  constexpr bool late = false;
-#endif
-  if (!late) {
-    for (int kt = 0; kt < nk; ++kt) {
-      GCLK_ADD(1);                                 // fragment reads + MFMAs of the previous tile
-      __builtin_amdgcn_s_barrier();
-      GCLK_ADD(0);                                 // waiting for tile kt
-      if (DVGR_DBG(P) & 4) continue;                     // timing aid: barriers only, no fragment reads, no MFMAs
-      read_frags(kt);
-      mma_tile(kt);
-    }
-  } else {
-    if (nk > 0) { __builtin_amdgcn_s_barrier(); read_frags(0); }
-    for (int kt = 1; kt < nk; ++kt) {
-      __builtin_amdgcn_s_barrier();
-      mma_tile(kt - 1);
-      read_frags(kt);
-    }
-    if (nk > 0) mma_tile(nk - 1);
+  // (Waves 4-7 half a K-tile behind waves 0-3 -- multiplying tile kt - 1 from registers while the SIMD partner reads tile kt --
+  // measured 0.45 % SLOWER per step at C2 and C5: profiles/patches/r04_stagger_waves_4_7.patch, experiments_r04.tsv.)
+  for (int kt = 0; kt < nk; ++kt) {
+    GCLK_ADD(1);                                   // fragment reads + MFMAs of the previous tile
+    __builtin_amdgcn_s_barrier();
+    GCLK_ADD(0);                                   // waiting for tile kt
+    if (DVGR_DBG(P) & 4) continue;                       // timing aid: barriers only, no fragment reads, no MFMAs
+    read_frags(kt);
+    mma_tile(kt);
   }
   if (do_rs) {
 #pragma unroll

@@ -660,6 +660,239 @@ __global__ __launch_bounds__(64 * NW) void k_gat_attn_bwd(const GatAttnBwdArgs a
   CLK(6);
 }
 
+// =================================================================================================
+// S3 backward for N > 32, column-chunked (round 4).  The kernel above keeps the whole Wh and dP tiles of its (sample, head) in
+// LDS next to three N x N images: 153 KB at N = 64 -- ONE 8-wave workgroup per CU, whose load phase (150 KB at ~20 GB/s per
+// CU), two MFMA phases and row phases run strictly one after the other (the largest single item of a C5 step: 1.5 of 9.6 ms).
+// Here the F columns go through LDS in chunks of 64 (two 17 KB images), twice:
+//   pass 1  dalpha = dP . Wh^T accumulated over the chunks in registers (two 16 x 16 tiles per wave),
+//   then    softmax / LeakyReLU backward on the N x N images (alpha is kept, alpha * keep is rebuilt from the counter hash),
+//   pass 2  per chunk: dZ = alpha_d^T . dP, dWh = s dZ + du a_l + dv a_r (fp32 / planes), ds += dZ . Wh, d a_l / d a_r partials.
+// 74 KB at N = 64: TWO workgroups per CU, so one's loads run under the other's MFMA / row phases.  The price is a second read
+// of dz, out and Wh (served by L2 / the Infinity Cache: the whole working set of a launch is 150 MB).
+// =================================================================================================
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW, 4) void k_gat_attn_bwd_chunked(const GatAttnBwdArgs a) {   // 4 waves per SIMD = two workgroups per CU: <= 128 VGPRs
+  static_assert(NW == 8, "wave -> (strip, row-tile half) map of pass 2");
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int FC = 64, FCS = FC + 4;                     // chunk width, row stride of the chunk images
+  const int b = blockIdx.x, h = blockIdx.y, mod = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, kq = lane >> 4;
+  const int N = a.N, D = a.D, F = D / 4, HF = kHeads * F;
+  const int S = (N + 3) / 4, NP = N + 1;
+  const int g = h >> 2, hl = h & 3;
+  float* shW = sm;                    // [N + 1][FCS] Wh chunk; row N = 0
+  float* shP = shW + (N + 1) * FCS;   // [N + 1][FCS] dP chunk, later dZ chunk; row N = 0
+  float* shA = shP + (N + 1) * FCS;   // [N][NP] alpha
+  float* shG = shA + N * NP;          // [N][NP] dalpha, then dpre
+  float* shS = shG + N * NP;          // [N]
+  float* shU = shS + N;
+  float* shV = shU + N;
+  float* shDu = shV + N;
+  float* shDv = shDu + N;
+  float* shDs = shDv + N;             // [N] ds accumulated over the chunks
+  float* shRed = shDs + N;            // [16]
+  float* shDa = shRed + 16;           // [NW][2 FC] partials of d a_l / d a_r of one chunk
+  const float* Wh = a.Wh[mod] + (int64_t)b * N * HF + h * F;
+  const float* dz = a.dz[mod] + (int64_t)g * a.B * N * D + (int64_t)b * N * D + hl * F;
+  const float* outp = (g ? a.out_s[mod] : a.out_c[mod]) + (int64_t)b * N * D + hl * F;
+  const uint32_t ko = a.key_out[mod][g];
+  const uint32_t ka = a.key_alpha[mod][h];
+  const float sc = ko ? (1.0f - kDropP) : 1.0f;           // un-dropped ELU output where kept
+  // chunk c of both tiles as float4s: four rows per wave instruction (16 lanes x 16 B = a whole 256-byte row piece each)
+  auto load_chunk = [&](int c) {
+    for (int i = 4 * wave + kq; i <= N; i += 4 * NW) {      // row N is the zero row
+      float4 p = make_float4(0.f, 0.f, 0.f, 0.f), wv = p;
+      if (i < N) {
+        const int col = FC * c + 4 * r16;
+        wv = *reinterpret_cast<const float4*>(Wh + (int64_t)i * HF + col);
+        const float4 z = *reinterpret_cast<const float4*>(dz + (int64_t)i * D + col);
+        const float4 y = *reinterpret_cast<const float4*>(outp + (int64_t)i * D + col);
+        float kf[4];
+        drop_factor4(ko, (uint32_t)(((int64_t)b * N + i) * D + hl * F + col), kf);
+        p.x = z.x * kf[0] * elu_grad_from_out(y.x * sc);
+        p.y = z.y * kf[1] * elu_grad_from_out(y.y * sc);
+        p.z = z.z * kf[2] * elu_grad_from_out(y.z * sc);
+        p.w = z.w * kf[3] * elu_grad_from_out(y.w * sc);
+      }
+      *reinterpret_cast<float4*>(shW + i * FCS + 4 * r16) = wv;
+      *reinterpret_cast<float4*>(shP + i * FCS + 4 * r16) = p;
+    }
+  };
+  if (tid < N) {
+    shS[tid] = a.s[mod][b * N + tid];
+    shU[tid] = a.u[mod][((int64_t)b * kHeads + h) * N + tid];
+    shV[tid] = a.v[mod][((int64_t)b * kHeads + h) * N + tid];
+    shDs[tid] = 0.f;
+  }
+  load_chunk(0);
+  __syncthreads();
+  const float c = a.gat_c[mod][h];
+  for (int i = wave; i < N; i += NW) {                      // recompute alpha: one wave per row
+    float e = -INFINITY;
+    if (lane < N) { e = shU[i] + shV[lane] + c; e = e > 0.f ? e : kSlope * e; }
+    const float mx = wave_max(e);
+    const float pe = lane < N ? expf(e - mx) : 0.f;
+    const float sum = wave_sum(pe);
+    if (lane < N) shA[i * NP + lane] = pe / sum;
+  }
+  // ---- pass 1: dalpha_ij = keep_ij s_j (dP_i . Wh_j), tiles (I, J) dealt to the waves, accumulated over the chunks ----
+  constexpr int TPW = (NT * NT + NW - 1) / NW;              // tiles per wave
+  gat_f32x4 dacc[TPW];
+#pragma unroll
+  for (int k = 0; k < TPW; ++k) dacc[k] = gat_f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nch = F / FC;
+  for (int cidx = 0; cidx < nch; ++cidx) {
+    if (cidx > 0) { load_chunk(cidx); __syncthreads(); }
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+      const int tile = wave + NW * k;
+      if (tile < NT * NT) {
+        const int I = tile / NT, J = tile - I * NT;
+        const int ra = 16 * I + r16, rb = 16 * J + r16;
+        const float* pa = shP + (ra < N ? ra : N) * FCS + 4 * kq;
+        const float* pb = shW + (rb < N ? rb : N) * FCS + 4 * kq;
+#pragma unroll
+        for (int t = 0; t < FC / 16; ++t) {
+          const float4 x = *reinterpret_cast<const float4*>(pa + 16 * t), y = *reinterpret_cast<const float4*>(pb + 16 * t);
+          dacc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, y.x, dacc[k], 0, 0, 0);
+          dacc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, y.y, dacc[k], 0, 0, 0);
+          dacc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, y.z, dacc[k], 0, 0, 0);
+          dacc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, y.w, dacc[k], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();                                        // the chunk images may be overwritten
+  }
+#pragma unroll
+  for (int k = 0; k < TPW; ++k) {
+    const int tile = wave + NW * k;
+    if (tile < NT * NT) {
+      const int I = tile / NT, J = tile - I * NT, j = 16 * J + r16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * I + 4 * kq + r;
+        if (i < N && j < N) shG[i * NP + j] = dacc[k][r] * shS[j] * drop_factor(ka, (uint32_t)((b * N + i) * N + j));
+      }
+    }
+  }
+  __syncthreads();
+  // ---- softmax and LeakyReLU backward, du_i: one wave per row; then dv_j, dc ----
+  float dc_w = 0.f;
+  for (int i = wave; i < N; i += NW) {
+    const float al = lane < N ? shA[i * NP + lane] : 0.f;
+    const float da = lane < N ? shG[i * NP + lane] : 0.f;
+    const float rowdot = wave_sum(al * da);
+    const float pre = lane < N ? shU[i] + shV[lane] + c : 0.f;
+    const float dpre = al * (da - rowdot) * (pre > 0.f ? 1.f : kSlope);
+    if (lane < N) shG[i * NP + lane] = dpre;
+    const float du = wave_sum(lane < N ? dpre : 0.f);
+    if (lane == 0) shDu[i] = du;
+    dc_w += du;
+  }
+  if (lane == 0) shRed[wave] = dc_w;
+  __syncthreads();
+  if (tid < N) {
+    float dv = 0.f;
+    for (int i = 0; i < N; ++i) dv += shG[i * NP + tid];
+    shDv[tid] = dv;
+  }
+  if (tid == 0) {
+    float dc = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) dc += shRed[w];
+    a.dc_part[mod][b * kHeads + h] = dc;
+  }
+  // ---- pass 2.  Wave w = (strip Ft = w & 3 of the chunk's four 16-column strips, half Jh = w >> 2 of the row tiles of dZ) ----
+  constexpr int JH = (NT + 1) / 2;                          // row tiles per half
+  const int Ft = wave & 3, Jh = wave >> 2;
+  float af[JH][4 * NT];                                     // A fragments: alpha_d[i = 4 s4 + kq][j = 16 Jt + r16], Jt = JH Jh + jj
+#pragma unroll
+  for (int jj = 0; jj < JH; ++jj)
+#pragma unroll
+    for (int s4 = 0; s4 < 4 * NT; ++s4) {
+      const int i = 4 * s4 + kq, j = 16 * (JH * Jh + jj) + r16;
+      af[jj][s4] = (s4 < S && i < N && j < N) ? shA[i * NP + j] * drop_factor(ka, (uint32_t)((b * N + i) * N + j)) : 0.f;
+    }
+  float* dWh = a.dWh[mod] ? a.dWh[mod] + (int64_t)b * N * HF + h * F : nullptr;
+  for (int cidx = 0; cidx < nch; ++cidx) {
+    load_chunk(cidx);                                       // (the last barrier above / below released the images)
+    __syncthreads();
+    gat_f32x4 zacc[JH];
+#pragma unroll
+    for (int jj = 0; jj < JH; ++jj) zacc[jj] = gat_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s4 = 0; s4 < 4 * NT; ++s4) {
+      if (s4 < S) {
+        const int i = 4 * s4 + kq;
+        const float bf = shP[(i < N ? i : N) * FCS + 16 * Ft + r16];
+#pragma unroll
+        for (int jj = 0; jj < JH; ++jj) zacc[jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[jj][s4], bf, zacc[jj], 0, 0, 0);
+      }
+    }
+    __syncthreads();                                        // both halves have read the strip: dZ may replace dP
+#pragma unroll
+    for (int jj = 0; jj < JH; ++jj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * (JH * Jh + jj) + 4 * kq + r;
+        if (j < N && JH * Jh + jj < NT) shP[j * FCS + 16 * Ft + r16] = zacc[jj][r];
+      }
+    __syncthreads();
+    // chunk epilogue: four rows per wave pass, 16 lanes x 4 columns per row
+    const int col = FC * cidx + 4 * r16;
+    const float4 al4 = *reinterpret_cast<const float4*>(a.gat_a[mod] + h * 2 * F + col);
+    const float4 ar4 = *reinterpret_cast<const float4*>(a.gat_a[mod] + h * 2 * F + F + col);
+    float4 pal = make_float4(0.f, 0.f, 0.f, 0.f), par = pal;
+    for (int j = 4 * wave + kq; j < 4 * ((N + 3) / 4); j += 4 * NW) {
+      const bool ok = j < N;
+      const int jr = ok ? j : N;
+      const float sj = ok ? shS[j] : 0.f, duj = ok ? shDu[j] : 0.f, dvj = ok ? shDv[j] : 0.f;
+      const float4 z = *reinterpret_cast<const float4*>(shP + jr * FCS + 4 * r16), w = *reinterpret_cast<const float4*>(shW + jr * FCS + 4 * r16);
+      const float4 o = make_float4(sj * z.x + duj * al4.x + dvj * ar4.x, sj * z.y + duj * al4.y + dvj * ar4.y,
+                                   sj * z.z + duj * al4.z + dvj * ar4.z, sj * z.w + duj * al4.w + dvj * ar4.w);
+      if (ok) {
+        if (dWh) st4(reinterpret_cast<float4*>(dWh + (int64_t)j * HF + col), o);
+        split_store4(a.dWh_p[mod], a.lo_off, (int64_t)b * N * HF + h * F + (int64_t)j * HF + col, o);
+      }
+      float dsp = ok ? z.x * w.x + z.y * w.y + z.z * w.z + z.w * w.w : 0.f;
+      dsp += dpp_move<0xb1, 0xf>(0.f, dsp);
+      dsp += dpp_move<0x4e, 0xf>(0.f, dsp);
+      dsp += dpp_move<0x124, 0xf>(0.f, dsp);
+      dsp += dpp_move<0x128, 0xf>(0.f, dsp);
+      if (ok && r16 == 0) shDs[j] += dsp;                   // (row j belongs to this wave in every chunk)
+      pal.x += duj * w.x; pal.y += duj * w.y; pal.z += duj * w.z; pal.w += duj * w.w;
+      par.x += dvj * w.x; par.y += dvj * w.y; par.z += dvj * w.z; par.w += dvj * w.w;
+    }
+    // the four row groups of a wave hold the same columns: fold them (lanes l, l ^ 16, l ^ 32), then the waves through LDS
+    float v8[8] = {pal.x, pal.y, pal.z, pal.w, par.x, par.y, par.z, par.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v8[e] += __shfl_xor(v8[e], 16);
+      v8[e] += __shfl_xor(v8[e], 32);
+    }
+    if (kq == 0) {
+      *reinterpret_cast<float4*>(shDa + wave * 2 * FC + 4 * r16) = make_float4(v8[0], v8[1], v8[2], v8[3]);
+      *reinterpret_cast<float4*>(shDa + wave * 2 * FC + FC + 4 * r16) = make_float4(v8[4], v8[5], v8[6], v8[7]);
+    }
+    __syncthreads();                                        // partials complete; every wave is done with the chunk images
+    for (int f = tid; f < 2 * FC; f += 64 * NW) {
+      float acc = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) acc += shDa[w * 2 * FC + f];
+      const int half = f / FC, fc = f - half * FC;          // 0: d a_l, 1: d a_r
+      a.da_part[mod][((int64_t)b * kHeads + h) * 2 * F + half * F + FC * cidx + fc] = acc;
+    }
+  }
+  __syncthreads();
+  if (tid < N) a.ds_part[mod][((int64_t)b * kHeads + h) * N + tid] = shDs[tid];
+}
+
+static size_t gat_bwd_chunked_lds(int N) {
+  const size_t NP = N + 1, FCS = 64 + 4, NW = 8;
+  return sizeof(float) * (2 * (N + 1) * FCS + 2 * (size_t)N * NP + 6 * N + 16 + NW * 2 * 64);
+}
+
 static size_t gat_bwd_lds(int N, int F) {
   const size_t NP = N + 1, FS = F + 4;
   const size_t NW = gat_nt(N) == 4 ? kAttnWavesWide : kAttnWavesSmall;
@@ -681,8 +914,25 @@ static int gat_attn_bwd_nt(hipStream_t st, const GatAttnBwdArgs& a) {
   DVGR_LAUNCH_CHECK();
 }
 
+template <int NT>
+static int gat_attn_bwd_chunked_nt(hipStream_t st, const GatAttnBwdArgs& a) {
+  const size_t lds = gat_bwd_chunked_lds(a.N);
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gat_attn_bwd_chunked<NT, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  DVGR_LAUNCH((k_gat_attn_bwd_chunked<NT, 8>), dim3(a.B, kHeads, 2), dim3(64 * 8), lds, st, a);
+  DVGR_LAUNCH_CHECK();
+}
+
 int gat_attn_bwd(hipStream_t st, const GatAttnBwdArgs& a) {
   if (a.D / 4 > 512) return DVGR_E_DIMS;                    // the epilogue keeps two float4 column slots per lane
+#ifdef DVGR_TIMING_AIDS
+  static const bool no_chunked = []() { const char* e = getenv("DVGR_NO_CHUNKED_ATTN_BWD"); return e && e[0] == '1'; }();   // A/B timing aid
+#else
+  constexpr bool no_chunked = false;
+#endif
+  // N > 32: the whole-tile kernel's images allow ONE workgroup per CU; the column-chunked form fits two (80 KB each)
+  if (!no_chunked && a.N > 32 && ((a.D / 4) % 64) == 0 && gat_bwd_chunked_lds(a.N) <= 80 * 1024)
+    return gat_nt(a.N) == 3 ? gat_attn_bwd_chunked_nt<3>(st, a) : gat_attn_bwd_chunked_nt<4>(st, a);
   switch (gat_nt(a.N)) {
     case 1: return gat_attn_bwd_nt<1>(st, a);
     case 2: return gat_attn_bwd_nt<2>(st, a);

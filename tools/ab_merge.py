@@ -10,6 +10,8 @@ lines = open(out).read().splitlines(True)
 seen = {tuple(l.split("\t")[1:3] + l.split("\t")[5:8]) for l in lines[1:]}
 for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "ab_rows", "*.tsv"))):
     for l in open(f):
+        if not l[:13] >= "2026-10-04T13":          # (gpurun_out/ carries rows of earlier rounds as well: round 4 began 13:00Z)
+            continue
         k = tuple(l.split("\t")[1:3] + l.split("\t")[5:8])
         if k not in seen:
             seen.add(k)
