@@ -490,7 +490,10 @@ def main():
             reducer = red
             reducer_kind = "python: parallel.LayerBucketReducer over torch.distributed (host callback + issuer thread)"
 
-    probe_sites = {"fwd_gat_gemm": (L_.PROBE_FWD_GAT_GEMM, 8 * B * N * D * D, "S2 forward GAT projection Wh = X.Wcat^T, both modalities (TAG_FWD_GAT)"),
+    probe_sites = {"fwd_gat_gemm": (L_.PROBE_FWD_GAT_GEMM, 8 * B * N * D * D,
+                                    "S2 + S3: the fused GAT-view launch (k_gat_fused_fwd: projection Wh = X.Wcat^T of both modalities = the "
+                                    "algorithmic FLOPs counted here, with the attention -- logits, softmax, aggregation, ELU, dropouts, 47 MB of "
+                                    "stores -- as its epilogue; its K loop alone: tools/gatf_clocks.py); two launches where the shape is not taken"),
                    "fwd_sf_gemm": (L_.PROBE_FWD_SF_GEMM, 8 * B * N * D * D, "S4 forward tanh(z.P1^T), 2 views x 2 modalities (TAG_FWD_SF)"),
                    "bwd_gat_dw": (L_.PROBE_BWD_GAT_DW, 8 * B * N * D * D, "dWcat = dWh^T.X (TAG_BWD_GAT_DW)"),
                    "bwd_gat_dx": (L_.PROBE_BWD_GAT_DX, 8 * B * N * D * D, "dX += dWh.Wcat (TAG_BWD_GAT_DX)")}
@@ -588,6 +591,14 @@ def main():
     peak = PEAK_TFLOPS[args.dtype]
     f_train = 3 * f_fwd(N, Lr, T)
     pmc = pmc_record(args.config, args.dtype, not args.eval_mode) if args.probe == "fwd_gat_gemm" else None
+    # third probe, on its own short run after the timed region: the plain 240-tile contraction of the same shape (S4)
+    sf_pairs = [(L_.ProbeEvent(), L_.ProbeEvent()) for _ in range(8)]
+    for k in range(8):
+        m.set_probe(L_.PROBE_FWD_SF_GEMM, probe_layer, sf_pairs[k][0], sf_pairs[k][1])
+        step()
+    m.set_probe(0)
+    torch.cuda.synchronize()
+    sf_ms = float(np.mean([a.elapsed_time(b) for a, b in sf_pairs]))
     out = {
         "metric": "QA-pairs/sec (forward+backward) per GPU, SVQA num_clips=20",
         "value": value, "unit": "QA-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -625,6 +636,12 @@ def main():
                      "pmc_source": pmc.get("source") if pmc else None,
                      "kernel": probe_name, "launch_ms": probe_ms,
                      "algorithmic_gflop_per_launch": probe_flops / 1e9, "build": build_id(),
+                     # the plain contraction of the same shape and FLOPs (S4, tanh(z.P1^T), 240 tiles of 128 x 128), probed on 8
+                     # extra steps behind the timed region: the rate of the contraction engine without an attention epilogue
+                     "plain_contraction": {"kernel": "S4 forward tanh(z.P1^T), 2 views x 2 modalities (TAG_FWD_SF)", "launch_ms": sf_ms,
+                                           "achieved": 8 * B * N * D * D / (sf_ms * 1e-3) / 1e12,
+                                           "frac": 8 * B * N * D * D / (sf_ms * 1e-3) / 1e12 / peak,
+                                           "mfma_pipe_busy_pmc": (pmc.get("plain_contraction") or {}).get("mfma_busy") if pmc else None},
                      # the launch that dominates the profile by time (the GAT projection above is the kernel north_star names)
                      "dominant_by_time": None if probe2_ms is None else {
                          "kernel": probe2_name, "launch_ms": probe2_ms, "algorithmic_gflop_per_launch": probe2_flops / 1e9,

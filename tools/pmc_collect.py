@@ -34,9 +34,11 @@ def main():
         # "auto": bench.py times blocks of >= 1 s, so each pass ran its own number of steps; k_mfb_pool_fwd runs once a step
         if sys.argv[4] != "auto":
             return float(sys.argv[4])
-        n = [len(v[counter]) for k, v in acc.items() if "k_mfb_pool_fwd" in k]
+        n = [len(v[counter]) for k, v in acc.items() if "k_mfb_fwd" in k] or \
+            [len(v[counter]) for k, v in acc.items() if "k_mfb_pool_fwd" in k] or \
+            [len(v[counter]) for k, v in acc.items() if "k_bwd_head" in k]
         if not n:
-            sys.exit("steps 'auto' needs the once-per-step kernel k_mfb_pool_fwd in the trace")
+            sys.exit("steps 'auto' needs a once-per-step kernel (k_mfb_fwd / k_mfb_pool_fwd / k_bwd_head) in the trace")
         return float(n[0])
 
     steps_f, steps_w = steps_of(fetch, "FETCH_SIZE"), steps_of(write, "WRITE_SIZE")
@@ -61,20 +63,35 @@ def main():
     lines.append(f"total fabric bytes per step (forward + loss + backward; k_optim_* rows excluded: outside the timed step): {total / 1e9:.3f} GB")
     open(prefix + "_pmc_hbm.txt", "w").write("\n".join(lines) + "\n")
     print("\n".join(lines[-12:]))
-    # the probed kernel: the forward GAT projection contraction (template TAG 1 of the KC x KC engine)
-    probe = [r for r in rows if "TAG" not in r[0] and ("<0, 0, 1," in r[0] or "fwd_gat" in r[0].lower())]
+    # the probed kernel: the forward GAT projection -- since round 4 the fused GAT-view kernel (projection + attention in one
+    # launch); before, and for shapes it does not take, the contraction with template TAG 1 of the KC x KC engine
+    probe = [r for r in rows if "k_gat_fused_fwd" in r[0]]
+    if not probe:
+        probe = [r for r in rows if "TAG" not in r[0] and ("<0, 0, 1," in r[0] or "fwd_gat" in r[0].lower())]
     if not probe:       # from 384 tiles per launch up (C5) S2 runs on the 128 x 256-tile kernel, one symbol for S2 and S4 (same shape)
         probe = [r for r in rows if "gemm_planes_wide_kernel<0, 0," in r[0]]
     rec = {"build": bench.build_id(), "config": config, "dtype": dtype, "train": True,
            "source": os.path.relpath(prefix + "_pmc_hbm.txt", ROOT), "fabric_bytes_per_step": total}
-    if probe:
-        n, l, fk, wk, b = probe[0]
-        rec.update({"kernel": n, "traffic_bytes_per_launch": b, "fetch_kb": fk, "write_kb": wk})
-        s = sq.get(n, {})
+
+    def busy_of(name):
+        s = sq.get(name, {})
         if s.get("SQ_VALU_MFMA_BUSY_CYCLES") and s.get("GRBM_GUI_ACTIVE"):
             busy = sum(s["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(s["SQ_VALU_MFMA_BUSY_CYCLES"])
             act = sum(s["GRBM_GUI_ACTIVE"]) / len(s["GRBM_GUI_ACTIVE"])
-            rec["mfma_busy"] = (busy / (256 * 4)) / (act / 8)
+            return (busy / (256 * 4)) / (act / 8)
+        return None
+
+    if probe:
+        n, l, fk, wk, b = probe[0]
+        rec.update({"kernel": n, "traffic_bytes_per_launch": b, "fetch_kb": fk, "write_kb": wk})
+        mb = busy_of(n)
+        if mb is not None:
+            rec["mfma_busy"] = mb
+    # the plain 240-tile contraction of the same shape (S4: tanh(z . P1^T), template TAG 2), for comparison
+    plain = [r for r in rows if "gemm_planes_kernel<0, 0, 2," in r[0]]
+    if plain:
+        n, l, fk, wk, b = plain[0]
+        rec["plain_contraction"] = {"kernel": n, "traffic_bytes_per_launch": b, "mfma_busy": busy_of(n)}
     out = os.path.join(ROOT, "profiles", f"pmc_{config}_{dtype}.json")
     json.dump(rec, open(out, "w"), indent=1)
     print("wrote", out, rec.get("traffic_bytes_per_launch"), rec.get("mfma_busy"))
