@@ -211,8 +211,8 @@ def run_trial_children(args):
         env["DVGR_BENCH_TRIAL_CHILD"] = "1"
         if kind != "plain":
             # what RCCL chose (channels, algorithm, protocol) is read from its INFO log; the log goes to a file of the child's own
-            env.setdefault("NCCL_DEBUG", "INFO")
-            env.setdefault("NCCL_DEBUG_SUBSYS", "INIT,TUNING")
+            env["NCCL_DEBUG"] = "INFO"
+            env["NCCL_DEBUG_SUBSYS"] = "INIT,TUNING"
             env["NCCL_DEBUG_FILE"] = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"dvgr_rccl_{kind}_{os.getpid()}_%p.log")
         cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--trial", kind]
         t0 = time.perf_counter()
@@ -364,6 +364,8 @@ def main():
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPUs are visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if os.environ.get("DVGR_BENCH_STREAM", "0") == "1":      # the caller's stream = an ordinary non-blocking stream instead of
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))  # the legacy NULL stream (which synchronises with blocking streams)
     # DVGR_DDP_SELFTEST=1: run the data-parallel plumbing (process group, per-layer buckets gated by the library's events,
     # communication stream) with a single rank, to check it on a one-GPU box
     ddp = (world > 1 or os.environ.get("DVGR_DDP_SELFTEST", "0") == "1") and args.trial != "plain"
@@ -622,6 +624,7 @@ def main():
                    "optimizer": "clip_grad_norm_(12) + Adam over the unit's flat parameter / gradient buffers, two fused launches "
                                 "(dvgr_optim_*), OUTSIDE the timed step",
                    "distributed": dict(dist_info, reducer=reducer_kind, reducer_trial=trial_report,
+                                       comm_placement=getattr(reducer, "placement", None),
                                        allreduce_bytes_per_block={str(l): 4 * (b - a) for l, (a, b) in
                                                                   ((l, m.layer_param_range(l)) for l in parallel.block_order(Lr))},
                                        allreduce_bytes_per_step=4 * int(m.flat_params().numel())) if dist_info else None,
@@ -686,13 +689,17 @@ def bench_model(args, dev, rank, world, cfg, ddp, dist_info, choice=None, trial_
 
     unit_red = param_red = None
     reducer_kind = None
+    if os.environ.get("DVGR_STREAMS_EARLY", "0") == "1":      # tools/stream_order_probe.sh: the package's streams (DVGR_STREAM_ORDER,
+        from dualvgr_videoqa_amd import _lib as L_            # 'comm' included) before any reducer exists
+        L_.streams(dev)
     if ddp and choice == "native":
         # every gradient of the model on the library's own RCCL communicator: the unit's blocks enqueued by its backward call
         # (dvgr_opts.comm), the flat gradient buffers of the four BiLSTMs and of the answer head by theirs (grad_sink), the
         # embedding table and the motion projection from their accumulate hooks -- one issue order, no interpreter thread
         try:
             from dualvgr_videoqa_amd.clip import BiLSTM
-            unit_red = parallel.NativeUnitReducer(dev, force_single=(world == 1))
+            from dualvgr_videoqa_amd import _lib as L_
+            unit_red = parallel.NativeUnitReducer(dev, force_single=(world == 1), busy_streams=[L_.streams(dev)["encoder"]])
             unit.set_comm(unit_red)
             flat_mods = [m._head] + [x for x in m.modules() if isinstance(x, BiLSTM)]
             unit_ids = {id(p) for p in unit.parameters()}
@@ -739,7 +746,8 @@ def bench_model(args, dev, rank, world, cfg, ddp, dist_info, choice=None, trial_
         if ddp and world > 1:
             dist.all_reduce(dtt, op=dist.ReduceOp.MAX)
         if rank == 0 or True:            # every rank's parent reads its own child
-            emit({"trial": args.trial, "ms": float(dtt.item()), "rccl": rccl_info_from_log(args.trial) if args.trial != "plain" else None})
+            emit({"trial": args.trial, "ms": float(dtt.item()), "rccl": rccl_info_from_log(args.trial) if args.trial != "plain" else None,
+                  "comm_placement": getattr(unit_red, "placement", None)})
         return
     for _ in range(args.warmup):
         step()
@@ -758,6 +766,7 @@ def bench_model(args, dev, rank, world, cfg, ddp, dist_info, choice=None, trial_
                       "host_enqueue_ms_per_step": float(np.median(HOST_ENQUEUE_MS)),
                       "timing": {"blocks": len(blocks), "steps_per_block": args.steps, "timed_s": float(sum(blocks))},
                       "distributed": dict(dist_info, reducer=reducer_kind, reducer_trial=trial_report,
+                                          comm_placement=getattr(unit_red, "placement", None),
                                           collectives_per_step=(getattr(param_red, "count", None))) if dist_info else None,
                       "global_batch": world * B, "parallelism": f"dp{world}"}}
     if rank == 0:

@@ -23,8 +23,7 @@ DVGR_F32, DVGR_BF16, DVGR_BF16X3 = 0, 1, 2
 ERRORS = {-1: "DVGR_E_DIMS (unsupported dimensions)", -2: "DVGR_E_NULL (null pointer)",
           -3: "DVGR_E_WORKSPACE (saved/workspace buffer too small)", -4: "DVGR_E_ALIGN (pointer not 16-byte aligned)",
           -5: "DVGR_E_KIND (unknown tensor kind)",
-          -6: "DVGR_E_ORDER (create the communicator / reducer BEFORE the unit's first forward on this device: the runtime maps "
-              "streams to hardware queues in creation order, and a communication stream created last costs 3 x the step time)"}
+          -6: "DVGR_E_ORDER (rounds 2-3; no longer returned: dvgr_comm_place puts the communication stream on a free pipe)"}
 
 
 class Dims(C.Structure):
@@ -69,6 +68,8 @@ OPT_NO_FUSED_GAT = 4
 SYMBOLS = [
     ("dvgr_version", C.c_char_p, []),
     ("dvgr_streams_init", C.c_int, []),
+    ("dvgr_streams_place", C.c_int, [C.c_void_p]),
+    ("dvgr_stream_create_placed", C.c_int, [C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_float), C.c_int]),
     ("dvgr_check_dims", C.c_int, [C.POINTER(Dims)]),
     ("dvgr_param_count", C.c_int64, [C.POINTER(Dims)]),
     ("dvgr_param_offset", C.c_int, [C.POINTER(Dims), C.c_int, C.c_int, C.c_int,
@@ -154,29 +155,53 @@ class ProbeEvent:
 
 
 _streams = {}
-STREAM_ORDER = os.environ.get("DVGR_STREAM_ORDER", "encoder,side,copy").split(",")
+STREAM_ORDER = os.environ.get("DVGR_STREAM_ORDER", "side,encoder,copy").split(",")
+STREAM_RANK = {"encoder": 2, "copy": 9}      # importance when a later stream has to share a pipe (csrc/dvgr_side.h: kRank*)
+PLACEMENT = {}                                # device index -> {stream name: placement report} (bench.py prints it)
+
+
+def _report(rep):
+    nc, nb, best, mask = int(rep[0]), int(rep[1]), int(rep[2]), int(rep[3])
+    return {"candidates": nc, "measured_against": nb, "chosen": best, "collisions_of_chosen": mask,
+            "undisturbed_chain_us": [round(float(rep[4 + i]), 1) for i in range(nb)],
+            "chain_us_per_candidate": [[round(float(rep[4 + nb + k * nb + i]), 1) for i in range(nb)] for k in range(nc)]}
 
 
 def streams(dev):
-    """Every stream this package uses on `dev` besides the caller's, created ONCE and in a fixed order, whichever
-    component asks first: {'encoder': torch stream of DualVGR's question encoder, 'copy': torch stream of the loader's
-    host-to-device copies}; the library's internal side stream is created in between (dvgr_streams_init).  The HIP
-    runtime maps streams to hardware queues in creation order; with the loader's copy stream created before the
-    model's streams the whole-model step cost 10.7 ms instead of 5.3 ms."""
+    """Every stream this package uses on `dev` besides the caller's, created ONCE, whichever component asks first:
+    {'encoder': stream of DualVGR's question encoder, 'copy': stream of the loader's host-to-device copies} as
+    torch.cuda.ExternalStream; the library's internal side / query streams are created in the same pass.
+
+    Each is put on the hardware queue that disturbs the current stream and the streams placed before it least
+    (dvgr_streams_place / dvgr_stream_create_placed; csrc/dvgr_place.hip): two busy hardware queues on one of the command
+    processor's four pipes cost every dispatch of both ~25 us, and which queues share a pipe follows creation order across
+    the whole process (torch's pools, the process group, RCCL) -- with the loader's copy stream created before the model's
+    streams the whole-model step cost 10.7 ms instead of 5.3 ms, with a torch.distributed group initialised first 8.7 ms
+    (profiles/HISTORY.md section 5)."""
     import torch
     dev = torch.device(dev)
     if dev.index is None:
         dev = torch.device("cuda", torch.cuda.current_device())
     key = dev.index
     if key not in _streams:
-        made = {}
+        made, reports = {}, {}
+        lib = load()
         with torch.cuda.device(dev):
+            caller = torch.cuda.current_stream(dev).cuda_stream
             for name in STREAM_ORDER:
                 if name == "side":
-                    check(load().dvgr_streams_init(), "dvgr_streams_init")
+                    check(lib.dvgr_streams_place(caller), "dvgr_streams_place")
+                elif name == "comm":     # (rounds 2-3 probe: the communication stream at a chosen place in the creation order)
+                    h = C.c_void_p()
+                    check(lib.dvgr_comm_device_stream(C.byref(h)), "dvgr_comm_device_stream")
                 else:
-                    made[name] = torch.cuda.Stream(device=dev)
+                    h, rep = C.c_void_p(), (C.c_float * 64)()
+                    check(lib.dvgr_stream_create_placed(0, STREAM_RANK.get(name, 8), caller, C.byref(h), rep, 64),
+                          "dvgr_stream_create_placed")
+                    made[name] = torch.cuda.ExternalStream(h.value, device=dev)
+                    reports[name] = _report(rep)
         _streams[key] = made
+        PLACEMENT[key] = reports
     return _streams[key]
 
 

@@ -224,13 +224,14 @@ int check_common(const dvgr_dims* d, const void* params, const dvgr_io* io, cons
 extern "C" {
 
 const char* dvgr_version(void) { return "dvgr-hip 0.1.0 gfx950"; }
-int dvgr_streams_init(void) {
+int dvgr_streams_place(void* caller_stream) {
   int dev = 0;
   const hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return (int)e;
   if (dev < 0 || dev >= 16) return DVGR_E_DIMS;
-  return shared_side_stream(dev, 0) ? 0 : (int)hipErrorOutOfMemory;      // (the side, query and communication streams, in their one fixed order)
+  return shared_side_stream(dev, 1, true, (hipStream_t)caller_stream) ? 0 : (int)hipErrorOutOfMemory;   // side, then query
 }
+int dvgr_streams_init(void) { return dvgr_streams_place(nullptr); }
 
 int dvgr_check_dims(const dvgr_dims* d) {
   if (!d) return DVGR_E_NULL;
@@ -404,7 +405,7 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
   // alone on the main stream -- beside layer 0's Wh contraction each takes twice as long and the punish gate waits for
   // the slower one (measured: gate at 102 us with the two side by side, 62 us this way); the row kernels and the small
   // Wq contraction behind it go to the side stream, under layer 0's Wh contraction, and join in front of the gate.
-  SideStream* side = (O.flags & DVGR_OPT_SINGLE_STREAM) ? nullptr : side_stream();
+  SideStream* side = (O.flags & DVGR_OPT_SINGLE_STREAM) ? nullptr : side_stream(st);
   hipStream_t hs = side ? side->st : st;
   const Probe fprobe{O, st};
   for (int l0 = 0; l0 < L; l0 += kMaxBatch) {
@@ -752,7 +753,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
 
   // Two streams: `st` carries the critical path (the dX chain), `hs` every weight / bias gradient.
   // DVGR_OPT_SINGLE_STREAM (or a missing side stream) folds everything onto `st`.
-  SideStream* side = ((O.flags & DVGR_OPT_SINGLE_STREAM) || 4 * L + 16 > 256 || G > 1) ? nullptr : side_stream();
+  SideStream* side = ((O.flags & DVGR_OPT_SINGLE_STREAM) || 4 * L + 16 > 256 || G > 1) ? nullptr : side_stream(st);
   hipStream_t hs = side ? side->st : st;
   // query branch (see dvgr_side.h).  Small batches are bound by the host's enqueue rate, where a third stream only adds
   // event calls (C1, B N = 160: 0.43 ms per step without it, 0.48 ms with it).

@@ -73,6 +73,34 @@ int dvgr_comm_unique_id(void* id_out) {
   return 0;
 }
 
+int dvgr_comm_place(dvgr_comm* c, void* const* busy_streams, int n_busy, float* report, int report_len) {
+  if (!c) return DVGR_E_NULL;
+  if (n_busy < 0 || n_busy > 5 || (n_busy && !busy_streams)) return DVGR_E_DIMS;
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) return (int)e;
+  static bool placed[16] = {};               // once per device: other communicators of the process share the chosen stream
+  static std::mutex placed_mu;
+  std::lock_guard<std::mutex> lk(placed_mu);
+  if (placed[c->device]) {
+    c->stream = dvgr::shared_side_stream(c->device, 2);
+    if (report && report_len >= 4) { report[0] = 0.f; report[1] = 0.f; report[2] = 0.f; report[3] = 0.f; }
+    return 0;
+  }
+  hipStream_t caller = n_busy ? (hipStream_t)busy_streams[0] : nullptr;
+  for (int i = 1; i < n_busy; ++i) dvgr::note_placed(c->device, (hipStream_t)busy_streams[i], dvgr::kRankHost + i - 1);
+  // every queue of the package exists before the candidates are created: the side and the query stream
+  if (!dvgr::shared_side_stream(c->device, 1, true, caller)) return (int)hipErrorOutOfMemory;
+  dvgr::PlaceReport R;
+  hipStream_t s = dvgr::place_stream(c->device, /*priority: as created*/ [&]() { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); return hi; }(),
+                                     caller, dvgr::kRankComm, c->stream, &R);
+  if (!s) return (int)hipErrorOutOfMemory;
+  c->stream = s;
+  dvgr::set_shared_stream(c->device, 2, s);
+  placed[c->device] = true;
+  dvgr::write_place_report(R, report, report_len);
+  return R.mask < 0 ? (int)hipErrorUnknown : 0;
+}
+
 int dvgr_comm_create(const void* id, int rank, int world, dvgr_comm** out) {
   if (!id || !out) return DVGR_E_NULL;
   if (world < 1 || rank < 0 || rank >= world) return DVGR_E_DIMS;
@@ -81,9 +109,7 @@ int dvgr_comm_create(const void* id, int rank, int world, dvgr_comm** out) {
   c->world = world;
   hipError_t e = hipGetDevice(&c->device);
   if (e != hipSuccess || c->device < 0 || c->device >= 16) { delete c; return e != hipSuccess ? (int)e : DVGR_E_DIMS; }
-  // the device's one communication stream.  It must be created BEFORE the unit's side stream (dvgr_side.h: the runtime's
-  // stream -> hardware-queue mapping follows creation order; the other order costs 3 x the step time)
-  if (!dvgr::shared_side_stream(c->device, 2, false) && dvgr::shared_side_stream(c->device, 0, false)) { delete c; return DVGR_E_ORDER; }
+  // the device's one communication stream (which hardware queue it should sit on: dvgr_comm_place)
   c->stream = dvgr::shared_side_stream(c->device, 2);
   if (!c->stream) { delete c; return (int)hipErrorOutOfMemory; }
   ncclUniqueId uid;
@@ -122,13 +148,18 @@ int dvgr_comm_allreduce_avg(dvgr_comm* c, float* buf, int64_t count, void* wait_
   return nccl_rc(api.AllReduce(buf, buf, (size_t)count, ncclFloat32, ncclAvg, c->comm, c->stream));
 }
 
+int dvgr_comm_allreduce_avg_on(dvgr_comm* c, float* buf, int64_t count, void* stream) {
+  if (!c || !buf) return DVGR_E_NULL;
+  if (count <= 0) return 0;
+  return nccl_rc(api.AllReduce(buf, buf, (size_t)count, ncclFloat32, ncclAvg, c->comm, (hipStream_t)stream));
+}
+
 int dvgr_comm_device_stream(void** stream_out) {
   if (!stream_out) return DVGR_E_NULL;
   int dev = 0;
   const hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return (int)e;
   if (dev < 0 || dev >= 16) return DVGR_E_DIMS;
-  if (!dvgr::shared_side_stream(dev, 2, false) && dvgr::shared_side_stream(dev, 0, false)) return DVGR_E_ORDER;
   *stream_out = (void*)dvgr::shared_side_stream(dev, 2);
   return *stream_out ? 0 : (int)hipErrorOutOfMemory;
 }

@@ -363,7 +363,7 @@ int dvgr_head_backward(const dvgr_head_dims* dp, const float* params, const dvgr
   }
   // Two streams, as the unit's backward: the chain of input gradients stays on `st`, the weight gradients and column
   // sums follow on the side stream behind two forks (each fork costs `st` a ~6 us bubble, so not one per dependency).
-  SideStream* side = side_stream();
+  SideStream* side = side_stream(st);
   hipStream_t hs = side ? side->st : st;
   ColsumBatch cb{};
   // logits = yd W2^T + b2

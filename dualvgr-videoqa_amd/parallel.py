@@ -34,6 +34,32 @@ def layer_buckets(module) -> List[Tuple[int, int]]:
     return [module.layer_param_range(l) for l in block_order(module.layers)]
 
 
+def _placed_stream(device: torch.device, priority_class: int, rank: int):
+    """A stream on the hardware queue that disturbs the current stream and the package's other streams least
+    (dvgr_stream_create_placed, csrc/dvgr_place.hip); a plain torch stream where the library is not available (CPU jobs)."""
+    try:
+        import ctypes as C
+        from . import _lib as L_
+        lib = L_.load()
+    except Exception:
+        return torch.cuda.Stream(device=device, priority=-1 if priority_class < 0 else 0)
+    h = C.c_void_p()
+    with torch.cuda.device(device):
+        L_.check(lib.dvgr_stream_create_placed(priority_class, rank, torch.cuda.current_stream(device).cuda_stream, C.byref(h), None, 0),
+                 "dvgr_stream_create_placed")
+    return torch.cuda.ExternalStream(h.value, device=device)
+
+
+def _all_reduce_stream_ordered(t: torch.Tensor, op, group) -> None:
+    """One collective in the CURRENT stream's order.  NCCL / RCCL: a synchronous-style call (async_op=False) -- the backend
+    enqueues the kernel on the current stream itself, where an async_op=True call takes a stream of the process group's
+    own (one more hardware queue that spends the step waiting: csrc/dvgr_place.hip).  Other backends: issue, then wait."""
+    if dist.get_backend(group) == "nccl":
+        dist.all_reduce(t, op=op, group=group, async_op=False)
+    else:
+        dist.all_reduce(t, op=op, group=group, async_op=True).wait()
+
+
 class CollectiveIssuer:
     """The ONE ordered place from which a process enqueues its gradient collectives on a device.
 
@@ -55,7 +81,7 @@ class CollectiveIssuer:
         # sharing the caller's queue, where its event waits sit in front of the backward's later launches.  (Borrowing the
         # library's communication stream instead -- one stream fewer -- measured 3.3 ms per step against 1.25: the runtime's
         # stream-to-queue mapping is sensitive to creation order, csrc/dvgr_side.h.)
-        self.stream = torch.cuda.Stream(device=device, priority=-1)
+        self.stream = _placed_stream(device, priority_class=-1, rank=8)
         self.q = queue.Queue()
         self.errors = []
         self.log = None                      # tests: list that receives a tag per item, in execution order
@@ -133,7 +159,6 @@ class LayerBucketReducer:
         order = self._layer_order() if events is not None else [None] * len(self.buckets)
         if flat_grad.is_cuda and self.stream is not None:
             cur = torch.cuda.current_stream(flat_grad.device)
-            works = []
             avg = dist.get_backend(self.group) == "nccl"       # RCCL averages inside the collective (ncclAvg)
             with torch.cuda.stream(self.stream):
                 for (a, b), layer in zip(self.buckets, order):
@@ -142,10 +167,7 @@ class LayerBucketReducer:
                         self.stream.wait_event(ev)
                     else:
                         self.stream.wait_stream(cur)
-                    works.append(dist.all_reduce(flat_grad[a:b], op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM,
-                                                 group=self.group, async_op=True))
-                for w, (a, b) in zip(works, self.buckets):     # (gloo: scale bucket i while bucket i+1 is still on the wire)
-                    w.wait()
+                    _all_reduce_stream_ordered(flat_grad[a:b], dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, self.group)
                     if not avg:
                         flat_grad[a:b].mul_(1.0 / self.world)
             cur.wait_stream(self.stream)
@@ -179,12 +201,10 @@ class LayerBucketReducer:
                 flat_grad.record_stream(self.stream)           # may be a temporary of the caller: keep it alive for RCCL
                 # RCCL averages inside the collective (ncclAvg): no separate scaling pass over the bucket
                 avg = dist.get_backend(self.group) == "nccl"
-                w = dist.all_reduce(flat_grad[a:b], op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.group,
-                                    async_op=True)
-                w.wait()                                   # stream-ordered, no host block
+                _all_reduce_stream_ordered(flat_grad[a:b], dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, self.group)
                 if not avg:
                     flat_grad[a:b].mul_(1.0 / self.world)
-            self._works.append((w, a, b, flat_grad))
+            self._works.append((None, a, b, flat_grad))
         else:
             dist.all_reduce(flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group)
             flat_grad[a:b].mul_(1.0 / self.world)
@@ -229,6 +249,8 @@ def _comm_lib():
             ("dvgr_comm_world", C.c_int, [C.c_void_p]),
             ("dvgr_comm_allreduce_avg", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
             ("dvgr_comm_join", C.c_int, [C.c_void_p, C.c_void_p]),
+            ("dvgr_comm_allreduce_avg_on", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+            ("dvgr_comm_place", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_float), C.c_int]),
             ("dvgr_comm_device_stream", C.c_int, [C.POINTER(C.c_void_p)]),
         ]
         for name, restype, argtypes in COMM_SYMBOLS:
@@ -249,7 +271,11 @@ class NativeUnitReducer:
     where the launcher put it.  One communicator = one issue order by construction (the backward's program order, the same
     on every rank); it shares nothing with torch's process group, whose collectives (ParamBucketReducer) keep their own."""
 
-    def __init__(self, device: torch.device, group=None, force_single: bool = False):
+    def __init__(self, device: torch.device, group=None, force_single: bool = False, busy_streams: Sequence = (),
+                 place: bool = True):
+        """busy_streams: torch streams, besides the current one, that carry work during a step (the whole model: its
+        question-encoder stream) -- the communication stream is put on a hardware queue that disturbs none of them
+        (`place`: dvgr_comm_place, ~50 ms once; create this object AFTER those streams exist)."""
         import ctypes as C
         from . import _lib as L_
         if device.type != "cuda":
@@ -308,6 +334,21 @@ class NativeUnitReducer:
         with torch.cuda.device(device):     # (before the unit's first call on this device: DVGR_E_ORDER otherwise)
             L_.check(self.lib.dvgr_comm_create(ident, self.rank, self.world, C.byref(h)), "dvgr_comm_create")
         self.handle = h.value
+        self.placement = None
+        if place:
+            self.place(busy_streams)
+
+    def place(self, busy_streams: Sequence = ()) -> dict:
+        """dvgr_comm_place against [the current stream] + busy_streams (+ the library's own side / query stream)."""
+        import ctypes as C
+        from . import _lib as L_
+        ptrs = [torch.cuda.current_stream(self.device).cuda_stream] + [s.cuda_stream for s in busy_streams]
+        arr = (C.c_void_p * len(ptrs))(*[C.c_void_p(p) for p in ptrs])
+        rep = (C.c_float * 64)()
+        with torch.cuda.device(self.device):
+            L_.check(self.lib.dvgr_comm_place(self.handle, arr, len(ptrs), rep, 64), "dvgr_comm_place")
+        self.placement = L_._report(rep)
+        return self.placement
 
     def start(self, num_layers: int = 0) -> None:       # same call shape as LayerBucketReducer
         return None
@@ -511,8 +552,7 @@ class ParamBucketReducer:
             flat = self._flat_of(bi, self.buckets[bi][0].data)
             self._pack(bi, flat)
             avg = dist.get_backend(self.group) == "nccl"
-            w = dist.all_reduce(flat, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.group, async_op=True)
-            w.wait()                                              # stream-ordered
+            _all_reduce_stream_ordered(flat, dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, self.group)
             if not avg:
                 flat.mul_(1.0 / self.world)
             self._unpack(bi, flat)

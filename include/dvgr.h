@@ -40,7 +40,7 @@ extern "C" {
 #define DVGR_E_WORKSPACE (-3) /* saved/workspace buffer too small                       */
 #define DVGR_E_ALIGN (-4)     /* a pointer is not 16-byte aligned                       */
 #define DVGR_E_KIND (-5)      /* unknown parameter / saved-tensor kind                  */
-#define DVGR_E_ORDER (-6)     /* dvgr_comm_create after the unit already ran on this device (include/dvgr_comm.h) */
+#define DVGR_E_ORDER (-6)     /* (rounds 2-3: communicator created after the unit ran; no longer returned -- dvgr_comm_place) */
 
 /* Problem dimensions.  Mirrors the constructor arguments of DualVGRUnit_multiple
  * (model/models.py:87) plus the run-time batch shape of its forward (model/models.py:121-133). */
@@ -130,11 +130,20 @@ typedef struct dvgr_grads {
 
 /* Library version string "dvgr-hip <semver> gfx950". */
 const char *dvgr_version(void);
-/* Creates, for the calling thread's current device, the internal lower-priority side stream the two-stream schedules
- * use (otherwise created by the first forward / backward).  The HIP runtime maps streams onto its hardware queues in
- * creation order and the mapping decides what cross-stream dependencies cost, so a host program that creates streams of
- * its own (copy streams, encoder streams) calls this at a fixed place in that order (see _lib.py: streams()). */
-int dvgr_streams_init(void);
+/* Creates, for the calling thread's current device, the two internal lower-priority streams of the two-stream schedules
+ * (side, query; otherwise created by the first forward / backward) -- each on the hardware queue that disturbs
+ * `caller_stream` (hipStream_t, the stream the unit will be called on; NULL = the null stream) and the streams created before
+ * it least.  Background (csrc/dvgr_place.hip, tools/micro/pipe_probe.hip): the command processor serves a process's hardware
+ * queues on 4 pipes, and two busy queues of ONE pipe cost every dispatch of both ~25 us; which queues share a pipe follows
+ * creation order, so the library measures instead of assuming an order (~5-15 ms per stream, once; synchronises the device).
+ * DVGR_NO_STREAM_PLACEMENT=1 in the environment: plain stream creation. */
+int dvgr_streams_place(void *caller_stream);
+int dvgr_streams_init(void);                    /* = dvgr_streams_place(NULL) */
+/* A stream for the HOST side's own concurrent work (an encoder stream, a loader's copy stream), placed the same way against
+ * `caller_stream` and every stream placed before.  priority_class: -1 high, 0 normal, 1 low; rank: 2 .. 9, lower = more
+ * important when a later stream has to share a pipe with one of them; report (optional): as dvgr_comm_place.  The stream is
+ * never destroyed by the library; wrap it (torch.cuda.ExternalStream). */
+int dvgr_stream_create_placed(int priority_class, int rank, void *caller_stream, void **stream_out, float *report, int report_len);
 
 /* 0 when `d` is supported: B,N,T,L >= 1, 1 <= G <= 4, D % 64 == 0, Wd % 4 == 0, N <= 64, T <= 256. */
 int dvgr_check_dims(const dvgr_dims *d);

@@ -27,17 +27,30 @@ int dvgr_comm_load(const char* librccl_path);
  * channel it has: torch.distributed, MPI, a file). */
 int dvgr_comm_unique_id(void* id_out);
 /* Collective over all ranks: the communicator of `rank` in a job of `world` ranks on the CURRENT device, plus the device's
- * communication stream (highest priority).  Must be called BEFORE the unit's first forward / backward on this device
- * (DVGR_E_ORDER otherwise): the runtime maps streams to hardware queues in creation order, and a communication stream
- * created after the unit's side stream made a data-parallel step 3 x slower (csrc/dvgr_side.h). */
+ * communication stream (highest priority).  Any time before the first collective; follow it with dvgr_comm_place(). */
 int dvgr_comm_create(const void* id, int rank, int world, dvgr_comm** out);
+/* Put the communication stream on a hardware queue that shares no command-processor pipe with the streams that are busy
+ * during a step.  Why: the command processor serves the process's hardware queues on 4 pipes (a queue's pipe = its creation
+ * index mod 4); two non-idle queues of one pipe -- a kernel in flight, or a barrier packet waiting for another queue's signal,
+ * which is what the communication stream does for most of a step -- cost EVERY dispatch of the other ~34 us
+ * (tools/micro/pipe_probe.hip; a whole-model step went from 4.9 to 9.6 ms that way, rounds 2-3 knew it as "stream creation
+ * order matters").  How: up to four candidate streams (consecutive queues = all four pipes) are each held non-idle by a
+ * single-wave kernel for 0.8 ms while a chain of 24 empty dispatches is timed on every busy stream; the candidate that slows
+ * none of them (busy_streams[0] first, then [1] ..., then the library's side and query stream) becomes the communication
+ * stream, the others stay idle (destroying a queue re-maps the rest).  ~15 ms, synchronises the device; call it after every stream the step uses exists and
+ * before the first collective.  busy_streams: hipStream_t's of the CALLER (its compute stream first; NULL = the null stream),
+ * n_busy <= 5.  report (optional, floats): [candidates, busy streams, chosen, collision mask of the chosen one,
+ * undisturbed chain us per busy stream ..., chain us per (candidate, busy stream) ...]. */
+int dvgr_comm_place(dvgr_comm* c, void* const* busy_streams, int n_busy, float* report, int report_len);
 int dvgr_comm_destroy(dvgr_comm* c);
 int dvgr_comm_world(const dvgr_comm* c);
 /* Enqueue, on the communication stream: wait for `wait_event` (hipEvent_t; NULL: for everything `after_stream` holds
  * now), then buf[0 .. count) <- mean over ranks (fp32, in place).  Returns as soon as the work is enqueued. */
 int dvgr_comm_allreduce_avg(dvgr_comm* c, float* buf, int64_t count, void* wait_event, void* after_stream);
-/* The current device's communication stream (hipStream_t), created on first request under the same ordering rule as
- * dvgr_comm_create. */
+/* The same collective enqueued IN ORDER on `stream` (hipStream_t: the stream that produced buf) instead of the communication
+ * stream: no event, no second queue; the collective then does not overlap later work of that stream. */
+int dvgr_comm_allreduce_avg_on(dvgr_comm* c, float* buf, int64_t count, void* stream);
+/* The current device's communication stream (hipStream_t), created on first request. */
 int dvgr_comm_device_stream(void** stream_out);
 /* `stream` continues only after everything enqueued on the communication stream so far. */
 int dvgr_comm_join(dvgr_comm* c, void* stream);

@@ -301,8 +301,7 @@ def test_two_ranks_with_both_reducers_issue_one_order_and_average_exactly():
 
 
 # ---- the native path: all-reduces enqueued by the backward call itself (include/dvgr_comm.h) ----------------------------
-# The communicator must exist before the unit's first call on the device (DVGR_E_ORDER otherwise), and this pytest process
-# has long run the unit by now: each native test body runs in a fresh child process.
+# Each native test body runs in a fresh child process (a process has ONE communication stream per device, placed once).
 def _native_child(which, q):
     import time
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -310,6 +309,20 @@ def _native_child(which, q):
     # constructor) is what keeps the step fast (parallel.NativeUnitReducer)
     dist.init_process_group("nccl", init_method=_rendezvous(), rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
+        if which == "late":
+            # everything the rounds 2-3 rule forbade: the unit has run (side + query stream exist), two more streams carry
+            # work (six hardware queues on the command processor's four pipes), THEN the communicator is created --
+            # dvgr_comm_place must find it a queue that disturbs neither the caller's stream nor the side stream
+            m, t = _module()
+            m.reuse_buffers = True
+            extra = [torch.cuda.Stream(), torch.cuda.Stream()]
+            for s_ in extra:
+                with torch.cuda.stream(s_):
+                    torch.zeros(64, device="cuda").add_(1.0)
+            for _ in range(3):
+                m.zero_grad_flat()
+                _step(m, t)
+            torch.cuda.synchronize()
         red = parallel.NativeUnitReducer(torch.device("cuda", 0))
         assert red.world == 1 and red.handle and red.warmed
         if which == "correct":
@@ -336,16 +349,15 @@ def _native_child(which, q):
             red.reduce(buf)
             torch.cuda.synchronize()
             assert torch.equal(buf, want)
-            # a second communicator now -- after the unit has run -- is refused instead of silently costing 3 x
-            try:
-                parallel.NativeUnitReducer(torch.device("cuda", 0)).close()
-                late = "accepted"                                  # (same device stream exists already: allowed)
-            except RuntimeError as e:
-                late = str(e)
-            q.put(("ok", late))
+            # a second communicator of the process shares the device's (already placed) communication stream
+            second = parallel.NativeUnitReducer(torch.device("cuda", 0))
+            assert second.placement["candidates"] == 0
+            second.close()
+            q.put(("ok", red.placement))
         else:
-            m, t = _module()
-            m.reuse_buffers = True
+            if which != "late":
+                m, t = _module()
+                m.reuse_buffers = True
 
             def run(reducer, steps=60):
                 def one():
@@ -365,7 +377,7 @@ def _native_child(which, q):
             plain = run(None)
             m.set_comm(red)
             with_native = run(red)
-            q.put(("ok", plain, with_native))
+            q.put(("ok", plain, with_native, red.placement))
         red.close()
     except BaseException as e:
         q.put(("error", repr(e)))
@@ -402,23 +414,22 @@ def test_native_reducer_costs_the_step_little():
     work is five enqueues inside the backward call (measured 1.05 x).  The failure this test guards against is the 3 x slow
     set-up of DESIGN.md section 5 (stream creation / RCCL set-up order), so the gate sits at 1.5 x; the measured overhead is
     printed and bench.py reports it."""
-    _, plain, with_native = _run_native("speed")
+    _, plain, with_native, _ = _run_native("speed")
     print(f"  plain {plain * 1e3:.3f} ms, with the native reducer {with_native * 1e3:.3f} ms per step")
     assert with_native < 1.5 * plain, (plain, with_native)
 
 
-def test_a_communicator_created_after_the_unit_ran_is_refused():
-    """This process has run the unit (side stream exists, no communication stream): DVGR_E_ORDER, not a 3 x slower step."""
-    m, t = _module(train=False)
-    m.zero_grad_flat()
-    _step(m, t)
-    torch.cuda.synchronize()
-    dist.init_process_group("gloo", init_method=_rendezvous(), rank=0, world_size=1)
-    try:
-        with pytest.raises(RuntimeError, match="DVGR_E_ORDER"):
-            parallel.NativeUnitReducer(torch.device("cuda", 0))
-    finally:
-        dist.destroy_process_group()
+@pytest.mark.timeout(400)
+def test_a_communicator_created_late_is_placed_on_a_free_pipe():
+    """Rounds 2-3 refused a communicator created after the unit had run (DVGR_E_ORDER: "3 x slower, not understood").  Round 4
+    found the mechanism (two non-idle hardware queues on one command-processor pipe, tools/micro/pipe_probe.hip) and
+    dvgr_comm_place picks the communication stream's queue by measurement: created LAST, behind the unit's streams and two
+    more busy streams, the step with the reducer stays within the same gate as the early one."""
+    _, plain, with_native, placement = _run_native("late")
+    print(f"  plain {plain * 1e3:.3f} ms, with the native reducer created late {with_native * 1e3:.3f} ms per step; {placement}")
+    assert placement["candidates"] >= 2 and placement["measured_against"] >= 3
+    assert placement["collisions_of_chosen"] < 2 ** (placement["measured_against"] - 1), placement    # the caller's stream is undisturbed
+    assert with_native < 1.5 * plain, (plain, with_native)
 
 
 @pytest.mark.timeout(600)

@@ -30,7 +30,77 @@ qlen[0] = T
 q = torch.from_numpy((2 + (synth.uniform("b_q", (B, T), 0.0, 1.0, 666) * (VQ - 2)).astype(np.int64)).clip(2, VQ - 1)).to(dev)
 q = q * (torch.arange(T, device=dev)[None, :] < qlen[:, None])
 answers = torch.from_numpy((synth.uniform("b_ans", (B,), 0.0, float(VA), 666)).astype(np.int64)).to(dev)
-ts = dv.TrainStep(m, lr=1e-4, alpha=1.0, beta=1e-8, max_norm=12.0)
+unit_red = param_red = None
+_pads = []
+for spec in [x for x in os.environ.get("MHP_PAD", "").split(",") if x]:      # e.g. "h2,n1": throwaway streams of a priority, each
+    pr = {"h": -1, "n": 0, "l": 1}[spec[0]]                                   # used once, created BEFORE the reducer's streams
+    for _ in range(int(spec[1:])):                                            # (shifts which hardware queue / pipe the later ones get)
+        s_ = torch.cuda.Stream(device=dev, priority=pr)
+        with torch.cuda.stream(s_):
+            torch.zeros(8, device=dev).add_(1.0)
+        _pads.append(s_)
+torch.cuda.synchronize()
+MHP = os.environ.get("MHP_NATIVE", "0")               # 1 = both reducers, unit = only the unit's in-call communicator, param = only
+if MHP in ("1", "unit", "param", "dry", "inorder", "pgonly", "commonly", "gloo"):               # the encoders' / head's collectives, dry = those as event edges without RCCL      # the native reducers on ONE rank (bench.py's DVGR_DDP_SELFTEST set-up)
+    import torch.distributed as dist
+    from dualvgr_videoqa_amd import parallel
+    from dualvgr_videoqa_amd.clip import BiLSTM
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1,
+                            pg_options=dist.ProcessGroupNCCL.Options(is_high_priority_stream=os.environ.get("MHP_PG_HIGH", "1") == "1"))
+    if MHP == "pgonly":                 # torch's NCCL group initialised and used once, nothing else
+        w_ = torch.zeros(8, device=dev)
+        dist.all_reduce(w_)
+        torch.cuda.synchronize()
+    do_place = os.environ.get("MHP_PLACE", "1") == "1"
+    if MHP != "pgonly":
+        unit_red = parallel.NativeUnitReducer(dev, force_single=True, place=do_place,
+                                              busy_streams=[L_.streams(dev)["encoder"]] if do_place else ())
+        print("placement:", unit_red.placement)
+    if MHP in ("1", "unit"):
+        m.visual_input_unit.set_comm(unit_red)
+    flat_mods = [m._head] + [x for x in m.modules() if isinstance(x, BiLSTM)]
+    unit_ids = {id(p) for p in m.visual_input_unit.parameters()}
+    if MHP in ("1", "param", "dry", "inorder"):
+        param_red = parallel.NativeParamReducer(unit_red, flat_mods, [p for p in m.parameters() if id(p) not in unit_ids])
+    if MHP == "inorder":
+        def inorder(t):
+            cur = torch.cuda.current_stream(dev).cuda_stream
+            L_.check(unit_red.lib.dvgr_comm_allreduce_avg_on(unit_red.handle, t.data_ptr(), t.numel(), cur), "allreduce_on")
+            param_red.count += 1
+        param_red._enqueue = inorder
+        param_red.native = type("NoJoin", (), {"finish": staticmethod(lambda: None)})()
+    if MHP == "dry":
+        import ctypes as C_
+        h_ = C_.c_void_p()
+        L_.check(unit_red.lib.dvgr_comm_device_stream(C_.byref(h_)), "stream")
+        cs_ = torch.cuda.ExternalStream(h_.value, device=dev)
+
+        DRY = os.environ.get("MHP_DRY", "both")        # both | waits (nobody waits for the stream) | join (it waits for nothing) | torch
+        if DRY == "torch":                              # (an ordinary torch stream in the communication stream's role)
+            cs_ = torch.cuda.Stream(device=dev)
+
+        def dry(t):
+            if DRY != "join":
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
+                cs_.wait_event(ev)
+            param_red.count += 1
+        param_red._enqueue = dry
+
+        def dry_finish():
+            if DRY != "waits":
+                ev = torch.cuda.Event()
+                ev.record(cs_)
+                torch.cuda.current_stream(dev).wait_event(ev)
+        param_red.native = type("DryJoin", (), {"finish": staticmethod(dry_finish)})()
+m.overlap_encoders = os.environ.get("DVGR_NO_ENCODER_OVERLAP", "0") != "1"
+ts = dv.TrainStep(m, lr=1e-4, alpha=1.0, beta=1e-8, max_norm=12.0, unit_reducer=unit_red if MHP in ("1", "unit") else None,
+                  param_reducer=param_red)
+if MHP in ("param", "dry", "inorder"):
+    _pf = param_red.finish
+    param_red.finish = lambda: _pf()      # (its finish() joins the communication stream by itself)
 
 acc = collections.defaultdict(float)
 cnt = collections.defaultdict(int)
@@ -59,6 +129,13 @@ def wrap(lib):
 
 def step():
     ts(app, mot, q, qlen, answers)
+
+
+if param_red is not None:                                # the reducers' Python entry points, timed like the C ones
+    param_red._enqueue = Timed(param_red._enqueue, "py:NativeParamReducer._enqueue")
+    param_red.finish = Timed(param_red.finish, "py:NativeParamReducer.finish")
+_bw = torch.autograd.backward
+torch.autograd.backward = Timed(_bw, "py:torch.autograd.backward (whole)")
 
 
 for _ in range(8):
