@@ -12,12 +12,13 @@ before it makes any GPU call -- launches exactly that torchrun command as a chil
 whose world size differs from --gpus fails; it never silently measures fewer GPUs.
 
 Which gradient reducer runs the timed region (--reducer auto) is settled BEFORE this process touches the GPU: every rank
-starts three short child processes, one after the other -- the plain step (no collectives), the step with ONLY the native
-reducer set up, the step with ONLY the torch.distributed reducer set up -- each child of a rank meeting the same child of
-the other ranks in a process group of its own.  (Both reducers in one process slow each other down 3 x, and the native
-path's speed depends on the order in which streams and RCCL are set up: DESIGN.md section 5.)  The timed process then sets
-up the winner alone.  If neither candidate stays within 1.3 x (one rank) / 2.5 x (several ranks: real all-reduces) of the
-plain step, the run exits non-zero instead of printing a line that measures a broken set-up.
+starts four short child processes, one after the other -- the plain step (no collectives), the step with ONLY the native
+reducer on its communication stream, ONLY the native reducer in order on the producers' streams, ONLY the torch.distributed
+reducer -- each child of a rank meeting the same child of the other ranks in a process group of its own.  (Which form is
+fastest depends on the node: the communication stream overlaps everything but is one more hardware queue, the in-order
+form needs none but delays the side stream)  The timed process then sets up the winner alone.  If no
+candidate stays within 1.3 x (one rank) / 2.5 x (several ranks: real all-reduces) of the plain step, the run exits
+non-zero instead of printing a line that measures a broken set-up.
 
 Timing: W untimed warm-up steps, then blocks of EXACTLY K steps, each bracketed by barrier + device synchronise on both
 sides and MAX-reduced over ranks; blocks repeat until >= 5 s has been timed and the line reports the MEDIAN block
@@ -189,7 +190,8 @@ def spawn_ranks(n):
     return 0
 
 
-TRIAL_KINDS = ("plain", "native", "python")
+TRIAL_KINDS = ("plain", "native", "inorder", "python")
+REDUCER_KINDS = ("native", "inorder", "python")     # native: the library's communicator on its own stream; inorder: on the producers' streams
 SLOW_FACTOR_ONE_RANK, SLOW_FACTOR_RANKS = 1.3, 2.5
 
 
@@ -201,7 +203,7 @@ def run_trial_children(args):
     out = {}
     argv = [a for a in sys.argv[1:]]
     for idx, kind in enumerate(TRIAL_KINDS):
-        if kind == "native" and args.backend != "nccl":
+        if kind in ("native", "inorder") and args.backend != "nccl":
             out[kind] = None
             continue
         env = dict(os.environ)
@@ -320,7 +322,7 @@ def main():
                     help="with --model, A/B timing: swap tools/stock_encoders.py's nn.LSTM question encoder in")
     ap.add_argument("--appearance-encoder", default="hip", choices=["hip", "miopen"],
                     help="with --model, A/B timing: swap tools/stock_encoders.py's nn.LSTM appearance encoder in")
-    ap.add_argument("--reducer", default="auto", choices=["auto", "native", "python"],
+    ap.add_argument("--reducer", default="auto", choices=["auto", "native", "inorder", "python"],
                     help="gradient all-reduce of the unit under --gpus N: native = enqueued by the backward call itself over the "
                          "library's own RCCL communicator (include/dvgr_comm.h); python = parallel.LayerBucketReducer over "
                          "torch.distributed (host callback + issuer thread); auto = both are set up, a few untimed steps of each "
@@ -398,7 +400,7 @@ def main():
     cfg = CONFIGS[args.config]
     B, N, Lr, T = cfg["B"], cfg["N"], cfg["L"], cfg["T"]
     # ---- which reducer: the children's verdict (identical on every rank after the agreement below), or the command line
-    choice = args.trial if args.trial in ("native", "python") else (args.reducer if args.reducer != "auto" else None)
+    choice = args.trial if args.trial in REDUCER_KINDS else (args.reducer if args.reducer != "auto" else None)
     trial_report = None
     if ddp and trials is not None:
         ms = {k: (trials[k]["ms"] if trials.get(k) else float("inf")) for k in TRIAL_KINDS}
@@ -406,10 +408,10 @@ def main():
             tt = torch.tensor([min(ms[k], 1e9) for k in TRIAL_KINDS], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             ms = {k: (float(v) if float(v) < 1e9 else float("inf")) for k, v in zip(TRIAL_KINDS, tt.tolist())}
-        cands = {k: ms[k] for k in ("native", "python") if ms[k] != float("inf")}
+        cands = {k: ms[k] for k in REDUCER_KINDS if ms[k] != float("inf")}
         trial_report = {"ms_per_step": {k: (None if v == float("inf") else v) for k, v in ms.items()},
                         "how": "one child process per candidate and rank, before the timed process touched the GPU (MAX over ranks)",
-                        "rccl": {k: trials[k].get("rccl") for k in ("native", "python") if trials.get(k)}}
+                        "rccl": {k: trials[k].get("rccl") for k in REDUCER_KINDS if trials.get(k)}}
         if not cands:
             raise SystemExit("bench.py: neither gradient reducer could be set up in its trial process; no measurement")
         choice = min(cands, key=cands.get)
@@ -424,7 +426,7 @@ def main():
         print(f"[bench] reducer trials ms/step {ms} -> {choice}", file=sys.stderr, flush=True)
     elif ddp and choice is None:
         choice = "native" if args.backend == "nccl" else "python"
-    if ddp and choice == "native" and args.backend != "nccl":
+    if ddp and choice in ("native", "inorder") and args.backend != "nccl":
         choice = "python"
 
     if args.model:
@@ -471,12 +473,14 @@ def main():
     reducer = None
     reducer_kind = None
     if ddp:
-        if choice == "native":
+        if choice in ("native", "inorder"):
             try:
-                red = parallel.NativeUnitReducer(dev, force_single=(world == 1))
+                red = parallel.NativeUnitReducer(dev, force_single=(world == 1), inorder=(choice == "inorder"))
                 m.set_comm(red)               # every backward call enqueues its blocks' all-reduces itself (dvgr_opts.comm)
                 reducer = red
-                reducer_kind = "native: RCCL all-reduce per gradient block enqueued inside dvgr_unit_backward (dvgr_opts.comm)"
+                reducer_kind = (f"{choice}: RCCL all-reduce per gradient block enqueued inside dvgr_unit_backward (dvgr_opts.comm), " +
+                                ("on the stream that produced the block (in order)" if choice == "inorder"
+                                 else "on the library's communication stream"))
             except Exception as e:            # raised on EVERY rank together (parallel.NativeUnitReducer agrees before it raises)
                 print(f"[bench] native reducer unavailable ({e!r}); using the torch.distributed reducer", file=sys.stderr, flush=True)
                 choice = "python"
@@ -692,21 +696,24 @@ def bench_model(args, dev, rank, world, cfg, ddp, dist_info, choice=None, trial_
     if os.environ.get("DVGR_STREAMS_EARLY", "0") == "1":      # tools/stream_order_probe.sh: the package's streams (DVGR_STREAM_ORDER,
         from dualvgr_videoqa_amd import _lib as L_            # 'comm' included) before any reducer exists
         L_.streams(dev)
-    if ddp and choice == "native":
+    if ddp and choice in ("native", "inorder"):
         # every gradient of the model on the library's own RCCL communicator: the unit's blocks enqueued by its backward call
         # (dvgr_opts.comm), the flat gradient buffers of the four BiLSTMs and of the answer head by theirs (grad_sink), the
         # embedding table and the motion projection from their accumulate hooks -- one issue order, no interpreter thread
         try:
             from dualvgr_videoqa_amd.clip import BiLSTM
             from dualvgr_videoqa_amd import _lib as L_
-            unit_red = parallel.NativeUnitReducer(dev, force_single=(world == 1), busy_streams=[L_.streams(dev)["encoder"]])
+            unit_red = parallel.NativeUnitReducer(dev, force_single=(world == 1), busy_streams=[L_.streams(dev)["encoder"]],
+                                                  inorder=(choice == "inorder"))
             unit.set_comm(unit_red)
             flat_mods = [m._head] + [x for x in m.modules() if isinstance(x, BiLSTM)]
             unit_ids = {id(p) for p in unit.parameters()}
             rest = [p for p in m.parameters() if id(p) not in unit_ids]
             param_red = parallel.NativeParamReducer(unit_red, flat_mods, rest)
-            reducer_kind = ("native: one RCCL communicator of the library's own; unit blocks enqueued inside dvgr_unit_backward, "
-                            f"{len(flat_mods)} flat module buffers + {len(param_red.params)} tensors from their backward calls / hooks")
+            reducer_kind = (f"{choice}: one RCCL communicator of the library's own; unit blocks enqueued inside dvgr_unit_backward, "
+                            f"{len(flat_mods)} flat module buffers + {len(param_red.params)} tensors from their backward calls / hooks; " +
+                            ("each collective on the stream that produced its buffer (in order)" if choice == "inorder"
+                             else "all on the library's communication stream"))
         except Exception as e:
             print(f"[bench] native reducers unavailable ({e!r}); using the torch.distributed reducers", file=sys.stderr, flush=True)
             unit_red = param_red = None

@@ -790,7 +790,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     if (O.comm) {                            // the block's all-reduce enters the communication stream right here
       int64_t first = 0, last = 0;
       DVGR_TRY(dvgr_param_layer_range(dp, index, &first, &last));
-      DVGR_TRY(dvgr_comm_allreduce_avg((dvgr_comm*)O.comm, gp + first, last - first, (void*)ev, nullptr));
+      DVGR_TRY(dvgr_comm_allreduce_avg((dvgr_comm*)O.comm, gp + first, last - first, (void*)ev, (void*)on));
     }
     if (O.layer_done_cb && layer_done_events && layer_done_events[index]) O.layer_done_cb(index, O.layer_done_user);
     return 0;

@@ -37,6 +37,7 @@ struct dvgr_comm {
   int used = 0;
   int world = 1;
   int device = 0;
+  int inorder = 0;                 // dvgr_comm_set_inorder: collectives go onto the stream that produced the buffer
   hipEvent_t next() {
     if (used >= 64) used = 0;
     if (!ev[used] && hipEventCreateWithFlags(&ev[used], hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) return nullptr;
@@ -132,9 +133,17 @@ int dvgr_comm_destroy(dvgr_comm* c) {
 
 int dvgr_comm_world(const dvgr_comm* c) { return c ? c->world : 0; }
 
+int dvgr_comm_set_inorder(dvgr_comm* c, int on) {
+  if (!c) return DVGR_E_NULL;
+  c->inorder = on ? 1 : 0;
+  return 0;
+}
+
 int dvgr_comm_allreduce_avg(dvgr_comm* c, float* buf, int64_t count, void* wait_event, void* after_stream) {
   if (!c || !buf) return DVGR_E_NULL;
   if (count <= 0) return 0;
+  if (c->inorder)                            // (after_stream = the producing stream: whatever `wait_event` marks is already in its order)
+    return nccl_rc(api.AllReduce(buf, buf, (size_t)count, ncclFloat32, ncclAvg, c->comm, (hipStream_t)after_stream));
   hipError_t e = hipSuccess;
   if (wait_event) {
     e = hipStreamWaitEvent(c->stream, (hipEvent_t)wait_event, 0);
@@ -166,6 +175,7 @@ int dvgr_comm_device_stream(void** stream_out) {
 
 int dvgr_comm_join(dvgr_comm* c, void* stream) {
   if (!c) return DVGR_E_NULL;
+  if (c->inorder) return 0;                  // every collective sits in its producer's stream order already
   hipEvent_t ev = c->next();
   if (!ev) return (int)hipErrorOutOfMemory;
   hipError_t e = hipEventRecord(ev, c->stream);

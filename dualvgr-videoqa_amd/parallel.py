@@ -251,6 +251,7 @@ def _comm_lib():
             ("dvgr_comm_join", C.c_int, [C.c_void_p, C.c_void_p]),
             ("dvgr_comm_allreduce_avg_on", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
             ("dvgr_comm_place", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_float), C.c_int]),
+            ("dvgr_comm_set_inorder", C.c_int, [C.c_void_p, C.c_int]),
             ("dvgr_comm_device_stream", C.c_int, [C.POINTER(C.c_void_p)]),
         ]
         for name, restype, argtypes in COMM_SYMBOLS:
@@ -272,8 +273,10 @@ class NativeUnitReducer:
     on every rank); it shares nothing with torch's process group, whose collectives (ParamBucketReducer) keep their own."""
 
     def __init__(self, device: torch.device, group=None, force_single: bool = False, busy_streams: Sequence = (),
-                 place: bool = True):
-        """busy_streams: torch streams, besides the current one, that carry work during a step (the whole model: its
+                 place: bool = True, inorder: bool = False):
+        """inorder: every collective goes onto the stream that produced its buffer (dvgr_comm_set_inorder: no communication
+        stream, no cross-stream event; it delays that stream's later work instead of overlapping it).
+        busy_streams: torch streams, besides the current one, that carry work during a step (the whole model: its
         question-encoder stream) -- the communication stream is put on a hardware queue that disturbs none of them
         (`place`: dvgr_comm_place, ~50 ms once; create this object AFTER those streams exist)."""
         import ctypes as C
@@ -335,7 +338,10 @@ class NativeUnitReducer:
             L_.check(self.lib.dvgr_comm_create(ident, self.rank, self.world, C.byref(h)), "dvgr_comm_create")
         self.handle = h.value
         self.placement = None
-        if place:
+        self.inorder = bool(inorder)
+        if self.inorder:
+            L_.check(self.lib.dvgr_comm_set_inorder(self.handle, 1), "dvgr_comm_set_inorder")
+        elif place:
             self.place(busy_streams)
 
     def place(self, busy_streams: Sequence = ()) -> dict:

@@ -45,8 +45,15 @@ int dvgr_comm_place(dvgr_comm* c, void* const* busy_streams, int n_busy, float* 
 int dvgr_comm_destroy(dvgr_comm* c);
 int dvgr_comm_world(const dvgr_comm* c);
 /* Enqueue, on the communication stream: wait for `wait_event` (hipEvent_t; NULL: for everything `after_stream` holds
- * now), then buf[0 .. count) <- mean over ranks (fp32, in place).  Returns as soon as the work is enqueued. */
+ * now), then buf[0 .. count) <- mean over ranks (fp32, in place).  Returns as soon as the work is enqueued.  The library's
+ * backward passes both: the event that marks the block final and the stream it was recorded on. */
 int dvgr_comm_allreduce_avg(dvgr_comm* c, float* buf, int64_t count, void* wait_event, void* after_stream);
+/* In-order mode (on != 0): dvgr_comm_allreduce_avg enqueues on `after_stream` itself (which must then be the stream that
+ * produced buf; `wait_event` is ignored) and dvgr_comm_join does nothing -- no communication stream, no cross-stream event.
+ * The collective then delays the later work of its producer stream (the unit's side stream for the layer blocks) but still
+ * overlaps the other streams.  On one rank, where a collective is a copy kernel, this is the cheaper form (whole model
+ * 1.01 x the plain step against 1.16 x); with several ranks bench.py times both and takes the faster. */
+int dvgr_comm_set_inorder(dvgr_comm* c, int on);
 /* The same collective enqueued IN ORDER on `stream` (hipStream_t: the stream that produced buf) instead of the communication
  * stream: no event, no second queue; the collective then does not overlap later work of that stream. */
 int dvgr_comm_allreduce_avg_on(dvgr_comm* c, float* buf, int64_t count, void* stream);

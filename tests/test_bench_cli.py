@@ -41,11 +41,11 @@ def test_world_size_mismatch_is_refused():
 def test_reducer_trials_run_as_child_processes_before_the_timed_process():
     """--reducer auto under a data-parallel launch (here: the one-rank self-test): every candidate is tried in a child
     process of its own BEFORE the timed process touches the GPU.  Without a GPU each child stops at "needs a ROCm GPU"; the
-    parent must have started all three (plain / native / python), survive their failure, and then fail loudly itself --
+    parent must have started all of them (plain / native / inorder / python), survive their failure, and then fail loudly itself --
     never print a result line."""
     r = _run(["--steps", "1", "--warmup", "0", "--no-cpu-baseline"], {"DVGR_DDP_SELFTEST": "1", "MASTER_PORT": "29711"}, timeout=500)
     assert r.returncode != 0
-    for kind in ("plain", "native", "python"):
+    for kind in ("plain", "native", "inorder", "python"):
         assert f"trial child '{kind}'" in r.stderr, r.stderr[-2000:]
     assert '"metric"' not in r.stdout
     # an explicit --reducer starts no children

@@ -323,9 +323,29 @@ def _native_child(which, q):
                 m.zero_grad_flat()
                 _step(m, t)
             torch.cuda.synchronize()
-        red = parallel.NativeUnitReducer(torch.device("cuda", 0))
+        red = parallel.NativeUnitReducer(torch.device("cuda", 0), inorder=which.startswith("inorder"))
         assert red.world == 1 and red.handle and red.warmed
-        if which == "correct":
+        if which == "inorder_correct":
+            # the in-order form: each block's collective on the stream that produced it, no communication stream, finish() a no-op
+            m, t = _module(train=False)
+            m.zero_grad_flat()
+            _step(m, t)
+            torch.cuda.synchronize()
+            want = m.last_flat_grad.clone()
+            m.set_comm(red)
+            for rep in range(4):
+                m.zero_grad_flat()
+                _step(m, t)
+                red.finish()
+                torch.cuda.synchronize()
+                assert float((m.last_flat_grad - want).abs().max()) <= 2e-6 * float(want.abs().max()), rep
+            m.set_comm(None)
+            buf = want.clone()
+            red.reduce(buf)
+            torch.cuda.synchronize()
+            assert torch.equal(buf, want) and red.placement is None
+            q.put(("ok", None))
+        elif which == "correct":
             m, t = _module(train=False)
             m.zero_grad_flat()
             _step(m, t)
@@ -408,6 +428,16 @@ def test_native_reducer_averages_every_block_inside_the_backward_call():
 
 
 @pytest.mark.timeout(400)
+def test_native_reducer_in_order_on_the_producing_streams():
+    """dvgr_comm_set_inorder: the same gradients, each block's collective enqueued on the stream that wrote the block (the
+    side stream for the layer blocks, the caller's for the query block); and the step costs no more than the other form."""
+    _run_native("inorder_correct")
+    _, plain, with_native, _ = _run_native("inorder_speed")
+    print(f"  plain {plain * 1e3:.3f} ms, with the native reducer in order {with_native * 1e3:.3f} ms per step")
+    assert with_native < 1.5 * plain, (plain, with_native)
+
+
+@pytest.mark.timeout(400)
 def test_native_reducer_costs_the_step_little():
     """Verdict of round 2: the data-parallel plumbing cost one rank 16 % (host callbacks into the interpreter, a helper
     thread beside the launch path, the query stream given up).  The native path keeps the query stream and its only host
@@ -484,7 +514,7 @@ def test_bench_selftest_picks_its_reducer_from_child_trials():
     dist_cfg = d["config"]["distributed"]
     trial = dist_cfg["reducer_trial"]["ms_per_step"]
     print("  trials", trial, "->", dist_cfg["reducer"][:40], "timed", d["ms_per_step"])
-    assert trial["plain"] and (trial["native"] or trial["python"])
+    assert trial["plain"] and (trial["native"] or trial["inorder"] or trial["python"])
     cands = {k: v for k, v in trial.items() if k != "plain" and v}
     best = min(cands, key=cands.get)
     assert dist_cfg["reducer"].startswith(best)
