@@ -54,6 +54,7 @@ def main():
         rows.append((n, launches, fk, wk, (2 * fk + wk) * 1024))
     rows.sort(key=lambda r: -r[4] * r[1])
     # the optimiser's two launches run AFTER the timed steps (bench.py reports them as optimizer_ms): not part of a step
+    rows = [r for r in rows if "k_place_" not in r[0]]          # (the one-off stream-placement probe of the set-up: not a step's traffic)
     total = sum(r[4] * r[1] for r in rows if "k_optim" not in r[0])
     lines = [f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), {config} {dtype}, build {bench.build_id()}",
              "# per launch: bytes = 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE; per step = x launches per step",
