@@ -219,7 +219,7 @@ def run_trial_children(args):
         cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--trial", kind]
         t0 = time.perf_counter()
         try:
-            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
+            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
             line = next((l for l in r.stdout.splitlines() if l.startswith("{") and '"trial"' in l), None)
             out[kind] = json.loads(line) if (r.returncode == 0 and line) else None
             if out[kind] is None:

@@ -137,10 +137,12 @@ hipStream_t place_stream(int dev, int priority, hipStream_t caller, int rank, hi
   // The losing candidates are NOT destroyed: the runtime destroys a hardware queue with its last stream, the driver then
   // rebuilds the process's run list, and the pipe of every later queue -- the one just measured included -- moves (measured:
   // with the losers destroyed the plain C2 step went from 1.0 to 2.4 ms).  An idle stream costs nothing.
+#ifdef DVGR_TIMING_AIDS
   if (const char* f = getenv("DVGR_PLACE_FORCE")) {          // probe: "<side><query><comm><host>" digits, e.g. 0000 = always candidate 0
     const int slot = rank == kRankSide ? 0 : rank == kRankQuery ? 1 : rank == kRankComm ? 2 : 3;
     if ((int)strlen(f) > slot && f[slot] >= '0' && f[slot] < '0' + nc) best = f[slot] - '0';
   }
+#endif
   R.nc = nc; R.nb = nb; R.chosen = best; R.mask = e == hipSuccess ? best_key : -1;
   if (getenv("DVGR_PLACE_LOG")) {
     fprintf(stderr, "[dvgr place] rank %d: %d candidates against %d streams, chosen %d, mask %ld; base", rank, nc, nb, best, best_key);
