@@ -77,10 +77,9 @@ class CollectiveIssuer:
         import queue
         import threading
         self.device = device
-        # high priority: the runtime gives such a stream a hardware queue of its own; a normal-priority one was seen
-        # sharing the caller's queue, where its event waits sit in front of the backward's later launches.  (Borrowing the
-        # library's communication stream instead -- one stream fewer -- measured 3.3 ms per step against 1.25: the runtime's
-        # stream-to-queue mapping is sensitive to creation order, csrc/dvgr_side.h.)
+        # high priority, on a hardware queue that shares no command-processor pipe with the caller's stream and the package's
+        # other streams (csrc/dvgr_place.hip; an unplaced torch stream here cost the step 2.4 x once the package's streams
+        # were placed around it)
         self.stream = _placed_stream(device, priority_class=-1, rank=8)
         self.q = queue.Queue()
         self.errors = []
@@ -291,23 +290,18 @@ class NativeUnitReducer:
             self.rank, self.world = 0, 1
         else:
             raise RuntimeError("torch.distributed is not initialised (it carries the RCCL unique id to the ranks)")
-        # MEASURED, not understood (tools/native_order_probe.py, one rank, C2): the step with this reducer takes 1.10 ms when
-        # torch's own NCCL process group was initialised eagerly (init_process_group(..., device_id=...)) and has run a
-        # collective BEFORE this communicator is created, and 3.3 ms -- for every later step of the process, plain ones
-        # included in some orders -- when it has not (gloo rendezvous, lazily initialised NCCL group, or no collective yet).
-        # So: run that collective here.  Callers should still compare a few steps with and without the reducer (bench.py
-        # does, and falls back to LayerBucketReducer); a process whose default group is not NCCL gets a warning.
+        # Rounds 2-3 measured this reducer at 3.3 ms per step instead of 1.1 unless torch's NCCL group had run a collective
+        # first.  Round 4 found why (csrc/dvgr_place.hip): the group's streams get their hardware queues at their first use,
+        # and queues created AFTER the communication stream was placed can land on a busy stream's pipe.  So the group runs
+        # one collective here, before the communicator and its stream exist, and place() measures against everything.
         if dist.is_initialized() and dist.get_backend(group) == "nccl":
             warm = torch.zeros(8, device=device, dtype=torch.float32)
             dist.all_reduce(warm, group=group)
             torch.cuda.synchronize(device)
             self.warmed = True
         else:
-            self.warmed = False
-            import warnings
-            warnings.warn("NativeUnitReducer without an eagerly initialised NCCL default group: steps with it measured 3 x "
-                          "slower in that set-up (see parallel.py); time a few steps before trusting it")
-        # Everything that can fail on ONE rank only -- resolving RCCL (done above), the stream-order rule (DVGR_E_ORDER), the
+            self.warmed = False                      # (gloo rendezvous / single process: no other RCCL streams to come)
+        # Everything that can fail on ONE rank only -- resolving RCCL (done above), creating the communication stream, the
         # unique id on rank 0 -- happens BEFORE the first collective of the set-up, and the ranks agree on the outcome (MAX of
         # a failure flag) so that they raise together: a rank that failed alone would leave its peers blocked in the id
         # broadcast or in ncclCommInitRank while it moves on to a different collective.
@@ -316,7 +310,7 @@ class NativeUnitReducer:
         try:
             s_ = C.c_void_p()
             with torch.cuda.device(device):
-                L_.check(self.lib.dvgr_comm_device_stream(C.byref(s_)), "dvgr_comm_device_stream")   # order rule; creates the stream
+                L_.check(self.lib.dvgr_comm_device_stream(C.byref(s_)), "dvgr_comm_device_stream")   # creates the stream
             if self.rank == 0:
                 L_.check(self.lib.dvgr_comm_unique_id(ident), "dvgr_comm_unique_id")
         except Exception as e:                       # noqa: BLE001 -- reported on every rank below
@@ -334,7 +328,7 @@ class NativeUnitReducer:
             dist.broadcast_object_list(box, src=0, group=group)
             ident = C.create_string_buffer(box[0], 128)
         h = C.c_void_p()
-        with torch.cuda.device(device):     # (before the unit's first call on this device: DVGR_E_ORDER otherwise)
+        with torch.cuda.device(device):
             L_.check(self.lib.dvgr_comm_create(ident, self.rank, self.world, C.byref(h)), "dvgr_comm_create")
         self.handle = h.value
         self.placement = None
