@@ -455,6 +455,8 @@ def test_a_communicator_created_late_is_placed_on_a_free_pipe():
     found the mechanism (two non-idle hardware queues on one command-processor pipe, tools/micro/pipe_probe.hip) and
     dvgr_comm_place picks the communication stream's queue by measurement: created LAST, behind the unit's streams and two
     more busy streams, the step with the reducer stays within the same gate as the early one."""
+    if os.environ.get("DVGR_NO_STREAM_PLACEMENT", "0") == "1":
+        pytest.skip("stream placement switched off in the environment")
     _, plain, with_native, placement = _run_native("late")
     print(f"  plain {plain * 1e3:.3f} ms, with the native reducer created late {with_native * 1e3:.3f} ms per step; {placement}")
     assert placement["candidates"] >= 2 and placement["measured_against"] >= 3
