@@ -16,8 +16,10 @@
  *   - functions return 0 on success, a negative DVGR_E_* code for invalid arguments, or the
  *     positive hipError_t value of a failed launch;
  *   - calls are re-entrant and thread-safe (autograd calls backward from its own thread).  The library keeps exactly
- *     one piece of process-wide state: per device, one internal lower-priority side stream (created on first use or by
- *     dvgr_streams_init, shared by all threads, never destroyed) plus a per-thread pool of fork / join events on it.
+ *     one piece of process-wide state: per device, its internal lower-priority side / query streams (created on first use
+ *     or by dvgr_streams_place -- the one place where a call synchronises the device: their hardware queues are picked by
+ *     a ~15-30 ms measurement, see dvgr_streams_place below; shared by all threads, never destroyed) plus a per-thread
+ *     pool of fork / join events on them.
  *     It holds no pointer to caller memory between calls; DVGR_OPT_SINGLE_STREAM makes a call use neither.
  */
 #ifndef DVGR_H
