@@ -605,6 +605,13 @@ def main():
     m.set_probe(0)
     torch.cuda.synchronize()
     sf_ms = float(np.mean([a.elapsed_time(b) for a, b in sf_pairs]))
+    # operand bytes a launch of the S4 shape moves from L2 into LDS: 4 problems of (B N) x D x D on 128 x 128 tiles
+    # (from 384 tiles of 128 x 256 up the engine takes that variant: csrc/dvgr_gemm.hip, launch_ring)
+    sf_tiles = 4 * ((B * N + 127) // 128) * ((D + 127) // 128)
+    sf_tiles_w = 4 * ((B * N + 127) // 128) * ((D + 255) // 256)
+    sf_rows = (128 + 256) if sf_tiles_w >= 384 else (128 + 128)
+    sf_fill = (float((sf_tiles_w if sf_tiles_w >= 384 else sf_tiles) * (D // 32) * sf_rows * 32 * 2 * (2 if args.dtype == "bf16x3" else 1))
+               if args.dtype != "fp32" else None)
     out = {
         "metric": "QA-pairs/sec (forward+backward) per GPU, SVQA num_clips=20",
         "value": value, "unit": "QA-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -636,6 +643,9 @@ def main():
                    "unit_tflops": value / world * f_train / 1e12,
                    "unit_frac_of_mfma_peak": value / world * f_train / 1e12 / peak},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                     "bound_note": "priced against the dense MFMA peak as the contract asks; the K loop of these 240-256-workgroup launches "
+                                   "is bound by L2 -> LDS operand traffic (operand_fill_*, DESIGN.md section 3.1: ~10 TB/s over the chip in "
+                                   "the K loop, 32 algorithmic FLOP per operand byte with 128 x 128 tiles)",
                      # HBM bytes per launch of the probed kernel (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes) and the
                      # MFMA pipe's busy share, from the rocprofv3 record of THIS build under profiles/ -- null without one
                      "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
@@ -648,6 +658,9 @@ def main():
                      "plain_contraction": {"kernel": "S4 forward tanh(z.P1^T), 2 views x 2 modalities (TAG_FWD_SF)", "launch_ms": sf_ms,
                                            "achieved": 8 * B * N * D * D / (sf_ms * 1e-3) / 1e12,
                                            "frac": 8 * B * N * D * D / (sf_ms * 1e-3) / 1e12 / peak,
+                                           # what actually bounds it: the operand traffic from L2 into LDS by
+                                           # tile geometry -- tiles x K-tiles x (128 + 128 rows) x 32 k x 2 B x planes -- over the launch
+                                           "operand_fill_bytes": sf_fill, "operand_fill_TBps": (sf_fill / (sf_ms * 1e-3) / 1e12) if sf_fill else None,
                                            "mfma_pipe_busy_pmc": (pmc.get("plain_contraction") or {}).get("mfma_busy") if pmc else None},
                      # the launch that dominates the profile by time (the GAT projection above is the kernel north_star names)
                      "dominant_by_time": None if probe2_ms is None else {
