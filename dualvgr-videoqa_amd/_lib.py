@@ -59,6 +59,7 @@ LAYER_DONE_CB = C.CFUNCTYPE(None, C.c_int32, C.c_void_p)
 OPT_SINGLE_STREAM = 1
 OPT_NO_QUERY_STREAM = 2
 OPT_NO_FUSED_GAT = 4
+OPT_LEAVES_ON_QUERY = 8
 
 # enum dvgr_probe_site
 (PROBE_NONE, PROBE_FWD_QA_GEMM, PROBE_FWD_GAT_GEMM, PROBE_FWD_GAT_ATTN, PROBE_FWD_SF_GEMM, PROBE_FWD_MFB_GEMM,

@@ -943,9 +943,12 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     }
     return 0;
   };
-  auto query_leaves = [&](int lo, int hi, hipStream_t on) -> int {
+  // The leaves come in two kinds: d Wq / d bq need only d p (on_p: any stream ordered behind the punish pass that wrote it);
+  // d w2 / d b2 need d r, which the chain's row kernels write (on_r: behind the chain).
+  // (kinds: bit 0 = the d p leaves, bit 1 = the d r leaves -- a stream handle cannot say "none": the caller's may be the null stream)
+  auto query_leaves = [&](int lo, int hi, hipStream_t on_p, hipStream_t on_r, int kinds = 3) -> int {
     ColsumBatch cb{};
-    auto flush_cb = [&]() -> int {
+    auto flush_cb = [&](hipStream_t on) -> int {
       if (!cb.n) return 0;
       cb.chunks = 16;
       const int e = colsum(on, cb);
@@ -953,21 +956,23 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       return e;
     };
     GemmBatch gb{};   // dWq[l][m] = dp[l][m]^T . q[l]
-    for (int l = lo; l < hi; ++l)
+    for (int l = lo; l < hi && (kinds & 1); ++l)
       for (int m = 0; m < 2; ++m) {
         const float* dpc = ws + W.dp_cat + (int64_t)l * B * 2 * D + m * D;
         gb.p[gb.n++] = tn(dpc, 2 * D, ls(l) + S.qa_q, Wd, gqp(l, m) + P.wq, Wd, D, Wd, B);
-        if (gb.n == kMaxBatch || (l == hi - 1 && m == 1)) { DVGR_TRY(gemm_launch(on, IC, IC, gb, TAG_GENERIC, prec)); gb.n = 0; }
+        if (gb.n == kMaxBatch || (l == hi - 1 && m == 1)) { DVGR_TRY(gemm_launch(on_p, IC, IC, gb, TAG_GENERIC, prec)); gb.n = 0; }
         cb.j[cb.n++] = ColsumJob{dpc, nullptr, nullptr, nullptr, B, 0, D, 2 * D, gqp(l, m) + P.bq};
-        if (cb.n == kMaxColsumJobs) DVGR_TRY(flush_cb());
+        if (cb.n == kMaxColsumJobs) DVGR_TRY(flush_cb(on_p));
       }
+    if ((kinds & 1) && (on_r != on_p || !(kinds & 2))) DVGR_TRY(flush_cb(on_p));
+    if (!(kinds & 2)) return 0;
     for (int l = lo; l < hi; ++l) {
       cb.j[cb.n++] = ColsumJob{ls(l) + S.qa_d, nullptr, ws + W.dr + (int64_t)l * BT, nullptr, BT, 0, D, D, glp(l) + P.qa_w2};
-      if (cb.n == kMaxColsumJobs) DVGR_TRY(flush_cb());
+      if (cb.n == kMaxColsumJobs) DVGR_TRY(flush_cb(on_r));
       cb.j[cb.n++] = ColsumJob{ws + W.dr + (int64_t)l * BT, nullptr, nullptr, nullptr, BT, 0, 1, 1, glp(l) + P.qa_b2};
-      if (cb.n == kMaxColsumJobs) DVGR_TRY(flush_cb());
+      if (cb.n == kMaxColsumJobs) DVGR_TRY(flush_cb(on_r));
     }
-    return flush_cb();
+    return flush_cb(on_r);
   };
 
   // The whole branch of the layers [lo, hi) on the query stream, in dependency order.  Its kernels are small (a few dozen
@@ -978,6 +983,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
   // Order on the query stream: chain and contractions of the layers >= 1 (issued at layer 1, they finish in the gap
   // before layer 0's d p exists), then layer 0's chain and contractions, then the leaves of ALL layers in one small
   // contraction launch and one column-sum launch.
+  bool leaves_p_deferred = false;            // the d Wq / d bq leaves go to the side stream at the end of layer 0
   hipEvent_t chain0_done = nullptr;          // small batches: layer 0's chain is done (the main stream takes its contractions)
   auto query_branch = [&](int lo, int hi, int first) -> int {
     DVGR_TRY(query_chain(lo, hi, qs, first));
@@ -988,10 +994,19 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       if (!chain0_done) return (int)hipErrorOutOfMemory;
       const hipError_t e = hipEventRecord(chain0_done, qs);
       if (e != hipSuccess) return (int)e;
-      return query_leaves(0, L, qs);
+      return query_leaves(0, L, qs, qs);
+    }
+    if (lo == 0 && side && qs != hs && !(O.flags & DVGR_OPT_LEAVES_ON_QUERY)) {
+      // a query stream of its own: the d Wq / d bq leaves of all layers do not wait for layer 0's chain -- they go to the SIDE
+      // stream (ordered behind the same punish pass; enqueued at the end of layer 0, behind its column sums, where that stream
+      // goes idle) and run beside the chain instead of ending the step as the last two launches of the query stream (the
+      // step's tail was chain + contractions + leaves = 116 us)
+      DVGR_TRY(query_gemms(lo, hi, qs));
+      leaves_p_deferred = true;
+      return query_leaves(0, L, qs, qs, 2);
     }
     DVGR_TRY(query_gemms(lo, hi, qs));
-    return lo == 0 ? query_leaves(0, L, qs) : 0;
+    return lo == 0 ? query_leaves(0, L, qs, qs) : 0;
   };
 
   // ---- layers, last to first -----------------------------------------------------------------------
@@ -1288,6 +1303,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     }
   }
 
+  if (leaves_p_deferred) DVGR_TRY(query_leaves(0, L, hs, hs, 1));
   if (chain0_done) {
     const hipError_t e = hipStreamWaitEvent(st, chain0_done, 0);
     if (e != hipSuccess) return (int)e;

@@ -339,6 +339,7 @@ class DualVGRUnit_multiple(nn.Module):
         self._shapes = {}
         self.single_stream = bool(int(os.environ.get("DVGR_SINGLE_STREAM", "0")))   # DVGR_OPT_SINGLE_STREAM
         self.fused_gat = not bool(int(os.environ.get("DVGR_NO_FUSED_GAT", "0")))      # False: DVGR_OPT_NO_FUSED_GAT (two launches)
+        self.leaves_on_query = bool(int(os.environ.get("DVGR_LEAVES_ON_QUERY", "0")))  # True: DVGR_OPT_LEAVES_ON_QUERY (A/B timing)
         # (alpha, beta, dep_scale[, with_sum_vis = True]) or None: when set, forward_raw() also evaluates the scope-U loss
         # sum(vis) + alpha*common + beta*dep_scale*dependence with its gradients w.r.t. the outputs (dvgr_opts.loss)
         # and leaves (terms, upstream_grads) in `last_loss`, ready for torch.autograd.backward(raw, upstream_grads)
@@ -554,6 +555,8 @@ class DualVGRUnit_multiple(nn.Module):
             o.flags |= L_.OPT_SINGLE_STREAM
         if not self.fused_gat:
             o.flags |= L_.OPT_NO_FUSED_GAT
+        if self.leaves_on_query:
+            o.flags |= L_.OPT_LEAVES_ON_QUERY
         if self._events or getattr(self, "_layer_cb", None) is not None:
             o.flags |= L_.OPT_NO_QUERY_STREAM      # a reducer's streams run beside the call (include/dvgr.h)
         if self._probe is not None:

@@ -210,6 +210,10 @@ enum dvgr_probe_site {
 #define DVGR_OPT_NO_FUSED_GAT 4
 /* (The same bit also keeps S6 -- linear0 / linear1 + ELU + the pooled product, one launch on the planes path, k_mfb_fwd --
  * in its two-launch form: the flag means "no fused forward kernels".) */
+/* Backward with a query stream of its own: the d Wq / d bq leaves of the query block (needing only d p) are enqueued on the
+ * side stream beside layer 0's query chain instead of behind it.  DVGR_OPT_LEAVES_ON_QUERY keeps them on the query stream
+ * (A/B timing). */
+#define DVGR_OPT_LEAVES_ON_QUERY 8
 
 /* Scope-U loss evaluated by the forward itself (dvgr_opts.loss): the same arithmetic and outputs as
  * dvgr_scope_u_loss below, but the kernels are enqueued as soon as the last layer's list outputs exist and run on the
