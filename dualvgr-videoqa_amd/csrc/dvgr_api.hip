@@ -983,7 +983,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
   // Order on the query stream: chain and contractions of the layers >= 1 (issued at layer 1, they finish in the gap
   // before layer 0's d p exists), then layer 0's chain and contractions, then the leaves of ALL layers in one small
   // contraction launch and one column-sum launch.
-  bool leaves_p_deferred = false;            // the d Wq / d bq leaves go to the side stream at the end of layer 0
+  hipEvent_t leaves_deferred = nullptr;      // set: the query block's leaves go to the side stream at the end of layer 0 (event: chain done)
   hipEvent_t chain0_done = nullptr;          // small batches: layer 0's chain is done (the main stream takes its contractions)
   auto query_branch = [&](int lo, int hi, int first) -> int {
     DVGR_TRY(query_chain(lo, hi, qs, first));
@@ -1000,10 +1000,14 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       // a query stream of its own: the d Wq / d bq leaves of all layers do not wait for layer 0's chain -- they go to the SIDE
       // stream (ordered behind the same punish pass; enqueued at the end of layer 0, behind its column sums, where that stream
       // goes idle) and run beside the chain instead of ending the step as the last two launches of the query stream (the
-      // step's tail was chain + contractions + leaves = 116 us)
-      DVGR_TRY(query_gemms(lo, hi, qs));
-      leaves_p_deferred = true;
-      return query_leaves(0, L, qs, qs, 2);
+      // step's tail was chain + contractions + leaves = 116 us) ...
+      // ... and the d w2 / d b2 leaves need the chain but not its two contractions: they follow on the side stream behind an
+      // event recorded here, instead of ending the step behind the contractions
+      leaves_deferred = side->next();
+      if (!leaves_deferred) return (int)hipErrorOutOfMemory;
+      const hipError_t e = hipEventRecord(leaves_deferred, qs);
+      if (e != hipSuccess) return (int)e;
+      return query_gemms(lo, hi, qs);
     }
     DVGR_TRY(query_gemms(lo, hi, qs));
     return lo == 0 ? query_leaves(0, L, qs, qs) : 0;
@@ -1303,7 +1307,12 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     }
   }
 
-  if (leaves_p_deferred) DVGR_TRY(query_leaves(0, L, hs, hs, 1));
+  if (leaves_deferred) {
+    DVGR_TRY(query_leaves(0, L, hs, hs, 1));
+    const hipError_t e = hipStreamWaitEvent(hs, leaves_deferred, 0);
+    if (e != hipSuccess) return (int)e;
+    DVGR_TRY(query_leaves(0, L, hs, hs, 2));
+  }
   if (chain0_done) {
     const hipError_t e = hipStreamWaitEvent(st, chain0_done, 0);
     if (e != hipSuccess) return (int)e;
