@@ -41,8 +41,7 @@ __global__ void k_place_link(int* sink) {                                // one 
 constexpr int kChain = 24;             // dispatches per timed chain
 constexpr float kHoldMs = 1.0f;        // the candidate's head packet stays blocked this long (covers a slowed chain: 24 x <= 35 us)
 // Measured: an undisturbed chain of 24 links takes 91-92 us (+-2), one beside a blocked queue of the SAME PIPE 223-237 us,
-// one queued on the SAME HARDWARE QUEUE as the candidate 400-640 us.  Collision = more than 1.3 x undisturbed + 24 us.
-constexpr float kSlowUs = 1.f;
+// one queued on the SAME HARDWARE QUEUE as the candidate 400-640 us (under rocprofv3: 170-250, 297, 116).
 
 struct Placed { hipStream_t s; int rank; };
 std::vector<Placed>& registry(int dev) { static std::vector<Placed> r[16]; return r[dev]; }
@@ -111,29 +110,46 @@ hipStream_t place_stream(int dev, int priority, hipStream_t caller, int rank, hi
     R.base[i] = 1e30f;
     for (int rep = 0; rep < 3 && e == hipSuccess; ++rep) { e = chain_us(busy[i].s, t0, t1, &a); R.base[i] = std::min(R.base[i], a); }
   }
+  // PAIRED measurements: the chain beside the blocked candidate and, right behind it, the same chain with the candidate idle;
+  // five pairs, the median of their ratios decides.  (Under a profiler the undisturbed chain drifts between 170 and 250 us from one second to the next
+  // while a pipe collision sits at a steady 297: judged against one reference taken at the start, one run in three kept a
+  // colliding queue.)
+  float ratio[4][8];
   for (int k = 0; k < nc && e == hipSuccess; ++k)
     for (int i = 0; i < nb && e == hipSuccess; ++i) {
-      R.us[k][i] = 1e30f;
-      for (int rep = 0; rep < 2 && e == hipSuccess; ++rep) {
+      constexpr int kReps = 5;
+      float r[kReps], blocked[kReps];
+      for (int rep = 0; rep < kReps && e == hipSuccess; ++rep) {
         // the candidate in the state a busy stream is in for most of a step: a dispatch queued behind a kernel in flight
         k_place_hold<<<1, 64, 0, cand[k]>>>((unsigned long long)(kHoldMs * 1e5f), nullptr);
         k_place_tiny<<<1, 64, 0, cand[k]>>>(nullptr);
-        float a = 0.f;
+        float a = 0.f, f = 1.f;
         e = chain_us(busy[i].s, t0, t1, &a);
-        R.us[k][i] = std::min(R.us[k][i], a);
         if (e == hipSuccess) e = hipStreamSynchronize(cand[k]);
+        if (e == hipSuccess) e = chain_us(busy[i].s, t0, t1, &f);
+        blocked[rep] = a;
+        r[rep] = a / (f > 1.f ? f : 1.f);
       }
+      std::sort(r, r + kReps);
+      std::sort(blocked, blocked + kReps);
+      ratio[k][i] = r[kReps / 2];
+      R.us[k][i] = blocked[kReps / 2];
     }
   if (t0) (void)hipEventDestroy(t0);
   if (t1) (void)hipEventDestroy(t1);
   int best = 0;
   long best_key = -1;
-  if (e == hipSuccess)
+  if (e == hipSuccess) {
+    // disturbed = the MEDIAN over five pairs of (chain beside the blocked candidate) / (the same chain right afterwards, candidate
+    // idle) is above 1.12 -- one pipe: unprofiled 225 / 92 us = 2.4, under rocprofv3 297 / 170-250 = 1.2-1.7 -- or below 0.8:
+    // the candidate sits on the stream's very hardware queue, the chain queues behind the hold kernel and then runs back to
+    // back (116 / 176 us under rocprofv3; unprofiled that case shows as 400-640 us)
     for (int k = 0; k < nc; ++k) {
       long key = 0;
-      for (int i = 0; i < nb; ++i) key = key * 2 + (R.us[k][i] > 1.3f * R.base[i] + kChain * kSlowUs ? 1 : 0);
+      for (int i = 0; i < nb; ++i) key = key * 2 + ((ratio[k][i] > 1.12f || ratio[k][i] < 0.8f) ? 1 : 0);
       if (best_key < 0 || key < best_key) { best_key = key; best = k; }
     }
+  }
   // The losing candidates are NOT destroyed: the runtime destroys a hardware queue with its last stream, the driver then
   // rebuilds the process's run list, and the pipe of every later queue -- the one just measured included -- moves (measured:
   // with the losers destroyed the plain C2 step went from 1.0 to 2.4 ms).  An idle stream costs nothing.
