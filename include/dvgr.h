@@ -18,7 +18,7 @@
  *   - calls are re-entrant and thread-safe (autograd calls backward from its own thread).  The library keeps exactly
  *     one piece of process-wide state: per device, its internal lower-priority side / query streams (created on first use
  *     or by dvgr_streams_place -- the one place where a call synchronises the device: their hardware queues are picked by
- *     a ~15-30 ms measurement, see dvgr_streams_place below; shared by all threads, never destroyed) plus a per-thread
+ *     a ~0.1 s measurement, see dvgr_streams_place below; shared by all threads, never destroyed) plus a per-thread
  *     pool of fork / join events on them.
  *     It holds no pointer to caller memory between calls; DVGR_OPT_SINGLE_STREAM makes a call use neither.
  */
@@ -137,7 +137,7 @@ const char *dvgr_version(void);
  * `caller_stream` (hipStream_t, the stream the unit will be called on; NULL = the null stream) and the streams created before
  * it least.  Background (csrc/dvgr_place.hip, tools/micro/pipe_probe.hip): the command processor serves a process's hardware
  * queues on 4 pipes, and two busy queues of ONE pipe cost every dispatch of both ~25 us; which queues share a pipe follows
- * creation order, so the library measures instead of assuming an order (~5-15 ms per stream, once; synchronises the device).
+ * creation order, so the library measures instead of assuming an order (~20-100 ms per stream, once; synchronises the device).
  * DVGR_NO_STREAM_PLACEMENT=1 in the environment: plain stream creation. */
 int dvgr_streams_place(void *caller_stream);
 int dvgr_streams_init(void);                    /* = dvgr_streams_place(NULL) */

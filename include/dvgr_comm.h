@@ -35,9 +35,10 @@ int dvgr_comm_create(const void* id, int rank, int world, dvgr_comm** out);
  * which is what the communication stream does for most of a step -- cost EVERY dispatch of the other ~34 us
  * (tools/micro/pipe_probe.hip; a whole-model step went from 4.9 to 9.6 ms that way, rounds 2-3 knew it as "stream creation
  * order matters").  How: up to four candidate streams (consecutive queues = all four pipes) are each held non-idle by a
- * single-wave kernel for 0.8 ms while a chain of 24 empty dispatches is timed on every busy stream; the candidate that slows
- * none of them (busy_streams[0] first, then [1] ..., then the library's side and query stream) becomes the communication
- * stream, the others stay idle (destroying a queue re-maps the rest).  ~15 ms, synchronises the device; call it after every stream the step uses exists and
+ * single-wave kernel for 1 ms while a chain of 24 short dispatches is timed on every busy stream, paired with the same chain
+ * beside the idle candidate (median of five ratios); the candidate that slows none of them (busy_streams[0] first, then [1]
+ * ..., then the library's side and query stream) becomes the communication stream, the others stay idle (destroying a queue
+ * re-maps the rest).  ~0.1 s, synchronises the device; call it after every stream the step uses exists and
  * before the first collective.  busy_streams: hipStream_t's of the CALLER (its compute stream first; NULL = the null stream),
  * n_busy <= 5.  report (optional, floats): [candidates, busy streams, chosen, collision mask of the chosen one,
  * undisturbed chain us per busy stream ..., chain us per (candidate, busy stream) ...]. */
