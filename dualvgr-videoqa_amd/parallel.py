@@ -277,7 +277,7 @@ class NativeUnitReducer:
         stream, no cross-stream event; it delays that stream's later work instead of overlapping it).
         busy_streams: torch streams, besides the current one, that carry work during a step (the whole model: its
         question-encoder stream) -- the communication stream is put on a hardware queue that disturbs none of them
-        (`place`: dvgr_comm_place, ~50 ms once; create this object AFTER those streams exist)."""
+        (`place`: dvgr_comm_place, ~0.1 s once; create this object AFTER those streams exist)."""
         import ctypes as C
         from . import _lib as L_
         if device.type != "cuda":
