@@ -523,3 +523,40 @@ def test_bench_selftest_picks_its_reducer_from_child_trials():
     assert cands[best] <= 1.3 * trial["plain"]
     assert d["ms_per_step"] <= 1.5 * trial["plain"]            # the timed region runs the winner alone: no 3 x artefact
     assert set(dist_cfg["allreduce_bytes_per_block"]) == {"0", "1", "2", "3", "4"}
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_under_the_launcher_share_one_gpu():
+    """The control flow of `bench.py --gpus N` for N > 1 as the driver starts it (python -m torch.distributed.run ... bench.py
+    --gpus 2), rehearsed on ONE GPU: two ranks share the device (DVGR_BENCH_SHARE_GPU) over gloo.  Every rank runs its trial
+    children (the native forms are skipped for gloo), the ranks agree on MAX per candidate, the timed region runs the
+    torch.distributed reducer and rank 0 prints ONE line with the whole-job value.  (Gloo moves the 57 MB through the host, so
+    the sanity gate -- best candidate within 2.5 x of the plain step -- would refuse this set-up: first checked, then overridden.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["DVGR_BENCH_SHARE_GPU"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29761", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--min-seconds", "0.2", "--backend", "gloo", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode != 0 and "refusing to print a result" in r.stderr, r.stderr[-2000:]
+    assert '"metric"' not in r.stdout
+    env["DVGR_BENCH_ALLOW_SLOW"] = "1"
+    cmd[cmd.index("29761")] = "29771"
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    dist_cfg = d["config"]["distributed"]
+    print("  two ranks on one GPU over gloo:", d["ms_per_step"], "ms per step, trials", dist_cfg["reducer_trial"]["ms_per_step"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2"
+    assert abs(d["value"] - 2 * 64 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]       # whole-job QA-pairs/s
+    assert dist_cfg["world_size"] == 2 and dist_cfg["reducer"].startswith("python")
+    t = dist_cfg["reducer_trial"]["ms_per_step"]
+    assert t["plain"] and t["python"] and t["native"] is None and t["inorder"] is None
