@@ -14,11 +14,13 @@ whose world size differs from --gpus fails; it never silently measures fewer GPU
 Which gradient reducer runs the timed region (--reducer auto) is settled BEFORE this process touches the GPU: every rank
 starts four short child processes, one after the other -- the plain step (no collectives), the step with ONLY the native
 reducer on its communication stream, ONLY the native reducer in order on the producers' streams, ONLY the torch.distributed
-reducer -- each child of a rank meeting the same child of the other ranks in a process group of its own.  (Which form is
-fastest depends on the node: the communication stream overlaps everything but is one more hardware queue, the in-order
-form needs none but delays the side stream)  The timed process then sets up the winner alone.  If no
-candidate stays within 1.3 x (one rank) / 2.5 x (several ranks: real all-reduces) of the plain step, the run exits
-non-zero instead of printing a line that measures a broken set-up.
+reducer -- each child of a rank meeting the same child of the other ranks in a process group of its own (free ports picked
+by rank 0, shared over the launcher's agent store).  After every candidate the ranks exchange the outcome over that store:
+the figure kept is the MAX over ranks, and a candidate that failed on any rank ends the trial phase on all of them.  (Which
+form is fastest depends on the node: the communication stream overlaps everything but is one more hardware queue, the
+in-order form needs none but delays the side stream)  The timed process then sets up the winner alone.
+A winner slower than 1.3 x (one rank) / 2.5 x (several ranks: real all-reduces) the plain step is REPORTED
+(`config.distributed.reducer_trial.suspect_setup`), not refused: the line is still printed; DVGR_BENCH_STRICT=1 exits 3.
 
 Timing: W untimed warm-up steps, then blocks of EXACTLY K steps, each bracketed by barrier + device synchronise on both
 sides and MAX-reduced over ranks; blocks repeat until >= 5 s has been timed and the line reports the MEDIAN block
@@ -195,19 +197,89 @@ REDUCER_KINDS = ("native", "inorder", "python")     # native: the library's comm
 SLOW_FACTOR_ONE_RANK, SLOW_FACTOR_RANKS = 1.3, 2.5
 
 
+PROFILER_ENV_PREFIXES = ("ROCPROF", "ROCP_", "ROCPROFILER", "ROCTRACER", "ROCTX", "HSA_TOOLS", "ROCPD")
+TRIAL_CHILD_TIMEOUT_S = 150
+
+
+def child_env():
+    """Environment of a trial child: this process's, minus a profiler's preload and tool variables (a child must not be
+    traced into the parent's output directory: tools/ddp_timeline.sh runs bench.py under rocprofv3)."""
+    env = {k: v for k, v in os.environ.items() if not k.startswith(PROFILER_ENV_PREFIXES)}
+    pre = [x for x in env.get("LD_PRELOAD", "").replace(":", " ").split() if "rocprof" not in x and "roctracer" not in x and "rocpd" not in x]
+    if pre:
+        env["LD_PRELOAD"] = ":".join(pre)
+    else:
+        env.pop("LD_PRELOAD", None)
+    return env
+
+
+class TrialBoard:
+    """What the ranks share while their trial children run, BEFORE any of them touches the GPU: the children's rendezvous
+    ports (picked free on rank 0) and, after every candidate, each rank's outcome -- so that all ranks start the next
+    candidate together and stop together when one failed anywhere.  Carried by the launcher's agent store (torchrun exports
+    MASTER_ADDR / MASTER_PORT of a TCPStore it hosts itself, TORCHELASTIC_USE_AGENT_STORE=True); without one the ranks fall
+    back to fixed port offsets and to agreeing afterwards, in the timed process."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world, self.store = rank, world, None
+        if world > 1 and os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") == "True":
+            try:
+                import datetime
+                from torch.distributed import TCPStore       # host-side only: no GPU call
+                self.store = TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), None, False,
+                                      timeout=datetime.timedelta(seconds=TRIAL_CHILD_TIMEOUT_S + 60))
+            except Exception as e:                            # noqa: BLE001
+                print(f"[bench] no agent store for the trial phase ({e!r}): fixed port offsets", file=sys.stderr, flush=True)
+                self.store = None
+
+    def ports(self, n):
+        base = int(os.environ.get("MASTER_PORT", "29533"))
+        fixed = [base + 1 + i for i in range(n)]
+        if self.store is None:
+            return fixed if self.world > 1 else [free_port() for _ in range(n)]
+        try:
+            if self.rank == 0:
+                self.store.set("dvgr_trial_ports", json.dumps([free_port() for _ in range(n)]))
+            return json.loads(self.store.get("dvgr_trial_ports").decode())
+        except Exception as e:                                # noqa: BLE001
+            print(f"[bench] trial ports over the agent store failed ({e!r}): fixed port offsets", file=sys.stderr, flush=True)
+            self.store = None
+            return fixed
+
+    def agree(self, kind, ms):
+        """ms: this rank's result (None = its child failed).  Returns (MAX over ranks or None if it failed on any, all_ok)."""
+        if self.store is None:         # one rank, or no store: every candidate is tried; several ranks agree afterwards (MAX all-reduce)
+            return ms, True
+        try:
+            self.store.set(f"dvgr_trial_{kind}_{self.rank}", json.dumps(ms))
+            keys = [f"dvgr_trial_{kind}_{r}" for r in range(self.world)]
+            self.store.wait(keys)
+            vals = [json.loads(self.store.get(k).decode()) for k in keys]
+        except Exception as e:                                # noqa: BLE001
+            print(f"[bench] trial agreement on '{kind}' failed ({e!r})", file=sys.stderr, flush=True)
+            return None, False
+        if any(v is None for v in vals):
+            return None, False
+        return max(vals), True
+
+
 def run_trial_children(args):
     """Called by every rank BEFORE it makes a GPU call: one short child process per candidate (`--trial KIND`), sequentially.
-    A child inherits RANK / LOCAL_RANK / WORLD_SIZE and meets the same child of the other ranks on MASTER_PORT + 1 + index
-    (torchrun's agent store is not used: the rank-0 child creates the store).  Returns {kind: parsed JSON or None}."""
-    base_port = int(os.environ.get("MASTER_PORT", "29533"))
-    out = {}
+    A child inherits RANK / LOCAL_RANK / WORLD_SIZE and meets the same child of the other ranks on a port of its own (free
+    ports picked by rank 0 and shared over the launcher's agent store; the rank-0 child hosts the store).  After every
+    candidate the ranks exchange the outcome: the figure kept is the MAX over ranks, and a candidate that failed on ANY
+    rank ends the trial phase on ALL ranks (its peers' children were left waiting for it; the later candidates would start
+    out of step).  Returns {kind: {"ms": MAX over ranks, "rccl": ...} or None}."""
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    board = TrialBoard(rank, world)
+    ports = board.ports(len(TRIAL_KINDS))
+    out = {k: None for k in TRIAL_KINDS}
     argv = [a for a in sys.argv[1:]]
     for idx, kind in enumerate(TRIAL_KINDS):
         if kind in ("native", "inorder") and args.backend != "nccl":
-            out[kind] = None
             continue
-        env = dict(os.environ)
-        env["MASTER_PORT"] = str(base_port + 1 + idx)
+        env = child_env()
+        env["MASTER_PORT"] = str(ports[idx])
         env.setdefault("MASTER_ADDR", "127.0.0.1")
         env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
         env["DVGR_BENCH_TRIAL_CHILD"] = "1"
@@ -218,18 +290,25 @@ def run_trial_children(args):
             env["NCCL_DEBUG_FILE"] = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"dvgr_rccl_{kind}_{os.getpid()}_%p.log")
         cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--trial", kind]
         t0 = time.perf_counter()
+        res = None
         try:
-            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=TRIAL_CHILD_TIMEOUT_S)
             line = next((l for l in r.stdout.splitlines() if l.startswith("{") and '"trial"' in l), None)
-            out[kind] = json.loads(line) if (r.returncode == 0 and line) else None
-            if out[kind] is None:
+            res = json.loads(line) if (r.returncode == 0 and line) else None
+            if res is None:
                 tail = (r.stderr or "").strip().splitlines()[-6:]
                 print(f"[bench] trial child '{kind}' failed (rc {r.returncode}): " + " | ".join(tail), file=sys.stderr, flush=True)
         except subprocess.TimeoutExpired:
-            out[kind] = None
             print(f"[bench] trial child '{kind}' timed out", file=sys.stderr, flush=True)
-        print(f"[bench] trial child '{kind}': {out[kind] and out[kind].get('ms')} ms/step ({time.perf_counter() - t0:.0f} s)",
+        ms, all_ok = board.agree(kind, res and res.get("ms"))
+        if res is not None and ms is not None:
+            res["ms"] = ms
+            out[kind] = res
+        print(f"[bench] trial child '{kind}': {out[kind] and out[kind].get('ms')} ms/step, MAX over ranks ({time.perf_counter() - t0:.0f} s)",
               file=sys.stderr, flush=True)
+        if not all_ok:
+            print(f"[bench] '{kind}' failed on at least one rank: no further trials on any rank", file=sys.stderr, flush=True)
+            break
     return out
 
 
@@ -324,9 +403,11 @@ def main():
                     help="with --model, A/B timing: swap tools/stock_encoders.py's nn.LSTM appearance encoder in")
     ap.add_argument("--reducer", default="auto", choices=["auto", "native", "inorder", "python"],
                     help="gradient all-reduce of the unit under --gpus N: native = enqueued by the backward call itself over the "
-                         "library's own RCCL communicator (include/dvgr_comm.h); python = parallel.LayerBucketReducer over "
-                         "torch.distributed (host callback + issuer thread); auto = both are set up, a few untimed steps of each "
-                         "are measured (MAX over ranks) and the faster one runs the timed region")
+                         "library's own RCCL communicator on its communication stream (include/dvgr_comm.h); inorder = the same "
+                         "communicator, each collective on the stream that produced its block; python = parallel.LayerBucketReducer "
+                         "over torch.distributed (host callback + issuer thread); auto = before this process touches the GPU every "
+                         "rank runs one short child process per candidate (and one without collectives), the ranks agree on the "
+                         "MAX per candidate, and the timed process sets up the fastest one alone")
     ap.add_argument("--trial", default=None, choices=list(TRIAL_KINDS),
                     help="internal: a short untimed measurement of the step with ONE reducer set up (plain = none), printed as one "
                          "JSON line; started by --reducer auto as a child process before the timed process touches the GPU")
@@ -412,17 +493,33 @@ def main():
         trial_report = {"ms_per_step": {k: (None if v == float("inf") else v) for k, v in ms.items()},
                         "how": "one child process per candidate and rank, before the timed process touched the GPU (MAX over ranks)",
                         "rccl": {k: trials[k].get("rccl") for k in REDUCER_KINDS if trials.get(k)}}
-        if not cands:
-            raise SystemExit("bench.py: neither gradient reducer could be set up in its trial process; no measurement")
-        choice = min(cands, key=cands.get)
         limit = SLOW_FACTOR_ONE_RANK if world == 1 else SLOW_FACTOR_RANKS
-        if ms["plain"] != float("inf") and cands[choice] > limit * ms["plain"] and os.environ.get("DVGR_BENCH_ALLOW_SLOW", "0") != "1":
-            print(f"[bench] reducer trials {ms}: the best candidate is more than {limit} x the plain step -- this measures a broken "
-                  f"set-up (DESIGN.md section 5), not the path; refusing to print a result (DVGR_BENCH_ALLOW_SLOW=1 overrides)",
-                  file=sys.stderr, flush=True)
-            if ddp:
-                dist.destroy_process_group()
-            raise SystemExit(3)
+        strict = os.environ.get("DVGR_BENCH_STRICT", "0") == "1"
+        if not cands:
+            # no candidate finished its trial on every rank: the timed run still takes place, on the torch.distributed reducer
+            # (the form every test of the multi-process path runs), and the line says that nothing vouches for the set-up
+            if strict:
+                raise SystemExit("bench.py: no gradient reducer finished its trial process (DVGR_BENCH_STRICT=1); no measurement")
+            choice = "python"
+            trial_report["suspect_setup"] = True
+            trial_report["why"] = "no reducer candidate finished its trial on every rank; the torch.distributed reducer runs untried"
+        else:
+            choice = min(cands, key=cands.get)
+            ratio = cands[choice] / ms["plain"] if ms["plain"] not in (0.0, float("inf")) else None
+            trial_report["best_over_plain"] = ratio
+            trial_report["gate"] = limit
+            if ratio is not None and ratio > limit:
+                # A WARNING, not a refusal: on several ranks the collectives are real (14.8 M parameters = 59 MB of gradients per
+                # ~1 ms C2 step), so a ratio above the gate can be a bandwidth-bound but valid measurement.  The line is printed
+                # with the trial ratios and "suspect_setup": true; DVGR_BENCH_STRICT=1 (the one-rank self-test of the plumbing,
+                # where nothing is exchanged and 1.3 x means a broken stream set-up) turns it into exit 3.
+                print(f"[bench] reducer trials {ms}: the best candidate is {ratio:.2f} x the plain step (gate {limit}) -- "
+                      f"suspect set-up, reported in config.distributed.reducer_trial", file=sys.stderr, flush=True)
+                trial_report["suspect_setup"] = True
+                if strict:
+                    if ddp:
+                        dist.destroy_process_group()
+                    raise SystemExit(3)
         print(f"[bench] reducer trials ms/step {ms} -> {choice}", file=sys.stderr, flush=True)
     elif ddp and choice is None:
         choice = "native" if args.backend == "nccl" else "python"

@@ -99,7 +99,7 @@ int dvgr_comm_place(dvgr_comm* c, void* const* busy_streams, int n_busy, float* 
   dvgr::set_shared_stream(c->device, 2, s);
   placed[c->device] = true;
   dvgr::write_place_report(R, report, report_len);
-  return R.mask < 0 ? (int)hipErrorUnknown : 0;
+  return 0;         // a failed MEASUREMENT (R.mask < 0, reported as such) is not an error: candidate 0 is installed and usable
 }
 
 int dvgr_comm_create(const void* id, int rank, int world, dvgr_comm** out) {
@@ -142,8 +142,15 @@ int dvgr_comm_set_inorder(dvgr_comm* c, int on) {
 int dvgr_comm_allreduce_avg(dvgr_comm* c, float* buf, int64_t count, void* wait_event, void* after_stream) {
   if (!c || !buf) return DVGR_E_NULL;
   if (count <= 0) return 0;
-  if (c->inorder)                            // (after_stream = the producing stream: whatever `wait_event` marks is already in its order)
+  if (c->inorder) {
+    // after_stream = the producing stream.  A wait_event is honoured as well (free when it was recorded on that same
+    // stream): a caller of the event convention -- an event plus a NULL after_stream -- must not get an unordered collective.
+    if (wait_event) {
+      const hipError_t ew = hipStreamWaitEvent((hipStream_t)after_stream, (hipEvent_t)wait_event, 0);
+      if (ew != hipSuccess) return (int)ew;
+    }
     return nccl_rc(api.AllReduce(buf, buf, (size_t)count, ncclFloat32, ncclAvg, c->comm, (hipStream_t)after_stream));
+  }
   hipError_t e = hipSuccess;
   if (wait_event) {
     e = hipStreamWaitEvent(c->stream, (hipEvent_t)wait_event, 0);

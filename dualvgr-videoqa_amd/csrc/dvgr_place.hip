@@ -46,6 +46,8 @@ constexpr float kHoldMs = 1.0f;        // the candidate's head packet stays bloc
 struct Placed { hipStream_t s; int rank; };
 std::vector<Placed>& registry(int dev) { static std::vector<Placed> r[16]; return r[dev]; }
 std::mutex& place_mutex() { static std::mutex m; return m; }
+struct Idle { hipStream_t s; int priority; };
+std::vector<Idle>& idle_pool(int dev) { static std::vector<Idle> p[16]; return p[dev]; }   // under place_mutex()
 
 hipError_t chain_us(hipStream_t s, hipEvent_t t0, hipEvent_t t1, float* out_us) {
   hipError_t r = hipEventRecord(t0, s);
@@ -84,8 +86,17 @@ hipStream_t place_stream(int dev, int priority, hipStream_t caller, int rank, hi
     return s;
   };
   if (!placement_enabled()) return plain();
+  // No probe inside a capture -- on the caller's stream or, as far as this thread can tell, on any other: the probe
+  // synchronises the device, which invalidates a relaxed-mode capture elsewhere.  (hipThreadExchangeStreamCaptureMode swaps
+  // this thread's mode; in any mode but relaxed a device synchronise during a capture is an error the probe must not cause,
+  // so the check is: the caller's stream is not capturing AND a harmless legacy-stream query succeeds.)
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(caller, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return plain();   // (no probe inside a capture)
+  if (hipStreamIsCapturing(caller, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return plain();
+  if (hipStreamQuery(nullptr) == hipErrorStreamCaptureImplicit) { (void)hipGetLastError(); return plain(); }   // a global-mode capture is active
+  // at most kMaxCandidates candidate streams are ever created per device (the losers of a placement are kept alive, see
+  // below): later placements measure the idle losers again instead of creating more hardware queues
+  static int created[16] = {};
+  constexpr int kMaxCandidates = 12;
   // the streams placed before, most important first: the caller's, then by rank
   std::vector<Placed> busy;
   busy.push_back({caller, kRankCaller});
@@ -96,7 +107,17 @@ hipStream_t place_stream(int dev, int priority, hipStream_t caller, int rank, hi
   const int nb = (int)busy.size();
   hipStream_t cand[4] = {keep, nullptr, nullptr, nullptr};
   int nc = keep ? 1 : 0;
-  while (nc < 4 && hipStreamCreateWithPriority(&cand[nc], hipStreamNonBlocking, priority) == hipSuccess) ++nc;
+  {
+    auto& pool = idle_pool(dev);                 // losers of earlier placements, same priority: candidates again before new queues
+    for (size_t i = 0; i < pool.size() && nc < 4;) {
+      if (pool[i].priority == priority) { cand[nc++] = pool[i].s; pool.erase(pool.begin() + i); } else ++i;
+    }
+  }
+  while (nc < 4 && created[dev] < kMaxCandidates && hipStreamCreateWithPriority(&cand[nc], hipStreamNonBlocking, priority) == hipSuccess) {
+    ++nc;
+    ++created[dev];
+  }
+  if (nc == 0 && hipStreamCreateWithPriority(&cand[0], hipStreamNonBlocking, priority) == hipSuccess) nc = 1;   // (cap reached, pool empty)
   if (nc == 0) return nullptr;
   for (int k = 0; k < nc; ++k) k_place_tiny<<<1, 64, 0, cand[k]>>>(nullptr);      // (a stream's hardware queue exists from its first use on)
   for (int i = 0; i < nb; ++i) k_place_tiny<<<1, 64, 0, busy[i].s>>>(nullptr);
@@ -166,6 +187,8 @@ hipStream_t place_stream(int dev, int priority, hipStream_t caller, int rank, hi
     for (int k = 0; k < nc; ++k) { fprintf(stderr, " | c%d:", k); for (int i = 0; i < nb; ++i) fprintf(stderr, " %.0f", R.us[k][i]); }
     fprintf(stderr, "\n");
   }
+  for (int k = 0; k < nc; ++k)
+    if (k != best && cand[k] != keep) idle_pool(dev).push_back({cand[k], priority});
   registry(dev).push_back({cand[best], rank});
   return cand[best];
 }

@@ -453,7 +453,10 @@ int sf_bwd(hipStream_t st, const SfBwdArgs& a) {
 //   dZ[j][f] = sum_i alpha_d[i][j] dP[i][f]   A = alpha_d^T (registers), B = dP; a wave owns whole 16-column strips of f,
 //              so it overwrites its strip of shP with dZ without a barrier (only the owner reads those columns)
 // LDS images are zero padded to 16 NT rows (shW, shP) / 4 S rows and 16 NT columns (shAd) so fragments need no guards.
-template <int NT, int NW = 4>
+// TS = float4 column slots per lane in the epilogue: 1 when F <= 256 (D = 768: F4 = 48 of 64 lanes), else 2.  With one slot the
+// kernel needs <= 64 VGPRs, i.e. FOUR 8-wave workgroups per CU (what its 39 KB of LDS images allow at N = 20) instead of three:
+// the 1024 workgroups of a C2 launch then run as one round instead of 1.33.
+template <int NT, int NW = 4, int TS = 2>
 __global__ __launch_bounds__(64 * NW) void k_gat_attn_bwd(const GatAttnBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int b = blockIdx.x, h = blockIdx.y, mod = blockIdx.z;
@@ -609,9 +612,9 @@ __global__ __launch_bounds__(64 * NW) void k_gat_attn_bwd(const GatAttnBwdArgs a
   // ---- epilogue, one wave per row j: dWh_j = s_j dZ_j + du_j a_l + dv_j a_r (fp32 + planes), ds_j = dZ_j . Wh_j,
   //      d a_l += du_j Wh_j, d a_r += dv_j Wh_j (per-wave partials in registers, then summed through LDS) ----
   float* dWh = a.dWh[mod] ? a.dWh[mod] + (int64_t)b * N * HF + h * F : nullptr;   // fp32 copy: only where it has a reader
-  float4 pal[2], par[2], gal[2], gar[2];                    // this lane's columns 4 (lane + 64 t) .. + 3, t < 2 (F <= 512)
+  float4 pal[TS], par[TS], gal[TS], gar[TS];                    // this lane's columns 4 (lane + 64 t) .. + 3, t < 2 (F <= 512)
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
+  for (int t = 0; t < TS; ++t) {
     pal[t] = make_float4(0.f, 0.f, 0.f, 0.f); par[t] = pal[t]; gal[t] = pal[t]; gar[t] = pal[t];
     const int q = lane + 64 * t;
     if (q < F4) {
@@ -623,7 +626,7 @@ __global__ __launch_bounds__(64 * NW) void k_gat_attn_bwd(const GatAttnBwdArgs a
     const float sj = shS[j], duj = shDu[j], dvj = shDv[j];
     float dsp = 0.f;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < TS; ++t) {
       const int q = lane + 64 * t;
       if (q < F4) {
         const float4 z = *reinterpret_cast<const float4*>(shP + j * FS + 4 * q), w = *reinterpret_cast<const float4*>(shW + j * FS + 4 * q);
@@ -643,7 +646,7 @@ __global__ __launch_bounds__(64 * NW) void k_gat_attn_bwd(const GatAttnBwdArgs a
   __syncthreads();                                          // every wave is done with shW: it now holds the partials
   float* shDa = shW;                                        // [NW][2 F]
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
+  for (int t = 0; t < TS; ++t) {
     const int q = lane + 64 * t;
     if (q < F4) {
       *reinterpret_cast<float4*>(shDa + wave * 2 * F + 4 * q) = pal[t];
@@ -908,6 +911,12 @@ template <int NT>
 static int gat_attn_bwd_nt(hipStream_t st, const GatAttnBwdArgs& a) {
   constexpr int NW = NT == 4 ? kAttnWavesWide : kAttnWavesSmall;
   const size_t lds = gat_bwd_lds(a.N, a.D / 4);
+  if (a.D / 16 <= 64) {                                     // one float4 slot per lane covers the head's F columns
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gat_attn_bwd<NT, NW, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    DVGR_LAUNCH((k_gat_attn_bwd<NT, NW, 1>), dim3(a.B, kHeads, 2), dim3(64 * NW), lds, st, a);
+    DVGR_LAUNCH_CHECK();
+  }
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gat_attn_bwd<NT, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   DVGR_LAUNCH((k_gat_attn_bwd<NT, NW>), dim3(a.B, kHeads, 2), dim3(64 * NW), lds, st, a);

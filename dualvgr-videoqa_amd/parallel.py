@@ -327,16 +327,34 @@ class NativeUnitReducer:
             box = [ident.raw]
             dist.broadcast_object_list(box, src=0, group=group)
             ident = C.create_string_buffer(box[0], 128)
-        h = C.c_void_p()
-        with torch.cuda.device(device):
-            L_.check(self.lib.dvgr_comm_create(ident, self.rank, self.world, C.byref(h)), "dvgr_comm_create")
-        self.handle = h.value
+        # ncclCommInitRank and the stream placement come AFTER that first agreement and can still fail on one rank alone (a
+        # rank that raised by itself would fall back to another reducer while its peers keep this communicator: mismatched
+        # collectives, a hang until the process-group timeout).  So: a failed placement is not an error at all (the library
+        # keeps candidate 0 and reports mask -1), and whatever else failed is agreed on a second time before anyone raises.
+        failure = None
+        self.handle = None
         self.placement = None
         self.inorder = bool(inorder)
-        if self.inorder:
-            L_.check(self.lib.dvgr_comm_set_inorder(self.handle, 1), "dvgr_comm_set_inorder")
-        elif place:
-            self.place(busy_streams)
+        try:
+            h = C.c_void_p()
+            with torch.cuda.device(device):
+                L_.check(self.lib.dvgr_comm_create(ident, self.rank, self.world, C.byref(h)), "dvgr_comm_create")
+            self.handle = h.value
+            if self.inorder:
+                L_.check(self.lib.dvgr_comm_set_inorder(self.handle, 1), "dvgr_comm_set_inorder")
+            elif place:
+                self.place(busy_streams)
+        except Exception as e:                       # noqa: BLE001 -- reported on every rank below
+            failure = e
+        if self.world > 1:
+            on_dev = dist.get_backend(group) == "nccl"
+            flag = torch.tensor([1 if failure is not None else 0], dtype=torch.int32, device=device if on_dev else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+            if int(flag.item()) and failure is None:
+                failure = RuntimeError("NativeUnitReducer: creating the communicator failed on another rank")
+        if failure is not None:
+            self.close()
+            raise RuntimeError(f"NativeUnitReducer set-up failed (rank {self.rank}): {failure}") from failure
 
     def place(self, busy_streams: Sequence = ()) -> dict:
         """dvgr_comm_place against [the current stream] + busy_streams (+ the library's own side / query stream)."""

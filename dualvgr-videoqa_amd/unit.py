@@ -254,6 +254,9 @@ class _UnitFn(torch.autograd.Function):
         return (None, gA, gM, gdq, gwords, None, None, *pgrads)
 
 
+_PLACED_DEVICES = set()      # devices whose internal streams were placed by this host side (dvgr_streams_place)
+
+
 class DualVGRUnit_multiple(nn.Module):
     """Drop-in for the reference `DualVGRUnit_multiple` (model/models.py:86-173).
 
@@ -437,6 +440,13 @@ class DualVGRUnit_multiple(nn.Module):
             lib = L_.load()
             dims = L_.make_dims(B, N, T, self.module_dim, self.word_dim, self.layers, self.graph_layers, self.dtype_code)
             L_.check(lib.dvgr_check_dims(C.byref(dims)), "dvgr_check_dims")
+            if dev.type == "cuda" and not self.single_stream and dev.index not in _PLACED_DEVICES:
+                # set-up, not the hot path: the library's side / query streams get their hardware queues HERE (a device
+                # synchronise + ~0.1 s of probe kernels, include/dvgr.h dvgr_streams_place) instead of inside the first
+                # forward call; skipped by the library itself while a stream capture is active
+                with torch.cuda.device(dev):
+                    L_.check(lib.dvgr_streams_place(torch.cuda.current_stream(dev).cuda_stream), "dvgr_streams_place")
+                _PLACED_DEVICES.add(dev.index)
             st_ = {"dims": dims, "saved_bytes": lib.dvgr_saved_bytes(C.byref(dims)), "ws_bytes": lib.dvgr_workspace_bytes(C.byref(dims)),
                    "buf": {}}
             if len(self._shapes) > 16:

@@ -138,6 +138,11 @@ const char *dvgr_version(void);
  * it least.  Background (csrc/dvgr_place.hip, tools/micro/pipe_probe.hip): the command processor serves a process's hardware
  * queues on 4 pipes, and two busy queues of ONE pipe cost every dispatch of both ~25 us; which queues share a pipe follows
  * creation order, so the library measures instead of assuming an order (~20-100 ms per stream, once; synchronises the device).
+ * HOSTS SHOULD CALL THIS DURING SET-UP (the Python host side does, when the module moves to its device): left to the first
+ * forward / backward call, the measurement runs inside that call -- a device synchronise plus ~0.1 s of probe kernels on the
+ * caller's stream.  While a stream capture is active (on the caller's stream, or a global-mode capture anywhere) the probe is
+ * skipped and the streams are created plainly; at most 12 candidate streams are ever created per device (the losers of one
+ * placement are the first candidates of the next).
  * DVGR_NO_STREAM_PLACEMENT=1 in the environment: plain stream creation. */
 int dvgr_streams_place(void *caller_stream);
 int dvgr_streams_init(void);                    /* = dvgr_streams_place(NULL) */

@@ -41,7 +41,9 @@ int dvgr_comm_create(const void* id, int rank, int world, dvgr_comm** out);
  * re-maps the rest).  ~0.1 s, synchronises the device; call it after every stream the step uses exists and
  * before the first collective.  busy_streams: hipStream_t's of the CALLER (its compute stream first; NULL = the null stream),
  * n_busy <= 5.  report (optional, floats): [candidates, busy streams, chosen, collision mask of the chosen one,
- * undisturbed chain us per busy stream ..., chain us per (candidate, busy stream) ...]. */
+ * undisturbed chain us per busy stream ..., chain us per (candidate, busy stream) ...].  A measurement that fails (a HIP
+ * error inside the probe) is NOT an error of this call: the first candidate is installed, the collision mask reads -1 and
+ * the call returns 0 -- a rank must never leave the set-up alone because an advisory measurement failed. */
 int dvgr_comm_place(dvgr_comm* c, void* const* busy_streams, int n_busy, float* report, int report_len);
 int dvgr_comm_destroy(dvgr_comm* c);
 int dvgr_comm_world(const dvgr_comm* c);
@@ -50,7 +52,8 @@ int dvgr_comm_world(const dvgr_comm* c);
  * backward passes both: the event that marks the block final and the stream it was recorded on. */
 int dvgr_comm_allreduce_avg(dvgr_comm* c, float* buf, int64_t count, void* wait_event, void* after_stream);
 /* In-order mode (on != 0): dvgr_comm_allreduce_avg enqueues on `after_stream` itself (which must then be the stream that
- * produced buf; `wait_event` is ignored) and dvgr_comm_join does nothing -- no communication stream, no cross-stream event.
+ * produced buf; a non-NULL `wait_event` is waited for on it as well, which costs nothing when it was recorded on that same
+ * stream) and dvgr_comm_join does nothing -- no communication stream, no cross-stream event.
  * The collective then delays the later work of its producer stream (the unit's side stream for the layer blocks) but still
  * overlaps the other streams.  On one rank, where a collective is a copy kernel, this is the cheaper form (whole model
  * 1.01 x the plain step against 1.16 x); with several ranks bench.py times both and takes the faster. */

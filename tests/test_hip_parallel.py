@@ -500,13 +500,14 @@ def test_bench_selftest_picks_its_reducer_from_child_trials():
     """Round-3 review: with BOTH reducers set up in one process the torch.distributed path measured 3.2 ms per step against
     1.2 alone, so an in-process trial could print a line that measures the set-up, not the path.  `bench.py` (reducer auto)
     now tries each candidate in a child process of its own before it touches the GPU and sets up the winner alone; a best
-    candidate beyond 1.3 x the plain step makes it exit non-zero.  One rank, collectives really enqueued."""
+    candidate beyond 1.3 x the plain step is flagged `suspect_setup` (exit 3 under DVGR_BENCH_STRICT=1, which this self-test of
+    the plumbing sets).  One rank, collectives really enqueued."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
-    env.update({"DVGR_DDP_SELFTEST": "1", "MASTER_PORT": "29741", "MASTER_ADDR": "127.0.0.1"})
+    env.update({"DVGR_DDP_SELFTEST": "1", "MASTER_PORT": "29741", "MASTER_ADDR": "127.0.0.1", "DVGR_BENCH_STRICT": "1"})
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "20", "--warmup", "5", "--min-seconds", "0.5",
@@ -520,7 +521,7 @@ def test_bench_selftest_picks_its_reducer_from_child_trials():
     cands = {k: v for k, v in trial.items() if k != "plain" and v}
     best = min(cands, key=cands.get)
     assert dist_cfg["reducer"].startswith(best)
-    assert cands[best] <= 1.3 * trial["plain"]
+    assert cands[best] <= 1.3 * trial["plain"] and not dist_cfg["reducer_trial"].get("suspect_setup")
     assert d["ms_per_step"] <= 1.5 * trial["plain"]            # the timed region runs the winner alone: no 3 x artefact
     assert set(dist_cfg["allreduce_bytes_per_block"]) == {"0", "1", "2", "3", "4"}
 
@@ -529,9 +530,11 @@ def test_bench_selftest_picks_its_reducer_from_child_trials():
 def test_bench_two_ranks_under_the_launcher_share_one_gpu():
     """The control flow of `bench.py --gpus N` for N > 1 as the driver starts it (python -m torch.distributed.run ... bench.py
     --gpus 2), rehearsed on ONE GPU: two ranks share the device (DVGR_BENCH_SHARE_GPU) over gloo.  Every rank runs its trial
-    children (the native forms are skipped for gloo), the ranks agree on MAX per candidate, the timed region runs the
-    torch.distributed reducer and rank 0 prints ONE line with the whole-job value.  (Gloo moves the 57 MB through the host, so
-    the sanity gate -- best candidate within 2.5 x of the plain step -- would refuse this set-up: first checked, then overridden.)"""
+    children (the native forms are skipped for gloo) on free ports shared over the launcher's agent store, the ranks agree on
+    MAX per candidate after each one, the timed region runs the torch.distributed reducer and rank 0 prints ONE line with the
+    whole-job value.  Gloo moves the 57 MB through the host, so the best candidate is far beyond 2.5 x the plain step: by
+    default the line is printed WITH `suspect_setup` (a bandwidth-bound run is still a measurement); DVGR_BENCH_STRICT=1
+    turns the same finding into exit code 3 and no line."""
     import json
     import subprocess
     import sys
@@ -543,10 +546,11 @@ def test_bench_two_ranks_under_the_launcher_share_one_gpu():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29761", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
            "--min-seconds", "0.2", "--backend", "gloo", "--no-cpu-baseline"]
+    env["DVGR_BENCH_STRICT"] = "1"
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
-    assert r.returncode != 0 and "refusing to print a result" in r.stderr, r.stderr[-2000:]
+    assert r.returncode != 0 and "suspect set-up" in r.stderr, r.stderr[-2000:]
     assert '"metric"' not in r.stdout
-    env["DVGR_BENCH_ALLOW_SLOW"] = "1"
+    del env["DVGR_BENCH_STRICT"]
     cmd[cmd.index("29761")] = "29771"
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -560,3 +564,4 @@ def test_bench_two_ranks_under_the_launcher_share_one_gpu():
     assert dist_cfg["world_size"] == 2 and dist_cfg["reducer"].startswith("python")
     t = dist_cfg["reducer_trial"]["ms_per_step"]
     assert t["plain"] and t["python"] and t["native"] is None and t["inorder"] is None
+    assert dist_cfg["reducer_trial"]["suspect_setup"] is True and dist_cfg["reducer_trial"]["best_over_plain"] > 2.5
