@@ -60,6 +60,8 @@ OPT_SINGLE_STREAM = 1
 OPT_NO_QUERY_STREAM = 2
 OPT_NO_FUSED_GAT = 4
 OPT_LEAVES_ON_QUERY = 8
+OPT_NO_FUSED_GAT_BWD = 16
+OPT_FORCE_FUSED_GAT_BWD = 32
 
 # enum dvgr_probe_site
 (PROBE_NONE, PROBE_FWD_QA_GEMM, PROBE_FWD_GAT_GEMM, PROBE_FWD_GAT_ATTN, PROBE_FWD_SF_GEMM, PROBE_FWD_MFB_GEMM,

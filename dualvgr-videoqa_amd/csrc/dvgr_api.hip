@@ -47,7 +47,9 @@ FwdWs fwd_ws(const dvgr_dims& d) {
 struct BwdWs {
   int64_t dpo, dzf, dp0, dp1, dz[2], dxtmp[2], dspec[2];
   int64_t dw[2][2], dpre[2][2], dWh[2][2], ds_part[2][2], da_part[2][2], dc_part[2][2];   // [set][modality]
-  int64_t dp_cat, dqbar, dr, dy, qdots, total;                                             // [L] each
+  int64_t dp_cat, dqbar, dr, dy, qdots;                                                    // [L] each
+  int64_t p1t;            // [L][2] plane-only slots of D x D: P1^T of every (layer, modality) for the fused GAT-view backward
+  int64_t total;
 };
 BwdWs bwd_ws(const dvgr_dims& d) {
   BwdWs w{};
@@ -75,6 +77,7 @@ BwdWs bwd_ws(const dvgr_dims& d) {
   w.dr = o;     o += round64(L * d.B * d.T);
   w.dy = o;     o += round64(L * d.B * d.T * D);
   w.qdots = o;  o += round64(2 * L * d.B * d.T);
+  w.p1t = o;    o += 2 * L * round64(D * D);
   w.total = o;
   return w;
 }
@@ -839,6 +842,38 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     return 0;
   };
 
+  // S4 backward (data) + S3 backward as ONE launch per layer (dvgr_gatb.hip) where the shape allows it: the dz contraction
+  // on a tile of whole samples x one head's columns with the attention backward as its epilogue.  Its B operand is P1^T
+  // (rows = the head's columns, reduction index contiguous): the planes of every layer's P1 are transposed into plane-only
+  // workspace slots by one small launch, off the critical path (side stream; 14 MB at C2).
+  const bool fuse_bwd = PM.on && G == 1 && !(O.flags & (DVGR_OPT_NO_FUSED_GAT | DVGR_OPT_NO_FUSED_GAT_BWD)) && L * 2 <= kMaxTransposeJobs &&
+                        gat_fused_bwd_supported(B, N, D, prec) &&
+                        (gat_fused_bwd_preferred(B, N) || (O.flags & DVGR_OPT_FORCE_FUSED_GAT_BWD));
+  hipEvent_t p1t_done = nullptr;
+  int64_t p1t_lo = 0;
+  auto p1t_hi = [&](int l, int m) { return PM.out(ws + W.p1t + (int64_t)(l * 2 + m) * round64((int64_t)D * D), &p1t_lo); };
+  auto p1_transposed = [&](hipStream_t on) -> int {
+    if (!fuse_bwd) return 0;
+    TransposeBatch tb{};
+    int64_t slo = 0;
+    for (int l = 0; l < L; ++l)
+      for (int m = 0; m < 2; ++m) {
+        const uint16_t* src = PM.find(mp(l, m) + P.sf_p1, &slo);
+        uint16_t* dst = p1t_hi(l, m);
+        if (!src || !dst) return DVGR_E_DIMS;        // (cannot happen: PM.on implies planes of the parameters and of the workspace)
+        tb.j[tb.n++] = TransposeJob{src, dst};
+      }
+    tb.src_lo = slo; tb.dst_lo = p1t_lo; tb.D = D;
+    DVGR_TRY(transpose_planes(on, tb));
+    if (side && on != st) {
+      p1t_done = side->next();
+      if (!p1t_done) return (int)hipErrorOutOfMemory;
+      const hipError_t e = hipEventRecord(p1t_done, on);
+      if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+  };
+
   // ---- S6 backward (its ELU derivative went out with the zero list above) ---------------------------------
   {
     GemmBatch gd{};   // dz = dpo . Wo
@@ -878,11 +913,13 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
         else gn.p[gn.n++] = gb.p[i];
       }
       DVGR_TRY(side->order(st, hs));
+      DVGR_TRY(p1_transposed(hs));           // (first thing on the side stream: the last layer's fused kernel waits for it)
       DVGR_TRY(gemm_launch(st, KC, IC, gn, TAG_GENERIC, prec));
       DVGR_TRY(launch_dw(hs, gt, bt, TAG_GENERIC, cb));
       if (cb.n) { cb.chunks = 16; DVGR_TRY(colsum(hs, cb)); }
       DVGR_TRY(layer_done(L, hs));
     } else {
+      DVGR_TRY(p1_transposed(st));
       DVGR_TRY(launch_mixed(st, gb, bias, TAG_GENERIC, cb));
       if (cb.n) { cb.chunks = 16; DVGR_TRY(colsum(st, cb)); }
       DVGR_TRY(layer_done(L, st));
@@ -1045,6 +1082,44 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       a.rows = BN; a.D = D;
       DVGR_TRY(sf_bwd(st, a));
     }
+    if (fuse_bwd) {
+      // dz_v += dpre_v . P1 and the attention backward of graph layer 0 in one launch (dvgr_gatb.hip)
+      if (p1t_done) {                        // the transposed planes come from the side stream
+        const hipError_t e = hipStreamWaitEvent(st, p1t_done, 0);
+        if (e != hipSuccess) return (int)e;
+        p1t_done = nullptr;
+      }
+      GatFusedBwdArgs fa{};
+      GatAttnBwdArgs& a = fa.at;
+      int64_t alo = -1, lo1 = 0;
+      bool ok = true;
+      for (int m = 0; m < 2 && ok; ++m) {
+        a.dz[m] = ws + W.dz[m];
+        a.out_c[m] = (m == 0 ? io->com_app : io->com_mot) + (int64_t)l * BND;
+        a.out_s[m] = (m == 0 ? io->aq_fusion : io->mq_fusion) + (int64_t)l * BND;
+        a.Wh[m] = ms(l, m) + S.wh; a.s[m] = ms(l, m) + S.s; a.u[m] = ms(l, m) + S.u; a.v[m] = ms(l, m) + S.v;
+        a.gat_a[m] = mp(l, m) + P.gat_a; a.gat_c[m] = mp(l, m) + P.gat_c;
+        a.dWh[m] = lean ? nullptr : ws + W.dWh[set][m];
+        a.ds_part[m] = ws + W.ds_part[set][m];
+        a.da_part[m] = ws + W.da_part[set][m];
+        a.dc_part[m] = ws + W.dc_part[set][m];
+        for (int h = 0; h < 8; ++h) a.key_alpha[m][h] = K.alpha[m][h];
+        for (int gi = 0; gi < 2; ++gi) a.key_out[m][gi] = K.out[m][gi];
+        a.dWh_p[m] = PM.out(ws + W.dWh[set][m], &plo);
+        fa.ah[m] = PM.find(ws + W.dpre[set][m], &lo1);
+        ok = ok && fa.ah[m] && (alo < 0 || alo == lo1);
+        alo = lo1;
+        fa.bh[m] = p1t_hi(l, m);
+        ok = ok && fa.bh[m];
+      }
+      if (!ok) return DVGR_E_DIMS;           // (cannot happen: fuse_bwd implies planes of every operand)
+      a.lo_off = plo;
+      fa.a_lo_off = alo; fa.b_lo_off = p1t_lo;
+      a.B = B; a.N = N; a.D = D;
+      DVGR_TRY(probe.begin(DVGR_PROBE_BWD_SF_DX, l));
+      DVGR_TRY(gat_fused_bwd(st, fa, prec));
+      DVGR_TRY(probe.end(DVGR_PROBE_BWD_SF_DX, l));
+    } else
     {
       GemmBatch gd{};   // dz_v += dpre_v . P1
       for (int m = 0; m < 2; ++m) {
@@ -1169,7 +1244,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       a.n = BND;
       DVGR_TRY(dz_build(st, a));
     }
-    DVGR_TRY(attn_bwd(0));
+    if (!fuse_bwd) DVGR_TRY(attn_bwd(0));
     auto punish = [&](int parts) -> int {   // S1 backward: bit 0 = d p (kept per layer for the query branch), bit 1 = dX
       PunishBwdArgs a{};
       for (int m = 0; m < 2; ++m) {

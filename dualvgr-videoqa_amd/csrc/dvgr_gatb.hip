@@ -1,0 +1,561 @@
+// dvgr_gatb.hip -- the fused GAT-view BACKWARD kernel: the S4 backward contraction dz_v += dpre_v . P1 (gradient of the
+// common / specific GAT outputs through AttentionSFGCN's project[0], model/Attention.py:15-17,20-23) with the attention
+// backward of model/GraphNN.py:95-111 as its epilogue, in ONE launch per layer.
+//
+// Why this seam and not the other one: the attention backward's OUTPUT dWh feeds dX = dWh . Wcat, a reduction over all 8 heads,
+// so making it the producer stage of the dX contraction needs either a 6-fold recomputation or 63 MB of float atomics (round 4,
+// DESIGN.md section 3.2).  Its INPUT side is tile-local: head h of GAT g of sample b needs exactly the N rows of sample b x the
+// F columns hl F .. (hl + 1) F of dz_g (h = 4 g + hl) -- which is what ONE workgroup of the dz contraction produces when its
+// output tile is SPT whole samples x one head's columns, the tile of the forward kernel (dvgr_gatf.hip).  As two launches
+// (gemm_planes_kernel<TAG_BWD_SF_DX> then k_gat_attn_bwd) dz (2 x B N x D fp32, 15.7 MB at C2) is read-modify-written by the
+// contraction's generic epilogue and read again by 1024 attention workgroups; phase clocks of the attention kernel alone:
+// 19.7 us per workgroup, 6.9 of it its load phase (profiles/r05_attn_bwd_phase_clocks.txt).
+//
+// Work decomposition (C2: B = 64, N = 20, F = 192): as dvgr_gatf.hip -- 16 row tiles x (2 views x 4 heads) x 2 modalities = 256
+// workgroups, 12 waves: 4 loaders (LDS-DMA ring), 8 computing (bf16x3 MFMA).  K loop: A = 16 MTILES rows of view g of dpre
+// (planes written by k_sf_bwd), B = rows hl F .. of P1^T (planes transposed once per backward call by k_transpose_planes: with
+// P1 as [k][n] the B tile would need the IC fragment path at a 192-column tile width), reduction over D.
+// Epilogue, all 12 waves, in the ring's (now idle) LDS -- SPT samples at once:
+//   B0  every thread issues its global loads of the three fp32 tiles the attention needs (dz's part written by k_sf_bwd:
+//       beta_g do + the list gradient; the saved GAT output for ELU'; the saved projection Wh); accumulators -> shP;
+//       the loaders fill s, u, v, a_l, a_r and clear the padded images
+//   B1  alpha_ij = softmax_j LeakyReLU(u_i + v_j + c) recomputed (4 rows per wave pass, DPP row reductions), alpha and
+//       alpha * keep; then the loads land: dP = (acc + dz) * keep_out * ELU'(out) -> shP, Wh -> shW
+//   B2  dalpha_ij = keep_ij s_j (dP_i . Wh_j) on the fp32 MFMA, one (sample, 16 x 16 tile) per wave at a time
+//   B3  softmax and LeakyReLU backward, du_i (4 rows per wave pass)
+//   B4  dv_j, dc (a thread per column / sample) beside dZ = alpha_d^T . dP on the fp32 MFMA, one (sample, 16-column strip)
+//       per wave at a time; the wave overwrites its strip of shP
+//   B5  dWh_j = s_j dZ_j + du_j a_l + dv_j a_r -> bf16 planes (+ fp32 where it has a reader), ds_j = dZ_j . Wh_j;
+//       d a_l = du^T . Wh, d a_r = dv^T . Wh per sample as one more MFMA pass (rows 0 / 1 of a 16-row A operand)
+// Outputs are those of k_gat_attn_bwd (dWh planes, ds / da / dc partials per (sample, head)); dz itself is not written: nobody
+// else reads it at graph_layers = 1.
+#include <type_traits>
+
+#include "dvgr_gatf.h"
+
+#define DVGR_LAUNCH_CHECK() return (int)hipGetLastError()
+
+namespace dvgr {
+
+typedef float gatb_f32x4 __attribute__((ext_vector_type(4)));
+
+// Phase clocks (debug builds only, `make clk`; tools/gatb_clocks.py): thread 0 of every workgroup stamps the 100 MHz wall clock
+#ifdef DVGR_CLK
+__device__ long long g_gatb_clk[1024 * 8];
+#define GBCLK(k)                                                                                              \
+  do {                                                                                                        \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_gatb_clk[blockIdx.x * 8 + (k)] = wall_clock64();            \
+  } while (0)
+#else
+#define GBCLK(k) do { } while (0)
+#endif
+
+// ---- P1 -> P1^T, bf16 hi / lo planes, 64 x 64 tiles through LDS -----------------------------------------------------------
+__global__ __launch_bounds__(256) void k_transpose_planes(const TransposeBatch b) {
+  __shared__ uint16_t t[2][64][72];                       // (row stride 144 B: 16-byte aligned vectors, 36 banks apart)
+  const int D = b.D, tid = threadIdx.x;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const uint16_t* src = b.j[blockIdx.z].src;
+  uint16_t* dst = b.j[blockIdx.z].dst;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int v = tid + 256 * it, row = v >> 3, c8 = (v & 7) * 8;      // 512 vectors of 8 elements per plane
+    const uint4 hi = *reinterpret_cast<const uint4*>(src + (int64_t)(r0 + row) * D + c0 + c8);
+    const uint4 lo = *reinterpret_cast<const uint4*>(src + b.src_lo + (int64_t)(r0 + row) * D + c0 + c8);
+    *reinterpret_cast<uint4*>(&t[0][row][c8]) = hi;
+    *reinterpret_cast<uint4*>(&t[1][row][c8]) = lo;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int v = tid + 256 * it, orow = v >> 3, o8 = (v & 7) * 8;     // output row = source column
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      uint32_t w[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        w[k] = (uint32_t)t[p][o8 + 2 * k][orow] | ((uint32_t)t[p][o8 + 2 * k + 1][orow] << 16);
+      *reinterpret_cast<uint4*>(dst + (p ? b.dst_lo : 0) + (int64_t)(c0 + orow) * D + r0 + o8) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+}
+
+int transpose_planes(hipStream_t st, const TransposeBatch& b) {
+  if (b.n < 1 || b.n > kMaxTransposeJobs || b.D < 64 || (b.D % 64) != 0) return DVGR_E_DIMS;
+  DVGR_LAUNCH(k_transpose_planes, dim3(b.D / 64, b.D / 64, b.n), dim3(256), 0, st, b);
+  DVGR_LAUNCH_CHECK();
+}
+
+// ---- the fused kernel ------------------------------------------------------------------------------------------------
+// 16-lane row reductions by DPP rotations (every lane of the row ends with the total)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_move<0xb1, 0xf>(0.f, v);      // quad_perm [1,0,3,2]
+  v += dpp_move<0x4e, 0xf>(0.f, v);      // quad_perm [2,3,0,1]
+  v += dpp_move<0x124, 0xf>(0.f, v);     // row_ror 4
+  v += dpp_move<0x128, 0xf>(0.f, v);     // row_ror 8
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_move<0xb1, 0xf>(-INFINITY, v));
+  v = fmaxf(v, dpp_move<0x4e, 0xf>(-INFINITY, v));
+  v = fmaxf(v, dpp_move<0x124, 0xf>(-INFINITY, v));
+  v = fmaxf(v, dpp_move<0x128, 0xf>(-INFINITY, v));
+  return v;
+}
+
+template <int MTILES, int NTC>
+struct GatbEpi {                                          // epilogue images, in floats
+  static constexpr int RP = 16 * MTILES, F = 64 * NTC, FS = F + 4;
+  __host__ __device__ static constexpr size_t floats(int N, int SPT) {
+    return 2 * (size_t)(RP + 1) * FS + 2 * F + (size_t)SPT * (3 * N + 1) * (N + 1) + 5 * RP;
+  }
+};
+
+template <int TERMS, int MTILES, int NT, int NTC>
+__global__ __launch_bounds__(768) void k_gat_fused_bwd(const GatFusedBwdArgs a) {
+  using C = GatfCfg<TERMS, MTILES, NTC>;
+  extern __shared__ __attribute__((aligned(16))) uint16_t gatb_smem[];
+  uint16_t* smem = gatb_smem;
+  const int N = a.at.N, D = a.at.D, B = a.at.B, BN = B * N;
+  constexpr int F = C::F, RP = C::RP, F4 = F / 4, JT = F / 16, FS = GatbEpi<MTILES, NTC>::FS;
+  const int HF = kHeads * F;
+  const int SPT = a.spt;                                   // samples per tile (SPT * N <= RP)
+  const int mtiles = (B + SPT - 1) / SPT;
+  const int total = mtiles * kHeads * 2;
+  const int chunk = (int)gridDim.x >> 3;
+  const int idx = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);     // XCD x takes chunk x of the tile list
+  if (idx >= total) return;                                // uniform per workgroup, before any barrier
+  const int mod = idx / (mtiles * kHeads);
+  const int rem = idx - mod * mtiles * kHeads;
+  const int h = rem / mtiles, mt = rem - h * mtiles;
+  const int g = h >> 2, hl = h & 3;                        // view (GAT) and the head's column block inside its (B N, D) output
+  const int b0 = mt * SPT;
+  const int m0 = b0 * N;
+  const int spt_valid = (B - b0) < SPT ? (B - b0) : SPT;
+  const int rows_valid = spt_valid * N;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave12 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave12 >= 8;
+  const int nk = D / BK;
+
+  f32x4 acc[4][NTC];
+  int row0 = 0;
+  const int col0 = (wave12 & 3) * 16 * NTC;
+  float pre_al = 0.f, pre_ar = 0.f, pre_s = 0.f, pre_u = 0.f, pre_v = 0.f;
+  GBCLK(0);
+  if (loader) {
+    const int tl = tid - 512;                              // 0 .. 255
+    const float* ga = a.at.gat_a[mod] + h * 2 * F;
+    // (unconditional loads at clamped indices, issued ahead of the ring's first DMA: they land under the K loop)
+    const int ta = tl < F ? tl : F - 1, ts = tl < rows_valid ? tl : rows_valid - 1;
+    const int sx = ts / N, ix = ts - sx * N;
+    const int64_t uo = ((int64_t)(b0 + sx) * kHeads + h) * N + ix;
+    pre_al = ga[ta]; pre_ar = ga[F + ta];
+    pre_s = a.at.s[mod][m0 + ts];
+    pre_u = a.at.u[mod][uo]; pre_v = a.at.v[mod][uo];
+    const int w = wave12 - 8;
+    const uint16_t* xa = a.ah[mod] + (int64_t)g * BN * D;  // view g of dpre (2, B N, D)
+    if (C::IHI == C::ILO || w < (C::ITOT & 3)) gatf_loader<C, TERMS, C::IHI>(xa, a.a_lo_off, a.bh[mod], a.b_lo_off, smem, hl * F, m0, BN, D, nk, w, lane);
+    else gatf_loader<C, TERMS, (C::ILO > 0 ? C::ILO : 1)>(xa, a.a_lo_off, a.bh[mod], a.b_lo_off, smem, hl * F, m0, BN, D, nk, w, lane);
+  } else {
+    const int rg = wave12 >> 2;
+    if (rg == 0) { row0 = 0; gatf_compute<C, TERMS, C::MT0, NTC>(smem, nk, row0, col0, lane, acc); }
+    else { row0 = 16 * C::MT0; gatf_compute<C, TERMS, (MTILES - C::MT0 > 0 ? MTILES - C::MT0 : 1), NTC>(smem, nk, row0, col0, lane, acc); }
+  }
+  __builtin_amdgcn_s_barrier();                            // every fragment read of the ring is done: its LDS is free
+  GBCLK(1);
+
+  // ---- epilogue images (floats) -------------------------------------------------------------------------------------
+  const int S = (N + 3) >> 2, NP = N + 1;
+  float* shP = reinterpret_cast<float*>(smem);             // [RP + 1][FS]  acc, then dP, then dZ; row RP = 0
+  float* shW = shP + (RP + 1) * FS;                        // [RP + 1][FS]  Wh (unscaled); row RP = 0
+  float* shAl = shW + (RP + 1) * FS;                       // [F]
+  float* shAr = shAl + F;                                  // [F]
+  float* shA = shAr + F;                                   // [SPT][N][NP]      alpha
+  float* shAd = shA + SPT * N * NP;                        // [SPT][N + 1][NP]  alpha * keep; row N and column N = 0
+  float* shG = shAd + SPT * (N + 1) * NP;                  // [SPT][N][NP]      dalpha, then dpre
+  float* shS = shG + SPT * N * NP;                         // [RP]
+  float* shU = shS + RP;                                   // [RP]
+  float* shV = shU + RP;                                   // [RP]
+  float* shDu = shV + RP;                                  // [RP]
+  float* shDv = shDu + RP;                                 // [RP]
+  auto lgk_barrier = [&]() {                               // (raw barrier behind an LDS-only wait: global stores / loads stay in flight)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  const int rsub = lane >> 4, c16 = lane & 15;             // the row phases: 4 rows per wave pass, 16 lanes per row
+  const int r16 = lane & 15, kq = lane >> 4;               // the MFMA phases
+  const float inv_n = 1.0f / (float)N;
+  const uint32_t ko = a.at.key_out[mod][g];
+  const uint32_t ka = a.at.key_alpha[mod][h];
+  const float cc = a.at.gat_c[mod][h];
+
+  // B0: the three fp32 tiles, WV float4 pieces of each per thread, issued now and consumed in B1
+  constexpr int WV = (RP * F4 + 767) / 768;
+  gatb_f32x4 zv[WV], yv[WV], wv[WV];
+  {
+    const float* zg = a.at.dz[mod] + (int64_t)g * BN * D + (int64_t)m0 * D + hl * F;
+    const float* yg = (g ? a.at.out_s[mod] : a.at.out_c[mod]) + (int64_t)m0 * D + hl * F;
+    const float* wg = a.at.Wh[mod] + (int64_t)m0 * HF + h * F;
+    const int emax = rows_valid * F4 - 1;
+#pragma unroll
+    for (int k = 0; k < WV; ++k) {
+      int e = tid + 768 * k;
+      e = e < emax ? e : emax;
+      const int r = e / F4, q = e - r * F4;
+      zv[k] = *reinterpret_cast<const gatb_f32x4*>(zg + (int64_t)r * D + 4 * q);
+      yv[k] = *reinterpret_cast<const gatb_f32x4*>(yg + (int64_t)r * D + 4 * q);
+      wv[k] = *reinterpret_cast<const gatb_f32x4*>(wg + (int64_t)r * HF + 4 * q);
+    }
+  }
+  if (!loader) {
+    const int mtw = (wave12 >> 2) == 0 ? C::MT0 : MTILES - C::MT0;
+#pragma unroll
+    for (int j = 0; j < NTC; ++j) {
+      const int col = col0 + 16 * j + (lane & 15);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i < mtw) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) shP[(row0 + 16 * i + 4 * (lane >> 4) + r) * FS + col] = acc[i][j][r];
+        }
+      }
+    }
+  } else {
+    const int tl = tid - 512;                              // 0 .. 255
+    for (int e = tl; e < SPT * (N + 1) * NP; e += 256) shAd[e] = 0.f;
+    for (int e = tl; e < FS; e += 256) { shP[RP * FS + e] = 0.f; shW[RP * FS + e] = 0.f; }
+    static_assert(F <= 256 && RP <= 256, "one prefetched element per loader thread");
+    if (tl < F) { shAl[tl] = pre_al; shAr[tl] = pre_ar; }
+    if (tl < RP) {
+      const bool ok = tl < rows_valid;
+      shS[tl] = ok ? pre_s : 0.f; shU[tl] = ok ? pre_u : 0.f; shV[tl] = ok ? pre_v : 0.f;
+      shDu[tl] = 0.f; shDv[tl] = 0.f;
+    }
+  }
+  lgk_barrier();
+  GBCLK(2);
+  // B1a: alpha = softmax_j LeakyReLU(u_i + v_j + c) recomputed, and alpha * keep.  Lane (rsub, c16) takes j = c16 + 16 t of
+  // row 4 pass + rsub.
+  for (int pass = wave12; 4 * pass < rows_valid; pass += 12) {
+    const int r = 4 * pass + rsub;
+    const bool valid = r < rows_valid;
+    const int sidx = valid ? (int)(((float)r + 0.5f) * inv_n) : 0, i = valid ? r - sidx * N : 0;
+    const float ui = shU[valid ? r : 0];
+    float e[NT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int j = c16 + 16 * t;
+      e[t] = -INFINITY;
+      if (j < N) { const float x = ui + shV[sidx * N + j] + cc; e[t] = x > 0.f ? x : kSlope * x; }
+      mx = fmaxf(mx, e[t]);
+    }
+    mx = row16_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { e[t] = (c16 + 16 * t) < N ? expf(e[t] - mx) : 0.f; sum += e[t]; }
+    sum = row16_sum(sum);
+    if (valid) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int j = c16 + 16 * t;
+        if (j < N) {
+          const float al = e[t] / sum;
+          shA[(sidx * N + i) * NP + j] = al;
+          shAd[(sidx * (N + 1) + i) * NP + j] = al * drop_factor(ka, (uint32_t)(((b0 + sidx) * N + i) * N + j));
+        }
+      }
+    }
+  }
+  // B1b: dP = (acc + dz) * keep_out * ELU'(out) -> shP; Wh -> shW  (own elements only: no barrier since B0's writes of OTHER
+  // threads are read here -- the barrier above covers them)
+  {
+    const float sc = ko ? (1.0f - kDropP) : 1.0f;          // un-dropped ELU output where kept
+#pragma unroll
+    for (int k = 0; k < WV; ++k) {
+      const int e = tid + 768 * k;
+      if (e < rows_valid * F4) {
+        const int r = e / F4, q = e - r * F4;
+        float* pp = shP + r * FS + 4 * q;
+        const float4 ac = *reinterpret_cast<const float4*>(pp);
+        float kf[4];
+        drop_factor4(ko, (uint32_t)((int64_t)(m0 + r) * D + hl * F + 4 * q), kf);
+        float4 p;
+        p.x = (ac.x + zv[k][0]) * kf[0] * elu_grad_from_out(yv[k][0] * sc);
+        p.y = (ac.y + zv[k][1]) * kf[1] * elu_grad_from_out(yv[k][1] * sc);
+        p.z = (ac.z + zv[k][2]) * kf[2] * elu_grad_from_out(yv[k][2] * sc);
+        p.w = (ac.w + zv[k][3]) * kf[3] * elu_grad_from_out(yv[k][3] * sc);
+        *reinterpret_cast<float4*>(pp) = p;
+        *reinterpret_cast<gatb_f32x4*>(shW + r * FS + 4 * q) = wv[k];
+      }
+    }
+  }
+  lgk_barrier();
+  GBCLK(3);
+  // B2: dalpha_ij = keep_ij * s_j * (dP_i . Wh_j): items = (sample, I, J) 16 x 16 tiles, dealt round-robin to the waves.
+  // Fragment rows beyond the sample's N are redirected to the zero row RP.
+  {
+    const int nitems = spt_valid * NT * NT;
+    for (int item = wave12; item < nitems; item += 12) {
+      const int sidx = item / (NT * NT), t2 = item - sidx * NT * NT, I = t2 / NT, J = t2 - I * NT;
+      const int ra = 16 * I + r16, rb = 16 * J + r16;
+      const float* pa = shP + (ra < N ? sidx * N + ra : RP) * FS + 4 * kq;
+      const float* pb = shW + (rb < N ? sidx * N + rb : RP) * FS + 4 * kq;
+      gatb_f32x4 dacc = gatb_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+      for (int t = 0; t < F / 16; ++t) {
+        const float4 x = *reinterpret_cast<const float4*>(pa + 16 * t), y = *reinterpret_cast<const float4*>(pb + 16 * t);
+        dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, y.x, dacc, 0, 0, 0);
+        dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, y.y, dacc, 0, 0, 0);
+        dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, y.z, dacc, 0, 0, 0);
+        dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, y.w, dacc, 0, 0, 0);
+      }
+      const int j = 16 * J + r16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * I + 4 * kq + r;
+        if (i < N && j < N)
+          shG[(sidx * N + i) * NP + j] = dacc[r] * shS[sidx * N + j] * drop_factor(ka, (uint32_t)(((b0 + sidx) * N + i) * N + j));
+      }
+    }
+  }
+  lgk_barrier();
+  GBCLK(4);
+  // B3: softmax and LeakyReLU backward, du_i
+  for (int pass = wave12; 4 * pass < rows_valid; pass += 12) {
+    const int r = 4 * pass + rsub;
+    const bool valid = r < rows_valid;
+    const int sidx = valid ? (int)(((float)r + 0.5f) * inv_n) : 0, i = valid ? r - sidx * N : 0;
+    const float ui = shU[valid ? r : 0];
+    float al[NT], da[NT];
+    float rowdot = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int j = c16 + 16 * t;
+      const bool in = valid && j < N;
+      al[t] = in ? shA[(sidx * N + i) * NP + j] : 0.f;
+      da[t] = in ? shG[(sidx * N + i) * NP + j] : 0.f;
+      rowdot += al[t] * da[t];
+    }
+    rowdot = row16_sum(rowdot);
+    float du = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int j = c16 + 16 * t;
+      if (valid && j < N) {
+        const float pre = ui + shV[sidx * N + j] + cc;
+        const float dpre = al[t] * (da[t] - rowdot) * (pre > 0.f ? 1.f : kSlope);
+        shG[(sidx * N + i) * NP + j] = dpre;
+        du += dpre;
+      }
+    }
+    du = row16_sum(du);
+    if (valid && c16 == 0) shDu[r] = du;
+  }
+  lgk_barrier();
+  GBCLK(5);
+  // B4a: dv_j (a thread per column of a sample), dc (a thread per sample)
+  if (tid < rows_valid) {
+    const int sidx = (int)(((float)tid + 0.5f) * inv_n), j = tid - sidx * N;
+    float dv = 0.f;
+    for (int i = 0; i < N; ++i) dv += shG[(sidx * N + i) * NP + j];
+    shDv[tid] = dv;
+  } else if (tid >= 512 && tid < 512 + spt_valid) {
+    const int sidx = tid - 512;
+    float dc = 0.f;
+    for (int i = 0; i < N; ++i) dc += shDu[sidx * N + i];
+    a.at.dc_part[mod][(b0 + sidx) * kHeads + h] = dc;
+  }
+  // B4b: dZ = alpha_d^T . dP on the fp32 MFMA: items = (sample, 16-column strip); a wave takes a contiguous run of them, so
+  // its A fragments change only when the sample does; the wave overwrites its strip of shP (only the strip's owner reads those
+  // columns of that sample, and every load of an item is issued ahead of its stores)
+  const int items = spt_valid * JT, per = (items + 11) / 12;
+  const int it0 = wave12 * per, it1 = (it0 + per) < items ? (it0 + per) : items;
+  {
+    auto run = [&](auto sc_tag) {
+      constexpr int SC = decltype(sc_tag)::value;
+      constexpr int KS = SC ? SC : 4 * NT;
+      float af[NT][KS];
+      int cur = -1;
+      for (int item = it0; item < it1; ++item) {
+        const int sidx = item / JT, Ft = item - sidx * JT;
+        if (sidx != cur) {
+          cur = sidx;
+          const float* A_ = shAd + sidx * (N + 1) * NP;
+#pragma unroll
+          for (int Jt = 0; Jt < NT; ++Jt)
+#pragma unroll
+            for (int s4 = 0; s4 < KS; ++s4) {
+              const int i = 4 * s4 + kq, j = 16 * Jt + r16;
+              af[Jt][s4] = (SC || s4 < S) ? A_[(i < N ? i : N) * NP + (j < N ? j : N)] : 0.f;
+            }
+        }
+        float* P_ = shP + sidx * N * FS + 16 * Ft;
+        float bf[KS];
+#pragma unroll
+        for (int s4 = 0; s4 < KS; ++s4) {
+          const int i = 4 * s4 + kq;
+          bf[s4] = ((SC || s4 < S) && i < N) ? P_[i * FS + r16] : 0.f;
+        }
+        gatb_f32x4 zacc[NT];
+#pragma unroll
+        for (int Jt = 0; Jt < NT; ++Jt) zacc[Jt] = gatb_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s4 = 0; s4 < KS; ++s4) {
+          if (SC || s4 < S) {
+#pragma unroll
+            for (int Jt = 0; Jt < NT; ++Jt) zacc[Jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[Jt][s4], bf[s4], zacc[Jt], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int Jt = 0; Jt < NT; ++Jt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int j = 16 * Jt + 4 * kq + r;
+            if (j < N) P_[j * FS + r16] = zacc[Jt][r];
+          }
+      }
+    };
+    if (S == 4 * NT) run(std::integral_constant<int, 4 * NT>{});
+    else if (NT == 2 && S == 5) run(std::integral_constant<int, NT == 2 ? 5 : 1>{});
+    else if (NT == 1 && S == 2) run(std::integral_constant<int, NT == 1 ? 2 : 1>{});
+    else run(std::integral_constant<int, 0>{});
+  }
+  lgk_barrier();
+  GBCLK(6);
+  // B5a: dWh_j = s_j dZ_j + du_j a_l + dv_j a_r (planes; fp32 where it has a reader), ds_j = dZ_j . Wh_j.  Lane (rsub, c16)
+  // takes the columns 4 c16 + 64 k .. + 3 (k < NTC) of row 4 pass + rsub.
+  {
+    float4 al4[NTC], ar4[NTC];
+#pragma unroll
+    for (int k = 0; k < NTC; ++k) {
+      al4[k] = *reinterpret_cast<const float4*>(shAl + 4 * c16 + 64 * k);
+      ar4[k] = *reinterpret_cast<const float4*>(shAr + 4 * c16 + 64 * k);
+    }
+    float* dWh = a.at.dWh[mod] ? a.at.dWh[mod] + (int64_t)m0 * HF + h * F : nullptr;
+    for (int pass = wave12; 4 * pass < rows_valid; pass += 12) {
+      const int r = 4 * pass + rsub;
+      const bool valid = r < rows_valid;
+      const int rr = valid ? r : 0;
+      const float sj = shS[rr], duj = shDu[rr], dvj = shDv[rr];
+      float dsp = 0.f;
+#pragma unroll
+      for (int k = 0; k < NTC; ++k) {
+        const float4 z = *reinterpret_cast<const float4*>(shP + rr * FS + 4 * c16 + 64 * k);
+        const float4 w = *reinterpret_cast<const float4*>(shW + rr * FS + 4 * c16 + 64 * k);
+        const float4 o = make_float4(sj * z.x + duj * al4[k].x + dvj * ar4[k].x, sj * z.y + duj * al4[k].y + dvj * ar4[k].y,
+                                     sj * z.z + duj * al4[k].z + dvj * ar4[k].z, sj * z.w + duj * al4[k].w + dvj * ar4[k].w);
+        if (valid) {
+          if (dWh) st4(reinterpret_cast<float4*>(dWh + (int64_t)r * HF + 4 * c16 + 64 * k), o);
+          split_store4(a.at.dWh_p[mod], a.at.lo_off, (int64_t)(m0 + r) * HF + h * F + 4 * c16 + 64 * k, o);
+        }
+        dsp += z.x * w.x + z.y * w.y + z.z * w.z + z.w * w.w;
+      }
+      dsp = row16_sum(dsp);
+      if (valid && c16 == 0) {
+        const int sidx = (int)(((float)r + 0.5f) * inv_n), j = r - sidx * N;
+        a.at.ds_part[mod][((int64_t)(b0 + sidx) * kHeads + h) * N + j] = dsp;
+      }
+    }
+  }
+  // B5b: d a_l = du^T . Wh, d a_r = dv^T . Wh per sample: A = [du; dv; 0 ...] (16 x N, rows 0 / 1), B = the sample's rows of shW
+  for (int item = it0; item < it1; ++item) {
+    const int sidx = item / JT, Ft = item - sidx * JT;
+    gatb_f32x4 aacc = gatb_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s4 = 0; s4 < S; ++s4) {
+      const int j = 4 * s4 + kq;
+      const bool in = j < N;
+      const float av = !in ? 0.f : r16 == 0 ? shDu[sidx * N + j] : r16 == 1 ? shDv[sidx * N + j] : 0.f;
+      const float bv = in ? shW[(sidx * N + j) * FS + 16 * Ft + r16] : 0.f;
+      aacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, aacc, 0, 0, 0);
+    }
+    if (kq == 0) {                                         // rows m = 0 (d a_l) and m = 1 (d a_r) of the result
+      float* da = a.at.da_part[mod] + ((int64_t)(b0 + sidx) * kHeads + h) * 2 * F + 16 * Ft + r16;
+      da[0] = aacc[0];
+      da[F] = aacc[1];
+    }
+  }
+  GBCLK(7);
+}
+
+#ifdef DVGR_CLK
+extern "C" int dvgr_dbg_gatb_clocks(long long* host_out, int n) {
+  if (n > 1024 * 8) n = 1024 * 8;
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gatb_clk), sizeof(long long) * n, 0, hipMemcpyDeviceToHost);
+}
+#endif
+
+// ---- host side ----------------------------------------------------------------------------------------------------
+static size_t gatb_lds_bytes(const GatfShape& s, int N, int terms) {
+  constexpr int NTC = 3, F = 64 * NTC;
+  const int RP = 16 * s.mtiles16, planes = terms == 3 ? 2 : 1;
+  const size_t slot = (size_t)planes * ((size_t)RP * BK + (size_t)F * BK) * 2;      // bytes
+  const size_t ring = (4 * slot <= 150 * 1024 ? 4 : 3) * slot;
+  const size_t epi = sizeof(float) * (2 * (size_t)(RP + 1) * (F + 4) + 2 * F + (size_t)s.spt * (3 * N + 1) * (N + 1) + 5 * RP);
+  return (epi > ring ? epi : ring) + 16;
+}
+
+bool gat_fused_bwd_supported(int B, int N, int D, int prec) {
+  GatfShape s;
+  if (prec == DVGR_F32 || D != 768 || !gatf_shape(B, N, &s) || (int64_t)2 * B * N * D >= (1ll << 31)) return false;
+  if (s.nt > 2) return false;                              // (N > 32: the epilogue images of whole samples do not fit beside each other)
+  return gatb_lds_bytes(s, N, prec == DVGR_BF16X3 ? 3 : 1) <= 160 * 1024;
+}
+
+// Whether the fused form is the FASTER one (supported shapes only).  One workgroup per (row tile, head, modality): from ~200
+// workgroups up the launch fills the chip (C2, C3: 256 -- step -1.3 % / -1.6 %); at half of that (C4: 32 QA pairs of 16 clips
+// = 128 workgroups) each epilogue runs alone on its compute unit while the other half of the chip idles, and the two launches
+// with their 192 + 512 smaller workgroups are faster (+2.9 % fused); small batches (C1: 160 rows) are bound by the host's
+// enqueue rate, where one launch fewer per layer wins (-7 %).  profiles/experiments_r05.tsv, fused_gat_bwd_*.
+bool gat_fused_bwd_preferred(int B, int N) {
+  GatfShape s;
+  if (!gatf_shape(B, N, &s)) return false;
+  const int total = ((B + s.spt - 1) / s.spt) * kHeads * 2;
+  return total >= 200 || B * N <= 320;
+}
+
+template <int TERMS, int MTILES, int NT>
+static int gatb_launch(hipStream_t st, const GatFusedBwdArgs& a, const GatfShape& s) {
+  constexpr int NTC = 3;
+  const size_t lds = gatb_lds_bytes(s, a.at.N, TERMS);
+  if (lds > 160 * 1024) return DVGR_E_DIMS;
+  static bool attr_set = false;                            // (benign race: the attribute is idempotent)
+  if (!attr_set) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gat_fused_bwd<TERMS, MTILES, NT, NTC>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int mtiles = (a.at.B + a.spt - 1) / a.spt;
+  const int total = mtiles * kHeads * 2;
+  DVGR_LAUNCH((k_gat_fused_bwd<TERMS, MTILES, NT, NTC>), dim3(8 * ((total + 7) / 8)), dim3(768), lds, st, a);
+  DVGR_LAUNCH_CHECK();
+}
+
+template <int TERMS>
+static int gatb_dispatch(hipStream_t st, const GatFusedBwdArgs& a, const GatfShape& s) {
+  if (s.mtiles16 == 4 && s.nt == 1) return gatb_launch<TERMS, 4, 1>(st, a, s);
+  if (s.mtiles16 == 5 && s.nt == 2) return gatb_launch<TERMS, 5, 2>(st, a, s);
+  if (s.mtiles16 == 6 && s.nt == 2) return gatb_launch<TERMS, 6, 2>(st, a, s);
+  return DVGR_E_DIMS;
+}
+
+int gat_fused_bwd(hipStream_t st, const GatFusedBwdArgs& a_in, int prec) {
+  GatFusedBwdArgs a = a_in;
+  GatfShape s;
+  if (!gat_fused_bwd_supported(a.at.B, a.at.N, a.at.D, prec) || !gatf_shape(a.at.B, a.at.N, &s)) return DVGR_E_DIMS;
+  for (int m = 0; m < 2; ++m) {
+    if (!a.ah[m] || !a.bh[m] || !a.at.dz[m] || !a.at.out_c[m] || !a.at.out_s[m] || !a.at.Wh[m] || !a.at.s[m] || !a.at.u[m] ||
+        !a.at.v[m] || !a.at.gat_a[m] || !a.at.gat_c[m] || !a.at.dWh_p[m] || !a.at.ds_part[m] || !a.at.da_part[m] || !a.at.dc_part[m])
+      return DVGR_E_NULL;
+    if (((uintptr_t)a.ah[m] | (uintptr_t)a.bh[m]) & 15) return DVGR_E_ALIGN;
+  }
+  if ((a.a_lo_off & 7) || (a.b_lo_off & 7) || (a.at.lo_off & 3)) return DVGR_E_ALIGN;
+  a.spt = s.spt;
+  return prec == DVGR_BF16X3 ? gatb_dispatch<3>(st, a, s) : gatb_dispatch<1>(st, a, s);
+}
+
+}  // namespace dvgr

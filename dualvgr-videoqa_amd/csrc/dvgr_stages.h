@@ -151,6 +151,32 @@ struct GatAttnBwdArgs {
 };
 int gat_attn_bwd(hipStream_t st, const GatAttnBwdArgs& a);
 
+// S4 backward (data) + S3 backward in one launch (dvgr_gatb.hip): dz_g = [what k_sf_bwd left in at.dz] + dpre_g . P1 for a tile
+// of whole samples x one head's columns, with the attention backward of GatAttnBwdArgs as its epilogue.  bf16 modes with
+// pre-split planes of both operands, graph_layers = 1.  at.dz is READ (the part k_sf_bwd wrote); dz itself is not written back.
+struct GatFusedBwdArgs {
+  GatAttnBwdArgs at;
+  const uint16_t* ah[2];       // [mod] hi plane of dpre (2, B*N, D)
+  int64_t a_lo_off;            // lo plane = hi plane + a_lo_off elements
+  const uint16_t* bh[2];       // [mod] hi plane of P1^T (D, D): row = input feature i of project[0], reduction index o contiguous
+  int64_t b_lo_off;
+  int spt;                     // samples per tile (set by the launcher)
+};
+bool gat_fused_bwd_supported(int B, int N, int D, int prec);
+bool gat_fused_bwd_preferred(int B, int N);     // the fused form is also the faster one at this batch (measured rule)
+int gat_fused_bwd(hipStream_t st, const GatFusedBwdArgs& a, int prec);
+
+// bf16 planes of square matrices transposed (hi and lo plane of each job in one workgroup pass): dst[c][r] = src[r][c]
+constexpr int kMaxTransposeJobs = 24;
+struct TransposeJob { const uint16_t* src; uint16_t* dst; };
+struct TransposeBatch {
+  TransposeJob j[kMaxTransposeJobs];
+  int n;
+  int64_t src_lo, dst_lo;      // lo plane = hi plane + offset (elements)
+  int D;                       // multiple of 64
+};
+int transpose_planes(hipStream_t st, const TransposeBatch& b);
+
 // S1 backward: ds = sum_h ds_part; dtau = ds s (1-s); dX += dtau p (+ add); dp = sum_n dtau X.
 struct PunishBwdArgs {
   const float* ds_part[2];

@@ -342,6 +342,11 @@ class DualVGRUnit_multiple(nn.Module):
         self._shapes = {}
         self.single_stream = bool(int(os.environ.get("DVGR_SINGLE_STREAM", "0")))   # DVGR_OPT_SINGLE_STREAM
         self.fused_gat = not bool(int(os.environ.get("DVGR_NO_FUSED_GAT", "0")))      # False: DVGR_OPT_NO_FUSED_GAT (two launches)
+        # False: DVGR_OPT_NO_FUSED_GAT_BWD (dz contraction, then attention backward); "force": wherever the shape is supported,
+        # not only where it is measured faster (DVGR_OPT_FORCE_FUSED_GAT_BWD)
+        self.fused_gat_bwd = not bool(int(os.environ.get("DVGR_NO_FUSED_GAT_BWD", "0")))
+        if self.fused_gat_bwd and os.environ.get("DVGR_FORCE_FUSED_GAT_BWD", "0") == "1":
+            self.fused_gat_bwd = "force"
         self.leaves_on_query = bool(int(os.environ.get("DVGR_LEAVES_ON_QUERY", "0")))  # True: DVGR_OPT_LEAVES_ON_QUERY (A/B timing)
         # (alpha, beta, dep_scale[, with_sum_vis = True]) or None: when set, forward_raw() also evaluates the scope-U loss
         # sum(vis) + alpha*common + beta*dep_scale*dependence with its gradients w.r.t. the outputs (dvgr_opts.loss)
@@ -565,6 +570,10 @@ class DualVGRUnit_multiple(nn.Module):
             o.flags |= L_.OPT_SINGLE_STREAM
         if not self.fused_gat:
             o.flags |= L_.OPT_NO_FUSED_GAT
+        if not self.fused_gat_bwd:
+            o.flags |= L_.OPT_NO_FUSED_GAT_BWD
+        elif self.fused_gat_bwd == "force":
+            o.flags |= L_.OPT_FORCE_FUSED_GAT_BWD
         if self.leaves_on_query:
             o.flags |= L_.OPT_LEAVES_ON_QUERY
         if self._events or getattr(self, "_layer_cb", None) is not None:

@@ -219,6 +219,15 @@ enum dvgr_probe_site {
  * side stream beside layer 0's query chain instead of behind it.  DVGR_OPT_LEAVES_ON_QUERY keeps them on the query stream
  * (A/B timing). */
 #define DVGR_OPT_LEAVES_ON_QUERY 8
+/* Backward: the S4 data contraction dz_v += dpre_v . P1 and the attention backward (S3) of a layer run as ONE launch
+ * (csrc/dvgr_gatb.hip: the attention backward is the contraction's epilogue on a tile of whole samples x one head's columns;
+ * model/Attention.py:20-23 and model/GraphNN.py:95-111 backward) wherever the shape allows it -- bf16 modes, D = 768,
+ * graph_layers = 1, clip counts whose per-sample images fit the compute unit's LDS (N <= 20 at 4-5 row tiles).
+ * DVGR_OPT_NO_FUSED_GAT_BWD keeps the two-launch form (A/B timing, parity of the two forms); DVGR_OPT_NO_FUSED_GAT implies it. */
+#define DVGR_OPT_NO_FUSED_GAT_BWD 16
+/* The fused backward form is taken where it is supported AND measured faster (csrc/dvgr_gatb.hip gat_fused_bwd_preferred: launches
+ * of >= 200 workgroups, or host-bound small batches); DVGR_OPT_FORCE_FUSED_GAT_BWD takes it wherever it is supported (tests, A/B). */
+#define DVGR_OPT_FORCE_FUSED_GAT_BWD 32
 
 /* Scope-U loss evaluated by the forward itself (dvgr_opts.loss): the same arithmetic and outputs as
  * dvgr_scope_u_loss below, but the kernels are enqueued as soon as the last layer's list outputs exist and run on the

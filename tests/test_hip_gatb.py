@@ -1,0 +1,140 @@
+"""GPU: the fused GAT-view BACKWARD kernel (csrc/dvgr_gatb.hip: the S4 data contraction dz_v += dpre_v . P1 with the attention
+backward of model/GraphNN.py:95-111 as its epilogue, one launch per layer; model/Attention.py:20-23 backward) against
+
+  (1) the two-launch form of the same stage (DVGR_OPT_NO_FUSED_GAT_BWD: gemm_planes_kernel<TAG_BWD_SF_DX>, then
+      k_gat_attn_bwd) -- every input and parameter gradient to fp32 rounding (same operand planes, same MFMA chain per
+      element of the contraction; the attention's reductions run in a different order);
+  (2) the oracle, every gradient, at tile shapes the other test files do not reach: a last tile with fewer samples than the
+      others, N not a multiple of 4, both row-tile instantiations (4 and 5 row tiles), single-stream mode, eval and training
+      mode (all dropout sites: the alpha-site and out-site masks are recomputed inside the epilogue).
+Shapes the kernel does not take (N > 20 at D = 768: the per-sample images of whole samples do not fit one compute unit's LDS;
+graph_layers > 1) must run the two-launch form unchanged.  All through the C ABI via the drop-in module, D = 768, bf16x3
+(the bench's mode) and plain bf16."""
+import numpy as np
+import pytest
+import torch
+
+import dualvgr_videoqa_amd as dv
+from dualvgr_videoqa_amd import _lib as L
+from dualvgr_videoqa_amd import dropout, synth
+from helpers import aligned_oracle_backward, assert_flips_at_kink, assert_grads, device_logit_signs, rel_err
+from oracle import unit_torch as O
+
+pytestmark = pytest.mark.gpu
+D, WD, T = 768, 300, 9
+TOL, GTOL = 1e-4, 5e-4
+
+
+def _module(N, Lr, dtype, sd_np, train, fused_bwd, single=False, G=1):
+    m = dv.DualVGRUnit_multiple(word_dim=WD, module_dim=D, num_of_nodes=N, unit_layers=Lr, dtype=dtype,
+                                appearance_graph_layers=G, motion_graph_layers=G)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
+    m = m.cuda().train(train)
+    m.keep_saved = True
+    m.fused_gat_bwd = "force" if fused_bwd else False      # every supported shape, not only the ones it is faster at
+    m.single_stream = single
+    return m
+
+
+def _scalar(o, Rr, N):
+    c, d_ = O.aux_losses(o, N)
+    return (o[0] * Rr).sum() + 0.3 * ((o[1] * Rr).sum() + (o[2] * Rr).sum()) + c + 1e-8 * d_
+
+
+def _grads(m, inp, R, N, seed):
+    t = {k: torch.from_numpy(v.copy()).cuda() for k, v in inp.items()}
+    for k in ("A", "M", "dq", "words"):
+        t[k].requires_grad_(True)
+    m.forced_seed = seed
+    outs = m(t["A"], t["M"], t["dq"], t["words"], t["qlen"])
+    _scalar(outs, R.cuda(), N).backward()
+    torch.cuda.synchronize()
+    g = {k: t[k].grad.detach().cpu().clone() for k in ("A", "M", "dq", "words")}
+    g.update({"p:" + k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()})
+    return outs, t, g
+
+
+# (B, N, L): N = 20 -> 5 row tiles x 4 samples, B = 7 leaves a last tile of 3 samples; N = 8 / 16 / 13 -> 4 row tiles (13 is not a
+# multiple of 4: reduction steps past the sample's rows); B = 1 < samples per tile; B = 33, N = 20: 660 rows, lean planes
+# (dWh / dpre exist as planes only, as at the bench's batch)
+SHAPES = [(7, 20, 2), (17, 8, 2), (9, 16, 2), (10, 13, 2), (1, 20, 2), (33, 20, 1), (40, 8, 1)]
+
+
+@pytest.mark.parametrize("B,N,Lr", SHAPES)
+@pytest.mark.parametrize("train", [False, True])
+def test_fused_backward_equals_two_launch_form(B, N, Lr, train):
+    sd_np = synth.xavier_state_dict(O.param_shapes(WD, D, Lr), seed=51, bias_range=0.05)
+    inp = synth.unit_inputs(B, N, T, D, WD, seed=51)
+    R = torch.from_numpy(synth.normal("R_gatb", (B, N, D), 1.0, 51))
+    lib = L.load()
+    got, launches = {}, {}
+    for fused in (True, False):
+        m = _module(N, Lr, "bf16x3", sd_np, train, fused)
+        n0 = lib.dvgr_dbg_launch_count()
+        _, _, got[fused] = _grads(m, inp, R, N, 778)
+        launches[fused] = lib.dvgr_dbg_launch_count() - n0
+    worst, worst_k = 0.0, None
+    for k in got[True]:
+        if k.endswith((".fc.bias", ".a.bias")):   # gradients that are zero in exact arithmetic (softmax shift invariance): rounding noise
+            continue
+        e = rel_err(got[True][k], got[False][k])
+        if e > worst:
+            worst, worst_k = e, k
+    print(f"  fused backward vs two launches, B={B} N={N} train={train}: worst rel err {worst:.2e} ({worst_k}); "
+          f"launches {launches[True]} against {launches[False]}")
+    assert worst < 5e-5, (worst, worst_k)
+    # one launch per layer fewer, one more for the transposed P1 planes
+    assert launches[False] - launches[True] == Lr - 1, launches
+
+
+@pytest.mark.parametrize("B,N,Lr,single,train", [(6, 20, 2, False, True), (6, 20, 2, True, True), (5, 13, 2, True, True), (9, 8, 3, False, True),
+                                                (7, 16, 2, False, False), (70, 20, 1, False, True)])
+def test_fused_backward_against_oracle(B, N, Lr, single, train):
+    """Every gradient against the oracle with the device's dropout masks injected (the kink-aware gate of tests/helpers.py)."""
+    dtype = "bf16x3"
+    sd_np = synth.xavier_state_dict(O.param_shapes(WD, D, Lr), seed=53, bias_range=0.05)
+    inp = synth.unit_inputs(B, N, T, D, WD, seed=53)
+    R = torch.from_numpy(synth.normal("R_gatb", (B, N, D), 1.0, 53))
+    m = _module(N, Lr, dtype, sd_np, train, True, single=single)
+    seed = 4343
+    outs, t, _ = _grads(m, inp, R, N, seed)
+    masks = {k: torch.from_numpy(v) for k, v in dropout.site_masks(seed, B, N, D, Lr).items()} if train else None
+    sd = {k: torch.from_numpy(v.copy()) for k, v in sd_np.items()}
+    ti = {k: torch.from_numpy(v.copy()) for k, v in inp.items()}
+    signs = device_logit_signs(m, L.make_dims(B, N, T, D, WD, Lr), (B, N, Lr))
+    oo, gin, gw, dbg, stats = aligned_oracle_backward(sd, ti, Lr, masks, lambda o: _scalar(o, R, N), signs)
+    what = f"gatb B={B} N={N} L={Lr} {dtype} single={single} train={train}"
+    assert_flips_at_kink(stats, what)
+    assert_grads(m, t, gin, gw, dbg, Lr, GTOL, what)
+
+
+def test_shapes_the_kernel_does_not_take_keep_two_launches():
+    """N = 24 (6 row tiles: the images of 4 whole samples exceed 160 KB) and graph_layers = 2: the flag changes nothing."""
+    lib = L.load()
+    for (B, N, Lr, G) in [(6, 24, 2, 1), (6, 16, 2, 2)]:
+        sd_np = synth.xavier_state_dict(O.param_shapes(WD, D, Lr, G), seed=54, bias_range=0.05)
+        inp = synth.unit_inputs(B, N, T, D, WD, seed=54)
+        R = torch.from_numpy(synth.normal("R_gatb", (B, N, D), 1.0, 54))
+        got, launches = {}, {}
+        for fused in (True, False):
+            m = _module(N, Lr, "bf16x3", sd_np, True, fused, G=G)
+            n0 = lib.dvgr_dbg_launch_count()
+            _, _, got[fused] = _grads(m, inp, R, N, 5)
+            launches[fused] = lib.dvgr_dbg_launch_count() - n0
+        assert launches[True] == launches[False], (N, G, launches)
+        for k in got[True]:           # (not bit-equal run to run: d(dq) and the small-batch weight gradients add partial tiles atomically)
+            if not k.endswith((".fc.bias", ".a.bias")):
+                assert rel_err(got[True][k], got[False][k]) < 5e-5, (N, G, k)
+
+
+def test_plain_bf16_mode_takes_the_fused_backward_too():
+    B, N, Lr = 7, 20, 2
+    sd_np = synth.xavier_state_dict(O.param_shapes(WD, D, Lr), seed=55, bias_range=0.05)
+    inp = synth.unit_inputs(B, N, T, D, WD, seed=55)
+    R = torch.from_numpy(synth.normal("R_gatb", (B, N, D), 1.0, 55))
+    got = {}
+    for fused in (True, False):
+        _, _, got[fused] = _grads(_module(N, Lr, "bf16", sd_np, True, fused), inp, R, N, 6)
+    # one plane per operand: an fp32-rounding difference upstream can flip the bf16 rounding of a later operand element
+    worst = max(rel_err(got[True][k], got[False][k]) for k in got[True] if not k.endswith((".fc.bias", ".a.bias")))
+    assert worst < 5e-3, worst
