@@ -16,17 +16,18 @@
 // (planes written by k_sf_bwd), B = rows hl F .. of P1^T (planes transposed once per backward call by k_transpose_planes: with
 // P1 as [k][n] the B tile would need the IC fragment path at a 192-column tile width), reduction over D.
 // Epilogue, all 12 waves, in the ring's (now idle) LDS -- SPT samples at once:
-//   B0  every thread issues its global loads of the three fp32 tiles the attention needs (dz's part written by k_sf_bwd:
-//       beta_g do + the list gradient; the saved GAT output for ELU'; the saved projection Wh); accumulators -> shP;
-//       the loaders fill s, u, v, a_l, a_r and clear the padded images
-//   B1  alpha_ij = softmax_j LeakyReLU(u_i + v_j + c) recomputed (4 rows per wave pass, DPP row reductions), alpha and
-//       alpha * keep; then the loads land: dP = (acc + dz) * keep_out * ELU'(out) -> shP, Wh -> shW
+//   (ahead of the K loop: the computing waves fetch the saved projection Wh, the loader threads the saved GAT output -- two of
+//       the three fp32 tiles the attention needs; they land under the K loop)
+//   B0  the loader threads issue their loads of dz's part written by k_sf_bwd (beta_g do + the list gradient); accumulators -> shP,
+//       Wh -> shW; the loaders fill s, u, v, a_l, a_r and clear the padded images
+//   B1  computing waves: alpha_ij = softmax_j LeakyReLU(u_i + v_j + c) recomputed (4 rows per wave pass, DPP row reductions),
+//       alpha and alpha * keep; beside them the loader threads: dP = (acc + dz) * keep_out * ELU'(out) -> shP
 //   B2  dalpha_ij = keep_ij s_j (dP_i . Wh_j) on the fp32 MFMA, one (sample, 16 x 16 tile) per wave at a time
 //   B3  softmax and LeakyReLU backward, du_i (4 rows per wave pass)
 //   B4  dv_j, dc (a thread per column / sample) beside dZ = alpha_d^T . dP on the fp32 MFMA, one (sample, 16-column strip)
 //       per wave at a time; the wave overwrites its strip of shP
 //   B5  dWh_j = s_j dZ_j + du_j a_l + dv_j a_r -> bf16 planes (+ fp32 where it has a reader), ds_j = dZ_j . Wh_j;
-//       d a_l = du^T . Wh, d a_r = dv^T . Wh per sample as one more MFMA pass (rows 0 / 1 of a 16-row A operand)
+//       d a_l = du^T . Wh, d a_r = dv^T . Wh per sample (a thread per column)
 // Outputs are those of k_gat_attn_bwd (dWh planes, ds / da / dc partials per (sample, head)); dz itself is not written: nobody
 // else reads it at graph_layers = 1.
 #include <type_traits>
@@ -143,6 +144,16 @@ __global__ __launch_bounds__(768) void k_gat_fused_bwd(const GatFusedBwdArgs a) 
   int row0 = 0;
   const int col0 = (wave12 & 3) * 16 * NTC;
   float pre_al = 0.f, pre_ar = 0.f, pre_s = 0.f, pre_u = 0.f, pre_v = 0.f;
+  // The three fp32 tiles the attention needs (47 MB over the chip at C2) issued by every workgroup at once behind the K loop
+  // took 6.7 us (phase clocks, first version: the HBM rate); issued ahead of the ring's first DMA they delayed the K loop by 4.7.
+  // So they are fetched UNDER the K loop, whose operands come from L2 / the Infinity Cache: the saved projection Wh by the
+  // computing waves behind the first K-tile's barrier (WVC float4 pieces per thread: nothing in the K loop waits for vector
+  // memory), the saved GAT output by the loader threads behind the ring's prologue (WVL pieces; the counted waits of the first
+  // K-tiles leave them in flight).  Only the part of dz k_sf_bwd wrote follows behind the K loop, by the loader threads, under
+  // the computing waves' accumulator pass and the recomputation of alpha.
+  constexpr int WVC = (RP * F4 + 511) / 512, WVL = (RP * F4 + 255) / 256;
+  gatb_f32x4 whv[WVC], yv[WVL], zv[WVL];
+  const int emax = rows_valid * F4 - 1;
   GBCLK(0);
   if (loader) {
     const int tl = tid - 512;                              // 0 .. 255
@@ -154,14 +165,36 @@ __global__ __launch_bounds__(768) void k_gat_fused_bwd(const GatFusedBwdArgs a) 
     pre_al = ga[ta]; pre_ar = ga[F + ta];
     pre_s = a.at.s[mod][m0 + ts];
     pre_u = a.at.u[mod][uo]; pre_v = a.at.v[mod][uo];
+    const float* yg = (g ? a.at.out_s[mod] : a.at.out_c[mod]) + (int64_t)m0 * D + hl * F;
+    auto fetch_out = [&]() {                               // behind the ring's prologue (gatf_loader: NPF)
+#pragma unroll
+      for (int k = 0; k < WVL; ++k) {
+        int e = tl + 256 * k;
+        e = e < emax ? e : emax;
+        const int r = e / F4, q = e - r * F4;
+        yv[k] = *reinterpret_cast<const gatb_f32x4*>(yg + (int64_t)r * D + 4 * q);
+      }
+    };
     const int w = wave12 - 8;
     const uint16_t* xa = a.ah[mod] + (int64_t)g * BN * D;  // view g of dpre (2, B N, D)
-    if (C::IHI == C::ILO || w < (C::ITOT & 3)) gatf_loader<C, TERMS, C::IHI>(xa, a.a_lo_off, a.bh[mod], a.b_lo_off, smem, hl * F, m0, BN, D, nk, w, lane);
-    else gatf_loader<C, TERMS, (C::ILO > 0 ? C::ILO : 1)>(xa, a.a_lo_off, a.bh[mod], a.b_lo_off, smem, hl * F, m0, BN, D, nk, w, lane);
+    if (C::IHI == C::ILO || w < (C::ITOT & 3))
+      gatf_loader<C, TERMS, C::IHI, WVL>(xa, a.a_lo_off, a.bh[mod], a.b_lo_off, smem, hl * F, m0, BN, D, nk, w, lane, fetch_out);
+    else
+      gatf_loader<C, TERMS, (C::ILO > 0 ? C::ILO : 1), WVL>(xa, a.a_lo_off, a.bh[mod], a.b_lo_off, smem, hl * F, m0, BN, D, nk, w, lane, fetch_out);
   } else {
+    const float* wg = a.at.Wh[mod] + (int64_t)m0 * HF + h * F;
+    auto fetch_wh = [&]() {                                // behind the first K-tile's barrier (gatf_compute: first)
+#pragma unroll
+      for (int k = 0; k < WVC; ++k) {
+        int e = tid + 512 * k;
+        e = e < emax ? e : emax;
+        const int r = e / F4, q = e - r * F4;
+        whv[k] = *reinterpret_cast<const gatb_f32x4*>(wg + (int64_t)r * HF + 4 * q);
+      }
+    };
     const int rg = wave12 >> 2;
-    if (rg == 0) { row0 = 0; gatf_compute<C, TERMS, C::MT0, NTC>(smem, nk, row0, col0, lane, acc); }
-    else { row0 = 16 * C::MT0; gatf_compute<C, TERMS, (MTILES - C::MT0 > 0 ? MTILES - C::MT0 : 1), NTC>(smem, nk, row0, col0, lane, acc); }
+    if (rg == 0) { row0 = 0; gatf_compute<C, TERMS, C::MT0, NTC>(smem, nk, row0, col0, lane, acc, fetch_wh); }
+    else { row0 = 16 * C::MT0; gatf_compute<C, TERMS, (MTILES - C::MT0 > 0 ? MTILES - C::MT0 : 1), NTC>(smem, nk, row0, col0, lane, acc, fetch_wh); }
   }
   __builtin_amdgcn_s_barrier();                            // every fragment read of the ring is done: its LDS is free
   GBCLK(1);
@@ -192,22 +225,16 @@ __global__ __launch_bounds__(768) void k_gat_fused_bwd(const GatFusedBwdArgs a) 
   const uint32_t ka = a.at.key_alpha[mod][h];
   const float cc = a.at.gat_c[mod][h];
 
-  // B0: the three fp32 tiles, WV float4 pieces of each per thread, issued now and consumed in B1
-  constexpr int WV = (RP * F4 + 767) / 768;
-  gatb_f32x4 zv[WV], yv[WV], wv[WV];
-  {
+  // B0: the loader threads issue their loads of dz's pre-part (consumed in B1); accumulators and the prefetched Wh -> LDS
+  if (loader) {
+    const int tl = tid - 512;
     const float* zg = a.at.dz[mod] + (int64_t)g * BN * D + (int64_t)m0 * D + hl * F;
-    const float* yg = (g ? a.at.out_s[mod] : a.at.out_c[mod]) + (int64_t)m0 * D + hl * F;
-    const float* wg = a.at.Wh[mod] + (int64_t)m0 * HF + h * F;
-    const int emax = rows_valid * F4 - 1;
 #pragma unroll
-    for (int k = 0; k < WV; ++k) {
-      int e = tid + 768 * k;
+    for (int k = 0; k < WVL; ++k) {
+      int e = tl + 256 * k;
       e = e < emax ? e : emax;
       const int r = e / F4, q = e - r * F4;
       zv[k] = *reinterpret_cast<const gatb_f32x4*>(zg + (int64_t)r * D + 4 * q);
-      yv[k] = *reinterpret_cast<const gatb_f32x4*>(yg + (int64_t)r * D + 4 * q);
-      wv[k] = *reinterpret_cast<const gatb_f32x4*>(wg + (int64_t)r * HF + 4 * q);
     }
   }
   if (!loader) {
@@ -221,6 +248,14 @@ __global__ __launch_bounds__(768) void k_gat_fused_bwd(const GatFusedBwdArgs a) 
 #pragma unroll
           for (int r = 0; r < 4; ++r) shP[(row0 + 16 * i + 4 * (lane >> 4) + r) * FS + col] = acc[i][j][r];
         }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < WVC; ++k) {
+      const int e = tid + 512 * k;
+      if (e <= emax) {
+        const int r = e / F4, q = e - r * F4;
+        *reinterpret_cast<gatb_f32x4*>(shW + r * FS + 4 * q) = whv[k];
       }
     }
   } else {
@@ -237,9 +272,10 @@ __global__ __launch_bounds__(768) void k_gat_fused_bwd(const GatFusedBwdArgs a) 
   }
   lgk_barrier();
   GBCLK(2);
-  // B1a: alpha = softmax_j LeakyReLU(u_i + v_j + c) recomputed, and alpha * keep.  Lane (rsub, c16) takes j = c16 + 16 t of
-  // row 4 pass + rsub.
-  for (int pass = wave12; 4 * pass < rows_valid; pass += 12) {
+  // B1a (computing waves): alpha = softmax_j LeakyReLU(u_i + v_j + c) recomputed, and alpha * keep.  Lane (rsub, c16) takes
+  // j = c16 + 16 t of row 4 pass + rsub.
+  if (!loader)
+  for (int pass = wave12; 4 * pass < rows_valid; pass += 8) {
     const int r = 4 * pass + rsub;
     const bool valid = r < rows_valid;
     const int sidx = valid ? (int)(((float)r + 0.5f) * inv_n) : 0, i = valid ? r - sidx * N : 0;
@@ -270,14 +306,14 @@ __global__ __launch_bounds__(768) void k_gat_fused_bwd(const GatFusedBwdArgs a) 
       }
     }
   }
-  // B1b: dP = (acc + dz) * keep_out * ELU'(out) -> shP; Wh -> shW  (own elements only: no barrier since B0's writes of OTHER
-  // threads are read here -- the barrier above covers them)
-  {
+  // B1b (loader threads, beside B1a): dP = (acc + dz) * keep_out * ELU'(out) -> shP for the elements whose `out` they hold
+  if (loader) {
+    const int tl = tid - 512;
     const float sc = ko ? (1.0f - kDropP) : 1.0f;          // un-dropped ELU output where kept
 #pragma unroll
-    for (int k = 0; k < WV; ++k) {
-      const int e = tid + 768 * k;
-      if (e < rows_valid * F4) {
+    for (int k = 0; k < WVL; ++k) {
+      const int e = tl + 256 * k;
+      if (e <= emax) {
         const int r = e / F4, q = e - r * F4;
         float* pp = shP + r * FS + 4 * q;
         const float4 ac = *reinterpret_cast<const float4*>(pp);
@@ -289,7 +325,6 @@ __global__ __launch_bounds__(768) void k_gat_fused_bwd(const GatFusedBwdArgs a) 
         p.z = (ac.z + zv[k][2]) * kf[2] * elu_grad_from_out(yv[k][2] * sc);
         p.w = (ac.w + zv[k][3]) * kf[3] * elu_grad_from_out(yv[k][3] * sc);
         *reinterpret_cast<float4*>(pp) = p;
-        *reinterpret_cast<gatb_f32x4*>(shW + r * FS + 4 * q) = wv[k];
       }
     }
   }
@@ -461,22 +496,21 @@ __global__ __launch_bounds__(768) void k_gat_fused_bwd(const GatFusedBwdArgs a) 
       }
     }
   }
-  // B5b: d a_l = du^T . Wh, d a_r = dv^T . Wh per sample: A = [du; dv; 0 ...] (16 x N, rows 0 / 1), B = the sample's rows of shW
-  for (int item = it0; item < it1; ++item) {
-    const int sidx = item / JT, Ft = item - sidx * JT;
-    gatb_f32x4 aacc = gatb_f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int s4 = 0; s4 < S; ++s4) {
-      const int j = 4 * s4 + kq;
-      const bool in = j < N;
-      const float av = !in ? 0.f : r16 == 0 ? shDu[sidx * N + j] : r16 == 1 ? shDv[sidx * N + j] : 0.f;
-      const float bv = in ? shW[(sidx * N + j) * FS + 16 * Ft + r16] : 0.f;
-      aacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, aacc, 0, 0, 0);
+  // B5b: d a_l[f] = sum_j du_j Wh[j][f], d a_r[f] = sum_j dv_j Wh[j][f] per sample: a thread per (sample, column), j ascending
+  // (consecutive lanes read consecutive columns of a row: conflict free; du / dv are broadcast reads).  (As one more fp32-MFMA
+  // pass -- rows 0 / 1 of a 16-row A operand -- this cost 2.6 us: four dependent chains per wave behind scalar LDS reads.)
+  for (int e = tid; e < spt_valid * F; e += 768) {
+    const int sidx = e / F, f = e - sidx * F;
+    const float* wcol = shW + sidx * N * FS + f;
+    float dl = 0.f, dr = 0.f;
+    for (int j = 0; j < N; ++j) {
+      const float w = wcol[j * FS];
+      dl += shDu[sidx * N + j] * w;
+      dr += shDv[sidx * N + j] * w;
     }
-    if (kq == 0) {                                         // rows m = 0 (d a_l) and m = 1 (d a_r) of the result
-      float* da = a.at.da_part[mod] + ((int64_t)(b0 + sidx) * kHeads + h) * 2 * F + 16 * Ft + r16;
-      da[0] = aacc[0];
-      da[F] = aacc[1];
-    }
+    float* da = a.at.da_part[mod] + ((int64_t)(b0 + sidx) * kHeads + h) * 2 * F + f;
+    da[0] = dl;
+    da[F] = dr;
   }
   GBCLK(7);
 }

@@ -29,9 +29,13 @@ struct GatfCfg {
 // ---- loader waves -------------------------------------------------------------------------------------------------
 // xa / x_lo: hi plane of the A matrix (rows m0 .. of it, clamped to BN - 1) and its lo-plane offset; wb / w_lo: the same of
 // the B matrix, whose rows brow0 .. brow0 + F - 1 form the tile (forward: head h of Wcat; backward: the head's columns of P1^T)
-template <class C, int TERMS, int CNT>
+// NPF / pf: optionally, NPF further vector-memory instructions of this wave (plain loads into registers: an epilogue's inputs)
+// issued by pf() right behind the ring's prologue, i.e. YOUNGER than the first NS - 1 K-tiles: the counted waits for those
+// tiles leave them in flight (loads, stores and LDS-DMA share one in-order counter), every later wait covers them.
+struct GatfNoPrefetch { __device__ __forceinline__ void operator()() const {} };
+template <class C, int TERMS, int CNT, int NPF = 0, class PF = GatfNoPrefetch>
 __device__ __forceinline__ void gatf_loader(const uint16_t* xa, int64_t x_lo, const uint16_t* wb, int64_t w_lo, uint16_t* smem,
-                                            int brow0, int m0, int BN, int D, int nk, int wave, int lane) {
+                                            int brow0, int m0, int BN, int D, int nk, int wave, int lane, PF pf = PF()) {
   // instruction k of this wave is instruction i = wave + 4 k of the K-tile: i < IA -> rows 16 i .. 16 i + 15 of the A tile,
   // else rows 16 (i - IA) .. of the B tile.  Per-lane element offsets are computed once (the K loop moves a uniform base).
   uint32_t off[CNT];
@@ -72,10 +76,21 @@ __device__ __forceinline__ void gatf_loader(const uint16_t* xa, int64_t x_lo, co
 #pragma unroll
   for (int s = 0; s < C::NS - 1; ++s)
     if (s < nk) issue(s, smem + s * C::kSlot);
+  if (NPF > 0) {                                           // (program order IS the order the waits below count in)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    pf();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  }
   constexpr int kPer = C::kPlanes * CNT;                   // DMA instructions of this wave per K-tile
+  static_assert(2 * kPer + NPF < 64, "vmcnt is a 6-bit counter");
   for (int kt = 0; kt < nk; ++kt) {
     const int younger = (nk - 1 - kt) < C::NS - 2 ? (nk - 1 - kt) : C::NS - 2;
-    if (younger >= 2) wait_vmcnt<2 * kPer>();
+    // (the NPF loads sit between K-tile NS - 2 and K-tile NS - 1 in the queue: younger than the tile waited for while kt <= NS - 2;
+    // a K loop shorter than NS + 1 tiles simply waits for them as well)
+    if (NPF > 0 && kt <= C::NS - 2 && younger >= 2 && nk > C::NS) wait_vmcnt<2 * kPer + NPF>();
+    else if (younger >= 2) wait_vmcnt<2 * kPer>();
     else if (younger == 1) wait_vmcnt<kPer>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();                          // publishes tile kt, frees slot (kt - 1) % NS
@@ -84,8 +99,11 @@ __device__ __forceinline__ void gatf_loader(const uint16_t* xa, int64_t x_lo, co
 }
 
 // ---- computing waves ----------------------------------------------------------------------------------------------
-template <class C, int TERMS, int MTW, int NTC>
-__device__ __forceinline__ void gatf_compute(const uint16_t* smem, int nk, int row0, int col0, int lane, f32x4 (&acc)[4][NTC]) {
+// first(): optionally, work of the computing wave issued right behind the FIRST K-tile's barrier (an epilogue's prefetch loads:
+// the ring's prologue has landed by then, and nothing in this loop waits for vector memory)
+template <class C, int TERMS, int MTW, int NTC, class FIRST = GatfNoPrefetch>
+__device__ __forceinline__ void gatf_compute(const uint16_t* smem, int nk, int row0, int col0, int lane, f32x4 (&acc)[4][NTC],
+                                             FIRST first = FIRST()) {
 #pragma unroll
   for (int i = 0; i < MTW; ++i)
 #pragma unroll
@@ -119,6 +137,7 @@ __device__ __forceinline__ void gatf_compute(const uint16_t* smem, int nk, int r
   };
   for (int kt = 0; kt < nk; ++kt) {
     __builtin_amdgcn_s_barrier();
+    if (kt == 0) first();
     read_frags(kt);
     mma_tile();
   }
