@@ -598,6 +598,9 @@ def main():
                                     "algorithmic FLOPs counted here, with the attention -- logits, softmax, aggregation, ELU, dropouts, 47 MB of "
                                     "stores -- as its epilogue; its K loop alone: tools/gatf_clocks.py); two launches where the shape is not taken"),
                    "fwd_sf_gemm": (L_.PROBE_FWD_SF_GEMM, 8 * B * N * D * D, "S4 forward tanh(z.P1^T), 2 views x 2 modalities (TAG_FWD_SF)"),
+                   "bwd_sf_dx": (L_.PROBE_BWD_SF_DX, 8 * B * N * D * D,
+                                 "S4 + S3 backward: the fused GAT-view backward launch (k_gat_fused_bwd: dz += dpre.P1 = the FLOPs counted "
+                                 "here, attention backward as its epilogue); the dz contraction alone where the shape is not taken"),
                    "bwd_gat_dw": (L_.PROBE_BWD_GAT_DW, 8 * B * N * D * D, "dWcat = dWh^T.X (TAG_BWD_GAT_DW)"),
                    "bwd_gat_dx": (L_.PROBE_BWD_GAT_DX, 8 * B * N * D * D, "dX += dWh.Wcat (TAG_BWD_GAT_DX)")}
     site, probe_flops, probe_name = probe_sites[args.probe]
@@ -702,6 +705,14 @@ def main():
     m.set_probe(0)
     torch.cuda.synchronize()
     sf_ms = float(np.mean([a.elapsed_time(b) for a, b in sf_pairs]))
+    # fourth probe, the same way: the backward counterpart of the probed launch (dz contraction + attention backward)
+    gb_pairs = [(L_.ProbeEvent(), L_.ProbeEvent()) for _ in range(8)]
+    for k in range(8):
+        m.set_probe(L_.PROBE_BWD_SF_DX, probe_layer, gb_pairs[k][0], gb_pairs[k][1])
+        step()
+    m.set_probe(0)
+    torch.cuda.synchronize()
+    gb_ms = float(np.mean([a.elapsed_time(b) for a, b in gb_pairs]))
     # operand bytes a launch of the S4 shape moves from L2 into LDS: 4 problems of (B N) x D x D on 128 x 128 tiles
     # (from 384 tiles of 128 x 256 up the engine takes that variant: csrc/dvgr_gemm.hip, launch_ring)
     sf_tiles = 4 * ((B * N + 127) // 128) * ((D + 127) // 128)
@@ -759,6 +770,14 @@ def main():
                                            # tile geometry -- tiles x K-tiles x (128 + 128 rows) x 32 k x 2 B x planes -- over the launch
                                            "operand_fill_bytes": sf_fill, "operand_fill_TBps": (sf_fill / (sf_ms * 1e-3) / 1e12) if sf_fill else None,
                                            "mfma_pipe_busy_pmc": (pmc.get("plain_contraction") or {}).get("mfma_busy") if pmc else None},
+                     # the backward counterpart of the probed launch: S4's data contraction dz += dpre.P1 (8 B N D^2 FLOP) with the
+                     # attention backward as its epilogue (csrc/dvgr_gatb.hip) -- or, where the fused form is not taken, that
+                     # contraction alone (the attention backward is then a launch of its own behind it)
+                     "gat_view_backward": {"kernel": "S4 + S3 backward (k_gat_fused_bwd where taken; else the dz contraction alone)",
+                                           "launch_ms": gb_ms, "achieved": 8 * B * N * D * D / (gb_ms * 1e-3) / 1e12,
+                                           "frac": 8 * B * N * D * D / (gb_ms * 1e-3) / 1e12 / peak,
+                                           "traffic": (pmc.get("gat_view_backward") or {}).get("traffic_bytes_per_launch") if pmc else None,
+                                           "mfma_pipe_busy_pmc": (pmc.get("gat_view_backward") or {}).get("mfma_busy") if pmc else None},
                      # the launch that dominates the profile by time (the GAT projection above is the kernel north_star names)
                      "dominant_by_time": None if probe2_ms is None else {
                          "kernel": probe2_name, "launch_ms": probe2_ms, "algorithmic_gflop_per_launch": probe2_flops / 1e9,

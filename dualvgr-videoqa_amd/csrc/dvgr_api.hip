@@ -849,6 +849,9 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
   const bool fuse_bwd = PM.on && G == 1 && !(O.flags & (DVGR_OPT_NO_FUSED_GAT | DVGR_OPT_NO_FUSED_GAT_BWD)) && L * 2 <= kMaxTransposeJobs &&
                         gat_fused_bwd_supported(B, N, D, prec) &&
                         (gat_fused_bwd_preferred(B, N) || (O.flags & DVGR_OPT_FORCE_FUSED_GAT_BWD));
+  // ... and forms the part of dz that k_sf_bwd would write (beta_v do + the list gradient) itself, from the tensors k_sf_bwd reads
+  // anyway: 2 x (B N D) fp32 fewer to store and to read back, and the list gradients are read once instead of twice
+  const bool fuse_dz = fuse_bwd && !(O.flags & DVGR_OPT_FUSED_BWD_READS_DZ);
   hipEvent_t p1t_done = nullptr;
   int64_t p1t_lo = 0;
   auto p1t_hi = [&](int l, int m) { return PM.out(ws + W.p1t + (int64_t)(l * 2 + m) * round64((int64_t)D * D), &p1t_lo); };
@@ -1075,7 +1078,8 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
         const float* gs = m == 0 ? g->g_aq_fusion : g->g_mq_fusion;
         a.g_z0[m] = gc ? gc + e_last * BND : nullptr;
         a.g_z1[m] = gs ? gs + e_last * BND : nullptr;
-        a.dw[m] = ws + W.dw[set][m]; a.dpre[m] = lean ? nullptr : ws + W.dpre[set][m]; a.dz[m] = ws + W.dz[m];
+        a.dw[m] = ws + W.dw[set][m]; a.dpre[m] = lean ? nullptr : ws + W.dpre[set][m];
+        a.dz[m] = fuse_dz ? nullptr : ws + W.dz[m];         // (fuse_dz: the fused GAT-view backward forms dz's pre-part itself)
         a.dpre_p[m] = PM.out(ws + W.dpre[set][m], &plo);
       }
       a.lo_off = plo;
@@ -1094,7 +1098,16 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       int64_t alo = -1, lo1 = 0;
       bool ok = true;
       for (int m = 0; m < 2 && ok; ++m) {
-        a.dz[m] = ws + W.dz[m];
+        a.dz[m] = fuse_dz ? nullptr : ws + W.dz[m];
+        if (fuse_dz) {
+          const float* gc = m == 0 ? g->g_com_app : g->g_com_mot;
+          const float* gsx = m == 0 ? g->g_aq_fusion : g->g_mq_fusion;
+          fa.dx[m] = dXacc[m];
+          fa.g_embed[m] = (l == L - 1) ? (m == 0 ? g->g_aq_embed : g->g_mq_embed) : nullptr;
+          fa.g_z[m][0] = gc ? gc + (int64_t)l * BND : nullptr;
+          fa.g_z[m][1] = gsx ? gsx + (int64_t)l * BND : nullptr;
+          fa.beta[m] = ms(l, m) + S.beta;
+        }
         a.out_c[m] = (m == 0 ? io->com_app : io->com_mot) + (int64_t)l * BND;
         a.out_s[m] = (m == 0 ? io->aq_fusion : io->mq_fusion) + (int64_t)l * BND;
         a.Wh[m] = ms(l, m) + S.wh; a.s[m] = ms(l, m) + S.s; a.u[m] = ms(l, m) + S.u; a.v[m] = ms(l, m) + S.v;

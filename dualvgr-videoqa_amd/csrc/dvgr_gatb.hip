@@ -108,11 +108,11 @@ template <int MTILES, int NTC>
 struct GatbEpi {                                          // epilogue images, in floats
   static constexpr int RP = 16 * MTILES, F = 64 * NTC, FS = F + 4;
   __host__ __device__ static constexpr size_t floats(int N, int SPT) {
-    return 2 * (size_t)(RP + 1) * FS + 2 * F + (size_t)SPT * (3 * N + 1) * (N + 1) + 5 * RP;
+    return 2 * (size_t)(RP + 1) * FS + 2 * F + (size_t)SPT * (3 * N + 1) * (N + 1) + 6 * RP;
   }
 };
 
-template <int TERMS, int MTILES, int NT, int NTC>
+template <int TERMS, int MTILES, int NT, int NTC, bool FROM_DX>
 __global__ __launch_bounds__(768) void k_gat_fused_bwd(const GatFusedBwdArgs a) {
   using C = GatfCfg<TERMS, MTILES, NTC>;
   extern __shared__ __attribute__((aligned(16))) uint16_t gatb_smem[];
@@ -143,7 +143,8 @@ __global__ __launch_bounds__(768) void k_gat_fused_bwd(const GatFusedBwdArgs a) 
   f32x4 acc[4][NTC];
   int row0 = 0;
   const int col0 = (wave12 & 3) * 16 * NTC;
-  float pre_al = 0.f, pre_ar = 0.f, pre_s = 0.f, pre_u = 0.f, pre_v = 0.f;
+  float pre_al = 0.f, pre_ar = 0.f, pre_s = 0.f, pre_u = 0.f, pre_v = 0.f, pre_b = 0.f;
+  constexpr bool from_dx = FROM_DX;                        // dz's pre-part is formed here (GatFusedBwdArgs::dx), not read
   // The three fp32 tiles the attention needs (47 MB over the chip at C2) issued by every workgroup at once behind the K loop
   // took 6.7 us (phase clocks, first version: the HBM rate); issued ahead of the ring's first DMA they delayed the K loop by 4.7.
   // So they are fetched UNDER the K loop, whose operands come from L2 / the Infinity Cache: the saved projection Wh by the
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(768) void k_gat_fused_bwd(const GatFusedBwdArgs a) 
     pre_al = ga[ta]; pre_ar = ga[F + ta];
     pre_s = a.at.s[mod][m0 + ts];
     pre_u = a.at.u[mod][uo]; pre_v = a.at.v[mod][uo];
+    if (from_dx) pre_b = a.beta[mod][(int64_t)(m0 + ts) * 2 + g];
     const float* yg = (g ? a.at.out_s[mod] : a.at.out_c[mod]) + (int64_t)m0 * D + hl * F;
     auto fetch_out = [&]() {                               // behind the ring's prologue (gatf_loader: NPF)
 #pragma unroll
@@ -213,6 +215,7 @@ __global__ __launch_bounds__(768) void k_gat_fused_bwd(const GatFusedBwdArgs a) 
   float* shV = shU + RP;                                   // [RP]
   float* shDu = shV + RP;                                  // [RP]
   float* shDv = shDu + RP;                                 // [RP]
+  float* shB = shDv + RP;                                  // [RP]  beta_g of the row (from_dx)
   auto lgk_barrier = [&]() {                               // (raw barrier behind an LDS-only wait: global stores / loads stay in flight)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -225,8 +228,12 @@ __global__ __launch_bounds__(768) void k_gat_fused_bwd(const GatFusedBwdArgs a) 
   const uint32_t ka = a.at.key_alpha[mod][h];
   const float cc = a.at.gat_c[mod][h];
 
-  // B0: the loader threads issue their loads of dz's pre-part (consumed in B1); accumulators and the prefetched Wh -> LDS
-  if (loader) {
+  // B0: dz's pre-part.  Either the loader threads load what k_sf_bwd wrote (consumed in B1b), or (from_dx) the computing
+  // threads load the ingredients -- the running gradient dx (+ the direct gradient of the fused embedding) and the view's list
+  // gradient -- and add beta_g (dx + g_embed) + g_z onto the accumulator image in B0b.  Accumulators and the prefetched Wh -> LDS.
+  constexpr int WVD = WVC;
+  gatb_f32x4 dxv[WVD], gzv[WVD];
+  if (loader && !from_dx) {
     const int tl = tid - 512;
     const float* zg = a.at.dz[mod] + (int64_t)g * BN * D + (int64_t)m0 * D + hl * F;
 #pragma unroll
@@ -258,6 +265,20 @@ __global__ __launch_bounds__(768) void k_gat_fused_bwd(const GatFusedBwdArgs a) 
         *reinterpret_cast<gatb_f32x4*>(shW + r * FS + 4 * q) = whv[k];
       }
     }
+    if (from_dx) {                                         // (behind the two passes above: their registers are free now)
+      const float* xg = a.dx[mod] + (int64_t)m0 * D + hl * F;
+      const float* eg = a.g_embed[mod] ? a.g_embed[mod] + (int64_t)m0 * D + hl * F : nullptr;
+      const float* gg = a.g_z[mod][g] ? a.g_z[mod][g] + (int64_t)m0 * D + hl * F : nullptr;
+#pragma unroll
+      for (int k = 0; k < WVD; ++k) {
+        int e = tid + 512 * k;
+        e = e < emax ? e : emax;
+        const int r = e / F4, q = e - r * F4;
+        dxv[k] = *reinterpret_cast<const gatb_f32x4*>(xg + (int64_t)r * D + 4 * q);
+        gzv[k] = gg ? *reinterpret_cast<const gatb_f32x4*>(gg + (int64_t)r * D + 4 * q) : gatb_f32x4{0.f, 0.f, 0.f, 0.f};
+        if (eg) dxv[k] += *reinterpret_cast<const gatb_f32x4*>(eg + (int64_t)r * D + 4 * q);
+    }
+    }
   } else {
     const int tl = tid - 512;                              // 0 .. 255
     for (int e = tl; e < SPT * (N + 1) * NP; e += 256) shAd[e] = 0.f;
@@ -267,15 +288,15 @@ __global__ __launch_bounds__(768) void k_gat_fused_bwd(const GatFusedBwdArgs a) 
     if (tl < RP) {
       const bool ok = tl < rows_valid;
       shS[tl] = ok ? pre_s : 0.f; shU[tl] = ok ? pre_u : 0.f; shV[tl] = ok ? pre_v : 0.f;
-      shDu[tl] = 0.f; shDv[tl] = 0.f;
+      shDu[tl] = 0.f; shDv[tl] = 0.f; shB[tl] = ok ? pre_b : 0.f;
     }
   }
   lgk_barrier();
-  GBCLK(2);
-  // B1a (computing waves): alpha = softmax_j LeakyReLU(u_i + v_j + c) recomputed, and alpha * keep.  Lane (rsub, c16) takes
-  // j = c16 + 16 t of row 4 pass + rsub.
-  if (!loader)
-  for (int pass = wave12; 4 * pass < rows_valid; pass += 8) {
+  // alpha is recomputed by whoever is free: the passes [0, PX) by the loader waves while the computing threads add dz's
+  // pre-part (from_dx), the rest by the computing waves while the loader threads form dP
+  const int passes = (rows_valid + 3) >> 2;
+  const int PX = from_dx ? (passes < 8 ? passes : 8) : 0;
+  auto alpha_pass = [&](int pass) {
     const int r = 4 * pass + rsub;
     const bool valid = r < rows_valid;
     const int sidx = valid ? (int)(((float)r + 0.5f) * inv_n) : 0, i = valid ? r - sidx * N : 0;
@@ -305,7 +326,30 @@ __global__ __launch_bounds__(768) void k_gat_fused_bwd(const GatFusedBwdArgs a) 
         }
       }
     }
+  };
+  if (from_dx) {
+    // B0b: the computing threads add beta_g (dx + g_embed) + g_z onto their elements of the accumulator image
+    if (!loader) {
+#pragma unroll
+      for (int k = 0; k < WVD; ++k) {
+        const int e = tid + 512 * k;
+        if (e <= emax) {
+          const int r = e / F4, q = e - r * F4;
+          const float bg = shB[r];
+          gatb_f32x4* pp = reinterpret_cast<gatb_f32x4*>(shP + r * FS + 4 * q);
+          *pp = *pp + bg * dxv[k] + gzv[k];
+        }
+      }
+    } else {
+      for (int pass = wave12 - 8; pass < PX; pass += 4) alpha_pass(pass);
+    }
+    lgk_barrier();
   }
+  GBCLK(2);
+  // B1a (computing waves): alpha = softmax_j LeakyReLU(u_i + v_j + c) recomputed, and alpha * keep.  Lane (rsub, c16) takes
+  // j = c16 + 16 t of row 4 pass + rsub.
+  if (!loader)
+    for (int pass = PX + wave12; pass < passes; pass += 8) alpha_pass(pass);
   // B1b (loader threads, beside B1a): dP = (acc + dz) * keep_out * ELU'(out) -> shP for the elements whose `out` they hold
   if (loader) {
     const int tl = tid - 512;
@@ -320,10 +364,11 @@ __global__ __launch_bounds__(768) void k_gat_fused_bwd(const GatFusedBwdArgs a) 
         float kf[4];
         drop_factor4(ko, (uint32_t)((int64_t)(m0 + r) * D + hl * F + 4 * q), kf);
         float4 p;
-        p.x = (ac.x + zv[k][0]) * kf[0] * elu_grad_from_out(yv[k][0] * sc);
-        p.y = (ac.y + zv[k][1]) * kf[1] * elu_grad_from_out(yv[k][1] * sc);
-        p.z = (ac.z + zv[k][2]) * kf[2] * elu_grad_from_out(yv[k][2] * sc);
-        p.w = (ac.w + zv[k][3]) * kf[3] * elu_grad_from_out(yv[k][3] * sc);
+        const gatb_f32x4 zk = from_dx ? gatb_f32x4{0.f, 0.f, 0.f, 0.f} : zv[k];     // (from_dx: already inside the image)
+        p.x = (ac.x + zk[0]) * kf[0] * elu_grad_from_out(yv[k][0] * sc);
+        p.y = (ac.y + zk[1]) * kf[1] * elu_grad_from_out(yv[k][1] * sc);
+        p.z = (ac.z + zk[2]) * kf[2] * elu_grad_from_out(yv[k][2] * sc);
+        p.w = (ac.w + zk[3]) * kf[3] * elu_grad_from_out(yv[k][3] * sc);
         *reinterpret_cast<float4*>(pp) = p;
       }
     }
@@ -551,30 +596,30 @@ bool gat_fused_bwd_preferred(int B, int N) {
   return total >= 200 || B * N <= 320;
 }
 
-template <int TERMS, int MTILES, int NT>
+template <int TERMS, int MTILES, int NT, bool FROM_DX>
 static int gatb_launch(hipStream_t st, const GatFusedBwdArgs& a, const GatfShape& s) {
   constexpr int NTC = 3;
   const size_t lds = gatb_lds_bytes(s, a.at.N, TERMS);
   if (lds > 160 * 1024) return DVGR_E_DIMS;
   static bool attr_set = false;                            // (benign race: the attribute is idempotent)
   if (!attr_set) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gat_fused_bwd<TERMS, MTILES, NT, NTC>),
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gat_fused_bwd<TERMS, MTILES, NT, NTC, FROM_DX>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   const int mtiles = (a.at.B + a.spt - 1) / a.spt;
   const int total = mtiles * kHeads * 2;
-  DVGR_LAUNCH((k_gat_fused_bwd<TERMS, MTILES, NT, NTC>), dim3(8 * ((total + 7) / 8)), dim3(768), lds, st, a);
+  DVGR_LAUNCH((k_gat_fused_bwd<TERMS, MTILES, NT, NTC, FROM_DX>), dim3(8 * ((total + 7) / 8)), dim3(768), lds, st, a);
   DVGR_LAUNCH_CHECK();
 }
 
 template <int TERMS>
 static int gatb_dispatch(hipStream_t st, const GatFusedBwdArgs& a, const GatfShape& s) {
-  if (s.mtiles16 == 4 && s.nt == 1) return gatb_launch<TERMS, 4, 1>(st, a, s);
-  if (s.mtiles16 == 5 && s.nt == 2) return gatb_launch<TERMS, 5, 2>(st, a, s);
-  if (s.mtiles16 == 6 && s.nt == 2) return gatb_launch<TERMS, 6, 2>(st, a, s);
-  return DVGR_E_DIMS;
+  const bool fx = a.dx[0] != nullptr;
+  if (s.mtiles16 == 4 && s.nt == 1) return fx ? gatb_launch<TERMS, 4, 1, true>(st, a, s) : gatb_launch<TERMS, 4, 1, false>(st, a, s);
+  if (s.mtiles16 == 5 && s.nt == 2) return fx ? gatb_launch<TERMS, 5, 2, true>(st, a, s) : gatb_launch<TERMS, 5, 2, false>(st, a, s);
+  return DVGR_E_DIMS;                                      // (6 row tiles, N = 21 .. 32: the images do not fit, gat_fused_bwd_supported)
 }
 
 int gat_fused_bwd(hipStream_t st, const GatFusedBwdArgs& a_in, int prec) {
@@ -582,7 +627,9 @@ int gat_fused_bwd(hipStream_t st, const GatFusedBwdArgs& a_in, int prec) {
   GatfShape s;
   if (!gat_fused_bwd_supported(a.at.B, a.at.N, a.at.D, prec) || !gatf_shape(a.at.B, a.at.N, &s)) return DVGR_E_DIMS;
   for (int m = 0; m < 2; ++m) {
-    if (!a.ah[m] || !a.bh[m] || !a.at.dz[m] || !a.at.out_c[m] || !a.at.out_s[m] || !a.at.Wh[m] || !a.at.s[m] || !a.at.u[m] ||
+    if ((a.dx[m] != nullptr) != (a.dx[0] != nullptr)) return DVGR_E_NULL;
+    if (a.dx[m] ? !a.beta[m] : !a.at.dz[m]) return DVGR_E_NULL;
+    if (!a.ah[m] || !a.bh[m] || !a.at.out_c[m] || !a.at.out_s[m] || !a.at.Wh[m] || !a.at.s[m] || !a.at.u[m] ||
         !a.at.v[m] || !a.at.gat_a[m] || !a.at.gat_c[m] || !a.at.dWh_p[m] || !a.at.ds_part[m] || !a.at.da_part[m] || !a.at.dc_part[m])
       return DVGR_E_NULL;
     if (((uintptr_t)a.ah[m] | (uintptr_t)a.bh[m]) & 15) return DVGR_E_ALIGN;

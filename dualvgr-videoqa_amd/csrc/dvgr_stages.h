@@ -122,7 +122,8 @@ struct SfBwdArgs {
   const float* g_z1[2];
   float* dw[2];            // (2, B*N)
   float* dpre[2];          // (2, B*N, D)
-  float* dz[2];            // (2, B*N, D)  = beta_v * do + g_z_v   (GEMM adds dpre . P1)
+  float* dz[2];            // (2, B*N, D)  = beta_v * do + g_z_v   (GEMM adds dpre . P1); nullptr: not written (the fused
+                           // GAT-view backward forms it itself, GatFusedBwdArgs::dx), g_z0 / g_z1 are then not read
   uint16_t* dpre_p[2];     // bf16 planes of dpre (nullable)
   int64_t lo_off;
   int rows, D;
@@ -160,6 +161,15 @@ struct GatFusedBwdArgs {
   int64_t a_lo_off;            // lo plane = hi plane + a_lo_off elements
   const uint16_t* bh[2];       // [mod] hi plane of P1^T (D, D): row = input feature i of project[0], reduction index o contiguous
   int64_t b_lo_off;
+  // dx[mod] != nullptr: at.dz is NOT read; the part of dz that k_sf_bwd would have written is formed here instead,
+  //   dz_g = beta_g (dx + g_embed) + g_z[g]      (model/Attention.py:22-23 backward: o = sum_v beta_v z_v),
+  // from the running gradient of the layer output (B*N, D), the direct upstream gradient of the fused embedding (last layer;
+  // nullable), the list gradients of the view (nullable) and the saved softmax weights beta (B*N, 2): k_sf_bwd then skips
+  // its 2 x (B N D) fp32 store and the re-read of the two list gradients (SfBwdArgs::dz == nullptr).
+  const float* dx[2];
+  const float* g_embed[2];
+  const float* g_z[2][2];      // [mod][view]
+  const float* beta[2];
   int spt;                     // samples per tile (set by the launcher)
 };
 bool gat_fused_bwd_supported(int B, int N, int D, int prec);

@@ -415,12 +415,13 @@ __global__ __launch_bounds__(256) void k_sf_bwd(const SfBwdArgs a) {
   const float4* t0 = reinterpret_cast<const float4*>(a.tn[mod] + r0);
   const float4* t1 = reinterpret_cast<const float4*>(a.tn[mod] + r1);
   const float4* p2 = reinterpret_cast<const float4*>(a.p2[mod]);
-  const float4* g0 = a.g_z0[mod] ? reinterpret_cast<const float4*>(a.g_z0[mod] + r0) : nullptr;
-  const float4* g1 = a.g_z1[mod] ? reinterpret_cast<const float4*>(a.g_z1[mod] + r0) : nullptr;
+  const bool wdz = a.dz[mod] != nullptr;                   // (uniform) false: the fused GAT-view backward forms dz's pre-part itself
+  const float4* g0 = (wdz && a.g_z0[mod]) ? reinterpret_cast<const float4*>(a.g_z0[mod] + r0) : nullptr;
+  const float4* g1 = (wdz && a.g_z1[mod]) ? reinterpret_cast<const float4*>(a.g_z1[mod] + r0) : nullptr;
   float4* dpre0 = a.dpre[mod] ? reinterpret_cast<float4*>(a.dpre[mod] + r0) : nullptr;   // fp32 copy: only where it has a reader
   float4* dpre1 = a.dpre[mod] ? reinterpret_cast<float4*>(a.dpre[mod] + r1) : nullptr;
-  float4* dz0 = reinterpret_cast<float4*>(a.dz[mod] + r0);
-  float4* dz1 = reinterpret_cast<float4*>(a.dz[mod] + r1);
+  float4* dz0 = wdz ? reinterpret_cast<float4*>(a.dz[mod] + r0) : nullptr;
+  float4* dz1 = wdz ? reinterpret_cast<float4*>(a.dz[mod] + r1) : nullptr;
   for (int k = lane; k < D4; k += 64) {
     float4 d = dX[k];
     if (ge) { const float4 e = ge[k]; d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w; }
@@ -432,12 +433,14 @@ __global__ __launch_bounds__(256) void k_sf_bwd(const SfBwdArgs a) {
     if (dpre0) { st4(dpre0 + k, q0); st4(dpre1 + k, q1); }
     split_store4(a.dpre_p[mod], a.lo_off, r0 + 4 * k, q0);
     split_store4(a.dpre_p[mod], a.lo_off, r1 + 4 * k, q1);
-    float4 o0 = make_float4(b0 * d.x, b0 * d.y, b0 * d.z, b0 * d.w);
-    float4 o1 = make_float4(b1 * d.x, b1 * d.y, b1 * d.z, b1 * d.w);
-    if (g0) { const float4 e = g0[k]; o0.x += e.x; o0.y += e.y; o0.z += e.z; o0.w += e.w; }
-    if (g1) { const float4 e = g1[k]; o1.x += e.x; o1.y += e.y; o1.z += e.z; o1.w += e.w; }
-    st4(dz0 + k, o0);
-    st4(dz1 + k, o1);
+    if (wdz) {
+      float4 o0 = make_float4(b0 * d.x, b0 * d.y, b0 * d.z, b0 * d.w);
+      float4 o1 = make_float4(b1 * d.x, b1 * d.y, b1 * d.z, b1 * d.w);
+      if (g0) { const float4 e = g0[k]; o0.x += e.x; o0.y += e.y; o0.z += e.z; o0.w += e.w; }
+      if (g1) { const float4 e = g1[k]; o1.x += e.x; o1.y += e.y; o1.z += e.z; o1.w += e.w; }
+      st4(dz0 + k, o0);
+      st4(dz1 + k, o1);
+    }
   }
 }
 int sf_bwd(hipStream_t st, const SfBwdArgs& a) {

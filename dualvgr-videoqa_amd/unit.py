@@ -347,6 +347,7 @@ class DualVGRUnit_multiple(nn.Module):
         self.fused_gat_bwd = not bool(int(os.environ.get("DVGR_NO_FUSED_GAT_BWD", "0")))
         if self.fused_gat_bwd and os.environ.get("DVGR_FORCE_FUSED_GAT_BWD", "0") == "1":
             self.fused_gat_bwd = "force"
+        self.fused_bwd_reads_dz = bool(int(os.environ.get("DVGR_FUSED_BWD_READS_DZ", "0")))   # DVGR_OPT_FUSED_BWD_READS_DZ (A/B, parity)
         self.leaves_on_query = bool(int(os.environ.get("DVGR_LEAVES_ON_QUERY", "0")))  # True: DVGR_OPT_LEAVES_ON_QUERY (A/B timing)
         # (alpha, beta, dep_scale[, with_sum_vis = True]) or None: when set, forward_raw() also evaluates the scope-U loss
         # sum(vis) + alpha*common + beta*dep_scale*dependence with its gradients w.r.t. the outputs (dvgr_opts.loss)
@@ -574,6 +575,8 @@ class DualVGRUnit_multiple(nn.Module):
             o.flags |= L_.OPT_NO_FUSED_GAT_BWD
         elif self.fused_gat_bwd == "force":
             o.flags |= L_.OPT_FORCE_FUSED_GAT_BWD
+        if self.fused_bwd_reads_dz:
+            o.flags |= L_.OPT_FUSED_BWD_READS_DZ
         if self.leaves_on_query:
             o.flags |= L_.OPT_LEAVES_ON_QUERY
         if self._events or getattr(self, "_layer_cb", None) is not None:

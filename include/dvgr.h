@@ -228,6 +228,10 @@ enum dvgr_probe_site {
 /* The fused backward form is taken where it is supported AND measured faster (csrc/dvgr_gatb.hip gat_fused_bwd_preferred: launches
  * of >= 200 workgroups, or host-bound small batches); DVGR_OPT_FORCE_FUSED_GAT_BWD takes it wherever it is supported (tests, A/B). */
 #define DVGR_OPT_FORCE_FUSED_GAT_BWD 32
+/* The fused backward launch also forms the part of dz that the S5 / S4 row kernel (k_sf_bwd) would otherwise store and it would
+ * read back -- beta_v (dX' + g_embed) + the list gradient -- from the tensors themselves.  DVGR_OPT_FUSED_BWD_READS_DZ keeps the
+ * row kernel's store and the read (A/B timing, parity of the two forms). */
+#define DVGR_OPT_FUSED_BWD_READS_DZ 64
 
 /* Scope-U loss evaluated by the forward itself (dvgr_opts.loss): the same arithmetic and outputs as
  * dvgr_scope_u_loss below, but the kernels are enqueued as soon as the last layer's list outputs exist and run on the

@@ -25,7 +25,7 @@ D, WD, T = 768, 300, 9
 TOL, GTOL = 1e-4, 5e-4
 
 
-def _module(N, Lr, dtype, sd_np, train, fused_bwd, single=False, G=1):
+def _module(N, Lr, dtype, sd_np, train, fused_bwd, single=False, G=1, reads_dz=False):
     m = dv.DualVGRUnit_multiple(word_dim=WD, module_dim=D, num_of_nodes=N, unit_layers=Lr, dtype=dtype,
                                 appearance_graph_layers=G, motion_graph_layers=G)
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
@@ -33,6 +33,7 @@ def _module(N, Lr, dtype, sd_np, train, fused_bwd, single=False, G=1):
     m.keep_saved = True
     m.fused_gat_bwd = "force" if fused_bwd else False      # every supported shape, not only the ones it is faster at
     m.single_stream = single
+    m.fused_bwd_reads_dz = reads_dz       # True: k_sf_bwd stores dz's pre-part and the fused launch reads it (DVGR_OPT_FUSED_BWD_READS_DZ)
     return m
 
 
@@ -106,6 +107,20 @@ def test_fused_backward_against_oracle(B, N, Lr, single, train):
     what = f"gatb B={B} N={N} L={Lr} {dtype} single={single} train={train}"
     assert_flips_at_kink(stats, what)
     assert_grads(m, t, gin, gw, dbg, Lr, GTOL, what)
+
+
+@pytest.mark.parametrize("B,N,Lr,train", [(7, 20, 2, True), (17, 8, 2, False), (10, 13, 3, True)])
+def test_both_sources_of_dz_agree(B, N, Lr, train):
+    """The fused launch forms dz's pre-part itself (default) or reads what k_sf_bwd stored (DVGR_OPT_FUSED_BWD_READS_DZ): the same
+    arithmetic, beta_v (dX' + g_embed) + the list gradient, evaluated in two places; L = 3 covers a middle layer (no g_embed)."""
+    sd_np = synth.xavier_state_dict(O.param_shapes(WD, D, Lr), seed=57, bias_range=0.05)
+    inp = synth.unit_inputs(B, N, T, D, WD, seed=57)
+    R = torch.from_numpy(synth.normal("R_gatb", (B, N, D), 1.0, 57))
+    got = {}
+    for reads in (False, True):
+        _, _, got[reads] = _grads(_module(N, Lr, "bf16x3", sd_np, train, True, reads_dz=reads), inp, R, N, 99)
+    worst = max(rel_err(got[True][k], got[False][k]) for k in got[True] if not k.endswith((".fc.bias", ".a.bias")))
+    assert worst < 5e-5, worst
 
 
 def test_shapes_the_kernel_does_not_take_keep_two_launches():

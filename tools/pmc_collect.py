@@ -93,6 +93,11 @@ def main():
     if plain:
         n, l, fk, wk, b = plain[0]
         rec["plain_contraction"] = {"kernel": n, "traffic_bytes_per_launch": b, "mfma_busy": busy_of(n)}
+    # the fused GAT-view BACKWARD launch (round 5: dz contraction + attention backward, csrc/dvgr_gatb.hip)
+    gatb = [r for r in rows if "k_gat_fused_bwd" in r[0]]
+    if gatb:
+        n, l, fk, wk, b = gatb[0]
+        rec["gat_view_backward"] = {"kernel": n, "traffic_bytes_per_launch": b, "mfma_busy": busy_of(n)}
     out = os.path.join(ROOT, "profiles", f"pmc_{config}_{dtype}.json")
     json.dump(rec, open(out, "w"), indent=1)
     print("wrote", out, rec.get("traffic_bytes_per_launch"), rec.get("mfma_busy"))
