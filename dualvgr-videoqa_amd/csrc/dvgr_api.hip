@@ -352,6 +352,38 @@ int dvgr_pack_weights(const dvgr_dims* d, const float* params, void* params_lp, 
   return split_planes((hipStream_t)stream, sb);
 }
 
+size_t dvgr_p1t_elems(const dvgr_dims* d) {
+  if (!d || dvgr_check_dims(d) != 0) return 0;
+  return (size_t)4 * d->L * d->D * d->D;                  // hi + lo planes of L x 2 matrices of D x D
+}
+
+static bool backward_fuses(const dvgr_dims& d, int32_t flags) {
+  return d.dtype != DVGR_F32 && d.G == 1 && !(flags & (DVGR_OPT_NO_FUSED_GAT | DVGR_OPT_NO_FUSED_GAT_BWD)) && d.L * 2 <= kMaxTransposeJobs &&
+         gat_fused_bwd_supported(d.B, d.N, d.D, d.dtype) &&
+         (gat_fused_bwd_preferred(d.B, d.N) || (flags & DVGR_OPT_FORCE_FUSED_GAT_BWD));
+}
+
+int dvgr_backward_uses_p1t(const dvgr_dims* d, int32_t flags) {
+  if (!d || dvgr_check_dims(d) != 0) return 0;
+  return backward_fuses(*d, flags) ? 1 : 0;
+}
+
+int dvgr_pack_p1t(const dvgr_dims* d, const void* params_lp, void* p1t, void* stream) {
+  if (!d || !params_lp || !p1t) return DVGR_E_NULL;
+  DVGR_TRY(dvgr_check_dims(d));
+  if (d->dtype == DVGR_F32) return DVGR_E_KIND;
+  if ((d->D % 64) != 0 || 2 * d->L > kMaxTransposeJobs) return DVGR_E_DIMS;
+  const ParamLayout P = param_layout(*d);
+  const int64_t DD = (int64_t)d->D * d->D;
+  TransposeBatch tb{};
+  for (int l = 0; l < d->L; ++l)
+    for (int m = 0; m < 2; ++m)
+      tb.j[tb.n++] = TransposeJob{reinterpret_cast<const uint16_t*>(params_lp) + P.layer_stride * l + P.mod_stride * m + P.sf_p1,
+                                  reinterpret_cast<uint16_t*>(p1t) + (int64_t)(l * 2 + m) * DD};
+  tb.src_lo = P.total; tb.dst_lo = 2 * (int64_t)d->L * DD; tb.D = d->D;
+  return transpose_planes((hipStream_t)stream, tb);
+}
+
 // =================================================================================================
 // Forward schedule (stages S0..S6 of oracle/unit_manual.py)
 // =================================================================================================
@@ -846,23 +878,27 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
   // on a tile of whole samples x one head's columns with the attention backward as its epilogue.  Its B operand is P1^T
   // (rows = the head's columns, reduction index contiguous): the planes of every layer's P1 are transposed into plane-only
   // workspace slots by one small launch, off the critical path (side stream; 14 MB at C2).
-  const bool fuse_bwd = PM.on && G == 1 && !(O.flags & (DVGR_OPT_NO_FUSED_GAT | DVGR_OPT_NO_FUSED_GAT_BWD)) && L * 2 <= kMaxTransposeJobs &&
-                        gat_fused_bwd_supported(B, N, D, prec) &&
-                        (gat_fused_bwd_preferred(B, N) || (O.flags & DVGR_OPT_FORCE_FUSED_GAT_BWD));
+  const bool fuse_bwd = PM.on && backward_fuses(d, O.flags);
   // ... and forms the part of dz that k_sf_bwd would write (beta_v do + the list gradient) itself, from the tensors k_sf_bwd reads
   // anyway: 2 x (B N D) fp32 fewer to store and to read back, and the list gradients are read once instead of twice
   const bool fuse_dz = fuse_bwd && !(O.flags & DVGR_OPT_FUSED_BWD_READS_DZ);
   hipEvent_t p1t_done = nullptr;
   int64_t p1t_lo = 0;
-  auto p1t_hi = [&](int l, int m) { return PM.out(ws + W.p1t + (int64_t)(l * 2 + m) * round64((int64_t)D * D), &p1t_lo); };
+  auto p1t_hi = [&](int l, int m) -> const uint16_t* {
+    if (O.p1t) {                                   // prepared by the caller (dvgr_pack_p1t): nothing to transpose in this call
+      p1t_lo = 2 * (int64_t)L * D * D;
+      return reinterpret_cast<const uint16_t*>(O.p1t) + (int64_t)(l * 2 + m) * D * D;
+    }
+    return PM.out(ws + W.p1t + (int64_t)(l * 2 + m) * round64((int64_t)D * D), &p1t_lo);
+  };
   auto p1_transposed = [&](hipStream_t on) -> int {
-    if (!fuse_bwd) return 0;
+    if (!fuse_bwd || O.p1t) return 0;
     TransposeBatch tb{};
     int64_t slo = 0;
     for (int l = 0; l < L; ++l)
       for (int m = 0; m < 2; ++m) {
         const uint16_t* src = PM.find(mp(l, m) + P.sf_p1, &slo);
-        uint16_t* dst = p1t_hi(l, m);
+        uint16_t* dst = const_cast<uint16_t*>(p1t_hi(l, m));
         if (!src || !dst) return DVGR_E_DIMS;        // (cannot happen: PM.on implies planes of the parameters and of the workspace)
         tb.j[tb.n++] = TransposeJob{src, dst};
       }

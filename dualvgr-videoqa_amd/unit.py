@@ -238,7 +238,7 @@ class _UnitFn(torch.autograd.Function):
         gr = L_.Grads(*[None if u is None else u.data_ptr() for u in ups],
                       gA.data_ptr(), gM.data_ptr(), gdq.data_ptr(), gwords.data_ptr(), gflat.data_ptr())
         stream = torch.cuda.current_stream(dev).cuda_stream
-        opts = mod.make_opts(ctx.train, ctx.seed, backward=True)
+        opts = mod.make_opts(ctx.train, ctx.seed, backward=True, dims=dims)
         mod._backward_gflat = gflat
         L_.check(lib.dvgr_unit_backward(C.byref(dims), flat.data_ptr(), mod.lowp_ptr(), C.byref(io), C.byref(gr),
                                         saved.data_ptr(), saved.numel(), ws.data_ptr(), ws.numel(), C.byref(opts),
@@ -321,6 +321,8 @@ class DualVGRUnit_multiple(nn.Module):
         self._flat = None
         self._lowp = None
         self._lowp_version = None
+        self._p1t = None
+        self._p1t_stale = True
         self._ws = None
         self._events = None
         self._events_arr = None
@@ -347,6 +349,7 @@ class DualVGRUnit_multiple(nn.Module):
         self.fused_gat_bwd = not bool(int(os.environ.get("DVGR_NO_FUSED_GAT_BWD", "0")))
         if self.fused_gat_bwd and os.environ.get("DVGR_FORCE_FUSED_GAT_BWD", "0") == "1":
             self.fused_gat_bwd = "force"
+        self.hoist_p1t = not bool(int(os.environ.get("DVGR_P1T_PER_CALL", "0")))     # False: the backward transposes P1's planes itself, per call
         self.fused_bwd_reads_dz = bool(int(os.environ.get("DVGR_FUSED_BWD_READS_DZ", "0")))   # DVGR_OPT_FUSED_BWD_READS_DZ (A/B, parity)
         self.leaves_on_query = bool(int(os.environ.get("DVGR_LEAVES_ON_QUERY", "0")))  # True: DVGR_OPT_LEAVES_ON_QUERY (A/B timing)
         # (alpha, beta, dep_scale[, with_sum_vis = True]) or None: when set, forward_raw() also evaluates the scope-U loss
@@ -432,6 +435,8 @@ class DualVGRUnit_multiple(nn.Module):
         self._ptrs = tuple(p.data_ptr() for p in self._plist)
         self._lowp = None
         self._lowp_version = None
+        self._p1t = None
+        self._p1t_stale = True
 
     def _apply(self, fn, recurse=True):
         out = super()._apply(fn, recurse)
@@ -492,7 +497,29 @@ class DualVGRUnit_multiple(nn.Module):
             L_.check(L_.load().dvgr_pack_weights(C.byref(self._dims0), flat.data_ptr(), self._lowp.data_ptr(),
                                                  torch.cuda.current_stream(flat.device).cuda_stream), "dvgr_pack_weights")
             self._lowp_version = ver
+            self._p1t_stale = True
         return self._lowp.data_ptr()
+
+    def p1t_ptr(self):
+        """Transposed planes of every layer's project[0] weight for the fused GAT-view backward (dvgr_opts.p1t,
+        dvgr_pack_p1t), refreshed whenever the parameter planes were: by a repack here, or by a caller that was handed
+        lowp_planes() to rewrite them (trainer.ClipAdam does so once per optimizer step).  With static weights -- a benchmark's
+        timed loop, evaluation -- they are prepared once; the library transposes per call when this is None (fp32 mode)."""
+        lp = self.lowp_ptr()
+        if lp is None or self.graph_layers != 1:
+            return None
+        dev = self._flat.device
+        if self._p1t is None or self._p1t.device != dev:
+            n = L_.load().dvgr_p1t_elems(C.byref(self._dims0))
+            if n == 0:
+                return None
+            self._p1t = torch.empty(n, device=dev, dtype=torch.bfloat16)
+            self._p1t_stale = True
+        if self._p1t_stale:
+            L_.check(L_.load().dvgr_pack_p1t(C.byref(self._dims0), lp, self._p1t.data_ptr(),
+                                             torch.cuda.current_stream(dev).cuda_stream), "dvgr_pack_p1t")
+            self._p1t_stale = False
+        return self._p1t.data_ptr()
 
     def lowp_planes(self):
         """The bf16 hi / lo planes tensor of the flat parameter buffer (None in fp32 mode), allocated if need be; for a
@@ -501,6 +528,7 @@ class DualVGRUnit_multiple(nn.Module):
         if self.dtype_code == L_.DVGR_F32 or self.no_planes:
             return None
         self.lowp_ptr()
+        self._p1t_stale = True              # the caller rewrites the planes: their transposed copies follow at the next backward
         return self._lowp
 
     def params_changed(self):
@@ -564,7 +592,7 @@ class DualVGRUnit_multiple(nn.Module):
                 ev.record()          # torch creates the hipEvent lazily at the first record
         self._probe = (int(site), int(layer), begin, end) if site else None
 
-    def make_opts(self, train: bool, seed: int, backward: bool) -> "L_.Opts":
+    def make_opts(self, train: bool, seed: int, backward: bool, dims=None) -> "L_.Opts":
         o = L_.Opts()
         o.train, o.seed = int(bool(train)), int(seed)
         if self.single_stream:
@@ -588,6 +616,9 @@ class DualVGRUnit_multiple(nn.Module):
                 o.probe_begin, o.probe_end = b.cuda_event, e.cuda_event
         if backward and getattr(self, "_comm", None) is not None:
             o.comm = self._comm.handle
+        if backward and self.fused_gat_bwd and self.hoist_p1t and dims is not None and \
+                L_.load().dvgr_backward_uses_p1t(C.byref(dims), o.flags):
+            o.p1t = self.p1t_ptr()
         if backward and self._events:
             arr = (C.c_void_p * (self.layers + 2))()
             for i, ev in enumerate(self._events):

@@ -176,6 +176,15 @@ size_t dvgr_workspace_bytes(const dvgr_dims *d);
  * lo = bf16(w - hi) at dvgr_param_count() + o (same offsets as the fp32 buffer).  Call after every
  * optimizer step.  `params_lp` must hold 2 * dvgr_param_count() * 2 bytes. */
 int dvgr_pack_weights(const dvgr_dims *d, const float *params, void *params_lp, void *stream);
+/* Transposed planes of the SF attention's project[0] weights (model/Attention.py:15) for the fused GAT-view backward
+ * (dvgr_opts.p1t): `p1t` receives dvgr_p1t_elems(d) bf16 -- hi planes of (layer, modality) = (0,0), (0,1), (1,0) ... each
+ * (D, D) with out[i][o] = P1[o][i], then the lo planes in the same order -- read from the planes `params_lp` holds (call
+ * it after dvgr_pack_weights / after an optimizer step that rewrote the planes).  DVGR_E_KIND for DVGR_F32 dims. */
+size_t dvgr_p1t_elems(const dvgr_dims *d);
+/* 1 when dvgr_unit_backward at these dimensions and dvgr_opts.flags takes the fused GAT-view backward, i.e. reads P1^T
+ * (dvgr_opts.p1t, or its own per-call transposition); 0 otherwise -- a host prepares the transposed planes only then. */
+int dvgr_backward_uses_p1t(const dvgr_dims *d, int32_t flags);
+int dvgr_pack_p1t(const dvgr_dims *d, const void *params_lp, void *p1t, void *stream);
 
 /* Launch sites a caller can bracket with a pair of hipEvents (dvgr_opts.probe): the events are
  * recorded on the launch stream immediately before / after that one kernel launch, which is how
@@ -269,6 +278,11 @@ typedef struct dvgr_opts {
                           stream, behind the block's own event, the moment the block's last kernel has been enqueued -- no host
                           callback, no helper thread.  The caller makes its stream wait with dvgr_comm_join() before it reads
                           the gradients.  Independent of layer_done_events / layer_done_cb (which may stay NULL). */
+  const void *p1t;     /* backward only, nullable: the transposed bf16 planes of every layer's project[0] weight as written
+                          by dvgr_pack_p1t() from the CURRENT parameter planes.  The fused GAT-view backward (DVGR_OPT_NO_FUSED_
+                          GAT_BWD) contracts against P1^T; without this pointer the call transposes the planes itself into its
+                          workspace, one small launch per call (14 MB at C2) -- a caller whose parameters change once per
+                          optimizer step prepares them once per step instead, next to the planes themselves. */
 } dvgr_opts;
 
 /* Forward of the whole stacked unit: replaces DualVGRUnit_multiple.forward (model/models.py:
