@@ -63,6 +63,7 @@ OPT_LEAVES_ON_QUERY = 8
 OPT_NO_FUSED_GAT_BWD = 16
 OPT_FORCE_FUSED_GAT_BWD = 32
 OPT_FUSED_BWD_READS_DZ = 64
+OPT_S5_READS_TN = 128
 
 # enum dvgr_probe_site
 (PROBE_NONE, PROBE_FWD_QA_GEMM, PROBE_FWD_GAT_GEMM, PROBE_FWD_GAT_ATTN, PROBE_FWD_SF_GEMM, PROBE_FWD_MFB_GEMM,

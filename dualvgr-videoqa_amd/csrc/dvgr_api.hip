@@ -31,12 +31,13 @@ int sum_and_ones(hipStream_t st, const float* x, float* g_ones, int64_t n, float
 
 namespace {
 
-struct FwdWs { int64_t Y, R, total; };
+struct FwdWs { int64_t Y, R, wpart, total; };
 FwdWs fwd_ws(const dvgr_dims& d) {
   FwdWs w{};
   int64_t o = 0;
   w.Y = o; o += round64((int64_t)d.L * d.B * d.T * d.D);
   w.R = o; o += round64((int64_t)d.L * d.B * d.T);
+  w.wpart = o; o += 2 * round64((int64_t)2 * (d.D / 32) * d.B * d.N);     // [modality][view][D / 32][B N]: S4's partial logits for S5
   w.total = o;
   return w;
 }
@@ -633,6 +634,22 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
         for (int gi = 0; gi < 2; ++gi) a5.next_key[m][gi] = Kn.x[m][gi];
       }
       a5.next_xd_lo_off = plo;
+    }
+    // S4 hands S5 its logits tn_v . p2 as partial dots per 32-column block from its epilogue where the launch runs on whole
+    // tiles of the planes kernels: S5 then does not read the 2 x (B N D) tanh outputs back (they stay saved for the backward)
+    {
+      const int64_t wstride = round64((int64_t)2 * (D / 32) * BN);
+      for (int i = 0; i < gb4.n; ++i) {
+        const int m = i >> 1, v = i & 1;
+        gb4.p[i].rowdot_vec = mp(l, m) + P.sf_p2;
+        gb4.p[i].rowdot_out = ws + W.wpart + m * wstride + (int64_t)v * (D / 32) * BN;
+        gb4.p[i].rowdot_ld = BN;
+      }
+      if ((D % 32) == 0 && !(O.flags & (DVGR_OPT_NO_FUSED_GAT | DVGR_OPT_S5_READS_TN)) && gemm_rowdot_supported(KC, KC, gb4, prec)) {
+        for (int m = 0; m < 2; ++m) a5.wpart[m] = ws + W.wpart + m * wstride;
+      } else {
+        for (int i = 0; i < gb4.n; ++i) { gb4.p[i].rowdot_vec = nullptr; gb4.p[i].rowdot_out = nullptr; }
+      }
     }
     bool phased = false;
 #ifdef DVGR_TIMING_AIDS

@@ -55,6 +55,13 @@ struct GemmProblem {
   float* sum_out;      // nullable: *sum_out += the sum of every value stored to C (one float atomic per workgroup) -- the forward's
                        // last contraction carries sum(vis) and d sum(vis) / d vis = 1 of the scope-U loss this way instead of a
                        // k_sum_and_ones launch behind it.  Honoured by the planes kernels only: gemm_sum_supported().
+  // nullable, NT on the planes kernels (gemm_rowdot_supported): the partial row dots of the STORED values with a vector over the
+  // output columns, one per 32-column block: rowdot_out[(col / 32) * rowdot_ld + row] = sum_{c in block} C[row][c] * rowdot_vec[c]
+  // (every block of every row is written exactly once: no atomics, a reader sums the N / 32 partials in a fixed order).  S4 hands
+  // S5 its logits w_v = tanh(z_v P1^T + b) . p2 this way instead of S5 reading the 2 x (B N D) tanh outputs back.
+  const float* rowdot_vec;
+  float* rowdot_out;
+  int64_t rowdot_ld;
   float* rowsum;       // nullable, TN only (A = dY[k][m]): rowsum[m] += sum_k A[k][m], i.e. the bias gradient dY^T . 1 that
                        // belongs to the weight gradient C = dY^T . X, taken from the A fragments the kernel already holds
                        // (one extra MFMA against a ones fragment per A fragment, in the workgroups of output column 0).
@@ -76,6 +83,8 @@ enum : int { TAG_GENERIC = 0, TAG_FWD_GAT = 1, TAG_FWD_SF = 2, TAG_BWD_GAT_DW = 
 bool gemm_rowsum_supported(int la, int lb, const GemmBatch& batch, int prec);
 // True when gemm_launch will honour GemmProblem::ones_out / sum_out for this batch (NT problems on the planes kernels).
 bool gemm_sum_supported(int la, int lb, const GemmBatch& batch, int prec);
+// True when gemm_launch will honour GemmProblem::rowdot_out for this batch (NT on the planes kernels, every tile whole).
+bool gemm_rowdot_supported(int la, int lb, const GemmBatch& batch, int prec);
 
 // Problems of different layouts (GemmProblem::layout) in ONE launch where every problem qualifies for the planes kernel
 // (bf16 modes, pre-split operands, K % 32 == 0, not batch-sized); otherwise one gemm_launch per layout.  rowsum is honoured

@@ -200,6 +200,12 @@ __device__ __forceinline__ void epilogue_rows(const GemmProblem& P, const f32x4 
     for (int e = 0; e < 4; ++e)
       if (col0 + cc_lane + e < P.N) bias4[e] = P.bias[col0 + cc_lane + e];
   }
+  float dot4[4] = {0.f, 0.f, 0.f, 0.f};            // GemmProblem::rowdot_vec at this lane's columns (whole tiles only)
+  const bool rowdot = P.rowdot_out != nullptr && full && !atomic;
+  if (rowdot) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dot4[e] = P.rowdot_vec[col0 + cc_lane + e];
+  }
 #pragma unroll
   for (int i0 = 0; i0 < MT; i0 += MCH) {
 #pragma unroll
@@ -263,6 +269,15 @@ __device__ __forceinline__ void epilogue_rows(const GemmProblem& P, const f32x4 
         st4(reinterpret_cast<float4*>(cp + it * rstep), make_float4(x[0], x[1], x[2], x[3]));
         if (lsum) *lsum += (x[0] + x[1]) + (x[2] + x[3]);
         if (P.ones_out) st4(reinterpret_cast<float4*>(P.ones_out + (cp - P.C) + it * rstep), make_float4(1.f, 1.f, 1.f, 1.f));
+        if (rowdot) {
+          // the 8 lanes that hold a 32-column block of one row: quad sums, then lane i takes lane i + 4 (row_shl 4): lane 0
+          // of the group ends with the block's total
+          float pd = (x[0] * dot4[0] + x[1] * dot4[1]) + (x[2] * dot4[2] + x[3] * dot4[3]);
+          pd += dpp_move<0xb1, 0xf>(0.f, pd);      // quad_perm [1,0,3,2]
+          pd += dpp_move<0x4e, 0xf>(0.f, pd);      // quad_perm [2,3,0,1]
+          pd += dpp_move<0x104, 0xf>(0.f, pd);     // row_shl 4
+          if ((lane & 7) == 0) P.rowdot_out[(int64_t)((col0 + cc_lane) >> 5) * P.rowdot_ld + rbase + it * RPI] = pd;
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       continue;
@@ -1666,6 +1681,13 @@ bool gemm_sum_supported(int la, int lb, const GemmBatch& b, int prec) {
     if (b.p[i].atomic_ok || b.p[i].atomic_out) return false;      // (a split-K partial tile is not the value stored)
     if ((b.p[i].ldc & 3) || (((uintptr_t)b.p[i].C | (uintptr_t)b.p[i].ones_out) & 15)) return false;   // the row epilogue's vector path
   }
+  return true;
+}
+
+bool gemm_rowdot_supported(int la, int lb, const GemmBatch& b, int prec) {
+  if (!gemm_sum_supported(la, lb, b, prec)) return false;
+  for (int i = 0; i < b.n; ++i)                                  // every wave sub-tile of every tile shape lies inside the matrix
+    if ((b.p[i].M % 128) || (b.p[i].N % 256) || b.p[i].accumulate || b.p[i].drop_key_c) return false;
   return true;
 }
 

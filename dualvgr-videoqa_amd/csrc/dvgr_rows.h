@@ -12,10 +12,17 @@ __device__ __forceinline__ void sf_combine_row(const SfCombineArgs& a, int mod, 
   const float4* t1 = reinterpret_cast<const float4*>(a.tn[mod] + ((int64_t)a.rows + row) * a.D);
   const float4* p2 = reinterpret_cast<const float4*>(a.p2[mod]);
   float w0 = 0.f, w1 = 0.f;
-  for (int k = lane; k < D4; k += 64) {
-    const float4 u = t0[k], v = t1[k], p = p2[k];
-    w0 += u.x * p.x + u.y * p.y + u.z * p.z + u.w * p.w;
-    w1 += v.x * p.x + v.y * p.y + v.z * p.z + v.w * p.w;
+  if (a.wpart[mod]) {                                        // the S4 epilogue's partial dots, one per 32-column block: fixed order
+    const int nb = a.D / 32;
+    const float* q0 = a.wpart[mod] + row;
+    const float* q1 = q0 + (int64_t)nb * a.rows;
+    for (int k = lane; k < nb; k += 64) { w0 += q0[(int64_t)k * a.rows]; w1 += q1[(int64_t)k * a.rows]; }
+  } else {
+    for (int k = lane; k < D4; k += 64) {
+      const float4 u = t0[k], v = t1[k], p = p2[k];
+      w0 += u.x * p.x + u.y * p.y + u.z * p.z + u.w * p.w;
+      w1 += v.x * p.x + v.y * p.y + v.z * p.z + v.w * p.w;
+    }
   }
   w0 = wave_sum(w0); w1 = wave_sum(w1);
   const float mx = fmaxf(w0, w1);

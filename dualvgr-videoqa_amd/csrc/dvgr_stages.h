@@ -82,6 +82,8 @@ struct SfCombineArgs {
   const float* z1[2];    // specific output
   const float* tn[2];    // (2, B*N, D)
   const float* p2[2];    // (D)
+  const float* wpart[2]; // nullable: (2, D / 32, B*N) partial logits tn_v[row] . p2 per 32-column block, written by the S4
+                         // contraction's epilogue (GemmProblem::rowdot_out): tn is then not read here
   float* beta[2];        // (B*N, 2) saved
   float* o[2];           // fused embedding (B*N, D); nullable
   float* Xout[2];        // X' (B*N, D)

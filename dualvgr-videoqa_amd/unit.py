@@ -350,6 +350,7 @@ class DualVGRUnit_multiple(nn.Module):
         if self.fused_gat_bwd and os.environ.get("DVGR_FORCE_FUSED_GAT_BWD", "0") == "1":
             self.fused_gat_bwd = "force"
         self.hoist_p1t = not bool(int(os.environ.get("DVGR_P1T_PER_CALL", "0")))     # False: the backward transposes P1's planes itself, per call
+        self.s5_reads_tn = bool(int(os.environ.get("DVGR_S5_READS_TN", "0")))                # DVGR_OPT_S5_READS_TN (A/B, parity)
         self.fused_bwd_reads_dz = bool(int(os.environ.get("DVGR_FUSED_BWD_READS_DZ", "0")))   # DVGR_OPT_FUSED_BWD_READS_DZ (A/B, parity)
         self.leaves_on_query = bool(int(os.environ.get("DVGR_LEAVES_ON_QUERY", "0")))  # True: DVGR_OPT_LEAVES_ON_QUERY (A/B timing)
         # (alpha, beta, dep_scale[, with_sum_vis = True]) or None: when set, forward_raw() also evaluates the scope-U loss
@@ -605,6 +606,8 @@ class DualVGRUnit_multiple(nn.Module):
             o.flags |= L_.OPT_FORCE_FUSED_GAT_BWD
         if self.fused_bwd_reads_dz:
             o.flags |= L_.OPT_FUSED_BWD_READS_DZ
+        if self.s5_reads_tn:
+            o.flags |= L_.OPT_S5_READS_TN
         if self.leaves_on_query:
             o.flags |= L_.OPT_LEAVES_ON_QUERY
         if self._events or getattr(self, "_layer_cb", None) is not None:

@@ -241,6 +241,10 @@ enum dvgr_probe_site {
  * read back -- beta_v (dX' + g_embed) + the list gradient -- from the tensors themselves.  DVGR_OPT_FUSED_BWD_READS_DZ keeps the
  * row kernel's store and the read (A/B timing, parity of the two forms). */
 #define DVGR_OPT_FUSED_BWD_READS_DZ 64
+/* Forward: the S4 contraction's epilogue hands S5 the logits tanh(z_v P1^T + b) . p2 as partial dots per 32-column block
+ * (GemmProblem::rowdot_out) where the launch runs on whole tiles of the planes kernels, so that S5 does not read the tanh
+ * outputs back.  DVGR_OPT_S5_READS_TN keeps S5's own dot products over them (A/B timing, parity of the two forms). */
+#define DVGR_OPT_S5_READS_TN 128
 
 /* Scope-U loss evaluated by the forward itself (dvgr_opts.loss): the same arithmetic and outputs as
  * dvgr_scope_u_loss below, but the kernels are enqueued as soon as the last layer's list outputs exist and run on the

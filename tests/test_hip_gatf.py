@@ -176,3 +176,21 @@ def test_launch_count_drops_by_one_per_fused_layer():
     # two-stream mode: layer 0 keeps two launches (its gate waits for the query chain), layers 1 .. L - 1 are fused; the same
     # flag also selects S6 as one launch (k_mfb_fwd: linear0 / linear1 + ELU + pooling) instead of contraction + pooling kernel
     assert counts[False] - counts[True] == (Lr - 1) + 1, counts
+
+
+@pytest.mark.parametrize("B,N,Lr,train", [(64, 20, 2, True), (32, 8, 2, False), (7, 20, 2, True)])
+def test_s5_logits_from_the_s4_epilogue_equal_its_own_dot_products(B, N, Lr, train):
+    """Round 5: the S4 contraction's epilogue hands S5 the logits tanh(z_v P1^T + b) . p2 as partial dots per 32-column block
+    (whole 128-row tiles only: B N % 128 == 0 -- the third case keeps S5's own pass); DVGR_OPT_S5_READS_TN is the old form.
+    Same values, different summation order: outputs to fp32 rounding."""
+    sd_np = synth.xavier_state_dict(O.param_shapes(WD, D, Lr), seed=61, bias_range=0.05)
+    inp = synth.unit_inputs(B, N, T, D, WD, seed=61)
+    got = {}
+    for reads_tn in (False, True):
+        m = _module(N, Lr, "bf16x3", sd_np, train, True)
+        m.s5_reads_tn = reads_tn
+        outs = _forward(m, inp, 123)
+        got[reads_tn] = [outs[0].cpu(), outs[1].cpu(), outs[2].cpu()] + [x.cpu() for lst in outs[3:] for x in lst]
+    worst = max(rel_err(a, b) for a, b in zip(got[True], got[False]))
+    print(f"  S5 logits from the S4 epilogue vs its own pass, B={B} N={N}: worst rel err {worst:.2e}")
+    assert worst < 5e-6, worst
