@@ -422,8 +422,11 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
     SplitBatch sb{};
     sb.lo_off = S.total;
     uint16_t* sv_hi = reinterpret_cast<uint16_t*>(saved + S.total);
-    sb.j[sb.n++] = SplitJob{io->A, sv_hi + S.in_a, BND};
-    sb.j[sb.n++] = SplitJob{io->M, sv_hi + S.in_m, BND};
+    // (the plain planes of A / M are read by layer 0's projection and weight gradient in EVAL mode only; in training mode those
+    // take the dropped copies written below, so the 2 x (B N D) bf16 store is skipped)
+    const bool am_planes = !(train && lean && G == 1);
+    sb.j[sb.n++] = SplitJob{io->A, am_planes ? sv_hi + S.in_a : nullptr, BND};
+    sb.j[sb.n++] = SplitJob{io->M, am_planes ? sv_hi + S.in_m : nullptr, BND};
     sb.j[sb.n++] = SplitJob{io->dq, sv_hi + S.in_dq, (int64_t)BT * D};
     if (train && lean) { // layer 0's x-site: the planes of the two dropped copies of A and M from the same pass (no k_drop_x)
       const Keys K0 = layer_keys(train, seed, 0);
@@ -621,7 +624,9 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
       a5.X[m] = Xin[m]; a5.z0[m] = outc[m]; a5.z1[m] = outs[m]; a5.tn[m] = ms(l, m) + S.tn;
       a5.p2[m] = mp(l, m) + P.sf_p2; a5.beta[m] = ms(l, m) + S.beta; a5.Xout[m] = ms(l, m) + S.x;
       a5.o[m] = (l == L - 1) ? (m == 0 ? io->aq_embed : io->mq_embed) : nullptr;
-      a5.xp[m] = PM.out(ms(l, m) + S.x, &plo);
+      // planes of X': read by the next layer's projection and weight gradient in EVAL mode and by the MFB after the last layer;
+      // in training mode those read the dropped copies instead, so layers < L - 1 skip the 2 x (B N D) bf16 store
+      a5.xp[m] = (train && G == 1 && l < L - 1) ? nullptr : PM.out(ms(l, m) + S.x, &plo);
     }
     a5.x_lo_off = plo;
     a5.rows = BN; a5.D = D; a5.N = N;
