@@ -128,7 +128,16 @@ __global__ __launch_bounds__(768) void k_gat_fused_bwd(const GatFusedBwdArgs a) 
   if (idx >= total) return;                                // uniform per workgroup, before any barrier
   const int mod = idx / (mtiles * kHeads);
   const int rem = idx - mod * mtiles * kHeads;
-  const int h = rem / mtiles, mt = rem - h * mtiles;
+  // An XCD's chunk of the tile list (workgroups b and b + 8 share an XCD) = 4 heads x HALF of the row tiles where the row-tile
+  // count is even: per L2 four B panels (2.4 MB of planes at C2) and half a view's A panels (2.0 MB) = 4.3 MB, against 5.1 MB
+  // with 2 heads x all row tiles (round 4) -- fabric bytes of the launch -16 %, step -0.6 % at C2, -0.4 % at C3
+  // (experiments_r05.tsv, xcd_map_4heads_x_half_rows_*).  Speed only: any mapping is correct.
+  int h, mt;
+  if ((mtiles & 1) == 0) {
+    const int hm = mtiles >> 1, blk = rem / (4 * hm), e = rem - blk * 4 * hm;
+    h = 4 * (blk >> 1) + e / hm;
+    mt = (blk & 1) * hm + e % hm;
+  } else { h = rem / mtiles; mt = rem - h * mtiles; }
   const int g = h >> 2, hl = h & 3;                        // view (GAT) and the head's column block inside its (B N, D) output
   const int b0 = mt * SPT;
   const int m0 = b0 * N;

@@ -52,8 +52,8 @@ __device__ long long g_gatf_clk[1024 * 8];
 #endif
 
 // grid: 8 * ceil(total / 8) workgroups, total = mtiles * 8 heads * 2 modalities.  Workgroups b and b + 8 share an XCD
-// (round-robin placement: speed only), so XCD x takes the contiguous chunk x of the (modality, head, row tile) list: with 256
-// workgroups that is 2 heads x all row tiles, i.e. two B panels and one modality's A panels per L2.
+// (round-robin placement: speed only), so XCD x takes the contiguous chunk x of the tile list, decoded below as 4 heads x half of
+// the row tiles.
 template <int TERMS, int MTILES, int NT, int NTC>
 __global__ __launch_bounds__(768) void k_gat_fused_fwd(const GatFusedArgs a) {
   using C = GatfCfg<TERMS, MTILES, NTC>;
@@ -70,7 +70,16 @@ __global__ __launch_bounds__(768) void k_gat_fused_fwd(const GatFusedArgs a) {
   if (idx >= total) return;                                // uniform per workgroup, before any barrier
   const int mod = idx / (mtiles * kHeads);
   const int rem = idx - mod * mtiles * kHeads;
-  const int h = rem / mtiles, mt = rem - h * mtiles;
+  // An XCD's chunk of the tile list (workgroups b and b + 8 share an XCD) = 4 heads x HALF of the row tiles where the row-tile
+  // count is even: per L2 four B panels (2.4 MB of planes at C2) and half a view's A panels (2.0 MB) = 4.3 MB, against 5.1 MB
+  // with 2 heads x all row tiles (round 4) -- fabric bytes of the launch -16 %, step -0.6 % at C2, -0.4 % at C3
+  // (experiments_r05.tsv, xcd_map_4heads_x_half_rows_*).  Speed only: any mapping is correct.
+  int h, mt;
+  if ((mtiles & 1) == 0) {
+    const int hm = mtiles >> 1, blk = rem / (4 * hm), e = rem - blk * 4 * hm;
+    h = 4 * (blk >> 1) + e / hm;
+    mt = (blk & 1) * hm + e % hm;
+  } else { h = rem / mtiles; mt = rem - h * mtiles; }
   const int g = h >> 2, hl = h & 3;
   const int b0 = mt * SPT;                                 // first sample of the tile
   const int m0 = b0 * N;                                   // first row
