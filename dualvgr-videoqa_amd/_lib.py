@@ -50,7 +50,7 @@ class Opts(C.Structure):
     _fields_ = [("train", C.c_int32), ("probe_site", C.c_int32), ("probe_layer", C.c_int32), ("flags", C.c_int32),
                 ("seed", C.c_uint64), ("probe_begin", C.c_void_p), ("probe_end", C.c_void_p),
                 ("layer_done_events", C.POINTER(C.c_void_p)), ("loss", C.POINTER(LossSpec)),
-                ("layer_done_cb", C.c_void_p), ("layer_done_user", C.c_void_p), ("comm", C.c_void_p), ("p1t", C.c_void_p)]
+                ("layer_done_cb", C.c_void_p), ("layer_done_user", C.c_void_p), ("comm", C.c_void_p), ("p1t", C.c_void_p), ("lo8", C.c_void_p)]
 
 
 LAYER_DONE_CB = C.CFUNCTYPE(None, C.c_int32, C.c_void_p)
@@ -64,6 +64,8 @@ OPT_NO_FUSED_GAT_BWD = 16
 OPT_FORCE_FUSED_GAT_BWD = 32
 OPT_FUSED_BWD_READS_DZ = 64
 OPT_S5_READS_TN = 128
+OPT_NO_LO8 = 256
+OPT_KB32 = 512
 
 # enum dvgr_probe_site
 (PROBE_NONE, PROBE_FWD_QA_GEMM, PROBE_FWD_GAT_GEMM, PROBE_FWD_GAT_ATTN, PROBE_FWD_SF_GEMM, PROBE_FWD_MFB_GEMM,
@@ -86,6 +88,8 @@ SYMBOLS = [
     ("dvgr_pack_weights", C.c_int, [C.POINTER(Dims), C.c_void_p, C.c_void_p, C.c_void_p]),
     ("dvgr_p1t_elems", C.c_size_t, [C.POINTER(Dims)]),
     ("dvgr_backward_uses_p1t", C.c_int, [C.POINTER(Dims), C.c_int32]),
+    ("dvgr_lo8_bytes", C.c_size_t, [C.POINTER(Dims)]),
+    ("dvgr_pack_lo8", C.c_int, [C.POINTER(Dims), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("dvgr_pack_p1t", C.c_int, [C.POINTER(Dims), C.c_void_p, C.c_void_p, C.c_void_p]),
     ("dvgr_unit_forward", C.c_int, [C.POINTER(Dims), C.c_void_p, C.c_void_p, C.POINTER(IO), C.c_void_p, C.c_size_t,
                                     C.c_void_p, C.c_size_t, C.POINTER(Opts), C.c_void_p]),

@@ -358,6 +358,47 @@ size_t dvgr_p1t_elems(const dvgr_dims* d) {
   return (size_t)4 * d->L * d->D * d->D;                  // hi + lo planes of L x 2 matrices of D x D
 }
 
+// Layout of the dvgr_pack_lo8 buffer (bytes): [Wcat q: L x 2 x (8F x D)] [P1^T q: L x 2 x (D x D)] [Wcat scales: L x 2 x 8F floats]
+// [P1^T scales: L x 2 x D floats]
+struct Lo8Layout { int64_t wq, pq, ws, ps, total; };
+static Lo8Layout lo8_layout(const dvgr_dims& d) {
+  Lo8Layout y{};
+  const int64_t D = d.D, HF = (int64_t)kHeads * (d.D / 4), n = 2 * (int64_t)d.L;
+  y.wq = 0;
+  y.pq = y.wq + n * HF * D;
+  y.ws = (y.pq + n * D * D + 255) / 256 * 256;
+  y.ps = y.ws + n * HF * 4;
+  y.total = y.ps + n * D * 4;
+  return y;
+}
+
+size_t dvgr_lo8_bytes(const dvgr_dims* d) {
+  if (!d || dvgr_check_dims(d) != 0 || d->dtype != DVGR_BF16X3) return 0;
+  return (size_t)lo8_layout(*d).total;
+}
+
+int dvgr_pack_lo8(const dvgr_dims* d, const void* params_lp, const void* p1t, void* lo8, void* stream) {
+  if (!d || !params_lp || !p1t || !lo8) return DVGR_E_NULL;
+  DVGR_TRY(dvgr_check_dims(d));
+  if (d->dtype != DVGR_BF16X3) return DVGR_E_KIND;
+  if (4 * d->L > kMaxLo8Jobs) return DVGR_E_DIMS;
+  const ParamLayout P = param_layout(*d);
+  const Lo8Layout Y = lo8_layout(*d);
+  const int64_t D = d->D, HF = (int64_t)kHeads * (d->D / 4), DD = D * D;
+  uint8_t* out = reinterpret_cast<uint8_t*>(lo8);
+  Lo8Batch qb{};
+  qb.D = d->D;
+  for (int l = 0; l < d->L; ++l)
+    for (int m = 0; m < 2; ++m) {
+      const int64_t i = l * 2 + m;
+      qb.j[qb.n++] = Lo8Job{reinterpret_cast<const uint16_t*>(params_lp) + P.total + P.layer_stride * l + P.mod_stride * m + P.gat_w,
+                            out + Y.wq + i * HF * D, reinterpret_cast<float*>(out + Y.ws) + i * HF, (int)HF};
+      qb.j[qb.n++] = Lo8Job{reinterpret_cast<const uint16_t*>(p1t) + 2 * (int64_t)d->L * DD + i * DD,
+                            out + Y.pq + i * DD, reinterpret_cast<float*>(out + Y.ps) + i * D, (int)D};
+    }
+  return quantize_lo8((hipStream_t)stream, qb);
+}
+
 static bool backward_fuses(const dvgr_dims& d, int32_t flags) {
   return d.dtype != DVGR_F32 && d.G == 1 && !(flags & (DVGR_OPT_NO_FUSED_GAT | DVGR_OPT_NO_FUSED_GAT_BWD)) && d.L * 2 <= kMaxTransposeJobs &&
          gat_fused_bwd_supported(d.B, d.N, d.D, d.dtype) &&
@@ -534,9 +575,16 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
         wlo = lo1;
         fa.bias[m] = gp_(k, m) + P.gat_b;
         fa.Wh_out[m] = gs_(l, m, j) + S.wh;
+        if (O.lo8 && prec == DVGR_BF16X3 && !(O.flags & DVGR_OPT_NO_LO8) && k < L) {      // (extra GAT sets, graph_layers > 1: bf16 lo planes)
+          const Lo8Layout Y = lo8_layout(d);
+          const uint8_t* base = reinterpret_cast<const uint8_t*>(O.lo8);
+          fa.wq[m] = base + Y.wq + (int64_t)(k * 2 + m) * HF * D;
+          fa.wscale[m] = reinterpret_cast<const float*>(base + Y.ws) + (int64_t)(k * 2 + m) * HF;
+        }
       }
       if (!ok) return DVGR_E_DIMS;          // (cannot happen: fuse_gat() implies planes of every operand)
       a.z_lo_off = plo;
+      fa.kb64 = (O.flags & DVGR_OPT_KB32) ? 0 : 1;
       fa.x_lo_off = xlo; fa.w_lo_off = wlo;
       a.B = B; a.N = N; a.D = D;
       DVGR_TRY(fprobe.begin(DVGR_PROBE_FWD_GAT_GEMM, l));
@@ -1182,9 +1230,16 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
         alo = lo1;
         fa.bh[m] = p1t_hi(l, m);
         ok = ok && fa.bh[m];
+        if (O.lo8 && O.p1t && prec == DVGR_BF16X3 && !(O.flags & DVGR_OPT_NO_LO8)) {      // (the pack was made from O.p1t's planes)
+          const Lo8Layout Y = lo8_layout(d);
+          const uint8_t* base = reinterpret_cast<const uint8_t*>(O.lo8);
+          fa.bq[m] = base + Y.pq + (int64_t)(l * 2 + m) * D * D;
+          fa.bscale[m] = reinterpret_cast<const float*>(base + Y.ps) + (int64_t)(l * 2 + m) * D;
+        }
       }
       if (!ok) return DVGR_E_DIMS;           // (cannot happen: fuse_bwd implies planes of every operand)
       a.lo_off = plo;
+      fa.kb64 = (O.flags & DVGR_OPT_KB32) ? 0 : 1;
       fa.a_lo_off = alo; fa.b_lo_off = p1t_lo;
       a.B = B; a.N = N; a.D = D;
       DVGR_TRY(probe.begin(DVGR_PROBE_BWD_SF_DX, l));

@@ -87,6 +87,38 @@ int transpose_planes(hipStream_t st, const TransposeBatch& b) {
   DVGR_LAUNCH_CHECK();
 }
 
+// ---- bf16 lo plane -> 8-bit block-scaled lo plane (one workgroup per row) ------------------------------------------------------
+__global__ __launch_bounds__(256) void k_quant_lo8(const Lo8Batch b) {
+  __shared__ float red[4];
+  const Lo8Job& J = b.j[blockIdx.y];
+  const int row = blockIdx.x, D = b.D, tid = threadIdx.x;
+  if (row >= J.rows) return;                                // (uniform per workgroup)
+  const uint16_t* src = J.lo + (int64_t)row * D;
+  float amax = 0.f;
+  for (int k = tid; k < D; k += 256) amax = fmaxf(amax, fabsf(__uint_as_float((uint32_t)src[k] << 16)));
+  amax = wave_max(amax);
+  if ((tid & 63) == 0) red[tid >> 6] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float s = amax * (1.0f / 127.0f), inv = amax > 0.f ? 127.0f / amax : 0.f;
+  if (tid == 0) J.scale[row] = s;
+  uint8_t* q = J.q + (int64_t)row * D;
+  for (int k = tid; k < D; k += 256) {
+    const float x = __uint_as_float((uint32_t)src[k] << 16);
+    int v = (int)rintf(x * inv) + 128;
+    v = v < 1 ? 1 : v > 255 ? 255 : v;
+    q[k] = (uint8_t)v;
+  }
+}
+
+int quantize_lo8(hipStream_t st, const Lo8Batch& b) {
+  if (b.n < 1 || b.n > kMaxLo8Jobs || b.D < 1) return DVGR_E_DIMS;
+  int mx = 0;
+  for (int i = 0; i < b.n; ++i) mx = b.j[i].rows > mx ? b.j[i].rows : mx;
+  DVGR_LAUNCH(k_quant_lo8, dim3(mx, b.n), dim3(256), 0, st, b);
+  DVGR_LAUNCH_CHECK();
+}
+
 // ---- the fused kernel ------------------------------------------------------------------------------------------------
 // 16-lane row reductions by DPP rotations (every lane of the row ends with the total)
 __device__ __forceinline__ float row16_sum(float v) {
@@ -112,9 +144,9 @@ struct GatbEpi {                                          // epilogue images, in
   }
 };
 
-template <int TERMS, int MTILES, int NT, int NTC, bool FROM_DX>
+template <int TERMS, int MTILES, int NT, int NTC, bool FROM_DX, bool LO8, int KB>
 __global__ __launch_bounds__(768) void k_gat_fused_bwd(const GatFusedBwdArgs a) {
-  using C = GatfCfg<TERMS, MTILES, NTC>;
+  using C = GatfCfg<TERMS, MTILES, NTC, LO8, KB>;
   extern __shared__ __attribute__((aligned(16))) uint16_t gatb_smem[];
   uint16_t* smem = gatb_smem;
   const int N = a.at.N, D = a.at.D, B = a.at.B, BN = B * N;
@@ -147,7 +179,7 @@ __global__ __launch_bounds__(768) void k_gat_fused_bwd(const GatFusedBwdArgs a) 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave12 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool loader = wave12 >= 8;
-  const int nk = D / BK;
+  const int nk = D / C::KB;
 
   f32x4 acc[4][NTC];
   int row0 = 0;
@@ -188,10 +220,8 @@ __global__ __launch_bounds__(768) void k_gat_fused_bwd(const GatFusedBwdArgs a) 
     };
     const int w = wave12 - 8;
     const uint16_t* xa = a.ah[mod] + (int64_t)g * BN * D;  // view g of dpre (2, B N, D)
-    if (C::IHI == C::ILO || w < (C::ITOT & 3))
-      gatf_loader<C, TERMS, C::IHI, WVL>(xa, a.a_lo_off, a.bh[mod], a.b_lo_off, smem, hl * F, m0, BN, D, nk, w, lane, fetch_out);
-    else
-      gatf_loader<C, TERMS, (C::ILO > 0 ? C::ILO : 1), WVL>(xa, a.a_lo_off, a.bh[mod], a.b_lo_off, smem, hl * F, m0, BN, D, nk, w, lane, fetch_out);
+    const GatfOperands op{xa, a.a_lo_off, a.bh[mod], a.b_lo_off, a.bq[mod]};
+    gatf_loader_wave<C, TERMS, WVL>(op, smem, hl * F, m0, BN, D, nk, w, lane, fetch_out);
   } else {
     const float* wg = a.at.Wh[mod] + (int64_t)m0 * HF + h * F;
     auto fetch_wh = [&]() {                                // behind the first K-tile's barrier (gatf_compute: first)
@@ -204,8 +234,9 @@ __global__ __launch_bounds__(768) void k_gat_fused_bwd(const GatFusedBwdArgs a) 
       }
     };
     const int rg = wave12 >> 2;
-    if (rg == 0) { row0 = 0; gatf_compute<C, TERMS, C::MT0, NTC>(smem, nk, row0, col0, lane, acc, fetch_wh); }
-    else { row0 = 16 * C::MT0; gatf_compute<C, TERMS, (MTILES - C::MT0 > 0 ? MTILES - C::MT0 : 1), NTC>(smem, nk, row0, col0, lane, acc, fetch_wh); }
+    const float* wsc = C::kLo8 ? a.bscale[mod] + hl * F : nullptr;
+    if (rg == 0) { row0 = 0; gatf_compute<C, TERMS, C::MT0, NTC>(smem, nk, row0, col0, lane, acc, fetch_wh, wsc); }
+    else { row0 = 16 * C::MT0; gatf_compute<C, TERMS, (MTILES - C::MT0 > 0 ? MTILES - C::MT0 : 1), NTC>(smem, nk, row0, col0, lane, acc, fetch_wh, wsc); }
   }
   __builtin_amdgcn_s_barrier();                            // every fragment read of the ring is done: its LDS is free
   GBCLK(1);
@@ -605,29 +636,29 @@ bool gat_fused_bwd_preferred(int B, int N) {
   return total >= 200 || B * N <= 320;
 }
 
-template <int TERMS, int MTILES, int NT, bool FROM_DX>
+template <int TERMS, int MTILES, int NT, bool FROM_DX, bool LO8, int KB = 32>
 static int gatb_launch(hipStream_t st, const GatFusedBwdArgs& a, const GatfShape& s) {
   constexpr int NTC = 3;
   const size_t lds = gatb_lds_bytes(s, a.at.N, TERMS);
   if (lds > 160 * 1024) return DVGR_E_DIMS;
   static bool attr_set = false;                            // (benign race: the attribute is idempotent)
   if (!attr_set) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gat_fused_bwd<TERMS, MTILES, NT, NTC, FROM_DX>),
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gat_fused_bwd<TERMS, MTILES, NT, NTC, FROM_DX, LO8, KB>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   const int mtiles = (a.at.B + a.spt - 1) / a.spt;
   const int total = mtiles * kHeads * 2;
-  DVGR_LAUNCH((k_gat_fused_bwd<TERMS, MTILES, NT, NTC, FROM_DX>), dim3(8 * ((total + 7) / 8)), dim3(768), lds, st, a);
+  DVGR_LAUNCH((k_gat_fused_bwd<TERMS, MTILES, NT, NTC, FROM_DX, LO8, KB>), dim3(8 * ((total + 7) / 8)), dim3(768), lds, st, a);
   DVGR_LAUNCH_CHECK();
 }
 
-template <int TERMS>
+template <int TERMS, bool LO8>
 static int gatb_dispatch(hipStream_t st, const GatFusedBwdArgs& a, const GatfShape& s) {
   const bool fx = a.dx[0] != nullptr;
-  if (s.mtiles16 == 4 && s.nt == 1) return fx ? gatb_launch<TERMS, 4, 1, true>(st, a, s) : gatb_launch<TERMS, 4, 1, false>(st, a, s);
-  if (s.mtiles16 == 5 && s.nt == 2) return fx ? gatb_launch<TERMS, 5, 2, true>(st, a, s) : gatb_launch<TERMS, 5, 2, false>(st, a, s);
+  if (s.mtiles16 == 4 && s.nt == 1) return fx ? gatb_launch<TERMS, 4, 1, true, LO8>(st, a, s) : gatb_launch<TERMS, 4, 1, false, LO8>(st, a, s);
+  if (s.mtiles16 == 5 && s.nt == 2) return fx ? gatb_launch<TERMS, 5, 2, true, LO8>(st, a, s) : gatb_launch<TERMS, 5, 2, false, LO8>(st, a, s);
   return DVGR_E_DIMS;                                      // (6 row tiles, N = 21 .. 32: the images do not fit, gat_fused_bwd_supported)
 }
 
@@ -645,7 +676,17 @@ int gat_fused_bwd(hipStream_t st, const GatFusedBwdArgs& a_in, int prec) {
   }
   if ((a.a_lo_off & 7) || (a.b_lo_off & 7) || (a.at.lo_off & 3)) return DVGR_E_ALIGN;
   a.spt = s.spt;
-  return prec == DVGR_BF16X3 ? gatb_dispatch<3>(st, a, s) : gatb_dispatch<1>(st, a, s);
+  if (a.kb64 && prec == DVGR_BF16X3 && a.dx[0] != nullptr && (a.at.D % 64) == 0) {      // 64-deep K-tiles, bf16 lo planes
+    if (s.mtiles16 == 4 && s.nt == 1) return gatb_launch<3, 4, 1, true, false, 64>(st, a, s);
+    if (s.mtiles16 == 5 && s.nt == 2) return gatb_launch<3, 5, 2, true, false, 64>(st, a, s);
+  }
+  const bool lo8 = prec == DVGR_BF16X3 && a.bq[0] != nullptr;
+  if (lo8) {
+    for (int m = 0; m < 2; ++m)
+      if (!a.bq[m] || !a.bscale[m] || ((uintptr_t)a.bq[m] & 15)) return DVGR_E_NULL;
+    return gatb_dispatch<3, true>(st, a, s);
+  }
+  return prec == DVGR_BF16X3 ? gatb_dispatch<3, false>(st, a, s) : gatb_dispatch<1, false>(st, a, s);
 }
 
 }  // namespace dvgr

@@ -7,71 +7,117 @@
 
 namespace dvgr {
 
-template <int TERMS, int MTILES, int NTC>
+// LO8: the lo plane of the B operand (the weights: 192 of a K-tile's 272 rows) arrives as 8 bits per element instead of 16 --
+// q = round(lo / s_row) + 128, one fp32 scale per row, prepared with the parameter planes (dvgr_pack_lo8) -- and becomes the
+// bf16 MFMA operand in the computing waves' registers (v_cvt_f32_ubyte*, one FMA, v_cvt_pk_bf16_f32 per pair).  The K loop runs at
+// the rate its operand bytes arrive (every extra byte costs its share of time), the conversion's VALU work
+// is free beside the MFMAs (experiments_r05.tsv, probe_lo_plane_conversion_valu_c2): 17.6 % fewer bytes per K-tile.  The lo
+// plane carries the 9th .. 16th significant bit of a weight; 8 bits against the row's largest |lo| keep it to 2^-17 of the
+// row's largest weight -- the grade of the bf16 lo plane itself.
+// KB: the depth of a K-tile, 32 or 64.  A row piece of a 32-deep tile is 64 bytes -- half a 128-byte line -- and every row piece
+// is one request to the L2: at C2 a launch's K loop asks for 155 G row pieces per second, 58 % of the L2's 269 G requests / s
+// (128 channels x 2.1 GHz), while its BYTES are 29 % of the L2's rate; fewer bytes at the same piece count (LO8) buy nothing.
+// 64-deep tiles move whole lines: half the requests for the same bytes, at the price of a 2-slot ring (68 KB per slot).
+template <int TERMS, int MTILES, int NTC, bool LO8 = false, int KB_ = 32>
 struct GatfCfg {
+  static constexpr int KB = KB_;
+  static_assert(KB == 32 || KB == 64, "K-tile depth");
+  static_assert(!(LO8 && KB == 64), "the 8-bit plane is laid out for 32-deep tiles");
+  static constexpr bool kLo8 = LO8 && TERMS == 3;
   static constexpr int kPlanes = TERMS == 3 ? 2 : 1;
   static constexpr int RP = 16 * MTILES;                  // rows of the A tile
   static constexpr int F = 64 * NTC;                      // columns of the tile = width of one head
   static constexpr int FS = F + 16;                       // shZ row stride (floats): 16 banks mod 64, the fp32 B fragment is conflict free
-  static constexpr int kTileA = RP * BK;                  // bf16 elements of one A plane tile
-  static constexpr int kTileB = F * BK;
-  static constexpr int kSlot = kPlanes * (kTileA + kTileB);
-  static constexpr int NS = (4 * kSlot * 2 <= 150 * 1024) ? 4 : 3;   // ring slots
-  static constexpr int IA = MTILES;                       // DMA instructions per plane and K-tile: A tile (64 chunks of 16 bytes each)
-  static constexpr int IB = F / 16;                       //   B tile
-  static constexpr int ITOT = IA + IB;
-  static constexpr int IHI = (ITOT + 3) / 4;              // instructions of loader wave w: IHI for w < ITOT % 4 (all of them when
-  static constexpr int ILO = ITOT / 4;                    //   ITOT % 4 == 0), ILO otherwise
+  static constexpr int CH = KB / 8;                       // 16-byte chunks per row of a plane tile
+  static constexpr int RPI = 64 / CH;                     // rows per DMA instruction (1 KB)
+  static constexpr int kTileA = RP * KB;                  // bf16 elements of one A plane tile
+  static constexpr int kTileB = F * KB;
+  static constexpr int kTileBlo = TERMS == 3 ? (kLo8 ? kTileB / 2 : kTileB) : 0;    // (in bf16-sized elements)
+  static constexpr int kSlot = kPlanes * kTileA + kTileB + kTileBlo;
+  static constexpr int NS = (4 * kSlot * 2 <= 150 * 1024) ? 4 : (3 * kSlot * 2 <= 150 * 1024) ? 3 : 2;   // ring slots
+  static constexpr int IA = RP / RPI;                     // DMA instructions per plane and K-tile: A tile (64 chunks of 16 bytes each)
+  static constexpr int IB = F / RPI;                      //   B tile (bf16 plane); the 8-bit lo plane: IB / 2 (32 rows each)
+  static constexpr int IBlo = TERMS == 3 ? (kLo8 ? IB / 2 : IB) : 0;
+  static constexpr int DTOT = kPlanes * IA + IB + IBlo;   // DMA instructions per K-tile, dealt round-robin to the 4 loader waves
+  static constexpr int IHI = (DTOT + 3) / 4;              // instructions of loader wave w: IHI for w < DTOT % 4 (all of them when
+  static constexpr int ILO = DTOT / 4;                    //   DTOT % 4 == 0), ILO otherwise
   static constexpr int MT0 = (MTILES + 1) / 2;            // row tiles of the row group 0 waves, MTILES - MT0 of the others
   static constexpr int kRingBytes = NS * kSlot * 2;
+  static_assert(!kLo8 || (IB % 2) == 0, "the 8-bit plane moves 32 rows per DMA instruction");
+};
+
+// LDS image of a plane tile: [rows][CH chunks of 8 bf16], DMA lane-linear; position `slot` of a row holds source chunk
+// gatf_swz(row, slot) (an involution), so a fragment read of chunk c goes to position gatf_swz(row, c).  32-deep: the swizzle of
+// dvgr_planes.h (b128 reads of 16 rows conflict free); 64-deep: rows are 128 bytes = 32 banks, chunk ^ ((row >> 1) & 7) puts the
+// 16 rows of a fragment read on 16 different 4-bank groups.
+template <int KB>
+__device__ __forceinline__ int gatf_swz(int row, int c) { return KB == 32 ? (c ^ ((-(row >> 2)) & 3)) : (c ^ ((row >> 1) & 7)); }
+// lane (r, g) of an MFMA operand: k = 32 hh + 8 g .. + 7 of tile row idx16 + r
+template <int KB>
+__device__ __forceinline__ bf16x8 gatf_frag(const uint16_t* tile, int idx16, int lane, int hh) {
+  const int row = idx16 + (lane & 15), c = 4 * hh + (lane >> 4);
+  return *reinterpret_cast<const bf16x8*>(tile + row * KB + gatf_swz<KB>(row, c) * 8);
+}
+
+// What the loader streams: hi plane pointers of A (rows m0 .. of it, clamped to BN - 1) and B (rows brow0 .. brow0 + F - 1: forward
+// head h of Wcat, backward the head's columns of P1^T), their bf16 lo planes at + x_lo / + w_lo elements, and -- LO8 -- the 8-bit
+// lo plane of B (row-major bytes, same shape as B).
+struct GatfOperands {
+  const uint16_t* xa; int64_t x_lo;
+  const uint16_t* wb; int64_t w_lo;
+  const uint8_t* wq;
 };
 
 // ---- loader waves -------------------------------------------------------------------------------------------------
-// xa / x_lo: hi plane of the A matrix (rows m0 .. of it, clamped to BN - 1) and its lo-plane offset; wb / w_lo: the same of
-// the B matrix, whose rows brow0 .. brow0 + F - 1 form the tile (forward: head h of Wcat; backward: the head's columns of P1^T)
+// The K-tile's DMA instructions as one flat list -- A hi row blocks, A lo, B hi, B lo (bf16: 16 rows of 64 bytes each; 8-bit: 32
+// rows of 32 bytes, the two 16-byte halves of a row 16 positions apart so that the 8-byte fragment reads of 16 rows are 256
+// contiguous bytes) -- of which wave w issues d = w + 4 k.
 // NPF / pf: optionally, NPF further vector-memory instructions of this wave (plain loads into registers: an epilogue's inputs)
 // issued by pf() right behind the ring's prologue, i.e. YOUNGER than the first NS - 1 K-tiles: the counted waits for those
 // tiles leave them in flight (loads, stores and LDS-DMA share one in-order counter), every later wait covers them.
 struct GatfNoPrefetch { __device__ __forceinline__ void operator()() const {} };
 template <class C, int TERMS, int CNT, int NPF = 0, class PF = GatfNoPrefetch>
-__device__ __forceinline__ void gatf_loader(const uint16_t* xa, int64_t x_lo, const uint16_t* wb, int64_t w_lo, uint16_t* smem,
-                                            int brow0, int m0, int BN, int D, int nk, int wave, int lane, PF pf = PF()) {
-  // instruction k of this wave is instruction i = wave + 4 k of the K-tile: i < IA -> rows 16 i .. 16 i + 15 of the A tile,
-  // else rows 16 (i - IA) .. of the B tile.  Per-lane element offsets are computed once (the K loop moves a uniform base).
-  uint32_t off[CNT];
-  bool is_a[CNT];
-  int dst[CNT];                                            // element offset of the instruction's 1 KB piece inside the slot (hi plane)
+__device__ __forceinline__ void gatf_loader(const GatfOperands& op, uint16_t* smem, int brow0, int m0, int BN, int D, int nk,
+                                            int wave, int lane, PF pf = PF()) {
+  const char* src[CNT];                                    // this lane's source address of instruction k at K-tile 0
+  int step[CNT];                                           // bytes per K-tile: 64 (bf16 planes), 32 (8-bit plane)
+  int dst[CNT];                                            // element offset of the instruction's 1 KB piece inside the slot
 #pragma unroll
   for (int k = 0; k < CNT; ++k) {
-    const int i = wave + 4 * k;
-    is_a[k] = i < C::IA;
-    const int j = is_a[k] ? i : i - C::IA;
-    const int S = j * 64 + lane;
-    const int row = S >> 2, slot = S & 3;
-    const int chunk = slot ^ ((-(row >> 2)) & 3);
-    if (is_a[k]) {
+    int d = wave + 4 * k;
+    d = d < C::DTOT ? d : C::DTOT - 1;                     // (never issued: CNT is chosen per wave so that d < DTOT)
+    const int S = lane;
+    if (d < C::kPlanes * C::IA) {                          // A: plane d / IA, row block d % IA
+      const int pl = d / C::IA, j = d - pl * C::IA;
+      const int row = j * C::RPI + S / C::CH, slot = S % C::CH;
+      const int chunk = gatf_swz<C::KB>(row, slot);
       int gi = m0 + row;
       gi = gi < BN ? gi : BN - 1;                          // rows past the matrix: any valid row (never stored)
-      off[k] = (uint32_t)gi * (uint32_t)D + (uint32_t)(chunk * 8);
-      dst[k] = j * 512;
-    } else {
-      off[k] = (uint32_t)(brow0 + row) * (uint32_t)D + (uint32_t)(chunk * 8);
-      dst[k] = C::kPlanes * C::kTileA + j * 512;
+      src[k] = reinterpret_cast<const char*>(op.xa + (pl ? op.x_lo : 0) + (int64_t)gi * D + chunk * 8);
+      step[k] = 2 * C::KB;
+      dst[k] = pl * C::kTileA + j * 512;
+    } else if (d < C::kPlanes * C::IA + C::IB + (C::kLo8 ? 0 : C::IBlo)) {       // B, bf16 planes
+      const int e = d - C::kPlanes * C::IA;
+      const int pl = e / C::IB, j = e - pl * C::IB;
+      const int row = j * C::RPI + S / C::CH, slot = S % C::CH;
+      const int chunk = gatf_swz<C::KB>(row, slot);
+      src[k] = reinterpret_cast<const char*>(op.wb + (pl ? op.w_lo : 0) + (int64_t)(brow0 + row) * D + chunk * 8);
+      step[k] = 2 * C::KB;
+      dst[k] = C::kPlanes * C::kTileA + pl * C::kTileB + j * 512;
+    } else {                                               // B, 8-bit lo plane: 32 rows per instruction
+      const int j8 = d - (C::kPlanes * C::IA + C::IB);
+      const int grp = S >> 5, q = S & 31, half = q >> 4, rr = q & 15;
+      const int row = 32 * j8 + 16 * grp + rr;
+      src[k] = reinterpret_cast<const char*>(op.wq + (int64_t)(brow0 + row) * D + half * 16);
+      step[k] = BK;
+      dst[k] = C::kPlanes * C::kTileA + C::kTileB + j8 * 512;
     }
   }
   auto issue = [&](int kt, uint16_t* slot_base) {
-    const int k0 = kt * BK;
 #pragma unroll
-    for (int k = 0; k < CNT; ++k) {
-      const uint16_t* base = (is_a[k] ? xa : wb) + k0;
-      const int64_t lo = is_a[k] ? x_lo : w_lo;
-      const int ptile = is_a[k] ? C::kTileA : C::kTileB;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off[k]),
+    for (int k = 0; k < CNT; ++k)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[k] + (int64_t)kt * step[k]),
                                        (__attribute__((address_space(3))) void*)(slot_base + dst[k]), 16, 0, 0);
-      if (TERMS == 3)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + lo + off[k]),
-                                         (__attribute__((address_space(3))) void*)(slot_base + dst[k] + ptile), 16, 0, 0);
-    }
   };
 #pragma unroll
   for (int s = 0; s < C::NS - 1; ++s)
@@ -83,13 +129,15 @@ __device__ __forceinline__ void gatf_loader(const uint16_t* xa, int64_t x_lo, co
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   }
-  constexpr int kPer = C::kPlanes * CNT;                   // DMA instructions of this wave per K-tile
-  static_assert(2 * kPer + NPF < 64, "vmcnt is a 6-bit counter");
+  constexpr int kPer = CNT;                                // DMA instructions of this wave per K-tile
+  constexpr int YM = C::NS - 2 < 2 ? C::NS - 2 : 2;        // K-tiles in flight behind the one waited for (at most)
+  static_assert(YM * kPer + NPF < 64, "vmcnt is a 6-bit counter");
   for (int kt = 0; kt < nk; ++kt) {
-    const int younger = (nk - 1 - kt) < C::NS - 2 ? (nk - 1 - kt) : C::NS - 2;
+    const int younger = (nk - 1 - kt) < YM ? (nk - 1 - kt) : YM;
     // (the NPF loads sit between K-tile NS - 2 and K-tile NS - 1 in the queue: younger than the tile waited for while kt <= NS - 2;
     // a K loop shorter than NS + 1 tiles simply waits for them as well)
-    if (NPF > 0 && kt <= C::NS - 2 && younger >= 2 && nk > C::NS) wait_vmcnt<2 * kPer + NPF>();
+    const bool pf_younger = NPF > 0 && kt <= C::NS - 2 && younger == YM && nk > C::NS;
+    if (pf_younger) wait_vmcnt<YM * kPer + NPF>();
     else if (younger >= 2) wait_vmcnt<2 * kPer>();
     else if (younger == 1) wait_vmcnt<kPer>();
     else wait_vmcnt<0>();
@@ -97,30 +145,57 @@ __device__ __forceinline__ void gatf_loader(const uint16_t* xa, int64_t x_lo, co
     if (kt + C::NS - 1 < nk) issue(kt + C::NS - 1, smem + ((kt + C::NS - 1) % C::NS) * C::kSlot);
   }
 }
+// (the loader waves of a workgroup: wave w carries IHI instructions per K-tile when w < DTOT % 4 or DTOT % 4 == 0, else ILO)
+template <class C, int TERMS, int NPF = 0, class PF = GatfNoPrefetch>
+__device__ __forceinline__ void gatf_loader_wave(const GatfOperands& op, uint16_t* smem, int brow0, int m0, int BN, int D, int nk,
+                                                 int w, int lane, PF pf = PF()) {
+  if (C::IHI == C::ILO || w < (C::DTOT & 3)) gatf_loader<C, TERMS, C::IHI, NPF, PF>(op, smem, brow0, m0, BN, D, nk, w, lane, pf);
+  else gatf_loader<C, TERMS, (C::ILO > 0 ? C::ILO : 1), NPF, PF>(op, smem, brow0, m0, BN, D, nk, w, lane, pf);
+}
 
 // ---- computing waves ----------------------------------------------------------------------------------------------
 // first(): optionally, work of the computing wave issued right behind the FIRST K-tile's barrier (an epilogue's prefetch loads:
 // the ring's prologue has landed by then, and nothing in this loop waits for vector memory)
+// wscale (LO8): the per-row scales of the B operand's 8-bit lo plane, indexed by the tile's row (= output column).
 template <class C, int TERMS, int MTW, int NTC, class FIRST = GatfNoPrefetch>
 __device__ __forceinline__ void gatf_compute(const uint16_t* smem, int nk, int row0, int col0, int lane, f32x4 (&acc)[4][NTC],
-                                             FIRST first = FIRST()) {
+                                             FIRST first = FIRST(), const float* wscale = nullptr) {
 #pragma unroll
   for (int i = 0; i < MTW; ++i)
 #pragma unroll
     for (int j = 0; j < NTC; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   bf16x8 ah[MTW], al[MTW], bh[NTC], bl[NTC];
-  auto read_frags = [&](int kt) {
+  float qs[NTC], qc[NTC];                                  // lo = q * s - 128 s for this lane's row of B fragment j
+#pragma unroll
+  for (int j = 0; j < NTC; ++j) {
+    qs[j] = C::kLo8 ? wscale[col0 + 16 * j + (lane & 15)] : 0.f;
+    qc[j] = -128.f * qs[j];
+  }
+  auto read_frags = [&](int kt, int hh) {
     const uint16_t* curA = smem + (kt % C::NS) * C::kSlot;
     const uint16_t* curB = curA + C::kPlanes * C::kTileA;
 #pragma unroll
     for (int i = 0; i < MTW; ++i) {
-      ah[i] = planes_frag<KC>(curA, row0 + i * 16, lane);
-      if (TERMS == 3) al[i] = planes_frag<KC>(curA + C::kTileA, row0 + i * 16, lane);
+      ah[i] = gatf_frag<C::KB>(curA, row0 + i * 16, lane, hh);
+      if (TERMS == 3) al[i] = gatf_frag<C::KB>(curA + C::kTileA, row0 + i * 16, lane, hh);
     }
 #pragma unroll
     for (int j = 0; j < NTC; ++j) {
-      bh[j] = planes_frag<KC>(curB, col0 + j * 16, lane);
-      if (TERMS == 3) bl[j] = planes_frag<KC>(curB + C::kTileB, col0 + j * 16, lane);
+      bh[j] = gatf_frag<C::KB>(curB, col0 + j * 16, lane, hh);
+      if (TERMS == 3 && !C::kLo8) bl[j] = gatf_frag<C::KB>(curB + C::kTileB, col0 + j * 16, lane, hh);
+      if (C::kLo8) {
+        // 8 bytes = k 8 g .. 8 g + 7 of row col0 + 16 j + r: position ((row >> 4) * 32 + (g >> 1) * 16 + (row & 15)) * 16 + (g & 1) * 8
+        const int r = lane & 15, g = lane >> 4;
+        const uint8_t* t8 = reinterpret_cast<const uint8_t*>(curB + C::kTileB);
+        const uint2 q = *reinterpret_cast<const uint2*>(t8 + ((((col0 >> 4) + j) * 32 + (g >> 1) * 16 + r) << 4) + ((g & 1) << 3));
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 w;
+        w[0] = pack_bf16(__builtin_fmaf((float)(q.x & 0xFFu), qs[j], qc[j]), __builtin_fmaf((float)((q.x >> 8) & 0xFFu), qs[j], qc[j]));
+        w[1] = pack_bf16(__builtin_fmaf((float)((q.x >> 16) & 0xFFu), qs[j], qc[j]), __builtin_fmaf((float)(q.x >> 24), qs[j], qc[j]));
+        w[2] = pack_bf16(__builtin_fmaf((float)(q.y & 0xFFu), qs[j], qc[j]), __builtin_fmaf((float)((q.y >> 8) & 0xFFu), qs[j], qc[j]));
+        w[3] = pack_bf16(__builtin_fmaf((float)((q.y >> 16) & 0xFFu), qs[j], qc[j]), __builtin_fmaf((float)(q.y >> 24), qs[j], qc[j]));
+        bl[j] = __builtin_bit_cast(bf16x8, w);
+      }
     }
   };
   auto mma_tile = [&]() {
@@ -138,8 +213,11 @@ __device__ __forceinline__ void gatf_compute(const uint16_t* smem, int nk, int r
   for (int kt = 0; kt < nk; ++kt) {
     __builtin_amdgcn_s_barrier();
     if (kt == 0) first();
-    read_frags(kt);
-    mma_tile();
+#pragma unroll
+    for (int hh = 0; hh < C::KB / 32; ++hh) {
+      read_frags(kt, hh);
+      mma_tile();
+    }
   }
 }
 

@@ -54,9 +54,9 @@ __device__ long long g_gatf_clk[1024 * 8];
 // grid: 8 * ceil(total / 8) workgroups, total = mtiles * 8 heads * 2 modalities.  Workgroups b and b + 8 share an XCD
 // (round-robin placement: speed only), so XCD x takes the contiguous chunk x of the tile list, decoded below as 4 heads x half of
 // the row tiles.
-template <int TERMS, int MTILES, int NT, int NTC>
+template <int TERMS, int MTILES, int NT, int NTC, bool LO8, int KB>
 __global__ __launch_bounds__(768) void k_gat_fused_fwd(const GatFusedArgs a) {
-  using C = GatfCfg<TERMS, MTILES, NTC>;
+  using C = GatfCfg<TERMS, MTILES, NTC, LO8, KB>;
   extern __shared__ __attribute__((aligned(16))) uint16_t gatf_smem[];
   uint16_t* smem = gatf_smem;
   const int N = a.at.N, D = a.at.D, B = a.at.B, BN = B * N;
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(768) void k_gat_fused_fwd(const GatFusedArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave12 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool loader = wave12 >= 8;
-  const int nk = D / BK;
+  const int nk = D / C::KB;
 
   f32x4 acc[4][NTC];                                       // (row group 0 uses MT0 of the 4 row slots, row group 1 MTILES - MT0)
   int row0 = 0;
@@ -110,15 +110,16 @@ __global__ __launch_bounds__(768) void k_gat_fused_fwd(const GatFusedArgs a) {
     pre_s = a.at.s[mod][m0 + ts];
     const int w = wave12 - 8;
     // waves w < ITOT % 4 carry IHI instructions per plane, the others ILO (equal when ITOT % 4 == 0)
-    if (C::IHI == C::ILO || w < (C::ITOT & 3)) gatf_loader<C, TERMS, C::IHI>(a.xh[mod][g], a.x_lo_off, a.wh[mod], a.w_lo_off, smem, h * F, m0, BN, D, nk, w, lane);
-    else gatf_loader<C, TERMS, (C::ILO > 0 ? C::ILO : 1)>(a.xh[mod][g], a.x_lo_off, a.wh[mod], a.w_lo_off, smem, h * F, m0, BN, D, nk, w, lane);
+    const GatfOperands op{a.xh[mod][g], a.x_lo_off, a.wh[mod], a.w_lo_off, a.wq[mod]};
+    gatf_loader_wave<C, TERMS>(op, smem, h * F, m0, BN, D, nk, w, lane);
   } else {
     const int rg = wave12 >> 2;
     const float* bias = a.bias[mod] + h * F;
 #pragma unroll
     for (int j = 0; j < NTC; ++j) bv[j] = bias[col0 + 16 * j + (lane & 15)];
-    if (rg == 0) { row0 = 0; gatf_compute<C, TERMS, C::MT0, NTC>(smem, nk, row0, col0, lane, acc); }
-    else { row0 = 16 * C::MT0; gatf_compute<C, TERMS, (MTILES - C::MT0 > 0 ? MTILES - C::MT0 : 1), NTC>(smem, nk, row0, col0, lane, acc); }
+    const float* wsc = C::kLo8 ? a.wscale[mod] + h * F : nullptr;
+    if (rg == 0) { row0 = 0; gatf_compute<C, TERMS, C::MT0, NTC>(smem, nk, row0, col0, lane, acc, GatfNoPrefetch(), wsc); }
+    else { row0 = 16 * C::MT0; gatf_compute<C, TERMS, (MTILES - C::MT0 > 0 ? MTILES - C::MT0 : 1), NTC>(smem, nk, row0, col0, lane, acc, GatfNoPrefetch(), wsc); }
   }
   __builtin_amdgcn_s_barrier();                            // every fragment read of the ring is done: its LDS is free
   GFCLK(1);
@@ -366,34 +367,34 @@ bool gat_fused_supported(int B, int N, int D, int prec) {
   return prec != DVGR_F32 && D == 768 && gatf_shape(B, N, &s) && (int64_t)B * N * D < (1ll << 31);
 }
 
-template <int TERMS, int MTILES, int NT>
+template <int TERMS, int MTILES, int NT, bool LO8, int KB = 32>
 static int gatf_launch(hipStream_t st, const GatFusedArgs& a) {
   constexpr int NTC = 3;
-  using C = GatfCfg<TERMS, MTILES, NTC>;
+  using C = GatfCfg<TERMS, MTILES, NTC, LO8, KB>;
   const int N = a.at.N, S = (N + 3) / 4, NP = 4 * S + 1;
   const size_t epi = sizeof(float) * ((size_t)(C::RP + 4) * C::FS + (size_t)a.spt * 16 * NT * NP + 2 * C::F + 3 * C::RP);
   const size_t lds = (epi > (size_t)C::kRingBytes ? epi : (size_t)C::kRingBytes) + 16;
   if (lds > 160 * 1024) return DVGR_E_DIMS;
-  static bool attr_set = false;                            // (benign race: the attribute is idempotent)
+  static bool attr_set = false;                            // (benign race: the attribute is idempotent; one flag per instantiation)
   if (!attr_set) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gat_fused_fwd<TERMS, MTILES, NT, NTC>),
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gat_fused_fwd<TERMS, MTILES, NT, NTC, LO8, KB>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   const int mtiles = (a.at.B + a.spt - 1) / a.spt;
   const int total = mtiles * kHeads * 2;
-  DVGR_LAUNCH((k_gat_fused_fwd<TERMS, MTILES, NT, NTC>), dim3(8 * ((total + 7) / 8)), dim3(768), lds, st, a);
+  DVGR_LAUNCH((k_gat_fused_fwd<TERMS, MTILES, NT, NTC, LO8, KB>), dim3(8 * ((total + 7) / 8)), dim3(768), lds, st, a);
   DVGR_LAUNCH_CHECK();
 }
 
-template <int TERMS>
+template <int TERMS, bool LO8>
 static int gatf_dispatch(hipStream_t st, const GatFusedArgs& a, const GatfShape& s) {
-  if (s.mtiles16 == 4 && s.nt == 1) return gatf_launch<TERMS, 4, 1>(st, a);
-  if (s.mtiles16 == 5 && s.nt == 2) return gatf_launch<TERMS, 5, 2>(st, a);
-  if (s.mtiles16 == 6 && s.nt == 2) return gatf_launch<TERMS, 6, 2>(st, a);
-  if (s.mtiles16 == 6 && s.nt == 3) return gatf_launch<TERMS, 6, 3>(st, a);
-  if (s.mtiles16 == 8 && s.nt == 4) return gatf_launch<TERMS, 8, 4>(st, a);
+  if (s.mtiles16 == 4 && s.nt == 1) return gatf_launch<TERMS, 4, 1, LO8>(st, a);
+  if (s.mtiles16 == 5 && s.nt == 2) return gatf_launch<TERMS, 5, 2, LO8>(st, a);
+  if (s.mtiles16 == 6 && s.nt == 2) return gatf_launch<TERMS, 6, 2, LO8>(st, a);
+  if (s.mtiles16 == 6 && s.nt == 3) return gatf_launch<TERMS, 6, 3, LO8>(st, a);
+  if (s.mtiles16 == 8 && s.nt == 4) return gatf_launch<TERMS, 8, 4, LO8>(st, a);
   return DVGR_E_DIMS;
 }
 
@@ -407,7 +408,17 @@ int gat_fused_fwd(hipStream_t st, const GatFusedArgs& a_in, int prec) {
   }
   if ((a.x_lo_off & 7) || (a.w_lo_off & 7)) return DVGR_E_ALIGN;
   a.spt = s.spt;
-  return prec == DVGR_BF16X3 ? gatf_dispatch<3>(st, a, s) : gatf_dispatch<1>(st, a, s);
+  if (a.kb64 && prec == DVGR_BF16X3 && (a.at.D % 64) == 0) {      // 64-deep K-tiles (whole 128-byte lines per row piece), bf16 lo planes
+    if (s.mtiles16 == 4 && s.nt == 1) return gatf_launch<3, 4, 1, false, 64>(st, a);
+    if (s.mtiles16 == 5 && s.nt == 2) return gatf_launch<3, 5, 2, false, 64>(st, a);
+  }
+  const bool lo8 = prec == DVGR_BF16X3 && a.wq[0] != nullptr;
+  if (lo8) {
+    for (int m = 0; m < 2; ++m)
+      if (!a.wq[m] || !a.wscale[m] || ((uintptr_t)a.wq[m] & 15)) return DVGR_E_NULL;
+    return gatf_dispatch<3, true>(st, a, s);
+  }
+  return prec == DVGR_BF16X3 ? gatf_dispatch<3, false>(st, a, s) : gatf_dispatch<1, false>(st, a, s);
 }
 
 }  // namespace dvgr

@@ -69,7 +69,12 @@ struct GatFusedArgs {
   const uint16_t* wh[2];       // [mod] hi plane of Wcat (8F, D)
   int64_t w_lo_off;
   const float* bias[2];        // bcat (8F)
+  // optional (both or neither; bf16x3 only): the 8-bit lo plane of Wcat (8F, D) bytes and its per-row scales (8F), dvgr_pack_lo8:
+  // the launch then streams it instead of the bf16 lo plane (dvgr_gatf.h, LO8)
+  const uint8_t* wq[2];
+  const float* wscale[2];
   float* Wh_out[2];            // (B*N, 8F) fp32, saved for the backward
+  int kb64;                    // != 0: 64-deep K-tiles (bf16x3, bf16 lo planes; dvgr_gatf.h KB)
   int spt;                     // samples per tile (set by the launcher)
 };
 bool gat_fused_supported(int B, int N, int D, int prec);
@@ -163,6 +168,8 @@ struct GatFusedBwdArgs {
   int64_t a_lo_off;            // lo plane = hi plane + a_lo_off elements
   const uint16_t* bh[2];       // [mod] hi plane of P1^T (D, D): row = input feature i of project[0], reduction index o contiguous
   int64_t b_lo_off;
+  const uint8_t* bq[2];        // optional (both or neither; bf16x3 only): the 8-bit lo plane of P1^T (D, D) bytes and its per-row
+  const float* bscale[2];      //   scales (D), dvgr_pack_lo8
   // dx[mod] != nullptr: at.dz is NOT read; the part of dz that k_sf_bwd would have written is formed here instead,
   //   dz_g = beta_g (dx + g_embed) + g_z[g]      (model/Attention.py:22-23 backward: o = sum_v beta_v z_v),
   // from the running gradient of the layer output (B*N, D), the direct upstream gradient of the fused embedding (last layer;
@@ -172,6 +179,7 @@ struct GatFusedBwdArgs {
   const float* g_embed[2];
   const float* g_z[2][2];      // [mod][view]
   const float* beta[2];
+  int kb64;                    // != 0: 64-deep K-tiles (bf16x3, bf16 lo planes, with dx; dvgr_gatf.h KB)
   int spt;                     // samples per tile (set by the launcher)
 };
 bool gat_fused_bwd_supported(int B, int N, int D, int prec);
@@ -188,6 +196,13 @@ struct TransposeBatch {
   int D;                       // multiple of 64
 };
 int transpose_planes(hipStream_t st, const TransposeBatch& b);
+
+// 8-bit block-scaled lo planes (dvgr_gatf.h, LO8): per row of `rows` x D bf16 lo values, s = max |lo| / 127 and
+// q = round(lo / s) + 128 (uint8, 128 = zero); lo ~ (q - 128) s.  One workgroup per row.
+constexpr int kMaxLo8Jobs = 48;
+struct Lo8Job { const uint16_t* lo; uint8_t* q; float* scale; int rows; };
+struct Lo8Batch { Lo8Job j[kMaxLo8Jobs]; int n; int D; };
+int quantize_lo8(hipStream_t st, const Lo8Batch& b);
 
 // S1 backward: ds = sum_h ds_part; dtau = ds s (1-s); dX += dtau p (+ add); dp = sum_n dtau X.
 struct PunishBwdArgs {

@@ -322,6 +322,7 @@ class DualVGRUnit_multiple(nn.Module):
         self._lowp = None
         self._lowp_version = None
         self._p1t = None
+        self._lo8 = None
         self._p1t_stale = True
         self._ws = None
         self._events = None
@@ -349,6 +350,10 @@ class DualVGRUnit_multiple(nn.Module):
         self.fused_gat_bwd = not bool(int(os.environ.get("DVGR_NO_FUSED_GAT_BWD", "0")))
         if self.fused_gat_bwd and os.environ.get("DVGR_FORCE_FUSED_GAT_BWD", "0") == "1":
             self.fused_gat_bwd = "force"
+        self.kb64 = not bool(int(os.environ.get("DVGR_KB32", "0")))                    # False: DVGR_OPT_KB32 (32-deep K-tiles in the fused kernels)
+        # 8-bit lo planes of the fused kernels' weight operands (dvgr_opts.lo8): an experiment of round 5 that applies to the
+        # 32-deep K-tiles only and bought nothing there (fewer bytes, the same number of L2 requests); off unless asked for
+        self.lo8_planes = bool(int(os.environ.get("DVGR_LO8", "0")))
         self.hoist_p1t = not bool(int(os.environ.get("DVGR_P1T_PER_CALL", "0")))     # False: the backward transposes P1's planes itself, per call
         self.s5_reads_tn = bool(int(os.environ.get("DVGR_S5_READS_TN", "0")))                # DVGR_OPT_S5_READS_TN (A/B, parity)
         self.fused_bwd_reads_dz = bool(int(os.environ.get("DVGR_FUSED_BWD_READS_DZ", "0")))   # DVGR_OPT_FUSED_BWD_READS_DZ (A/B, parity)
@@ -437,6 +442,7 @@ class DualVGRUnit_multiple(nn.Module):
         self._lowp = None
         self._lowp_version = None
         self._p1t = None
+        self._lo8 = None
         self._p1t_stale = True
 
     def _apply(self, fn, recurse=True):
@@ -517,10 +523,26 @@ class DualVGRUnit_multiple(nn.Module):
             self._p1t = torch.empty(n, device=dev, dtype=torch.bfloat16)
             self._p1t_stale = True
         if self._p1t_stale:
-            L_.check(L_.load().dvgr_pack_p1t(C.byref(self._dims0), lp, self._p1t.data_ptr(),
-                                             torch.cuda.current_stream(dev).cuda_stream), "dvgr_pack_p1t")
+            st = torch.cuda.current_stream(dev).cuda_stream
+            L_.check(L_.load().dvgr_pack_p1t(C.byref(self._dims0), lp, self._p1t.data_ptr(), st), "dvgr_pack_p1t")
+            # ... and, from both, the 8-bit block-scaled lo planes of the fused kernels' weight operands (dvgr_opts.lo8)
+            nb = L_.load().dvgr_lo8_bytes(C.byref(self._dims0))
+            if nb and self.lo8_planes:
+                if self._lo8 is None or self._lo8.device != dev:
+                    self._lo8 = torch.empty(nb, device=dev, dtype=torch.uint8)
+                L_.check(L_.load().dvgr_pack_lo8(C.byref(self._dims0), lp, self._p1t.data_ptr(), self._lo8.data_ptr(), st),
+                         "dvgr_pack_lo8")
+            else:
+                self._lo8 = None
             self._p1t_stale = False
         return self._p1t.data_ptr()
+
+    def lo8_ptr(self):
+        """8-bit block-scaled lo planes of Wcat / P1^T for the fused GAT-view kernels (dvgr_opts.lo8, dvgr_pack_lo8; bf16x3 only),
+        kept current together with p1t_ptr().  None: those kernels stream the bf16 lo planes."""
+        if not self.lo8_planes or self.p1t_ptr() is None or self._lo8 is None:
+            return None
+        return self._lo8.data_ptr()
 
     def lowp_planes(self):
         """The bf16 hi / lo planes tensor of the flat parameter buffer (None in fp32 mode), allocated if need be; for a
@@ -619,9 +641,15 @@ class DualVGRUnit_multiple(nn.Module):
                 o.probe_begin, o.probe_end = b.cuda_event, e.cuda_event
         if backward and getattr(self, "_comm", None) is not None:
             o.comm = self._comm.handle
+        if not self.kb64:
+            o.flags |= L_.OPT_KB32
+        if not self.lo8_planes:
+            o.flags |= L_.OPT_NO_LO8
         if backward and self.fused_gat_bwd and self.hoist_p1t and dims is not None and \
                 L_.load().dvgr_backward_uses_p1t(C.byref(dims), o.flags):
             o.p1t = self.p1t_ptr()
+        if self.lo8_planes and self.hoist_p1t and self.fused_gat and (not backward or o.p1t):
+            o.lo8 = self.lo8_ptr()
         if backward and self._events:
             arr = (C.c_void_p * (self.layers + 2))()
             for i, ev in enumerate(self._events):

@@ -184,6 +184,13 @@ size_t dvgr_p1t_elems(const dvgr_dims *d);
 /* 1 when dvgr_unit_backward at these dimensions and dvgr_opts.flags takes the fused GAT-view backward, i.e. reads P1^T
  * (dvgr_opts.p1t, or its own per-call transposition); 0 otherwise -- a host prepares the transposed planes only then. */
 int dvgr_backward_uses_p1t(const dvgr_dims *d, int32_t flags);
+/* 8-bit block-scaled lo planes of the weight operands of the fused GAT-view kernels (dvgr_opts.lo8; DVGR_BF16X3 only): per
+ * row, s = max |lo| / 127 and q = round(lo / s) + 128, where lo is the bf16 lo plane (the 9th .. 16th significant bit of the
+ * weight) -- the kernels rebuild lo ~ (q - 128) s in registers.  `lo8` receives dvgr_lo8_bytes(d) bytes: Wcat of every (layer,
+ * modality) from `params_lp`, P1^T of every (layer, modality) from `p1t` (dvgr_pack_p1t; call that first), then the scales.
+ * Call it whenever the planes were rewritten.  DVGR_E_KIND unless d->dtype == DVGR_BF16X3. */
+size_t dvgr_lo8_bytes(const dvgr_dims *d);
+int dvgr_pack_lo8(const dvgr_dims *d, const void *params_lp, const void *p1t, void *lo8, void *stream);
 int dvgr_pack_p1t(const dvgr_dims *d, const void *params_lp, void *p1t, void *stream);
 
 /* Launch sites a caller can bracket with a pair of hipEvents (dvgr_opts.probe): the events are
@@ -245,6 +252,13 @@ enum dvgr_probe_site {
  * (GemmProblem::rowdot_out) where the launch runs on whole tiles of the planes kernels, so that S5 does not read the tanh
  * outputs back.  DVGR_OPT_S5_READS_TN keeps S5's own dot products over them (A/B timing, parity of the two forms). */
 #define DVGR_OPT_S5_READS_TN 128
+/* The fused GAT-view kernels stream the bf16 lo planes of their weight operands even when dvgr_opts.lo8 is set (A/B timing,
+ * parity of the two forms). */
+#define DVGR_OPT_NO_LO8 256
+/* The fused GAT-view kernels run their K loops on 64-deep K-tiles where that form is built (bf16x3, 4- and 5-row-tile shapes):
+ * a row piece is then a whole 128-byte line, half the L2 requests per byte, on a 2-slot ring (csrc/dvgr_gatf.h, KB).
+ * DVGR_OPT_KB32 keeps the 32-deep tiles of round 4 (A/B timing; also what dvgr_opts.lo8 applies to). */
+#define DVGR_OPT_KB32 512
 
 /* Scope-U loss evaluated by the forward itself (dvgr_opts.loss): the same arithmetic and outputs as
  * dvgr_scope_u_loss below, but the kernels are enqueued as soon as the last layer's list outputs exist and run on the
@@ -287,6 +301,10 @@ typedef struct dvgr_opts {
                           GAT_BWD) contracts against P1^T; without this pointer the call transposes the planes itself into its
                           workspace, one small launch per call (14 MB at C2) -- a caller whose parameters change once per
                           optimizer step prepares them once per step instead, next to the planes themselves. */
+  const void *lo8;     /* forward and backward, nullable: the 8-bit block-scaled lo planes of the fused GAT-view kernels' weight
+                          operands as written by dvgr_pack_lo8() from the CURRENT planes (Wcat for the forward, P1^T for the
+                          backward).  Those launches then stream 3 bytes per weight element instead of 4 (csrc/dvgr_gatf.h, LO8);
+                          without the pointer -- or with DVGR_OPT_NO_LO8 -- they stream the bf16 lo planes. */
 } dvgr_opts;
 
 /* Forward of the whole stacked unit: replaces DualVGRUnit_multiple.forward (model/models.py:

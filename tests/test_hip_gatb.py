@@ -25,7 +25,7 @@ D, WD, T = 768, 300, 9
 TOL, GTOL = 1e-4, 5e-4
 
 
-def _module(N, Lr, dtype, sd_np, train, fused_bwd, single=False, G=1, reads_dz=False):
+def _module(N, Lr, dtype, sd_np, train, fused_bwd, single=False, G=1, reads_dz=False, lo8=False, kb64=True):
     m = dv.DualVGRUnit_multiple(word_dim=WD, module_dim=D, num_of_nodes=N, unit_layers=Lr, dtype=dtype,
                                 appearance_graph_layers=G, motion_graph_layers=G)
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
@@ -33,6 +33,8 @@ def _module(N, Lr, dtype, sd_np, train, fused_bwd, single=False, G=1, reads_dz=F
     m.keep_saved = True
     m.fused_gat_bwd = "force" if fused_bwd else False      # every supported shape, not only the ones it is faster at
     m.single_stream = single
+    m.lo8_planes = lo8                    # True: 8-bit lo planes of the weight operands in the fused kernels (dvgr_opts.lo8; 32-deep tiles)
+    m.kb64 = kb64                         # False: 32-deep K-tiles (DVGR_OPT_KB32)
     m.fused_bwd_reads_dz = reads_dz       # True: k_sf_bwd stores dz's pre-part and the fused launch reads it (DVGR_OPT_FUSED_BWD_READS_DZ)
     return m
 
@@ -121,6 +123,32 @@ def test_both_sources_of_dz_agree(B, N, Lr, train):
         _, _, got[reads] = _grads(_module(N, Lr, "bf16x3", sd_np, train, True, reads_dz=reads), inp, R, N, 99)
     worst = max(rel_err(got[True][k], got[False][k]) for k in got[True] if not k.endswith((".fc.bias", ".a.bias")))
     assert worst < 5e-5, worst
+
+
+@pytest.mark.parametrize("kb64,lo8", [(False, False), (False, True)])
+def test_fused_backward_32_deep_forms_against_oracle(kb64, lo8):
+    """The 32-deep K-tile forms of the fused kernels (DVGR_OPT_KB32), with the bf16 and with the 8-bit lo plane of the weight
+    operands, hold the same gates against the oracle as the default 64-deep form."""
+    B, N, Lr = 6, 20, 2
+    sd_np = synth.xavier_state_dict(O.param_shapes(WD, D, Lr), seed=59, bias_range=0.05)
+    inp = synth.unit_inputs(B, N, T, D, WD, seed=59)
+    R = torch.from_numpy(synth.normal("R_gatb", (B, N, D), 1.0, 59))
+    m = _module(N, Lr, "bf16x3", sd_np, True, True, single=True, kb64=kb64, lo8=lo8)
+    seed = 4545
+    outs, t, _ = _grads(m, inp, R, N, seed)
+    masks = {k: torch.from_numpy(v) for k, v in dropout.site_masks(seed, B, N, D, Lr).items()}
+    sd = {k: torch.from_numpy(v.copy()) for k, v in sd_np.items()}
+    ti = {k: torch.from_numpy(v.copy()) for k, v in inp.items()}
+    signs = device_logit_signs(m, L.make_dims(B, N, T, D, WD, Lr), (B, N, Lr))
+    oo, gin, gw, dbg, stats = aligned_oracle_backward(sd, ti, Lr, masks, lambda o: _scalar(o, R, N), signs)
+    what = f"gatb bf16x3 kb64={kb64} lo8={lo8}"
+    flat_h = [outs[0], outs[1], outs[2]] + outs[3] + outs[4] + outs[5] + outs[6]
+    flat_o = [oo[0], oo[1], oo[2]] + oo[3] + oo[4] + oo[5] + oo[6]
+    ferr = max(rel_err(h.detach().cpu(), o) for h, o in zip(flat_h, flat_o))
+    print(f"  {what}: forward {ferr:.2e}")
+    assert ferr < TOL, ferr
+    assert_flips_at_kink(stats, what)
+    assert_grads(m, t, gin, gw, dbg, Lr, GTOL, what)
 
 
 def test_shapes_the_kernel_does_not_take_keep_two_launches():

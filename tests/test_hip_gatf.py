@@ -24,7 +24,7 @@ D, WD, T = 768, 300, 9
 TOL, GTOL = 1e-4, 5e-4
 
 
-def _module(N, Lr, dtype, sd_np, train, fused, single=False, G=1):
+def _module(N, Lr, dtype, sd_np, train, fused, single=False, G=1, lo8=False, kb64=True):
     m = dv.DualVGRUnit_multiple(word_dim=WD, module_dim=D, num_of_nodes=N, unit_layers=Lr, dtype=dtype,
                                 appearance_graph_layers=G, motion_graph_layers=G)
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
@@ -32,6 +32,8 @@ def _module(N, Lr, dtype, sd_np, train, fused, single=False, G=1):
     m.keep_saved = True
     m.fused_gat = fused
     m.single_stream = single
+    m.lo8_planes = lo8          # True: the fused kernels stream an 8-bit lo plane of their weight operand (dvgr_opts.lo8; 32-deep tiles)
+    m.kb64 = kb64               # False: 32-deep K-tiles (DVGR_OPT_KB32)
     return m
 
 
@@ -65,7 +67,9 @@ def test_fused_equals_two_launch_form(B, N, Lr, train):
     dims = L.make_dims(B, N, T, D, WD, Lr)
     got = {}
     for fused in (True, False):
-        m = _module(N, Lr, "bf16x3", sd_np, train, fused, single=True)      # single stream: layer 0 takes the fused kernel too
+        # single stream: layer 0 takes the fused kernel too; bf16 lo planes in both forms (the bit-identity claim is about those:
+        # a 64-deep K-tile is two 32-deep steps in the same order, so the MFMA chain per element is the same either way)
+        m = _module(N, Lr, "bf16x3", sd_np, train, fused, single=True, lo8=False)
         outs = _forward(m, inp, 777)
         sv = {}
         for l in range(Lr):
@@ -194,3 +198,53 @@ def test_s5_logits_from_the_s4_epilogue_equal_its_own_dot_products(B, N, Lr, tra
     worst = max(rel_err(a, b) for a, b in zip(got[True], got[False]))
     print(f"  S5 logits from the S4 epilogue vs its own pass, B={B} N={N}: worst rel err {worst:.2e}")
     assert worst < 5e-6, worst
+
+
+@pytest.mark.parametrize("B,N,Lr,train", [(64, 20, 2, True), (17, 8, 2, False), (7, 20, 3, True)])
+def test_8_bit_lo_plane_of_the_weight_operand(B, N, Lr, train):
+    """Round 5: the fused kernels stream the lo plane of their weight operand as 8 bits per element + one scale per row
+    (dvgr_pack_lo8, csrc/dvgr_gatf.h LO8) instead of bf16.  The lo plane carries bits 9 .. 16 of a weight: 8 bits against the
+    row's largest |lo| keep the operand to 2^-17 of the row's largest weight, the grade of the bf16 lo plane.  Forward outputs
+    and the saved projection / logit halves against the bf16-lo form (single stream: every layer takes the fused kernel);
+    gradients are NOT compared between the two device runs -- a 1e-5 change of a logit next to the LeakyReLU kink flips its
+    branch (the oracle tests of this file and of test_hip_gatb.py, which run with the 8-bit plane, hold the gradients with the
+    device's branches injected)."""
+    sd_np = synth.xavier_state_dict(O.param_shapes(WD, D, Lr), seed=63, bias_range=0.05)
+    inp = synth.unit_inputs(B, N, T, D, WD, seed=63)
+    dims = L.make_dims(B, N, T, D, WD, Lr)
+    got = {}
+    for lo8 in (True, False):
+        m = _module(N, Lr, "bf16x3", sd_np, train, True, single=True, lo8=lo8, kb64=False)
+        outs = _forward(m, inp, 31)
+        g = {"out:%d" % i: x.cpu() for i, x in enumerate([outs[0], outs[1], outs[2]] + [y for lst in outs[3:] for y in lst])}
+        for l in range(Lr):
+            for mi in range(2):
+                g["Wh:%d:%d" % (l, mi)] = _saved(m, dims, L.S_WH, l, mi, (B, N, 8 * (D // 4)))
+                g["u:%d:%d" % (l, mi)] = _saved(m, dims, L.S_U, l, mi, (B, 8, N))
+        got[lo8] = g
+    worst, wk = 0.0, None
+    for k in got[True]:
+        e = rel_err(got[True][k], got[False][k])
+        if e > worst:
+            worst, wk = e, k
+    print(f"  8-bit lo plane vs bf16 lo plane, B={B} N={N} train={train}: worst rel err {worst:.2e} ({wk})")
+    assert 0.0 < worst < 5e-5, (worst, wk)          # (> 0: the 8-bit plane really was used)
+
+
+@pytest.mark.parametrize("B,N,Lr,train", [(64, 20, 2, True), (17, 8, 2, False), (7, 13, 2, True)])
+def test_64_deep_k_tiles_equal_32_deep_ones(B, N, Lr, train):
+    """Round 5: the fused kernels' K loops on 64-deep K-tiles (whole 128-byte lines per row piece, 2-slot ring) against the
+    32-deep tiles (DVGR_OPT_KB32): a 64-deep tile is consumed as two 32-deep MFMA steps in the same order, so every accumulator
+    sees the same chain -- outputs and saved projections BIT-identical."""
+    sd_np = synth.xavier_state_dict(O.param_shapes(WD, D, Lr), seed=67, bias_range=0.05)
+    inp = synth.unit_inputs(B, N, T, D, WD, seed=67)
+    dims = L.make_dims(B, N, T, D, WD, Lr)
+    got = {}
+    for kb64 in (True, False):
+        m = _module(N, Lr, "bf16x3", sd_np, train, True, single=True, kb64=kb64)
+        outs = _forward(m, inp, 17)
+        g = [x.cpu() for x in [outs[0], outs[1], outs[2]] + [y for lst in outs[3:] for y in lst]]
+        g += [_saved(m, dims, L.S_WH, l, mi, (B, N, 8 * (D // 4))) for l in range(Lr) for mi in range(2)]
+        got[kb64] = g
+    for a, b in zip(got[True], got[False]):
+        assert torch.equal(a, b)
