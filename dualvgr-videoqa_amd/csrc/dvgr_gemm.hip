@@ -856,21 +856,27 @@ constexpr int kPlaneTile = RT * BK;          // bf16 elements per plane tile
 
 // NI = DMA instructions per loader wave and plane tile: 2 for a 128-row (or 128-column) tile, 1 for the 64-row KC tile of
 // the half-height variant (256 chunks).
-template <int LAYOUT, int NI = 2>
+// KB = depth of the K-tile (32, or 64 for row-major operands whose row piece then is a whole 128-byte line: round 5, DESIGN.md
+// section 3.1).  LDS images: KC tile [rows][KB / 8 chunks], position `slot` of a row holds source chunk kc_swz<KB>(row, slot);
+// IC tile [KB k-rows][16 chunks], the swizzle of a k-row depends on k & 31 only (a 64-deep tile is two 32-deep blocks).
+template <int KB>
+__device__ __forceinline__ int kc_swz(int row, int c) { return KB == 32 ? (c ^ ((-(row >> 2)) & 3)) : (c ^ ((row >> 1) & 7)); }
+
+template <int LAYOUT, int NI = 2, int KB = 32>
 __device__ __forceinline__ void planes_prep(const GemmOperand& op, int idx0, int dim, int wave, int lane, uint32_t (&off)[NI]) {
-  static_assert(NI == 2 || LAYOUT == KC, "the 64-row tile exists for row-major (KC) operands only");
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {             // 512 (256) 16-byte chunks per plane tile = 4 waves x NI instructions x 64 lanes
+  for (int i = 0; i < NI; ++i) {             // 16-byte chunks of a plane tile = 4 waves x NI instructions x 64 lanes
     const int S = (wave * NI + i) * 64 + lane;
     if (LAYOUT == KC) {
-      const int row = S >> 2, slot = S & 3;
-      const int chunk = slot ^ ((-(row >> 2)) & 3);
+      constexpr int CH = KB / 8;
+      const int row = S / CH, slot = S % CH;
+      const int chunk = kc_swz<KB>(row, slot);
       int gi = idx0 + row;
       gi = gi < dim ? gi : dim - 1;
       off[i] = (uint32_t)gi * (uint32_t)op.ld + (uint32_t)(chunk * 8);
     } else {
       const int krow = S >> 4, slot = S & 15;
-      const int chunk = slot ^ plane_swz_ic(krow);
+      const int chunk = slot ^ plane_swz_ic(krow & 31);
       int gi = idx0 + chunk * 8;
       gi = gi < dim ? gi : dim - 8;
       off[i] = (uint32_t)krow * (uint32_t)op.ld + (uint32_t)gi;
@@ -906,6 +912,16 @@ __device__ __forceinline__ void planes_issue(const GemmOperand& op, int k0, int 
                                        (__attribute__((address_space(3))) void*)(lds_hi + kTile + S0 * 8), 16, 0, 0);
   }
 }
+// lane (r, g) of an MFMA operand of the 32-deep half hh of a KB-deep plane tile: k = 32 hh + 8 g .. + 7 of row / column idx16 + r
+template <int LAYOUT, int KB>
+__device__ __forceinline__ bf16x8 planes_frag_kb(const uint16_t* tile, int idx16, int lane, int hh) {
+  if (KB == 32) return planes_frag<LAYOUT>(tile, idx16, lane);
+  if (LAYOUT == KC) {
+    const int row = idx16 + (lane & 15), c = 4 * hh + (lane >> 4);
+    return *reinterpret_cast<const bf16x8*>(tile + row * KB + kc_swz<KB>(row, c) * 8);
+  }
+  return planes_frag<IC>(tile + hh * 32 * RT, idx16, lane);       // (the k-rows 32 hh .. of the [KB][128] image)
+}
 // Phase clocks (debug builds only, `make clk`; read back by tools/gemm_clocks.py): where the first loader wave and the
 // first computing wave of every workgroup spend their time.
 #ifdef DVGR_CLK
@@ -925,33 +941,37 @@ __device__ long long g_gemm_clk[4096 * 8];
 #define GCLK_FLUSH(base) do { } while (0)
 #endif
 
-template <int TERMS, int NS, int RTM = RT>
+template <int TERMS, int NS, int RTM = RT, int KB = 32>
 struct PlanesLds {
   static constexpr int kPlanes = (TERMS == 3) ? 2 : 1;
-  static constexpr int kTileA = RTM * BK;                      // bf16 elements of one A plane tile (RTM rows)
-  static constexpr int kSlot = kPlanes * (kTileA + kPlaneTile);  // A planes, then B planes
+  static constexpr int kTileA = RTM * KB;                      // bf16 elements of one A plane tile (RTM rows)
+  static constexpr int kTileB = RT * KB;                       //   of one B plane tile
+  static constexpr int kSlot = kPlanes * (kTileA + kTileB);    // A planes, then B planes
   static constexpr int kEpi = 8 * 32 * (16 * 2 + 4) * 2;       // epilogue scratch (8 waves), in bf16-sized elements
   static constexpr int kLds = (NS * kSlot) > kEpi ? (NS * kSlot) : kEpi;
 };
 
 // one 128 x 128 output tile of problem P (the whole workgroup: 8 computing + 4 loader waves)
-template <int LA, int LB, int TERMS, int NS, int RTM = RT>
+template <int LA, int LB, int TERMS, int NS, int RTM = RT, int KB = 32>
 __device__ __forceinline__ void planes_tile(const GemmProblem& P, uint16_t* smem) {
   static_assert(RTM == RT || (RTM == 64 && LA == KC), "half-height tiles: row-major A only");
+  static_assert(KB == 32 || (KB == 64 && LA == KC), "64-deep K-tiles: row-major A only (a column-major tile's row pieces are 256 bytes already)");
   int m0, n0;
   if (!tile_coords(P.M, P.N, RTM, RT, &m0, &n0)) return;
 
-  constexpr int kPlanes = PlanesLds<TERMS, NS, RTM>::kPlanes;
-  constexpr int kSlot = PlanesLds<TERMS, NS, RTM>::kSlot;
-  constexpr int kTileA = PlanesLds<TERMS, NS, RTM>::kTileA;
-  constexpr int NIA = RTM / 64;                  // DMA instructions per loader wave for one A plane tile
+  constexpr int kPlanes = PlanesLds<TERMS, NS, RTM, KB>::kPlanes;
+  constexpr int kSlot = PlanesLds<TERMS, NS, RTM, KB>::kSlot;
+  constexpr int kTileA = PlanesLds<TERMS, NS, RTM, KB>::kTileA;
+  constexpr int kTileB = PlanesLds<TERMS, NS, RTM, KB>::kTileB;
+  constexpr int NIA = RTM * KB / 2048;           // DMA instructions per loader wave for one A plane tile
+  constexpr int NIB = KB / 16;                   //   for one B plane tile (128 rows x KB / 8 chunks, or KB k-rows x 16 chunks)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave12 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool loader = wave12 >= 8;
   const int wave = loader ? wave12 - 8 : wave12;
   constexpr int MT = RTM / 32, NT = 2;           // 8 computing waves as 2 x 4: (RTM / 2) x 32 of the tile each
 
-  const int nk_all = P.K / BK;
+  const int nk_all = P.K / KB;
   const int per = (nk_all + (int)gridDim.y - 1) / (int)gridDim.y;
   const int kbeg = (int)blockIdx.y * per;
   const int nk_real = (nk_all - kbeg) < per ? (nk_all - kbeg) : per;
@@ -959,15 +979,15 @@ __device__ __forceinline__ void planes_tile(const GemmProblem& P, uint16_t* smem
   const int nk = (DVGR_DBG(P) & 2) ? 0 : nk_real;
 
   if (loader) {
-    uint32_t offA[NIA], offB[2];
-    planes_prep<LA, NIA>(P.A, m0, P.M, wave, lane, offA);
-    planes_prep<LB>(P.B, n0, P.N, wave, lane, offB);
+    uint32_t offA[NIA], offB[NIB];
+    planes_prep<LA, NIA, KB>(P.A, m0, P.M, wave, lane, offA);
+    planes_prep<LB, NIB, KB>(P.B, n0, P.N, wave, lane, offB);
     const bool nodma = (DVGR_DBG(P) & 8) != 0;         // timing aid (tools/gemm_shapes.py): barriers only
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
       if (s < nk && !nodma) {
-        planes_issue<LA, TERMS, NIA>(P.A, (kbeg + s) * BK, P.kseg, wave, lane, offA, smem + s * kSlot);
-        planes_issue<LB, TERMS>(P.B, (kbeg + s) * BK, P.kseg, wave, lane, offB, smem + s * kSlot + kPlanes * kTileA);
+        planes_issue<LA, TERMS, NIA>(P.A, (kbeg + s) * KB, P.kseg, wave, lane, offA, smem + s * kSlot);
+        planes_issue<LB, TERMS, NIB>(P.B, (kbeg + s) * KB, P.kseg, wave, lane, offB, smem + s * kSlot + kPlanes * kTileA);
       }
     GCLK_DECL;
     GCLK_START();
@@ -975,7 +995,8 @@ __device__ __forceinline__ void planes_tile(const GemmProblem& P, uint16_t* smem
       // kPlanes * (NIA + 2) DMA instructions per K-tile from this wave: keep the (up to two) younger tiles in flight
       const int younger = (nk - 1 - kt) < NS - 2 ? (nk - 1 - kt) : NS - 2;
       GCLK_ADD(2);                                 // DMA issue (back-pressure of the vector memory path)
-      constexpr int kPer = kPlanes * (NIA + 2);   // DMA instructions of this wave per K-tile
+      constexpr int kPer = kPlanes * (NIA + NIB); // DMA instructions of this wave per K-tile
+      static_assert((NS - 2 < 0 ? 0 : NS - 2) * kPer < 64, "vmcnt is a 6-bit counter");
       if (younger >= 3) wait_vmcnt<3 * kPer>();
       else if (younger == 2) wait_vmcnt<2 * kPer>();
       else if (younger == 1) wait_vmcnt<kPer>();
@@ -985,8 +1006,8 @@ __device__ __forceinline__ void planes_tile(const GemmProblem& P, uint16_t* smem
       GCLK_ADD(1);                                 // waiting for the consumers at the barrier
       if (kt + NS - 1 < nk && !nodma) {
         uint16_t* dst = smem + ((kt + NS - 1) % NS) * kSlot;
-        planes_issue<LA, TERMS, NIA>(P.A, (kbeg + kt + NS - 1) * BK, P.kseg, wave, lane, offA, dst);
-        planes_issue<LB, TERMS>(P.B, (kbeg + kt + NS - 1) * BK, P.kseg, wave, lane, offB, dst + kPlanes * kTileA);
+        planes_issue<LA, TERMS, NIA>(P.A, (kbeg + kt + NS - 1) * KB, P.kseg, wave, lane, offA, dst);
+        planes_issue<LB, TERMS, NIB>(P.B, (kbeg + kt + NS - 1) * KB, P.kseg, wave, lane, offB, dst + kPlanes * kTileA);
       }
     }
     __builtin_amdgcn_s_barrier();
@@ -1012,18 +1033,18 @@ __device__ __forceinline__ void planes_tile(const GemmProblem& P, uint16_t* smem
   GCLK_DECL;
   GCLK_START();
   bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
-  auto read_frags = [&](int kt) {
+  auto read_frags = [&](int kt, int hh) {
     const uint16_t* curA = smem + (kt % NS) * kSlot;
     const uint16_t* curB = curA + kPlanes * kTileA;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      ah[i] = planes_frag<LA>(curA, wm + i * 16, lane);
-      if (TERMS == 3) al[i] = planes_frag<LA>(curA + kTileA, wm + i * 16, lane);
+      ah[i] = planes_frag_kb<LA, KB>(curA, wm + i * 16, lane, hh);
+      if (TERMS == 3) al[i] = planes_frag_kb<LA, KB>(curA + kTileA, wm + i * 16, lane, hh);
     }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      bh[j] = planes_frag<LB>(curB, wn + j * 16, lane);
-      if (TERMS == 3) bl[j] = planes_frag<LB>(curB + kPlaneTile, wn + j * 16, lane);
+      bh[j] = planes_frag_kb<LB, KB>(curB, wn + j * 16, lane, hh);
+      if (TERMS == 3) bl[j] = planes_frag_kb<LB, KB>(curB + kTileB, wn + j * 16, lane, hh);
     }
   };
   auto mma_tile = [&](int kt) {
@@ -1058,8 +1079,11 @@ __device__ __forceinline__ void planes_tile(const GemmProblem& P, uint16_t* smem
     __builtin_amdgcn_s_barrier();
     GCLK_ADD(0);                                   // waiting for tile kt
     if (DVGR_DBG(P) & 4) continue;                       // timing aid: barriers only, no fragment reads, no MFMAs
-    read_frags(kt);
-    mma_tile(kt);
+#pragma unroll
+    for (int hh = 0; hh < KB / 32; ++hh) {
+      read_frags(kt, hh);
+      mma_tile(kt);
+    }
   }
   if (do_rs) {
 #pragma unroll
@@ -1295,11 +1319,11 @@ int fwd_sf_phase_launch(hipStream_t stream, const GemmBatch& b, const SfCombineA
 }
 #endif  // DVGR_TIMING_AIDS
 
-template <int LA, int LB, int TAG, int TERMS, int NS = RS, int RTM = RT>
+template <int LA, int LB, int TAG, int TERMS, int NS = RS, int RTM = RT, int KB = 32>
 __global__ __launch_bounds__(768) void gemm_planes_kernel(const GemmBatch batch) {
-  __shared__ __attribute__((aligned(16))) uint16_t smem[PlanesLds<TERMS, NS, RTM>::kLds];
+  __shared__ __attribute__((aligned(16))) uint16_t smem[PlanesLds<TERMS, NS, RTM, KB>::kLds];
   const GemmProblem P = batch.p[blockIdx.z];
-  planes_tile<LA, LB, TERMS, NS, RTM>(P, smem);
+  planes_tile<LA, LB, TERMS, NS, RTM, KB>(P, smem);
 }
 
 // Problems of DIFFERENT operand layouts in one launch (GemmProblem::layout): the backward's data gradient dX += dWh . Wcat
@@ -1550,6 +1574,15 @@ static int launch_ring(hipStream_t stream, const GemmBatch& b, int prec) {
   const dim3 grid(8 * ((tiles + 7) / 8), split, b.n), block(768);
   if (split > 1) { const int ez = zero_split_outputs(stream, b); if (ez) return ez; }
   if (prec != DVGR_F32 && planes_eligible(b, LA, LB)) {
+    // Row-major A (NT, NN) in bf16x3 with every K a multiple of 64: 64-deep K-tiles -- A's (and a row-major B's) row pieces
+    // are then whole 128-byte lines, half the L2 requests per byte, on a 2-slot ring of 64 KB slots (round 5: the K loops are
+    // bound by L2 requests more than by bytes; -DDVGR_GEMM_KB32 builds the 32-deep form for A/B).
+    constexpr int KBX = LA == KC ? 64 : 32, NSX = LA == KC ? 2 : RS;
+    bool kb64 = LA == KC && prec == DVGR_BF16X3;
+#ifdef DVGR_GEMM_KB32
+    kb64 = false;
+#endif
+    for (int i = 0; i < b.n; ++i) kb64 = kb64 && (b.p[i].K % 64) == 0 && (b.p[i].kseg % 64) == 0;
     // (2 ring slots = 64 KB would let two workgroups share a CU; measured slower alone and under the side stream)
     if (LA == KC && split == 1 && total <= 128) {
       // few tiles (the MFB contractions, the query branch, everything at small B N): 64-row tiles put twice as many
@@ -1567,12 +1600,14 @@ static int launch_ring(hipStream_t stream, const GemmBatch& b, int prec) {
       if (!no_half) {
         const dim3 grid_h(8 * ((tiles_h + 7) / 8), 1, b.n);
         constexpr int LAH = KC;                    // (the branch is dead for LA == IC; keeps the instantiation legal)
-        if (prec == DVGR_BF16X3) DVGR_LAUNCH((gemm_planes_kernel<LAH, LB, TAG, 3, RS, 64>), grid_h, block, 0, stream, b);
+        if (kb64) DVGR_LAUNCH((gemm_planes_kernel<LAH, LB, TAG, 3, 2, 64, 64>), grid_h, block, 0, stream, b);
+        else if (prec == DVGR_BF16X3) DVGR_LAUNCH((gemm_planes_kernel<LAH, LB, TAG, 3, RS, 64>), grid_h, block, 0, stream, b);
         else DVGR_LAUNCH((gemm_planes_kernel<LAH, LB, TAG, 1, RS, 64>), grid_h, block, 0, stream, b);
         return (int)hipGetLastError();
       }
     }
-    if (prec == DVGR_BF16X3) DVGR_LAUNCH((gemm_planes_kernel<LA, LB, TAG, 3>), grid, block, 0, stream, b);
+    if (kb64) DVGR_LAUNCH((gemm_planes_kernel<LA, LB, TAG, 3, NSX, RT, KBX>), grid, block, 0, stream, b);
+    else if (prec == DVGR_BF16X3) DVGR_LAUNCH((gemm_planes_kernel<LA, LB, TAG, 3>), grid, block, 0, stream, b);
     else DVGR_LAUNCH((gemm_planes_kernel<LA, LB, TAG, 1>), grid, block, 0, stream, b);
     return (int)hipGetLastError();
   }
