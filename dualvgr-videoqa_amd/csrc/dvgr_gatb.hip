@@ -221,7 +221,11 @@ __global__ __launch_bounds__(768) void k_gat_fused_bwd(const GatFusedBwdArgs a) 
     const int w = wave12 - 8;
     const uint16_t* xa = a.ah[mod] + (int64_t)g * BN * D;  // view g of dpre (2, B N, D)
     const GatfOperands op{xa, a.a_lo_off, a.bh[mod], a.b_lo_off, a.bq[mod]};
+#if defined(DVGR_CLK) && defined(DVGR_GATB_DBG_NOFETCH_OUT)  // (phase-clock experiments: the K loop without the loaders' tile fetch)
+    gatf_loader_wave<C, TERMS>(op, smem, hl * F, m0, BN, D, nk, w, lane);
+#else
     gatf_loader_wave<C, TERMS, WVL>(op, smem, hl * F, m0, BN, D, nk, w, lane, fetch_out);
+#endif
   } else {
     const float* wg = a.at.Wh[mod] + (int64_t)m0 * HF + h * F;
     auto fetch_wh = [&]() {                                // behind the first K-tile's barrier (gatf_compute: first)
@@ -230,7 +234,11 @@ __global__ __launch_bounds__(768) void k_gat_fused_bwd(const GatFusedBwdArgs a) 
         int e = tid + 512 * k;
         e = e < emax ? e : emax;
         const int r = e / F4, q = e - r * F4;
+#if defined(DVGR_CLK) && defined(DVGR_GATB_DBG_NOFETCH_WH)   // (phase-clock experiments: the K loop without the computing waves' tile fetch)
+        whv[k] = gatb_f32x4{(float)r, (float)q, 0.f, 0.f};
+#else
         whv[k] = *reinterpret_cast<const gatb_f32x4*>(wg + (int64_t)r * HF + 4 * q);
+#endif
       }
     };
     const int rg = wave12 >> 2;

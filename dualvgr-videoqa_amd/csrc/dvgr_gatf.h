@@ -18,6 +18,21 @@ namespace dvgr {
 // is one request to the L2: at C2 a launch's K loop asks for 155 G row pieces per second, 58 % of the L2's 269 G requests / s
 // (128 channels x 2.1 GHz), while its BYTES are 29 % of the L2's rate; fewer bytes at the same piece count (LO8) buy nothing.
 // 64-deep tiles move whole lines: half the requests for the same bytes, at the price of a 2-slot ring (68 KB per slot).
+// EARLY (-DDVGR_GATF_EARLY=1, the 2-slot ring only; measured slower, kept as an experiment): a slot is handed back to the loaders
+// as soon as every computing wave holds the K-tile's fragments in REGISTERS -- a second barrier per K-tile, in front of the MFMAs
+// instead of behind them -- so that the registers are the ring's third stage and the DMA of K-tile kt + 2 is in flight while kt
+// is multiplied.  Phase clocks at C2 (profiles/r05_kloop_decomposition.txt): the DMA alone 14.4 -> 11.8 us (its latency is hidden:
+// 70 GB/s per CU, the L2's gather rate), the computing waves alone 12.0 -> 13.8 (all reads, then all MFMAs), together 18.2 against
+// 16.5 -- LDS-DMA writes and fragment reads slow each other whenever both are in flight, and the early form keeps them so.
+#ifndef DVGR_GATF_EARLY
+#define DVGR_GATF_EARLY 0
+#endif
+#ifndef DVGR_GATF_LOADER_PRIO
+#define DVGR_GATF_LOADER_PRIO 0
+#endif
+#ifndef DVGR_GATF_MMA_PRIO
+#define DVGR_GATF_MMA_PRIO 0
+#endif
 template <int TERMS, int MTILES, int NTC, bool LO8 = false, int KB_ = 32>
 struct GatfCfg {
   static constexpr int KB = KB_;
@@ -43,6 +58,8 @@ struct GatfCfg {
   static constexpr int ILO = DTOT / 4;                    //   DTOT % 4 == 0), ILO otherwise
   static constexpr int MT0 = (MTILES + 1) / 2;            // row tiles of the row group 0 waves, MTILES - MT0 of the others
   static constexpr int kRingBytes = NS * kSlot * 2;
+  static constexpr bool kEarly = DVGR_GATF_EARLY != 0 && NS == 2 && KB == 64;
+  static constexpr int RD = kEarly ? NS + 1 : NS;         // K-tiles the ring holds: its slots (+ the computing waves' registers)
   static_assert(!kLo8 || (IB % 2) == 0, "the 8-bit plane moves 32 rows per DMA instruction");
 };
 
@@ -79,6 +96,9 @@ struct GatfNoPrefetch { __device__ __forceinline__ void operator()() const {} };
 template <class C, int TERMS, int CNT, int NPF = 0, class PF = GatfNoPrefetch>
 __device__ __forceinline__ void gatf_loader(const GatfOperands& op, uint16_t* smem, int brow0, int m0, int BN, int D, int nk,
                                             int wave, int lane, PF pf = PF()) {
+#if defined(DVGR_CLK) && defined(DVGR_GATF_DBG_SAMETILE)    // (phase-clock experiments: every workgroup streams the SAME tiles -- all L2 hits)
+  brow0 = 0; m0 = 0;
+#endif
   const char* src[CNT];                                    // this lane's source address of instruction k at K-tile 0
   int step[CNT];                                           // bytes per K-tile: 64 (bf16 planes), 32 (8-bit plane)
   int dst[CNT];                                            // element offset of the instruction's 1 KB piece inside the slot
@@ -114,14 +134,18 @@ __device__ __forceinline__ void gatf_loader(const GatfOperands& op, uint16_t* sm
     }
   }
   auto issue = [&](int kt, uint16_t* slot_base) {
+#if defined(DVGR_CLK) && defined(DVGR_GATF_DBG_NODMA)       // (phase-clock experiments: the K loop without its DMA)
+    return;
+#endif
 #pragma unroll
     for (int k = 0; k < CNT; ++k)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[k] + (int64_t)kt * step[k]),
                                        (__attribute__((address_space(3))) void*)(slot_base + dst[k]), 16, 0, 0);
   };
+  if (DVGR_GATF_LOADER_PRIO) __builtin_amdgcn_s_setprio(DVGR_GATF_LOADER_PRIO);
 #pragma unroll
-  for (int s = 0; s < C::NS - 1; ++s)
-    if (s < nk) issue(s, smem + s * C::kSlot);
+  for (int s = 0; s < C::RD - 1; ++s)
+    if (s < nk) issue(s, smem + (s % C::NS) * C::kSlot);
   if (NPF > 0) {                                           // (program order IS the order the waits below count in)
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -130,20 +154,22 @@ __device__ __forceinline__ void gatf_loader(const GatfOperands& op, uint16_t* sm
     __builtin_amdgcn_sched_barrier(0);
   }
   constexpr int kPer = CNT;                                // DMA instructions of this wave per K-tile
-  constexpr int YM = C::NS - 2 < 2 ? C::NS - 2 : 2;        // K-tiles in flight behind the one waited for (at most)
+  constexpr int YM = C::RD - 2 < 2 ? C::RD - 2 : 2;        // K-tiles in flight behind the one waited for (at most)
   static_assert(YM * kPer + NPF < 64, "vmcnt is a 6-bit counter");
   for (int kt = 0; kt < nk; ++kt) {
     const int younger = (nk - 1 - kt) < YM ? (nk - 1 - kt) : YM;
-    // (the NPF loads sit between K-tile NS - 2 and K-tile NS - 1 in the queue: younger than the tile waited for while kt <= NS - 2;
-    // a K loop shorter than NS + 1 tiles simply waits for them as well)
-    const bool pf_younger = NPF > 0 && kt <= C::NS - 2 && younger == YM && nk > C::NS;
+    // (the NPF loads sit between K-tile RD - 2 and K-tile RD - 1 in the queue: younger than the tile waited for while kt <= RD - 2;
+    // a K loop shorter than RD + 1 tiles simply waits for them as well)
+    const bool pf_younger = NPF > 0 && kt <= C::RD - 2 && younger == YM && nk > C::RD;
     if (pf_younger) wait_vmcnt<YM * kPer + NPF>();
     else if (younger >= 2) wait_vmcnt<2 * kPer>();
     else if (younger == 1) wait_vmcnt<kPer>();
     else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();                          // publishes tile kt, frees slot (kt - 1) % NS
-    if (kt + C::NS - 1 < nk) issue(kt + C::NS - 1, smem + ((kt + C::NS - 1) % C::NS) * C::kSlot);
+    __builtin_amdgcn_s_barrier();                          // publishes tile kt; !EARLY: frees slot (kt - 1) % NS
+    if (C::kEarly) __builtin_amdgcn_s_barrier();           // EARLY: tile kt is in the computing waves' registers, its slot is free
+    if (kt + C::RD - 1 < nk) issue(kt + C::RD - 1, smem + ((kt + C::RD - 1) % C::NS) * C::kSlot);
   }
+  if (DVGR_GATF_LOADER_PRIO) __builtin_amdgcn_s_setprio(0);
 }
 // (the loader waves of a workgroup: wave w carries IHI instructions per K-tile when w < DTOT % 4 or DTOT % 4 == 0, else ILO)
 template <class C, int TERMS, int NPF = 0, class PF = GatfNoPrefetch>
@@ -164,25 +190,38 @@ __device__ __forceinline__ void gatf_compute(const uint16_t* smem, int nk, int r
   for (int i = 0; i < MTW; ++i)
 #pragma unroll
     for (int j = 0; j < NTC; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  bf16x8 ah[MTW], al[MTW], bh[NTC], bl[NTC];
+  constexpr int NH = C::kEarly ? C::KB / 32 : 1;           // fragment sets held at once: EARLY every 32-deep half of the K-tile
+  bf16x8 ah[NH][MTW], al[NH][MTW], bh[NH][NTC], bl[NH][NTC];
   float qs[NTC], qc[NTC];                                  // lo = q * s - 128 s for this lane's row of B fragment j
 #pragma unroll
   for (int j = 0; j < NTC; ++j) {
     qs[j] = C::kLo8 ? wscale[col0 + 16 * j + (lane & 15)] : 0.f;
     qc[j] = -128.f * qs[j];
   }
-  auto read_frags = [&](int kt, int hh) {
+#if defined(DVGR_CLK) && defined(DVGR_GATF_DBG_NOREADS)     // (phase-clock experiments: MFMAs on whatever the registers hold, no LDS reads)
+#pragma unroll
+  for (int s = 0; s < NH; ++s) {
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) { ah[s][i] = bf16x8{}; al[s][i] = bf16x8{}; asm volatile("" : "+v"(ah[s][i]), "+v"(al[s][i])); }
+#pragma unroll
+    for (int j = 0; j < NTC; ++j) { bh[s][j] = bf16x8{}; bl[s][j] = bf16x8{}; asm volatile("" : "+v"(bh[s][j]), "+v"(bl[s][j])); }
+  }
+#endif
+  auto read_frags = [&](int kt, int hh, int set) {
+#if defined(DVGR_CLK) && defined(DVGR_GATF_DBG_NOREADS)
+    return;
+#endif
     const uint16_t* curA = smem + (kt % C::NS) * C::kSlot;
     const uint16_t* curB = curA + C::kPlanes * C::kTileA;
 #pragma unroll
     for (int i = 0; i < MTW; ++i) {
-      ah[i] = gatf_frag<C::KB>(curA, row0 + i * 16, lane, hh);
-      if (TERMS == 3) al[i] = gatf_frag<C::KB>(curA + C::kTileA, row0 + i * 16, lane, hh);
+      ah[set][i] = gatf_frag<C::KB>(curA, row0 + i * 16, lane, hh);
+      if (TERMS == 3) al[set][i] = gatf_frag<C::KB>(curA + C::kTileA, row0 + i * 16, lane, hh);
     }
 #pragma unroll
     for (int j = 0; j < NTC; ++j) {
-      bh[j] = gatf_frag<C::KB>(curB, col0 + j * 16, lane, hh);
-      if (TERMS == 3 && !C::kLo8) bl[j] = gatf_frag<C::KB>(curB + C::kTileB, col0 + j * 16, lane, hh);
+      bh[set][j] = gatf_frag<C::KB>(curB, col0 + j * 16, lane, hh);
+      if (TERMS == 3 && !C::kLo8) bl[set][j] = gatf_frag<C::KB>(curB + C::kTileB, col0 + j * 16, lane, hh);
       if (C::kLo8) {
         // 8 bytes = k 8 g .. 8 g + 7 of row col0 + 16 j + r: position ((row >> 4) * 32 + (g >> 1) * 16 + (row & 15)) * 16 + (g & 1) * 8
         const int r = lane & 15, g = lane >> 4;
@@ -194,29 +233,60 @@ __device__ __forceinline__ void gatf_compute(const uint16_t* smem, int nk, int r
         w[1] = pack_bf16(__builtin_fmaf((float)((q.x >> 16) & 0xFFu), qs[j], qc[j]), __builtin_fmaf((float)(q.x >> 24), qs[j], qc[j]));
         w[2] = pack_bf16(__builtin_fmaf((float)(q.y & 0xFFu), qs[j], qc[j]), __builtin_fmaf((float)((q.y >> 8) & 0xFFu), qs[j], qc[j]));
         w[3] = pack_bf16(__builtin_fmaf((float)((q.y >> 16) & 0xFFu), qs[j], qc[j]), __builtin_fmaf((float)(q.y >> 24), qs[j], qc[j]));
-        bl[j] = __builtin_bit_cast(bf16x8, w);
+        bl[set][j] = __builtin_bit_cast(bf16x8, w);
       }
     }
   };
-  auto mma_tile = [&]() {
+  auto mma_tile = [&](int set) {
+#if defined(DVGR_CLK) && defined(DVGR_GATF_DBG_NOMFMA)      // (phase-clock experiments: the fragment reads without their MFMAs)
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) asm volatile("" ::"v"(ah[set][i]), "v"(al[set][i]));
+#pragma unroll
+    for (int j = 0; j < NTC; ++j) asm volatile("" ::"v"(bh[set][j]), "v"(bl[set][j]));
+    return;
+#endif
+    if (DVGR_GATF_MMA_PRIO) __builtin_amdgcn_s_setprio(DVGR_GATF_MMA_PRIO);
 #pragma unroll
     for (int i = 0; i < MTW; ++i)
 #pragma unroll
       for (int j = 0; j < NTC; ++j) {
         if (TERMS == 3) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[set][i], bh[set][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[set][i], bl[set][j], acc[i][j], 0, 0, 0);
         }
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[set][i], bh[set][j], acc[i][j], 0, 0, 0);
       }
+    if (DVGR_GATF_MMA_PRIO) __builtin_amdgcn_s_setprio(0);
   };
   for (int kt = 0; kt < nk; ++kt) {
     __builtin_amdgcn_s_barrier();
     if (kt == 0) first();
+#if defined(DVGR_CLK) && defined(DVGR_GATF_DBG_NOMMA)       // (phase-clock experiments: the K loop without fragment reads and MFMAs)
+    if (C::kEarly) __builtin_amdgcn_s_barrier();
+    continue;
+#endif
+    if (C::kEarly) {
 #pragma unroll
-    for (int hh = 0; hh < C::KB / 32; ++hh) {
-      read_frags(kt, hh);
-      mma_tile();
+      for (int hh = 0; hh < NH; ++hh) read_frags(kt, hh, hh);
+      __builtin_amdgcn_sched_barrier(0);                   // (the scheduler would sink the second half's reads between the MFMAs)
+#if DVGR_GATF_EARLY == 2                                   // (A/B form: the first half's MFMAs in front of the hand-back)
+      mma_tile(0);
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every fragment of the K-tile is in registers:
+      __builtin_amdgcn_s_barrier();                        // the slot goes back to the loaders
+      __builtin_amdgcn_sched_barrier(0);
+#if DVGR_GATF_EARLY != 2
+      mma_tile(0);
+#endif
+#pragma unroll
+      for (int hh = 1; hh < NH; ++hh) mma_tile(hh);
+    } else {
+#pragma unroll
+      for (int hh = 0; hh < C::KB / 32; ++hh) {
+        read_frags(kt, hh, 0);
+        mma_tile(0);
+      }
     }
   }
 }

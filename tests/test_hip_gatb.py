@@ -181,3 +181,42 @@ def test_plain_bf16_mode_takes_the_fused_backward_too():
     # one plane per operand: an fp32-rounding difference upstream can flip the bf16 rounding of a later operand element
     worst = max(rel_err(got[True][k], got[False][k]) for k in got[True] if not k.endswith((".fc.bias", ".a.bias")))
     assert worst < 5e-3, worst
+
+
+def test_race_screen_of_the_64_deep_rings_at_the_bench_size():
+    """The 2-slot rings of 64-deep K-tiles (fused forward, fused backward, the engine's NT / NN launches) order LDS-DMA writes
+    and fragment reads by counted vmcnt + one barrier per K-tile; a read that beat its DMA would show as a rare wrong tile, not
+    as a failing reference check.  So: C2's own size (B = 64, N = 20, 3 layers: 256 workgroups, every CU busy), training mode,
+    60 repetitions of forward + backward with one seed while a second stream keeps the fabric busy -- the forward outputs and
+    the saved projections must be BIT-identical to the first repetition's every time (no atomics on that path), every gradient
+    equal to 2e-4 (column sums and the punish gate's gradient are float atomic adds: measured 6e-5 between repetitions)."""
+    B, N, Lr = 64, 20, 3
+    sd_np = synth.xavier_state_dict(O.param_shapes(WD, D, Lr), seed=61, bias_range=0.05)
+    inp = synth.unit_inputs(B, N, T, D, WD, seed=61)
+    R = torch.from_numpy(synth.normal("R_race", (B, N, D), 1.0, 61))
+    dims = L.make_dims(B, N, T, D, WD, Lr)
+    m = _module(N, Lr, "bf16x3", sd_np, True, True)
+    noise = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    side = torch.cuda.Stream()
+    first, worst, worst_k = None, 0.0, None
+    for it in range(60):
+        with torch.cuda.stream(side):                      # ~ 128 MB of copies per repetition beside the step
+            noise[: 32 << 20].copy_(noise[32 << 20:])
+        m.zero_grad(set_to_none=True)
+        outs, _, g = _grads(m, inp, R, N, 779)
+        fw = [outs[0].cpu(), outs[1].cpu(), outs[2].cpu()] + [x.cpu() for lst in outs[3:] for x in lst]
+        off = L.saved_offset(dims, L.S_WH, Lr - 1, 0)
+        fw.append(m.last_saved[off:off + 4 * B * N * 8 * (D // 4)].cpu().clone())
+        if first is None:
+            first = (fw, g)
+            continue
+        for a, b in zip(fw, first[0]):
+            assert torch.equal(a, b), f"repetition {it}: a forward tensor differs from the first repetition's"
+        for k in g:
+            if k.endswith((".fc.bias", ".a.bias")):
+                continue
+            e = rel_err(g[k], first[1][k])
+            if e > worst:
+                worst, worst_k = e, k
+        assert worst < 2e-4, (it, worst, worst_k)         # (a wrong 80 x 192 tile would be an error of order 1e-1 .. 1)
+    print(f"  race screen: 60 repetitions at C2, forward bit-identical, worst gradient difference {worst:.2e} ({worst_k})")
