@@ -190,11 +190,21 @@ __global__ __launch_bounds__(768) void k_gat_fused_bwd(const GatFusedBwdArgs a) 
   // took 6.7 us (phase clocks, first version: the HBM rate); issued ahead of the ring's first DMA they delayed the K loop by 4.7.
   // So they are fetched UNDER the K loop, whose operands come from L2 / the Infinity Cache: the saved projection Wh by the
   // computing waves behind the first K-tile's barrier (WVC float4 pieces per thread: nothing in the K loop waits for vector
-  // memory), the saved GAT output by the loader threads behind the ring's prologue (WVL pieces; the counted waits of the first
+  // memory) together with YC pieces per thread of the saved GAT output, the other YL pieces per thread of that tile by the loader
+  // threads behind the ring's prologue (a loader's counted wait covers its own older loads: 15 pieces there blocked the ring at
+  // its second K-tile, and made the loader threads' dP pass the longest thing in B1; the counted waits of the first
   // K-tiles leave them in flight).  Only the part of dz k_sf_bwd wrote follows behind the K loop, by the loader threads, under
   // the computing waves' accumulator pass and the recomputation of alpha.
-  constexpr int WVC = (RP * F4 + 511) / 512, WVL = (RP * F4 + 255) / 256;
-  gatb_f32x4 whv[WVC], yv[WVL], zv[WVL];
+  constexpr int WVC = (RP * F4 + 511) / 512;
+  // (the form that reads dz's pre-part keeps the whole tile with the loader threads: its computing threads would carry dz pieces too)
+#ifndef DVGR_GATB_YC_NUM
+#define DVGR_GATB_YC_NUM 2
+#endif
+  constexpr int YC = FROM_DX ? (RP * F4 * DVGR_GATB_YC_NUM / 5 + 511) / 512 : 0;   // pieces of the GAT-output tile per computing thread: elements [0, 512 YC) ...
+  constexpr int EC = 512 * YC;
+  constexpr int YL = (RP * F4 - EC + 255) / 256;           // ... and per loader thread: elements [512 YC, RP F4)
+  static_assert(EC < RP * F4, "the loader threads' share of the tile");
+  gatb_f32x4 whv[WVC], yv[YL], zv[YL], yc[YC > 0 ? YC : 1];
   const int emax = rows_valid * F4 - 1;
   GBCLK(0);
   if (loader) {
@@ -211,8 +221,8 @@ __global__ __launch_bounds__(768) void k_gat_fused_bwd(const GatFusedBwdArgs a) 
     const float* yg = (g ? a.at.out_s[mod] : a.at.out_c[mod]) + (int64_t)m0 * D + hl * F;
     auto fetch_out = [&]() {                               // behind the ring's prologue (gatf_loader: NPF)
 #pragma unroll
-      for (int k = 0; k < WVL; ++k) {
-        int e = tl + 256 * k;
+      for (int k = 0; k < YL; ++k) {
+        int e = EC + tl + 256 * k;
         e = e < emax ? e : emax;
         const int r = e / F4, q = e - r * F4;
         yv[k] = *reinterpret_cast<const gatb_f32x4*>(yg + (int64_t)r * D + 4 * q);
@@ -224,11 +234,21 @@ __global__ __launch_bounds__(768) void k_gat_fused_bwd(const GatFusedBwdArgs a) 
 #if defined(DVGR_CLK) && defined(DVGR_GATB_DBG_NOFETCH_OUT)  // (phase-clock experiments: the K loop without the loaders' tile fetch)
     gatf_loader_wave<C, TERMS>(op, smem, hl * F, m0, BN, D, nk, w, lane);
 #else
-    gatf_loader_wave<C, TERMS, WVL>(op, smem, hl * F, m0, BN, D, nk, w, lane, fetch_out);
+    gatf_loader_wave<C, TERMS, YL>(op, smem, hl * F, m0, BN, D, nk, w, lane, fetch_out);
 #endif
   } else {
     const float* wg = a.at.Wh[mod] + (int64_t)m0 * HF + h * F;
+    const float* yg = (g ? a.at.out_s[mod] : a.at.out_c[mod]) + (int64_t)m0 * D + hl * F;
     auto fetch_wh = [&]() {                                // behind the first K-tile's barrier (gatf_compute: first)
+      if constexpr (YC > 0) {
+#pragma unroll
+        for (int k = 0; k < YC; ++k) {
+          int e = tid + 512 * k;
+          e = e < emax ? e : emax;
+          const int r = e / F4, q = e - r * F4;
+          yc[k] = *reinterpret_cast<const gatb_f32x4*>(yg + (int64_t)r * D + 4 * q);
+        }
+      }
 #pragma unroll
       for (int k = 0; k < WVC; ++k) {
         int e = tid + 512 * k;
@@ -285,8 +305,8 @@ __global__ __launch_bounds__(768) void k_gat_fused_bwd(const GatFusedBwdArgs a) 
     const int tl = tid - 512;
     const float* zg = a.at.dz[mod] + (int64_t)g * BN * D + (int64_t)m0 * D + hl * F;
 #pragma unroll
-    for (int k = 0; k < WVL; ++k) {
-      int e = tl + 256 * k;
+    for (int k = 0; k < YL; ++k) {
+      int e = EC + tl + 256 * k;
       e = e < emax ? e : emax;
       const int r = e / F4, q = e - r * F4;
       zv[k] = *reinterpret_cast<const gatb_f32x4*>(zg + (int64_t)r * D + 4 * q);
@@ -398,26 +418,48 @@ __global__ __launch_bounds__(768) void k_gat_fused_bwd(const GatFusedBwdArgs a) 
   // j = c16 + 16 t of row 4 pass + rsub.
   if (!loader)
     for (int pass = PX + wave12; pass < passes; pass += 8) alpha_pass(pass);
-  // B1b (loader threads, beside B1a): dP = (acc + dz) * keep_out * ELU'(out) -> shP for the elements whose `out` they hold
-  if (loader) {
-    const int tl = tid - 512;
-    const float sc = ko ? (1.0f - kDropP) : 1.0f;          // un-dropped ELU output where kept
+  // B1b (the loader threads beside B1a, the computing threads behind it): dP = (acc + dz) * keep_out * ELU'(out) -> shP for the
+  // elements whose `out` they hold
+  {
+    if (loader) {
+      const int tl = tid - 512;
+      const float sc = ko ? (1.0f - kDropP) : 1.0f;        // un-dropped ELU output where kept
 #pragma unroll
-    for (int k = 0; k < WVL; ++k) {
-      const int e = tl + 256 * k;
-      if (e <= emax) {
-        const int r = e / F4, q = e - r * F4;
-        float* pp = shP + r * FS + 4 * q;
-        const float4 ac = *reinterpret_cast<const float4*>(pp);
-        float kf[4];
-        drop_factor4(ko, (uint32_t)((int64_t)(m0 + r) * D + hl * F + 4 * q), kf);
-        float4 p;
-        const gatb_f32x4 zk = from_dx ? gatb_f32x4{0.f, 0.f, 0.f, 0.f} : zv[k];     // (from_dx: already inside the image)
-        p.x = (ac.x + zk[0]) * kf[0] * elu_grad_from_out(yv[k][0] * sc);
-        p.y = (ac.y + zk[1]) * kf[1] * elu_grad_from_out(yv[k][1] * sc);
-        p.z = (ac.z + zk[2]) * kf[2] * elu_grad_from_out(yv[k][2] * sc);
-        p.w = (ac.w + zk[3]) * kf[3] * elu_grad_from_out(yv[k][3] * sc);
-        *reinterpret_cast<float4*>(pp) = p;
+      for (int k = 0; k < YL; ++k) {
+        const int e = EC + tl + 256 * k;
+        if (e <= emax) {
+          const int r = e / F4, q = e - r * F4;
+          float* pp = shP + r * FS + 4 * q;
+          const float4 ac = *reinterpret_cast<const float4*>(pp);
+          float kf[4];
+          drop_factor4(ko, (uint32_t)((int64_t)(m0 + r) * D + hl * F + 4 * q), kf);
+          float4 p;
+          const gatb_f32x4 zk = from_dx ? gatb_f32x4{0.f, 0.f, 0.f, 0.f} : zv[k];     // (from_dx: already inside the image)
+          p.x = (ac.x + zk[0]) * kf[0] * elu_grad_from_out(yv[k][0] * sc);
+          p.y = (ac.y + zk[1]) * kf[1] * elu_grad_from_out(yv[k][1] * sc);
+          p.z = (ac.z + zk[2]) * kf[2] * elu_grad_from_out(yv[k][2] * sc);
+          p.w = (ac.w + zk[3]) * kf[3] * elu_grad_from_out(yv[k][3] * sc);
+          *reinterpret_cast<float4*>(pp) = p;
+        }
+      }
+    } else if constexpr (YC > 0) {                         // (from_dx only: dz's pre-part is already inside the image)
+      const float sc = ko ? (1.0f - kDropP) : 1.0f;
+#pragma unroll
+      for (int k = 0; k < YC; ++k) {
+        const int e = tid + 512 * k;
+        if (e <= emax) {
+          const int r = e / F4, q = e - r * F4;
+          float* pp = shP + r * FS + 4 * q;
+          const float4 ac = *reinterpret_cast<const float4*>(pp);
+          float kf[4];
+          drop_factor4(ko, (uint32_t)((int64_t)(m0 + r) * D + hl * F + 4 * q), kf);
+          float4 p;
+          p.x = ac.x * kf[0] * elu_grad_from_out(yc[k][0] * sc);
+          p.y = ac.y * kf[1] * elu_grad_from_out(yc[k][1] * sc);
+          p.z = ac.z * kf[2] * elu_grad_from_out(yc[k][2] * sc);
+          p.w = ac.w * kf[3] * elu_grad_from_out(yc[k][3] * sc);
+          *reinterpret_cast<float4*>(pp) = p;
+        }
       }
     }
   }
