@@ -691,12 +691,16 @@ static int gatb_launch(hipStream_t st, const GatFusedBwdArgs& a, const GatfShape
   constexpr int NTC = 3;
   const size_t lds = gatb_lds_bytes(s, a.at.N, TERMS);
   if (lds > 160 * 1024) return DVGR_E_DIMS;
-  static bool attr_set = false;                            // (benign race: the attribute is idempotent)
-  if (!attr_set) {
+  // the raised dynamic-LDS limit belongs to the (function, device) pair: one flag per instantiation and device (benign race:
+  // the attribute is idempotent)
+  static bool attr_set[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+  if (dev < 0 || !attr_set[dev]) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gat_fused_bwd<TERMS, MTILES, NT, NTC, FROM_DX, LO8, KB>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    if (dev >= 0) attr_set[dev] = true;
   }
   const int mtiles = (a.at.B + a.spt - 1) / a.spt;
   const int total = mtiles * kHeads * 2;

@@ -375,12 +375,16 @@ static int gatf_launch(hipStream_t st, const GatFusedArgs& a) {
   const size_t epi = sizeof(float) * ((size_t)(C::RP + 4) * C::FS + (size_t)a.spt * 16 * NT * NP + 2 * C::F + 3 * C::RP);
   const size_t lds = (epi > (size_t)C::kRingBytes ? epi : (size_t)C::kRingBytes) + 16;
   if (lds > 160 * 1024) return DVGR_E_DIMS;
-  static bool attr_set = false;                            // (benign race: the attribute is idempotent; one flag per instantiation)
-  if (!attr_set) {
+  // the raised dynamic-LDS limit belongs to the (function, device) pair: one flag per instantiation and device (benign race:
+  // the attribute is idempotent)
+  static bool attr_set[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+  if (dev < 0 || !attr_set[dev]) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gat_fused_fwd<TERMS, MTILES, NT, NTC, LO8, KB>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    if (dev >= 0) attr_set[dev] = true;
   }
   const int mtiles = (a.at.B + a.spt - 1) / a.spt;
   const int total = mtiles * kHeads * 2;
