@@ -1600,7 +1600,12 @@ static int launch_ring(hipStream_t stream, const GemmBatch& b, int prec) {
       if (!no_half) {
         const dim3 grid_h(8 * ((tiles_h + 7) / 8), 1, b.n);
         constexpr int LAH = KC;                    // (the branch is dead for LA == IC; keeps the instantiation legal)
-        if (kb64) DVGR_LAUNCH((gemm_planes_kernel<LAH, LB, TAG, 3, 2, 64, 64>), grid_h, block, 0, stream, b);
+        // (a half-height 64-deep slot is 48 KB: THREE fit.  Per launch -0.5 .. -3.6 %, C2 -0.5 %, C1 -0.2 %, half_tile_ring_3_slots_*:
+        // a third slot is not what the 2-slot rings of the full tiles are missing either)
+#ifndef DVGR_GEMM_HALF_NS
+#define DVGR_GEMM_HALF_NS 3
+#endif
+        if (kb64) DVGR_LAUNCH((gemm_planes_kernel<LAH, LB, TAG, 3, DVGR_GEMM_HALF_NS, 64, 64>), grid_h, block, 0, stream, b);
         else if (prec == DVGR_BF16X3) DVGR_LAUNCH((gemm_planes_kernel<LAH, LB, TAG, 3, RS, 64>), grid_h, block, 0, stream, b);
         else DVGR_LAUNCH((gemm_planes_kernel<LAH, LB, TAG, 1, RS, 64>), grid_h, block, 0, stream, b);
         return (int)hipGetLastError();
