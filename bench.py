@@ -414,6 +414,12 @@ def main():
     ap.add_argument("--loss", default="fused", choices=["fused", "fused-after", "precomputed"],
                     help="fused: the scope-U loss and its gradients are computed inside every timed step by "
                          "dvgr_scope_u_loss; precomputed: fixed upstream gradients (unit kernels only)")
+    # the reference's config surface (train.py:372-375, configs/*.yml): a yml written for the reference sets the clip count and
+    # the module widths of the workload; --unit_layers / --alpha / --beta as there.  None = keep --config's values.
+    ap.add_argument("--cfg", dest="cfg_file", default=None, help="a reference configs/*.yml: num_of_nodes (and, with --model, vision_dim) from it")
+    ap.add_argument("--unit_layers", dest="unit_layers", type=int, default=None)
+    ap.add_argument("--alpha", dest="alpha", type=float, default=None)
+    ap.add_argument("--beta", dest="beta", type=float, default=None)
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -478,7 +484,20 @@ def main():
     from dualvgr_videoqa_amd import _lib as L_
     from dualvgr_videoqa_amd import losses, parallel, synth, trainer
 
-    cfg = CONFIGS[args.config]
+    cfg = dict(CONFIGS[args.config])
+    if args.cfg_file or args.unit_layers is not None:
+        from dualvgr_videoqa_amd import config as refcfg
+        if args.cfg_file:
+            rc = refcfg.cfg_from_file(args.cfg_file)
+            if rc.train["module_dim"] != D or rc.train["word_dim"] != WD:
+                raise SystemExit(f"--cfg: module_dim {rc.train['module_dim']} / word_dim {rc.train['word_dim']}: the bench runs {D} / {WD}")
+            cfg["N"] = int(rc.train["num_of_nodes"])
+            cfg["name"] = f"{rc.dataset['name']} ({os.path.basename(args.cfg_file)}) num_clips={cfg['N']}"
+        if args.unit_layers is not None:
+            cfg["L"] = int(args.unit_layers)
+        cfg["name"] = f"{cfg['name'].split(' unit_layers=')[0]} unit_layers={cfg['L']} batch={cfg['B']} [--cfg/--unit_layers override of {args.config}]"
+    alpha = 1.0 if args.alpha is None else float(args.alpha)
+    beta = 1e-8 if args.beta is None else float(args.beta)
     B, N, Lr, T = cfg["B"], cfg["N"], cfg["L"], cfg["T"]
     # ---- which reducer: the children's verdict (identical on every rank after the agreement below), or the command line
     choice = args.trial if args.trial in REDUCER_KINDS else (args.reducer if args.reducer != "auto" else None)
@@ -540,7 +559,7 @@ def main():
     m.reuse_buffers = True        # outputs / saved state / gradients of the one benchmark shape are allocated once
     if args.loss == "fused":
         # every rank's losses are means over its shard; the batch-SUM HSIC term is scaled by world under averaging
-        m.loss_in_forward = (1.0, 1e-8, float(world), not args.head)
+        m.loss_in_forward = (alpha, beta, float(world), not args.head)
     head = None
     if args.head:
         if args.loss != "fused":
@@ -860,7 +879,7 @@ def bench_model(args, dev, rank, world, cfg, ddp, dist_info, choice=None, trial_
         unit_red.force = param_red.force = world == 1
         unit.set_layer_callback(lambda idx, g: unit_red.launch(idx, g, events[idx]))
         reducer_kind = "python: parallel.LayerBucketReducer + ParamBucketReducer over torch.distributed (one issuer thread)"
-    ts = dv.TrainStep(m, lr=1e-4, alpha=1.0, beta=1e-8, max_norm=12.0, world=world, unit_reducer=unit_red, param_reducer=param_red)
+    ts = dv.TrainStep(m, lr=1e-4, alpha=1.0 if args.alpha is None else args.alpha, beta=1e-8 if args.beta is None else args.beta, max_norm=12.0, world=world, unit_reducer=unit_red, param_reducer=param_red)
     opt_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def step(i=None):

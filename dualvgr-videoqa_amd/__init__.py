@@ -5,6 +5,7 @@ hand-written HIP for gfx950 behind the C ABI of include/dvgr.h (libdvgr_hip.so).
 from . import synth  # noqa: F401
 from . import dropout  # noqa: F401
 from . import _lib  # noqa: F401
+from . import config  # noqa: F401
 from .unit import DualVGRUnit_multiple, param_table  # noqa: F401
 from .head import AnswerHead  # noqa: F401
 from .clip import ClipEncoder  # noqa: F401

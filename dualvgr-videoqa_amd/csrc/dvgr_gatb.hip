@@ -663,7 +663,9 @@ static size_t gatb_lds_bytes(const GatfShape& s, int N, int terms) {
   const int RP = 16 * s.mtiles16, planes = terms == 3 ? 2 : 1;
   const size_t slot = (size_t)planes * ((size_t)RP * BK + (size_t)F * BK) * 2;      // bytes
   const size_t ring = (4 * slot <= 150 * 1024 ? 4 : 3) * slot;
-  const size_t epi = sizeof(float) * (2 * (size_t)(RP + 1) * (F + 4) + 2 * F + (size_t)s.spt * (3 * N + 1) * (N + 1) + 5 * RP);
+  // (the kernel's own layout: shP, shW, a_l / a_r, the three N x N images, SIX per-row arrays shS .. shB -- GatbEpi::floats)
+  const size_t epi = sizeof(float) * (s.mtiles16 == 4 ? GatbEpi<4, NTC>::floats(N, s.spt) : s.mtiles16 == 5 ? GatbEpi<5, NTC>::floats(N, s.spt)
+                                                                                       : GatbEpi<6, NTC>::floats(N, s.spt));
   return (epi > ring ? epi : ring) + 16;
 }
 

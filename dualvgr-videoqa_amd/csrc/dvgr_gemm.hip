@@ -1727,7 +1727,9 @@ bool gemm_sum_supported(int la, int lb, const GemmBatch& b, int prec) {
 bool gemm_rowdot_supported(int la, int lb, const GemmBatch& b, int prec) {
   if (!gemm_sum_supported(la, lb, b, prec)) return false;
   for (int i = 0; i < b.n; ++i)                                  // every wave sub-tile of every tile shape lies inside the matrix
-    if ((b.p[i].M % 128) || (b.p[i].N % 256) || b.p[i].accumulate || b.p[i].drop_key_c) return false;
+    if ((b.p[i].M % 128) || (b.p[i].N % 256) || b.p[i].accumulate || b.p[i].drop_key_c ||
+        (b.p[i].ldc % 4) || ((uintptr_t)b.p[i].C & 15))           // epilogue_rows emits the dots only on its 16-byte whole-row store path
+      return false;
   return true;
 }
 

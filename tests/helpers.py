@@ -208,7 +208,8 @@ def bias_scales(dbg, Lr, D):
 def assert_grads(m, t, gin, gw, dbg, Lr, gtol, what="", scale_tol=None):
     """Input gradients and every weight-matrix gradient within `gtol` (max |err| / max |want| per tensor).  Gradients that
     are column sums over rows (the biases; the a.bias scalars) cancel heavily: they are held to 1e-5 of the sum of the
-    absolute terms (what their arithmetic can deliver) and, as a sanity bound only, to 40 x gtol in the plain metric
+    absolute terms (what their arithmetic can deliver) and, as a sanity bound only, to 10 x gtol (bias vectors) / 40 x gtol
+    (a.bias scalars) in the plain metric
     (a scalar a.bias gradient that cancels to 1e-3 of its terms shows 6e-3 there at bf16x3's 1e-5 operand error)."""
     gerr, werrs = grad_errors(m, t, gin, gw)
     if scale_tol is None:          # the terms themselves carry the operand mode's rounding: 1e-7 (fp32), 1e-5 (bf16x3)
@@ -228,4 +229,9 @@ def assert_grads(m, t, gin, gw, dbg, Lr, gtol, what="", scale_tol=None):
     assert worst[0][1] < gtol, worst
     assert max(ab.values()) < scale_tol, sorted(ab.items(), key=lambda kv: -kv[1])[:3]
     assert max(bb.values()) < scale_tol, sorted(bb.items(), key=lambda kv: -kv[1])[:3]
-    assert max(werrs[k] for k in special) < 40 * gtol, sorted(((k, werrs[k]) for k in special), key=lambda kv: -kv[1])[:3]
+    # plain-metric sanity bounds, per kind (round 6: one 40 x bound for both was wider than the vectors need): bias VECTORS
+    # (max |err| / max |want| over D or 8 F entries: the largest entry does not cancel) 10 x gtol; the a.bias SCALARS -- one
+    # number per head that is zero in exact arithmetic up to the kink terms (softmax shift invariance), cancelling to 1e-3 of
+    # its terms -- 40 x gtol, their real gate being the Sigma|terms| one above.
+    assert max(werrs[k] for k in bsc) < 10 * gtol, sorted(((k, werrs[k]) for k in bsc), key=lambda kv: -kv[1])[:3]
+    assert max(werrs[k] for k in scales) < 40 * gtol, sorted(((k, werrs[k]) for k in scales), key=lambda kv: -kv[1])[:3]

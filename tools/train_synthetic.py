@@ -17,8 +17,18 @@ import torch
 
 import dualvgr_videoqa_amd as dv
 
-epochs = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+# the reference's switches (train.py:372-375) and yml keys (config.py:7-56) through dualvgr_videoqa_amd.config: a yml written for the
+# reference sets clip count, widths, learning rate, batch size and seed; without --cfg the small defaults below
+import argparse
+_ap = argparse.ArgumentParser()
+_ap.add_argument("epochs", nargs="?", type=int, default=6)
+rcfg, args = dv.config.parse(parser=_ap)
+epochs = args.epochs
 V, N, FR, FEAT, Q, T, VQ, VA, B = 48, 8, 16, 2048, 768, 10, 200, 12, 32
+LR, UNIT_LAYERS = 1e-3, 2
+if args.cfg_file:
+    N, FEAT, B, LR = rcfg.train["num_of_nodes"], rcfg.train["vision_dim"], min(rcfg.train["batch_size"], 64), rcfg.train["lr"]
+    UNIT_LAYERS = args.unit_layers
 rng = np.random.default_rng(3)
 root = tempfile.mkdtemp(prefix="dvgr_train_")
 ids = np.arange(1000, 1000 + V)
@@ -35,14 +45,17 @@ vocab = {"question_token_to_idx": {str(i): i for i in range(VQ)}, "answer_token_
          "question_answer_token_to_idx": {}}
 json.dump(vocab, open(os.path.join(root, "v.json"), "w"))
 
-torch.manual_seed(0)
+torch.manual_seed(rcfg.seed if args.cfg_file else 0)
 loader = dv.VideoQAFlatLoader(vocab_json=os.path.join(root, "v.json"), question_pt=os.path.join(root, "q.pt"),
                               appearance_feat=os.path.join(root, "a.dvgrf"), motion_feat=os.path.join(root, "m.dvgrf"),
                               batch_size=B, shuffle=True, seed=0)
-model = dv.DualVGR(vision_dim=FEAT, module_dim=768, word_dim=300, vocab=vocab, num_of_nodes=N, graph_module="GAT", graph_layers=1,
-                   unit_layers=2, dtype="bf16x3").cuda().train()
+mk = dv.config.model_kwargs(rcfg, unit_layers=UNIT_LAYERS, vocab=vocab) if args.cfg_file else dict(
+    vision_dim=FEAT, module_dim=768, word_dim=300, vocab=vocab, num_of_nodes=N, graph_module="GAT", graph_layers=1, unit_layers=UNIT_LAYERS)
+model = dv.DualVGR(dtype="bf16x3", **mk).cuda().train()
 model.visual_input_unit.reuse_buffers = True
-step = dv.TrainStep(model, lr=1e-3, alpha=1.0, beta=1e-8, max_norm=12.0)          # train.py:139-159 on the package's kernels
+sk = dv.config.step_kwargs(rcfg, args.alpha, args.beta)
+sk["lr"] = LR
+step = dv.TrainStep(model, **sk)          # train.py:139-159 on the package's kernels
 first = last = None
 for ep in range(epochs):
     t0, tot, correct, n = time.perf_counter(), 0.0, 0, 0
