@@ -484,6 +484,8 @@ def main():
     from dualvgr_videoqa_amd import _lib as L_
     from dualvgr_videoqa_amd import losses, parallel, synth, trainer
 
+    if os.environ.get("DVGR_BENCH_XMAP") is not None:       # A/B aid: which launch-site tags of the contraction engine take the XCD block map
+        L_.load().dvgr_dbg_xmap_tags(int(os.environ["DVGR_BENCH_XMAP"]))
     cfg = dict(CONFIGS[args.config])
     if args.cfg_file or args.unit_layers is not None:
         from dualvgr_videoqa_amd import config as refcfg
@@ -770,9 +772,13 @@ def main():
                    "unit_tflops": value / world * f_train / 1e12,
                    "unit_frac_of_mfma_peak": value / world * f_train / 1e12 / peak},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                     "bound_note": "priced against the dense MFMA peak as the contract asks; the K loop of these 240-256-workgroup launches "
-                                   "is bound by L2 -> LDS operand traffic (operand_fill_*, DESIGN.md section 3.1: ~10 TB/s over the chip in "
-                                   "the K loop, 32 algorithmic FLOP per operand byte with 128 x 128 tiles)",
+                     "bound_note": "priced against the dense bf16 MFMA peak as the contract asks.  The ceiling of this launch at C2 (DESIGN.md "
+                                   "section 7.0, every floor measured: profiles/r06_operand_paths.txt, r05_kloop_decomposition.txt): per CU the "
+                                   "MFMAs need 7.3 us (3 per product: bf16x3, the 1e-4 gate), the operand planes arrive through LDS-DMA at "
+                                   "70-96 GB/s per CU = 10.3-11.8 us, the attention epilogue takes 8.7 us and the 47 MB of stores ~7 us: best "
+                                   "case ~27 us = MFMA pipe busy 0.27, frac 0.09.  The north star's >= 40 % MFMA utilisation is NOT reachable "
+                                   "at this size with this tile (80 rows x one head) nor with 160-row tiles on half the chip (0.19 of the chip) "
+                                   "nor in plain bf16 (0.11, and outside the parity gate)",
                      # HBM bytes per launch of the probed kernel (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes) and the
                      # MFMA pipe's busy share, from the rocprofv3 record of THIS build under profiles/ -- null without one
                      "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,

@@ -118,6 +118,7 @@ SYMBOLS += [
                                                  C.c_int64, C.c_int64, C.c_void_p, C.c_int64] + [C.c_int] * 6 + [C.c_void_p, C.c_int, C.c_void_p]),
     ("dvgr_dbg_event_destroy", C.c_int, [C.c_void_p]),
     ("dvgr_dbg_launch_count", C.c_longlong, []),
+    ("dvgr_dbg_xmap_tags", C.c_int, [C.c_int]),
 ]
 
 _lib = None

@@ -1655,6 +1655,8 @@ int dvgr_dbg_event_destroy(void* event) { return event ? (int)hipEventDestroy((h
 
 long long dvgr_dbg_launch_count(void) { return dvgr::g_launch_count.load(std::memory_order_relaxed); }
 
+int dvgr_dbg_xmap_tags(int mask) { return dvgr::gemm_xmap_tags(mask); }
+
 uint32_t dvgr_dbg_site_key(uint64_t seed, int layer, int mod, int gat, int which) {
   return site_key(seed, drop_site(layer, mod, gat, which));
 }

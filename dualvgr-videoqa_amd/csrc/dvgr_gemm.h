@@ -69,9 +69,18 @@ struct GemmProblem {
 };
 
 constexpr int kMaxBatch = 12;
+// XCD block map of a planes launch (round 6; set by the launcher, never by callers): XCD x works on at most two rectangular
+// blocks of output tiles, each inside ONE problem -- so its 4 MiB L2 streams the operand panels of one or two problems instead
+// of a slice of every problem's (the default map cuts every problem's tile list into eight chunks of its own: each L2 then
+// fetches ~1/3 of EVERY problem's panels).  Problems of one reduction length form a class; a class of P problems (8 % P == 0)
+// gives each problem 8 / P XCDs, its tile grid cut into that many equal rectangles; two classes (the weight-gradient launch:
+// dP1 reduces over 2 B N rows, dWcat over B N) give every XCD one block of each, so the XCDs carry equal work.
+struct XcdSeg { unsigned char prob, m_lo, m_cnt, n_lo, n_cnt; };
 struct GemmBatch {
   GemmProblem p[kMaxBatch];
   int n;
+  int xmap;                 // 1: seg[][] is the workgroup -> tile map (grid = 8 x the largest per-XCD tile count, y = z = 1)
+  XcdSeg seg[8][2];
 };
 
 // Launch-site tags: each tag is a separate instantiation (= its own kernel symbol in a profile).
@@ -91,6 +100,9 @@ bool gemm_rowdot_supported(int la, int lb, const GemmBatch& batch, int prec);
 // when gemm_mixed_supported().
 bool gemm_mixed_supported(const GemmBatch& batch, int prec);
 int gemm_launch_mixed(hipStream_t stream, const GemmBatch& batch, int tag = TAG_GENERIC, int prec = DVGR_F32);
+
+// Which launch-site tags take the XCD block map (bit per tag); returns the previous mask, mask < 0 = the build's default.
+int gemm_xmap_tags(int mask);
 
 // Enqueue the batch on `stream`.  la / lb in {KC, IC}.  Returns hipError_t as int.
 int gemm_launch(hipStream_t stream, int la, int lb, const GemmBatch& batch, int tag = TAG_GENERIC, int prec = DVGR_F32);

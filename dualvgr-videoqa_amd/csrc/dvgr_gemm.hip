@@ -7,6 +7,7 @@
 //                   lo = bf16(x - hi); a.b ~ hi.hi + hi.lo + lo.hi, relative error ~2^-16 per product,
 //                   i.e. fp32-grade results at 3/16 of the fp32-MFMA cost).
 #include <stdlib.h>
+#include <atomic>
 
 #include "dvgr_gemm.h"
 #include "dvgr_planes.h"
@@ -49,6 +50,25 @@ __device__ __forceinline__ bool tile_coords(int M, int N, int BM, int BN, int* m
   *m0 = (local / gw) * BM;
   *n0 = (first_n + local % gw) * BN;
   return true;
+}
+
+// XCD block map (GemmBatch::xmap): slot s of XCD x = the s-th tile of its (at most two) blocks.  Returns the problem or -1.
+__device__ __forceinline__ int tile_coords_blocks(const GemmBatch& b, int BM, int BN, int* m0, int* n0) {
+  const int x = (int)(blockIdx.x & 7);
+  int s = (int)(blockIdx.x >> 3);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const XcdSeg g = b.seg[x][k];
+    const int cnt = (int)g.m_cnt * (int)g.n_cnt;
+    if (s < cnt) {
+      const int mi = s / (int)g.n_cnt;
+      *m0 = ((int)g.m_lo + mi) * BM;
+      *n0 = ((int)g.n_lo + s - mi * (int)g.n_cnt) * BN;
+      return (int)g.prob;
+    }
+    s -= cnt;
+  }
+  return -1;
 }
 
 template <int LAYOUT, int BT>
@@ -953,11 +973,9 @@ struct PlanesLds {
 
 // one 128 x 128 output tile of problem P (the whole workgroup: 8 computing + 4 loader waves)
 template <int LA, int LB, int TERMS, int NS, int RTM = RT, int KB = 32>
-__device__ __forceinline__ void planes_tile(const GemmProblem& P, uint16_t* smem) {
+__device__ __forceinline__ void planes_tile(const GemmProblem& P, uint16_t* smem, int m0, int n0) {
   static_assert(RTM == RT || (RTM == 64 && LA == KC), "half-height tiles: row-major A only");
   static_assert(KB == 32 || (KB == 64 && LA == KC), "64-deep K-tiles: row-major A only (a column-major tile's row pieces are 256 bytes already)");
-  int m0, n0;
-  if (!tile_coords(P.M, P.N, RTM, RT, &m0, &n0)) return;
 
   constexpr int kPlanes = PlanesLds<TERMS, NS, RTM, KB>::kPlanes;
   constexpr int kSlot = PlanesLds<TERMS, NS, RTM, KB>::kSlot;
@@ -1291,7 +1309,9 @@ template <int TERMS>
 __global__ __launch_bounds__(768) void fwd_sf_phase_kernel(const GemmBatch batch, const SfCombineArgs sf) {
   __shared__ __attribute__((aligned(16))) uint16_t smem[PlanesLds<TERMS, RS>::kLds];
   const GemmProblem P = batch.p[blockIdx.z];
-  planes_tile<KC, KC, TERMS, RS>(P, smem);                      // phase 1: tanh(z_v . P1^T + bP), this workgroup's tile (if any)
+  int m0 = 0, n0 = 0;
+  if (tile_coords(P.M, P.N, RT, RT, &m0, &n0))
+    planes_tile<KC, KC, TERMS, RS>(P, smem, m0, n0);            // phase 1: tanh(z_v . P1^T + bP), this workgroup's tile (if any)
   grid_barrier_xcd(1u);
   // phase 2: S5, one wave per (modality, row)
   const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
@@ -1322,8 +1342,14 @@ int fwd_sf_phase_launch(hipStream_t stream, const GemmBatch& b, const SfCombineA
 template <int LA, int LB, int TAG, int TERMS, int NS = RS, int RTM = RT, int KB = 32>
 __global__ __launch_bounds__(768) void gemm_planes_kernel(const GemmBatch batch) {
   __shared__ __attribute__((aligned(16))) uint16_t smem[PlanesLds<TERMS, NS, RTM, KB>::kLds];
-  const GemmProblem P = batch.p[blockIdx.z];
-  planes_tile<LA, LB, TERMS, NS, RTM, KB>(P, smem);
+  int m0, n0, pi = (int)blockIdx.z;
+  if (batch.xmap) {
+    pi = tile_coords_blocks(batch, RTM, RT, &m0, &n0);
+    if (pi < 0) return;                                           // uniform per workgroup, before any barrier
+  }
+  const GemmProblem P = batch.p[pi];
+  if (!batch.xmap && !tile_coords(P.M, P.N, RTM, RT, &m0, &n0)) return;
+  planes_tile<LA, LB, TERMS, NS, RTM, KB>(P, smem, m0, n0);
 }
 
 // Problems of DIFFERENT operand layouts in one launch (GemmProblem::layout): the backward's data gradient dX += dWh . Wcat
@@ -1335,9 +1361,11 @@ template <int TAG, int TERMS>
 __global__ __launch_bounds__(768) void gemm_planes_mixed_kernel(const GemmBatch batch) {
   __shared__ __attribute__((aligned(16))) uint16_t smem[PlanesLds<TERMS, RS>::kLds];
   const GemmProblem P = batch.p[blockIdx.z];
-  if (P.layout == LAYOUT_NT) planes_tile<KC, KC, TERMS, RS>(P, smem);
-  else if (P.layout == LAYOUT_NN) planes_tile<KC, IC, TERMS, RS>(P, smem);
-  else planes_tile<IC, IC, TERMS, RS>(P, smem);
+  int m0, n0;
+  if (!tile_coords(P.M, P.N, RT, RT, &m0, &n0)) return;
+  if (P.layout == LAYOUT_NT) planes_tile<KC, KC, TERMS, RS>(P, smem, m0, n0);
+  else if (P.layout == LAYOUT_NN) planes_tile<KC, IC, TERMS, RS>(P, smem, m0, n0);
+  else planes_tile<IC, IC, TERMS, RS>(P, smem, m0, n0);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1348,9 +1376,13 @@ __global__ __launch_bounds__(768) void gemm_planes_mixed_kernel(const GemmBatch 
 // -------------------------------------------------------------------------------------------------
 template <int LA, int LB, int TERMS>
 __global__ __launch_bounds__(768) void gemm_planes_wide_kernel(const GemmBatch batch) {
-  const GemmProblem P = batch.p[blockIdx.z];
-  int m0, n0;
-  if (!tile_coords(P.M, P.N, RT, 2 * RT, &m0, &n0)) return;
+  int m0, n0, pi = (int)blockIdx.z;
+  if (batch.xmap) {
+    pi = tile_coords_blocks(batch, RT, 2 * RT, &m0, &n0);
+    if (pi < 0) return;                                          // uniform per workgroup, before any barrier
+  }
+  const GemmProblem P = batch.p[pi];
+  if (!batch.xmap && !tile_coords(P.M, P.N, RT, 2 * RT, &m0, &n0)) return;
 
   constexpr int NSW = 3;
   constexpr int kPlanes = (TERMS == 3) ? 2 : 1;
@@ -1491,8 +1523,85 @@ static int zero_split_outputs(hipStream_t stream, const GemmBatch& b) {
   return (int)hipGetLastError();
 }
 
+// Which launch sites take the XCD block map: all of them (round 6, one device, alternating runs: C2 0.9177 -> 0.9048 ms per step,
+// C3 0.9479 -> 0.9171; the weight-gradient launch alone -0.9 %, S4 alone -0.3 %, dX alone +0.6 % but -0.7 % on top of the others;
+// profiles/experiments_r06.tsv, xcd_block_map_*).  Round 3's ONE tile list over the whole batch cut into eight chunks halved the
+// weight-gradient launch's bytes just the same and made the step 2 % SLOWER: its chunks gave three XCDs the long dP1 tiles
+// (reduction 2 B N) and the others the short dWcat tiles -- this map gives every XCD one block of each class.
+#ifndef DVGR_XMAP_TAGS_DEFAULT
+#define DVGR_XMAP_TAGS_DEFAULT 127        // bit mask of launch-site tags (TAG_*) that take the XCD block map
+#endif
+static std::atomic<int> g_xmap_tags{-1};    // -1: the build's default (DVGR_XMAP_TAGS in the environment of an aids build)
+static int xmap_tags_now() {
+  const int m = g_xmap_tags.load(std::memory_order_relaxed);
+  if (m >= 0) return m;
+#ifdef DVGR_TIMING_AIDS
+  static const int env_tags = []() { const char* e = getenv("DVGR_XMAP_TAGS"); return e ? atoi(e) : DVGR_XMAP_TAGS_DEFAULT; }();   // A/B timing aid
+  return env_tags;
+#else
+  return DVGR_XMAP_TAGS_DEFAULT;
+#endif
+}
+int gemm_xmap_tags(int mask) {
+  const int prev = xmap_tags_now();
+  g_xmap_tags.store(mask < 0 ? -1 : mask, std::memory_order_relaxed);
+  return prev;
+}
+
+// The XCD block map of a planes launch of BM x BN tiles (GemmBatch::xmap, dvgr_gemm.h).  Returns the grid's x extent
+// (8 x the largest per-XCD tile count), or 0 when the batch does not fit the scheme (the default map runs then).
+static int plan_xcd_blocks(GemmBatch* b, int BM = RT, int BN = RT, int max_per_xcd = 32) {
+  b->xmap = 0;
+  if (b->n < 1 || b->n > 8) return 0;
+  int cls_k[2] = {0, 0}, cls_n[2] = {0, 0}, ncls = 0, cls_of[kMaxBatch];
+  for (int i = 0; i < b->n; ++i) {
+    int c = 0;
+    while (c < ncls && cls_k[c] != b->p[i].K) ++c;
+    if (c == ncls) { if (ncls == 2) return 0; cls_k[ncls++] = b->p[i].K; }
+    cls_of[i] = c;
+    ++cls_n[c];
+  }
+  for (int x = 0; x < 8; ++x)
+    for (int k = 0; k < 2; ++k) b->seg[x][k] = XcdSeg{0, 0, 0, 0, 0};
+  int per_xcd = 0;
+  for (int c = 0; c < ncls; ++c) {
+    const int P = cls_n[c];
+    if (8 % P) return 0;
+    const int g = 8 / P;                                     // XCDs per problem: its tile grid in g equal rectangles gm x gn
+    int j = 0, cnt_c = 0;
+    for (int i = 0; i < b->n; ++i) {
+      if (cls_of[i] != c) continue;
+      const int tm = (b->p[i].M + BM - 1) / BM, tn = (b->p[i].N + BN - 1) / BN;
+      if (tm > 255 || tn > 255) return 0;
+      int gm = 0, gn = 0, best = 1 << 30;
+      for (int a = 1; a <= g; ++a) {
+        if (g % a || tm % a || tn % (g / a)) continue;
+        const int cost = tm / a + tn / (g / a);              // operand panels one XCD streams
+        if (cost < best) { best = cost; gm = a; gn = g / a; }
+      }
+      if (!gm) return 0;
+      const int bm = tm / gm, bn = tn / gn;
+      if (cnt_c && cnt_c != bm * bn) return 0;               // equal work per XCD inside a class
+      cnt_c = bm * bn;
+      for (int q = 0; q < g; ++q)
+        b->seg[j * g + q][c] = XcdSeg{(unsigned char)i, (unsigned char)((q / gn) * bm), (unsigned char)bm, (unsigned char)((q % gn) * bn),
+                                      (unsigned char)bn};
+      ++j;
+    }
+    per_xcd += cnt_c;
+  }
+  // (128 x 128 tiles: one workgroup per CU and an XCD's blocks in ONE round of its 32 CUs; the wide launches run up to three
+  // rounds, in slot order: row-major inside a block, so the workgroups in flight together share a few row panels and the block's
+  // column panels)
+  if (per_xcd < 1 || per_xcd > max_per_xcd) return 0;
+  b->xmap = 1;
+  return 8 * per_xcd;
+}
+
 template <int LA, int LB, int TAG>
-static int launch_ring(hipStream_t stream, const GemmBatch& b, int prec) {
+static int launch_ring(hipStream_t stream, const GemmBatch& b_in, int prec) {
+  GemmBatch b = b_in;
+  b.xmap = 0;
   int tiles = 0;
   for (int i = 0; i < b.n; ++i) {
     const int t = ((b.p[i].M + RT - 1) / RT) * ((b.p[i].N + RT - 1) / RT);
@@ -1564,8 +1673,12 @@ static int launch_ring(hipStream_t stream, const GemmBatch& b, int prec) {
           if (cost < best) { best = cost; split_w = sp; }
         }
       }
-      const dim3 grid_w(8 * ((tiles_w + 7) / 8), split_w, b.n);
+      dim3 grid_w(8 * ((tiles_w + 7) / 8), split_w, b.n);
       if (split_w > 1) { const int ez = zero_split_outputs(stream, b); if (ez) return ez; }
+      if (split_w == 1 && ((xmap_tags_now() >> TAG) & 1)) {
+        const int gx = plan_xcd_blocks(&b, RT, 2 * RT, 96);
+        if (gx) grid_w = dim3(gx, 1, 1);
+      }
       if (prec == DVGR_BF16X3) DVGR_LAUNCH((gemm_planes_wide_kernel<LA, LB, 3>), grid_w, dim3(768), 0, stream, b);
       else DVGR_LAUNCH((gemm_planes_wide_kernel<LA, LB, 1>), grid_w, dim3(768), 0, stream, b);
       return (int)hipGetLastError();
@@ -1598,7 +1711,11 @@ static int launch_ring(hipStream_t stream, const GemmBatch& b, int prec) {
       constexpr bool no_half = false;
 #endif
       if (!no_half) {
-        const dim3 grid_h(8 * ((tiles_h + 7) / 8), 1, b.n);
+        dim3 grid_h(8 * ((tiles_h + 7) / 8), 1, b.n);
+        if ((xmap_tags_now() >> TAG) & 1) {
+          const int gx = plan_xcd_blocks(&b, 64, RT, 32);
+          if (gx) grid_h = dim3(gx, 1, 1);
+        }
         constexpr int LAH = KC;                    // (the branch is dead for LA == IC; keeps the instantiation legal)
         // (a half-height 64-deep slot is 48 KB: THREE fit.  Per launch -0.5 .. -3.6 %, C2 -0.5 %, C1 -0.2 %, half_tile_ring_3_slots_*:
         // a third slot is not what the 2-slot rings of the full tiles are missing either)
@@ -1611,9 +1728,16 @@ static int launch_ring(hipStream_t stream, const GemmBatch& b, int prec) {
         return (int)hipGetLastError();
       }
     }
-    if (kb64) DVGR_LAUNCH((gemm_planes_kernel<LA, LB, TAG, 3, NSX, RT, KBX>), grid, block, 0, stream, b);
-    else if (prec == DVGR_BF16X3) DVGR_LAUNCH((gemm_planes_kernel<LA, LB, TAG, 3>), grid, block, 0, stream, b);
-    else DVGR_LAUNCH((gemm_planes_kernel<LA, LB, TAG, 1>), grid, block, 0, stream, b);
+    // full 128 x 128 tiles, K not split: the XCD block map where the batch fits it (GemmBatch::xmap)
+    dim3 gridx = grid;
+    const int xmap_tags = xmap_tags_now();
+    if (split == 1 && ((xmap_tags >> TAG) & 1)) {
+      const int gx = plan_xcd_blocks(&b);
+      if (gx) gridx = dim3(gx, 1, 1);
+    }
+    if (kb64) DVGR_LAUNCH((gemm_planes_kernel<LA, LB, TAG, 3, NSX, RT, KBX>), gridx, block, 0, stream, b);
+    else if (prec == DVGR_BF16X3) DVGR_LAUNCH((gemm_planes_kernel<LA, LB, TAG, 3>), gridx, block, 0, stream, b);
+    else DVGR_LAUNCH((gemm_planes_kernel<LA, LB, TAG, 1>), gridx, block, 0, stream, b);
     return (int)hipGetLastError();
   }
   if (prec == DVGR_BF16X3) DVGR_LAUNCH((gemm_ring_kernel<LA, LB, TAG, DVGR_BF16X3>), grid, block, 0, stream, b);

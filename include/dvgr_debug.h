@@ -62,6 +62,12 @@ int dvgr_dbg_event_create(void **event);
 int dvgr_dbg_event_elapsed_ms(void *begin, void *end, float *ms);   /* synchronises on `end` first */
 int dvgr_dbg_event_destroy(void *event);
 
+/* The XCD block map of the contraction engine's 128 x 128-tile launches (csrc/dvgr_gemm.h, GemmBatch::xmap): bit t of `mask`
+ * turns it on for launch-site tag t (0 generic .. 6).  Returns the previous mask; mask < 0 restores the build's default.
+ * Any map gives bit-identical results (a workgroup's arithmetic does not depend on which tile list it came from) -- the
+ * parity tests hold the engine to that (tests/test_hip_blocks.py). */
+int dvgr_dbg_xmap_tags(int mask);
+
 #ifdef __cplusplus
 }
 #endif

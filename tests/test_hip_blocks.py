@@ -394,3 +394,48 @@ def test_gemm_nn_several_problems_add_into_one_output(M, N, K, count, prec):
     want = count * (A.double() @ Bm.double()).cpu()
     tol = 2e-6 if prec == L.DVGR_F32 else 2e-5
     assert float((Cm.double().cpu() - want).abs().max()) < tol * float(want.abs().max())
+
+
+# ---- the XCD block map (round 6): a different workgroup -> tile map, the same arithmetic -------------------------------------
+@pytest.mark.parametrize("mode,M,N,K,count,tag", [(0, 1280, 768, 768, 4, 2),      # S4: 4 problems of 10 x 6 tiles -> 2 XCDs each
+                                                  (1, 1280, 768, 768, 4, 4),      # dX
+                                                  (2, 768, 768, 1280, 4, 3),      # dWcat alone: one class of 4
+                                                  (0, 1280, 1536, 768, 2, 1),     # layer 0's projection: 2 problems, 2 x 2 blocks each
+                                                  (0, 1024, 768, 768, 4, 2),      # C3's row count
+                                                  (0, 1200, 768, 768, 4, 2),      # a partial last row tile
+                                                  (0, 1280, 768, 768, 3, 2),      # 8 % 3 != 0: the default map runs
+                                                  (2, 1536, 768, 1280, 2, 3)])
+def test_xcd_block_map_is_bit_identical(mode, M, N, K, count, tag):
+    """GemmBatch::xmap (include/dvgr_debug.h: dvgr_dbg_xmap_tags) changes which workgroup computes which tile, nothing else:
+    the outputs (and the TN launch's row sums up to their atomic adds' order: compared to rounding) equal the default map's."""
+    lib, st = L.load(), _stream
+    g = torch.Generator().manual_seed(11)
+    if mode == 2:
+        A, Bm = torch.randn(K, M, generator=g).cuda(), torch.randn(K, N, generator=g).cuda()
+    elif mode == 1:
+        A, Bm = torch.randn(M, K, generator=g).cuda(), torch.randn(K, N, generator=g).cuda()
+    else:
+        A, Bm = torch.randn(M, K, generator=g).cuda(), torch.randn(N, K, generator=g).cuda()
+    pa, na = _planes(A)
+    pb, nb = _planes(Bm)
+    outs = {}
+    prev = lib.dvgr_dbg_xmap_tags(0)
+    try:
+        for mask in (0, 127):
+            lib.dvgr_dbg_xmap_tags(mask)
+            Cm = torch.full((count * M, N), float("nan"), device="cuda")
+            rs = torch.zeros(count * M, device="cuda") if mode == 2 else None
+            rc = lib.dvgr_dbg_gemm_planes_batch(mode, M, N, K, 0, A.data_ptr(), pa.data_ptr(), A.stride(0), na, Bm.data_ptr(),
+                                                pb.data_ptr(), Bm.stride(0), nb, Cm.data_ptr(), N, 0, 0, 0, L.DVGR_BF16X3, count, tag,
+                                                None if rs is None else rs.data_ptr(), 0, st())
+            assert rc == 0, rc
+            torch.cuda.synchronize()
+            outs[mask] = (Cm.cpu(), None if rs is None else rs.cpu())
+    finally:
+        lib.dvgr_dbg_xmap_tags(prev if prev >= 0 else -1)
+    assert torch.equal(outs[0][0], outs[127][0])
+    assert not torch.isnan(outs[127][0]).any()
+    want = (A.double().T @ Bm.double() if mode == 2 else A.double() @ (Bm.double() if mode == 1 else Bm.double().T)).cpu()
+    assert float((outs[127][0][:M].double() - want).abs().max()) < 2e-5 * float(want.abs().max())
+    if mode == 2:
+        assert float((outs[0][1] - outs[127][1]).abs().max()) <= 1e-5 * float(outs[0][1].abs().max())

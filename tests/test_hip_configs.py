@@ -233,3 +233,44 @@ def test_c5_training_mode_shard_on_the_kernels_the_full_batch_runs():
         e = rel_err(b[:Bs].detach().cpu(), a.cpu())
         assert e < 5e-5, e
     assert float((outsf[3][0] == 0).float().mean()) > 0.1          # dropout ran
+
+
+def test_c2_xcd_block_map_changes_no_result():
+    """Round 6: the contraction engine's XCD block map (GemmBatch::xmap; dvgr_dbg_xmap_tags) against the default workgroup -> tile
+    map on the headline shape, training mode: the forward is bit-identical, every gradient equal up to the order of the float
+    atomics that exist in either form (column sums, loss scalars)."""
+    cfg = dict(B=64, N=20, L=3, T=15)
+    B, N, Lr, T = cfg["B"], cfg["N"], cfg["L"], cfg["T"]
+    sd_np = synth.xavier_state_dict(O.param_shapes(300, 768, Lr), seed=61, bias_range=0.05)
+    inp = synth.unit_inputs(B, N, T, 768, 300, seed=61)
+    lib = L.load()
+    got = {}
+    prev = lib.dvgr_dbg_xmap_tags(0)
+    try:
+        for mask in (0, 127):
+            lib.dvgr_dbg_xmap_tags(mask)
+            m = dv.DualVGRUnit_multiple(word_dim=300, module_dim=768, num_of_nodes=N, unit_layers=Lr, dtype="bf16x3")
+            m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
+            m = m.cuda().train()
+            m.forced_seed = 977
+            t = {k: torch.from_numpy(v.copy()).cuda() for k, v in inp.items()}
+            for k in ("A", "M", "dq", "words"):
+                t[k].requires_grad_(True)
+            outs = m(t["A"], t["M"], t["dq"], t["words"], t["qlen"])
+            O.bench_scalar_loss(outs, N).backward()
+            torch.cuda.synchronize()
+            got[mask] = ([outs[0].detach().cpu(), outs[3][-1].detach().cpu(), outs[6][-1].detach().cpu()],
+                         {k: t[k].grad.detach().cpu() for k in ("A", "M", "dq", "words")},
+                         {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()})
+    finally:
+        lib.dvgr_dbg_xmap_tags(prev if prev >= 0 else -1)
+    for a, b in zip(got[0][0], got[127][0]):
+        assert torch.equal(a, b)
+    # (float atomics whose order differs from run to run -- the batched d(dq), the column sums -- feed the query block: two runs of
+    # ONE map differ by ~2e-6 there as well)
+    for k in got[0][1]:
+        assert rel_err(got[127][1][k], got[0][1][k]) < 1e-5, k
+    for k in got[0][2]:
+        if k.endswith((".fc.bias", ".a.bias")):     # zero in exact arithmetic: rounding noise in either form
+            continue
+        assert rel_err(got[127][2][k], got[0][2][k]) < 1e-5, k

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B (or A/B/C/...) of library builds and/or environment switches on ONE device: the variants' bench.py runs alternate
 round-robin (devices of the pool differ by several per cent, so only same-device alternation is evidence), and one TSV row
-per variant is appended to profiles/experiments_r05.tsv: experiment, variant, lib, env, build id of the sources, median /
+per variant is appended to profiles/experiments_r06.tsv: experiment, variant, lib, env, build id of the sources, median /
 min ms per step over the rounds, launches per step, bench arguments.
 
     tools/ab.py <experiment-name> [--rounds 3] [--bench "--config c2"] <variant> [<variant> ...]
@@ -23,7 +23,7 @@ def main():
     ap.add_argument("variants", nargs="+")
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--bench", default="")
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "experiments_r05.tsv"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "experiments_r06.tsv"))
     a = ap.parse_args()
     sys.path.insert(0, ROOT)
     import bench
@@ -55,7 +55,7 @@ def main():
             res[name].append(d["ms_per_step"])
             launches[name] = d["config"].get("launches_per_step")
             print(f"round {r} {name}: {d['ms_per_step']:.4f} ms/step", flush=True)
-    # rows go to profiles/experiments_r05.tsv AND to gpurun_out/ab_rows/<experiment>.tsv: a GPU box starts from the repo's
+    # rows go to profiles/experiments_r06.tsv AND to gpurun_out/ab_rows/<experiment>.tsv: a GPU box starts from the repo's
     # copy of profiles/, so only gpurun_out/ carries this run's rows back (tools/ab_merge.py folds them in)
     side = os.path.join(ROOT, "gpurun_out", "ab_rows")
     os.makedirs(side, exist_ok=True)
