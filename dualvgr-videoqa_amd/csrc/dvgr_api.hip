@@ -402,7 +402,9 @@ int dvgr_pack_lo8(const dvgr_dims* d, const void* params_lp, const void* p1t, vo
 static bool backward_fuses(const dvgr_dims& d, int32_t flags) {
   return d.dtype != DVGR_F32 && d.G == 1 && !(flags & (DVGR_OPT_NO_FUSED_GAT | DVGR_OPT_NO_FUSED_GAT_BWD)) && d.L * 2 <= kMaxTransposeJobs &&
          gat_fused_bwd_supported(d.B, d.N, d.D, d.dtype) &&
-         (gat_fused_bwd_preferred(d.B, d.N) || (flags & DVGR_OPT_FORCE_FUSED_GAT_BWD));
+         (gat_fused_bwd_preferred(d.B, d.N, d.dtype == DVGR_BF16X3 && (d.D % 64) == 0 &&
+                                             !(flags & (DVGR_OPT_KB32 | DVGR_OPT_NO_HALF_GAT_TILES | DVGR_OPT_FUSED_BWD_READS_DZ))) ||
+          (flags & DVGR_OPT_FORCE_FUSED_GAT_BWD));
 }
 
 int dvgr_backward_uses_p1t(const dvgr_dims* d, int32_t flags) {
@@ -585,6 +587,7 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
       if (!ok) return DVGR_E_DIMS;          // (cannot happen: fuse_gat() implies planes of every operand)
       a.z_lo_off = plo;
       fa.kb64 = (O.flags & DVGR_OPT_KB32) ? 0 : 1;
+      fa.no_half = (O.flags & DVGR_OPT_NO_HALF_GAT_TILES) ? 1 : 0;
       fa.x_lo_off = xlo; fa.w_lo_off = wlo;
       a.B = B; a.N = N; a.D = D;
       DVGR_TRY(fprobe.begin(DVGR_PROBE_FWD_GAT_GEMM, l));
@@ -1240,6 +1243,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       if (!ok) return DVGR_E_DIMS;           // (cannot happen: fuse_bwd implies planes of every operand)
       a.lo_off = plo;
       fa.kb64 = (O.flags & DVGR_OPT_KB32) ? 0 : 1;
+      fa.no_half = (O.flags & DVGR_OPT_NO_HALF_GAT_TILES) ? 1 : 0;
       fa.a_lo_off = alo; fa.b_lo_off = p1t_lo;
       a.B = B; a.N = N; a.D = D;
       DVGR_TRY(probe.begin(DVGR_PROBE_BWD_SF_DX, l));

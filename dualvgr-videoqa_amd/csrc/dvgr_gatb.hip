@@ -664,8 +664,10 @@ static size_t gatb_lds_bytes(const GatfShape& s, int N, int terms) {
   const size_t slot = (size_t)planes * ((size_t)RP * BK + (size_t)F * BK) * 2;      // bytes
   const size_t ring = (4 * slot <= 150 * 1024 ? 4 : 3) * slot;
   // (the kernel's own layout: shP, shW, a_l / a_r, the three N x N images, SIX per-row arrays shS .. shB -- GatbEpi::floats)
-  const size_t epi = sizeof(float) * (s.mtiles16 == 4 ? GatbEpi<4, NTC>::floats(N, s.spt) : s.mtiles16 == 5 ? GatbEpi<5, NTC>::floats(N, s.spt)
-                                                                                       : GatbEpi<6, NTC>::floats(N, s.spt));
+  const size_t epi = sizeof(float) * (s.mtiles16 == 2   ? GatbEpi<2, NTC>::floats(N, s.spt)
+                                     : s.mtiles16 == 4 ? GatbEpi<4, NTC>::floats(N, s.spt)
+                                     : s.mtiles16 == 5 ? GatbEpi<5, NTC>::floats(N, s.spt)
+                                                       : GatbEpi<6, NTC>::floats(N, s.spt));
   return (epi > ring ? epi : ring) + 16;
 }
 
@@ -681,9 +683,10 @@ bool gat_fused_bwd_supported(int B, int N, int D, int prec) {
 // = 128 workgroups) each epilogue runs alone on its compute unit while the other half of the chip idles, and the two launches
 // with their 192 + 512 smaller workgroups are faster (+2.9 % fused); small batches (C1: 160 rows) are bound by the host's
 // enqueue rate, where one launch fewer per layer wins (-7 %).  profiles/experiments_r05.tsv, fused_gat_bwd_*.
-bool gat_fused_bwd_preferred(int B, int N) {
+bool gat_fused_bwd_preferred(int B, int N, bool half_tiles_ok) {
   GatfShape s;
   if (!gatf_shape(B, N, &s)) return false;
+  if (half_tiles_ok) gatf_half_shape(B, N, &s);            // (round 6: C4's shape runs 256 half-height workgroups, dvgr_gatf.h)
   const int total = ((B + s.spt - 1) / s.spt) * kHeads * 2;
   return total >= 200 || B * N <= 320;
 }
@@ -733,6 +736,11 @@ int gat_fused_bwd(hipStream_t st, const GatFusedBwdArgs& a_in, int prec) {
   if ((a.a_lo_off & 7) || (a.b_lo_off & 7) || (a.at.lo_off & 3)) return DVGR_E_ALIGN;
   a.spt = s.spt;
   if (a.kb64 && prec == DVGR_BF16X3 && a.dx[0] != nullptr && (a.at.D % 64) == 0) {      // 64-deep K-tiles, bf16 lo planes
+    GatfShape hs = s;
+    if (!a.no_half && gatf_half_shape(a.at.B, a.at.N, &hs)) {
+      a.spt = hs.spt;
+      return gatb_launch<3, 2, 1, true, false, 64>(st, a, hs);
+    }
     if (s.mtiles16 == 4 && s.nt == 1) return gatb_launch<3, 4, 1, true, false, 64>(st, a, s);
     if (s.mtiles16 == 5 && s.nt == 2) return gatb_launch<3, 5, 2, true, false, 64>(st, a, s);
   }

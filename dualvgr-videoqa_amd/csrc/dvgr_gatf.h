@@ -322,4 +322,22 @@ inline bool gatf_shape(int B, int N, GatfShape* s) {
   return s->spt >= 1;
 }
 
+// Half-height tiles (round 6, the 64-deep bf16x3 kernels only): where the 64-row tile (N <= 16) leaves most of the chip idle --
+// C4's 32 QA pairs of 16 clips are 8 row tiles x 8 heads x 2 modalities = 128 workgroups, and every epilogue then runs on half
+// the compute units -- a tile of 32 rows (32 / N samples) doubles the workgroups: per workgroup 56 KB of operand planes per K-tile
+// instead of 64 (the weight panel is streamed by twice as many workgroups: +75 % bytes over the chip, on twice the compute
+// units) and half the epilogue.  Taken when the full-height grid has < 200 workgroups and the half-height one fits one round.
+// `s`: in = gatf_shape's choice, out = the half-height shape.
+inline bool gatf_half_shape(int B, int N, GatfShape* s) {
+  if (s->mtiles16 != 4 || s->nt != 1 || N > 16) return false;
+  int spt2 = 32 / N;
+  if (spt2 < 1) return false;
+  if (spt2 > B) spt2 = B;
+  const int wg_full = ((B + s->spt - 1) / s->spt) * kHeads * 2, wg_half = ((B + spt2 - 1) / spt2) * kHeads * 2;
+  if (wg_full >= 200 || wg_half <= wg_full || wg_half > 256) return false;
+  s->mtiles16 = 2;
+  s->spt = spt2;
+  return true;
+}
+
 }  // namespace dvgr

@@ -413,6 +413,11 @@ int gat_fused_fwd(hipStream_t st, const GatFusedArgs& a_in, int prec) {
   if ((a.x_lo_off & 7) || (a.w_lo_off & 7)) return DVGR_E_ALIGN;
   a.spt = s.spt;
   if (a.kb64 && prec == DVGR_BF16X3 && (a.at.D % 64) == 0) {      // 64-deep K-tiles (whole 128-byte lines per row piece), bf16 lo planes
+    GatfShape hs = s;
+    if (!a.no_half && gatf_half_shape(a.at.B, a.at.N, &hs)) {     // few samples of <= 16 clips: 32-row tiles fill the chip (dvgr_gatf.h)
+      a.spt = hs.spt;
+      return gatf_launch<3, 2, 1, false, 64>(st, a);
+    }
     if (s.mtiles16 == 4 && s.nt == 1) return gatf_launch<3, 4, 1, false, 64>(st, a);
     if (s.mtiles16 == 5 && s.nt == 2) return gatf_launch<3, 5, 2, false, 64>(st, a);
   }

@@ -1360,9 +1360,13 @@ __global__ __launch_bounds__(768) void gemm_planes_kernel(const GemmBatch batch)
 template <int TAG, int TERMS>
 __global__ __launch_bounds__(768) void gemm_planes_mixed_kernel(const GemmBatch batch) {
   __shared__ __attribute__((aligned(16))) uint16_t smem[PlanesLds<TERMS, RS>::kLds];
-  const GemmProblem P = batch.p[blockIdx.z];
-  int m0, n0;
-  if (!tile_coords(P.M, P.N, RT, RT, &m0, &n0)) return;
+  int m0, n0, pi = (int)blockIdx.z;
+  if (batch.xmap) {
+    pi = tile_coords_blocks(batch, RT, RT, &m0, &n0);
+    if (pi < 0) return;                                           // uniform per workgroup, before any barrier
+  }
+  const GemmProblem P = batch.p[pi];
+  if (!batch.xmap && !tile_coords(P.M, P.N, RT, RT, &m0, &n0)) return;
   if (P.layout == LAYOUT_NT) planes_tile<KC, KC, TERMS, RS>(P, smem, m0, n0);
   else if (P.layout == LAYOUT_NN) planes_tile<KC, IC, TERMS, RS>(P, smem, m0, n0);
   else planes_tile<IC, IC, TERMS, RS>(P, smem, m0, n0);
@@ -1827,13 +1831,20 @@ int gemm_launch_mixed(hipStream_t stream, const GemmBatch& b, int tag, int prec)
     tiles = t > tiles ? t : tiles;
   }
   if (tiles == 0) return 0;
-  const dim3 grid(8 * ((tiles + 7) / 8), 1, b.n), block(768);
+  dim3 grid(8 * ((tiles + 7) / 8), 1, b.n);
+  const dim3 block(768);
+  GemmBatch bx = b;                                               // (the XCD block map where the batch fits it: classes by reduction length)
+  bx.xmap = 0;
+  if ((xmap_tags_now() >> (tag == TAG_BWD_GAT_DX ? TAG_BWD_GAT_DX : TAG_GENERIC)) & 1) {
+    const int gx = plan_xcd_blocks(&bx);
+    if (gx) grid = dim3(gx, 1, 1);
+  }
   if (tag == TAG_BWD_GAT_DX) {
-    if (prec == DVGR_BF16X3) DVGR_LAUNCH((gemm_planes_mixed_kernel<TAG_BWD_GAT_DX, 3>), grid, block, 0, stream, b);
-    else DVGR_LAUNCH((gemm_planes_mixed_kernel<TAG_BWD_GAT_DX, 1>), grid, block, 0, stream, b);
+    if (prec == DVGR_BF16X3) DVGR_LAUNCH((gemm_planes_mixed_kernel<TAG_BWD_GAT_DX, 3>), grid, block, 0, stream, bx);
+    else DVGR_LAUNCH((gemm_planes_mixed_kernel<TAG_BWD_GAT_DX, 1>), grid, block, 0, stream, bx);
   } else {
-    if (prec == DVGR_BF16X3) DVGR_LAUNCH((gemm_planes_mixed_kernel<TAG_GENERIC, 3>), grid, block, 0, stream, b);
-    else DVGR_LAUNCH((gemm_planes_mixed_kernel<TAG_GENERIC, 1>), grid, block, 0, stream, b);
+    if (prec == DVGR_BF16X3) DVGR_LAUNCH((gemm_planes_mixed_kernel<TAG_GENERIC, 3>), grid, block, 0, stream, bx);
+    else DVGR_LAUNCH((gemm_planes_mixed_kernel<TAG_GENERIC, 1>), grid, block, 0, stream, bx);
   }
   return (int)hipGetLastError();
 }

@@ -75,6 +75,7 @@ struct GatFusedArgs {
   const float* wscale[2];
   float* Wh_out[2];            // (B*N, 8F) fp32, saved for the backward
   int kb64;                    // != 0: 64-deep K-tiles (bf16x3, bf16 lo planes; dvgr_gatf.h KB)
+  int no_half;                 // != 0: never the half-height (32-row) tiles (DVGR_OPT_NO_HALF_GAT_TILES)
   int spt;                     // samples per tile (set by the launcher)
 };
 bool gat_fused_supported(int B, int N, int D, int prec);
@@ -180,10 +181,11 @@ struct GatFusedBwdArgs {
   const float* g_z[2][2];      // [mod][view]
   const float* beta[2];
   int kb64;                    // != 0: 64-deep K-tiles (bf16x3, bf16 lo planes, with dx; dvgr_gatf.h KB)
+  int no_half;                 // != 0: never the half-height (32-row) tiles (DVGR_OPT_NO_HALF_GAT_TILES)
   int spt;                     // samples per tile (set by the launcher)
 };
 bool gat_fused_bwd_supported(int B, int N, int D, int prec);
-bool gat_fused_bwd_preferred(int B, int N);     // the fused form is also the faster one at this batch (measured rule)
+bool gat_fused_bwd_preferred(int B, int N, bool half_tiles_ok = false);     // the fused form is also the faster one at this batch (measured rule); half_tiles_ok: the launch may take 32-row tiles (dvgr_gatf.h)
 int gat_fused_bwd(hipStream_t st, const GatFusedBwdArgs& a, int prec);
 
 // bf16 planes of square matrices transposed (hi and lo plane of each job in one workgroup pass): dst[c][r] = src[r][c]

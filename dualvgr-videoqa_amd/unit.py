@@ -350,6 +350,7 @@ class DualVGRUnit_multiple(nn.Module):
         self.fused_gat_bwd = not bool(int(os.environ.get("DVGR_NO_FUSED_GAT_BWD", "0")))
         if self.fused_gat_bwd and os.environ.get("DVGR_FORCE_FUSED_GAT_BWD", "0") == "1":
             self.fused_gat_bwd = "force"
+        self.half_gat_tiles = not bool(int(os.environ.get("DVGR_NO_HALF_GAT_TILES", "0")))   # False: DVGR_OPT_NO_HALF_GAT_TILES (64-row tiles of the fused kernels at every batch)
         self.kb64 = not bool(int(os.environ.get("DVGR_KB32", "0")))                    # False: DVGR_OPT_KB32 (32-deep K-tiles in the fused kernels)
         # 8-bit lo planes of the fused kernels' weight operands (dvgr_opts.lo8): an experiment of round 5 that applies to the
         # 32-deep K-tiles only and bought nothing there (fewer bytes, the same number of L2 requests); off unless asked for
@@ -643,6 +644,8 @@ class DualVGRUnit_multiple(nn.Module):
             o.comm = self._comm.handle
         if not self.kb64:
             o.flags |= L_.OPT_KB32
+        if not self.half_gat_tiles:
+            o.flags |= L_.OPT_NO_HALF_GAT_TILES
         if not self.lo8_planes:
             o.flags |= L_.OPT_NO_LO8
         if backward and self.fused_gat_bwd and self.hoist_p1t and dims is not None and \

@@ -259,6 +259,10 @@ enum dvgr_probe_site {
  * a row piece is then a whole 128-byte line, half the L2 requests per byte, on a 2-slot ring (csrc/dvgr_gatf.h, KB).
  * DVGR_OPT_KB32 keeps the 32-deep tiles of round 4 (A/B timing; also what dvgr_opts.lo8 applies to). */
 #define DVGR_OPT_KB32 512
+/* Where a launch of the fused GAT-view kernels on 64-row tiles (N <= 16) would leave most of the chip idle they run on 32-row
+ * tiles -- twice the workgroups (csrc/dvgr_gatf.h, gatf_half_shape; round 6: MSRVTT-QA's per-GPU batch of 32 x 16 clips).
+ * DVGR_OPT_NO_HALF_GAT_TILES keeps the 64-row tiles (A/B timing, parity of the two forms). */
+#define DVGR_OPT_NO_HALF_GAT_TILES 1024
 
 /* Scope-U loss evaluated by the forward itself (dvgr_opts.loss): the same arithmetic and outputs as
  * dvgr_scope_u_loss below, but the kernels are enqueued as soon as the last layer's list outputs exist and run on the

@@ -271,6 +271,7 @@ def test_c2_xcd_block_map_changes_no_result():
     for k in got[0][1]:
         assert rel_err(got[127][1][k], got[0][1][k]) < 1e-5, k
     for k in got[0][2]:
-        if k.endswith((".fc.bias", ".a.bias")):     # zero in exact arithmetic: rounding noise in either form
+        if k.endswith(".bias"):     # column sums by float atomics (cancelling: two runs of ONE map differ by 2e-5 there); a.bias / fc.bias are zero in exact arithmetic
+            assert rel_err(got[127][2][k], got[0][2][k]) < 5e-4 or k.endswith((".fc.bias", ".a.bias")), k
             continue
         assert rel_err(got[127][2][k], got[0][2][k]) < 1e-5, k

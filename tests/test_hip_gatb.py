@@ -222,3 +222,38 @@ def test_race_screen_of_the_64_deep_rings_at_the_bench_size():
                 worst, worst_k = e, k
         assert worst < 2e-4, (it, worst, worst_k)         # (a wrong 80 x 192 tile would be an error of order 1e-1 .. 1)
     print(f"  race screen: 60 repetitions at C2, forward bit-identical, worst gradient difference {worst:.2e} ({worst_k})")
+
+
+@pytest.mark.parametrize("B,N,Lr,train", [(17, 8, 2, True), (9, 16, 2, False), (10, 13, 3, True), (32, 16, 2, True)])
+def test_half_height_tiles_backward_equals_full_height_tiles(B, N, Lr, train):
+    """Round 6: the fused backward on 32-row tiles (csrc/dvgr_gatf.h, gatf_half_shape; (32, 16) is C4's per-GPU batch) against the
+    64-row form (DVGR_OPT_NO_HALF_GAT_TILES): the same arithmetic per sample, partial sums over samples in another order."""
+    sd_np = synth.xavier_state_dict(O.param_shapes(WD, D, Lr), seed=59, bias_range=0.05)
+    inp = synth.unit_inputs(B, N, T, D, WD, seed=59)
+    R = torch.from_numpy(synth.normal("R_gatb", (B, N, D), 1.0, 59))
+    got = {}
+    for half in (True, False):
+        m = _module(N, Lr, "bf16x3", sd_np, train, True)
+        m.half_gat_tiles = half
+        _, _, got[half] = _grads(m, inp, R, N, 31)
+    worst = max(rel_err(got[True][k], got[False][k]) for k in got[True] if not k.endswith((".fc.bias", ".a.bias")))
+    assert worst < 5e-5, worst
+
+
+def test_half_height_tiles_backward_against_oracle():
+    """C4's per-GPU shape (32 QA pairs of 16 clips: 256 half-height workgroups) in training mode against the oracle."""
+    B, N, Lr = 32, 16, 2
+    sd_np = synth.xavier_state_dict(O.param_shapes(WD, D, Lr), seed=63, bias_range=0.05)
+    inp = synth.unit_inputs(B, N, T, D, WD, seed=63)
+    R = torch.from_numpy(synth.normal("R_gatb", (B, N, D), 1.0, 63))
+    m = _module(N, Lr, "bf16x3", sd_np, True, True)
+    seed = 515
+    outs, t, _ = _grads(m, inp, R, N, seed)
+    masks = {k: torch.from_numpy(v) for k, v in dropout.site_masks(seed, B, N, D, Lr).items()}
+    sd = {k: torch.from_numpy(v.copy()) for k, v in sd_np.items()}
+    ti = {k: torch.from_numpy(v.copy()) for k, v in inp.items()}
+    signs = device_logit_signs(m, L.make_dims(B, N, T, D, WD, Lr), (B, N, Lr))
+    oo, gin, gw, dbg, stats = aligned_oracle_backward(sd, ti, Lr, masks, lambda o: _scalar(o, R, N), signs)
+    what = f"gatb half-height tiles B={B} N={N} L={Lr} bf16x3 train"
+    assert_flips_at_kink(stats, what)
+    assert_grads(m, t, gin, gw, dbg, Lr, GTOL, what)

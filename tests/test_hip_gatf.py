@@ -248,3 +248,20 @@ def test_64_deep_k_tiles_equal_32_deep_ones(B, N, Lr, train):
         got[kb64] = g
     for a, b in zip(got[True], got[False]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,N,Lr,train", [(17, 8, 2, True), (9, 16, 2, False), (10, 13, 2, True), (32, 16, 2, True), (5, 5, 2, True)])
+def test_half_height_tiles_equal_full_height_tiles(B, N, Lr, train):
+    """Round 6: at N <= 16 a launch whose 64-row tiles would leave most of the chip idle runs 32-row tiles (csrc/dvgr_gatf.h,
+    gatf_half_shape -- the shapes above all qualify; (32, 16) is C4's per-GPU batch).  A sample's arithmetic does not depend on
+    the tile it sits in: every output equals the 64-row form's (DVGR_OPT_NO_HALF_GAT_TILES) bit for bit."""
+    sd_np = synth.xavier_state_dict(O.param_shapes(WD, D, Lr), seed=43, bias_range=0.05)
+    inp = synth.unit_inputs(B, N, T, D, WD, seed=43)
+    got = {}
+    for half in (True, False):
+        m = _module(N, Lr, "bf16x3", sd_np, train, True, single=True)
+        m.half_gat_tiles = half
+        outs = _forward(m, inp, 4242)
+        got[half] = [outs[0].cpu(), outs[1].cpu(), outs[2].cpu()] + [x.cpu() for x in outs[3]] + [x.cpu() for x in outs[5]]
+    for a, b in zip(got[True], got[False]):
+        assert torch.equal(a, b)
