@@ -67,6 +67,7 @@ OPT_S5_READS_TN = 128
 OPT_NO_LO8 = 256
 OPT_KB32 = 512
 OPT_NO_HALF_GAT_TILES = 1024
+OPT_NO_FOLDED_PUNISH = 2048
 
 # enum dvgr_probe_site
 (PROBE_NONE, PROBE_FWD_QA_GEMM, PROBE_FWD_GAT_GEMM, PROBE_FWD_GAT_ATTN, PROBE_FWD_SF_GEMM, PROBE_FWD_MFB_GEMM,

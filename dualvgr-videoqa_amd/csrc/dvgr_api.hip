@@ -1164,6 +1164,8 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
 
   // ---- layers, last to first -----------------------------------------------------------------------
   hipEvent_t side_done[2] = {nullptr, nullptr};   // side stream finished the layer that used buffer set 0 / 1
+  const bool fold_punish = G == 1 && !(O.flags & DVGR_OPT_NO_FOLDED_PUNISH);
+  int fold_layer = -1;                             // the layer whose dX half of the S1 backward the next k_sf_bwd completes
   for (int l = L - 1; l >= 0; --l) {
     const int set = l & 1;
     const int e_last = l * G + G - 1;                 // list entry of the layer's last graph layer: the pair the SF attention saw
@@ -1190,7 +1192,16 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
         a.dw[m] = ws + W.dw[set][m]; a.dpre[m] = lean ? nullptr : ws + W.dpre[set][m];
         a.dz[m] = fuse_dz ? nullptr : ws + W.dz[m];         // (fuse_dz: the fused GAT-view backward forms dz's pre-part itself)
         a.dpre_p[m] = PM.out(ws + W.dpre[set][m], &plo);
+        if (fold_layer == l + 1) {         // the layer above left the dX half of its S1 backward to this pass (SfBwdArgs::fin_*)
+          const int us = (l + 1) & 1;
+          a.fin_dX[m] = dXacc[m];
+          a.fin_add[m] = train ? ws + W.dxtmp[m] : nullptr;
+          a.fin_ds_part[m] = ws + W.ds_part[us][m];
+          a.fin_s[m] = ms(l + 1, m) + S.s;
+          a.fin_p[m] = ms(l + 1, m) + S.p;
+        }
       }
+      a.fin_N = N;
       a.lo_off = plo;
       a.rows = BN; a.D = D;
       DVGR_TRY(sf_bwd(st, a));
@@ -1440,7 +1451,11 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     }
     // S1 backward: the dX update (folding the specific GAT's partial of the training-mode S2 backward in) and, for the
     // layers > 0, d p in the same launch
-    DVGR_TRY(punish(l == 0 ? 2 : 3));
+    // Layers >= 1 (graph_layers 1): only d p here; the dX half -- dX += dtau p + the specific GAT's partial -- is done by the NEXT
+    // layer's k_sf_bwd on the rows it reads anyway (round 6: one kernel of ~20 us fewer on the critical path per layer >= 1).
+    // Layer 0's dX is the call's output: its dX half stays a launch of its own.
+    if (l >= 1 && fold_punish) { DVGR_TRY(punish(1)); fold_layer = l; }
+    else DVGR_TRY(punish(l == 0 ? 2 : 3));
     if (l == 1) {                           // every d p of the layers >= 1 exists: their query branch, under layer 0
       DVGR_TRY(to_query());
       DVGR_TRY(query_branch(1, L, 1));

@@ -135,6 +135,18 @@ struct SfBwdArgs {
   uint16_t* dpre_p[2];     // bf16 planes of dpre (nullable)
   int64_t lo_off;
   int rows, D;
+  // Round 6: the dX half of the layer ABOVE's S1 backward (k_punish_bwd, parts bit 1) folded into this pass, which reads the
+  // running gradient anyway: with fin_dX[mod] != nullptr (= dX[mod]) the row's gradient is FIRST completed in place,
+  //   dX[row] <- dX[row] + fin_add[row] (nullable) + dtau_row * fin_p[row / fin_N],   dtau = (sum_h fin_ds_part) s (1 - s),
+  // (the tensors of the layer above: its attention backward's ds partials (B, 8, N), its gates s (B N), its punish vector p
+  // (B, D), the second partial of its dX contraction) and everything below uses the completed row.  One launch fewer on the
+  // critical path per layer >= 1, and the row is read once instead of twice.
+  float* fin_dX[2];
+  const float* fin_add[2];
+  const float* fin_ds_part[2];
+  const float* fin_s[2];
+  const float* fin_p[2];
+  int fin_N;
 };
 int sf_bwd(hipStream_t st, const SfBwdArgs& a);
 

@@ -399,9 +399,33 @@ __global__ __launch_bounds__(256) void k_sf_bwd(const SfBwdArgs a) {
   const float4* ge = a.g_embed[mod] ? reinterpret_cast<const float4*>(a.g_embed[mod] + r0) : nullptr;
   const float4* z0 = reinterpret_cast<const float4*>(a.z0[mod] + r0);
   const float4* z1 = reinterpret_cast<const float4*>(a.z1[mod] + r0);
+  // the dX half of the layer above's S1 backward, on the row while it is read (SfBwdArgs::fin_*): d = dX + add + dtau p.  Both
+  // passes over the row form d from the SAME inputs (no read of a value this launch stored); the second one stores it.
+  const bool fin = a.fin_dX[mod] != nullptr;               // (uniform)
+  float dtau = 0.f;
+  const float4* fadd = nullptr;
+  const float4* fp = nullptr;
+  if (fin) {
+    const int bs = row / a.fin_N, n = row - bs * a.fin_N;
+    float part = lane < kHeads ? a.fin_ds_part[mod][((int64_t)bs * kHeads + lane) * a.fin_N + n] : 0.f;
+    part = wave_sum(part);
+    const float sg = a.fin_s[mod][row];
+    dtau = part * sg * (1.f - sg);
+    fadd = a.fin_add[mod] ? reinterpret_cast<const float4*>(a.fin_add[mod] + r0) : nullptr;
+    fp = reinterpret_cast<const float4*>(a.fin_p[mod] + (int64_t)bs * D);
+  }
+  auto row_grad = [&](int k) -> float4 {
+    float4 d = dX[k];
+    if (fin) {
+      const float4 pp = fp[k];
+      if (fadd) { const float4 e = fadd[k]; d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w; }
+      d.x += dtau * pp.x; d.y += dtau * pp.y; d.z += dtau * pp.z; d.w += dtau * pp.w;
+    }
+    return d;
+  };
   float db0 = 0.f, db1 = 0.f;
   for (int k = lane; k < D4; k += 64) {
-    float4 d = dX[k];
+    float4 d = row_grad(k);
     if (ge) { const float4 e = ge[k]; d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w; }
     const float4 u = z0[k], v = z1[k];
     db0 += d.x * u.x + d.y * u.y + d.z * u.z + d.w * u.w;
@@ -422,8 +446,10 @@ __global__ __launch_bounds__(256) void k_sf_bwd(const SfBwdArgs a) {
   float4* dpre1 = a.dpre[mod] ? reinterpret_cast<float4*>(a.dpre[mod] + r1) : nullptr;
   float4* dz0 = wdz ? reinterpret_cast<float4*>(a.dz[mod] + r0) : nullptr;
   float4* dz1 = wdz ? reinterpret_cast<float4*>(a.dz[mod] + r1) : nullptr;
+  float4* dXf = fin ? reinterpret_cast<float4*>(a.fin_dX[mod] + r0) : nullptr;
   for (int k = lane; k < D4; k += 64) {
-    float4 d = dX[k];
+    float4 d = row_grad(k);
+    if (fin) dXf[k] = d;                                   // the completed running gradient (read by the fused backward's B0 and the dX contraction)
     if (ge) { const float4 e = ge[k]; d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w; }
     const float4 ta = t0[k], tb = t1[k], p = p2[k];
     const float4 q0 = make_float4(dw0 * p.x * (1.f - ta.x * ta.x), dw0 * p.y * (1.f - ta.y * ta.y),

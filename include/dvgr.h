@@ -263,6 +263,10 @@ enum dvgr_probe_site {
  * tiles -- twice the workgroups (csrc/dvgr_gatf.h, gatf_half_shape; round 6: MSRVTT-QA's per-GPU batch of 32 x 16 clips).
  * DVGR_OPT_NO_HALF_GAT_TILES keeps the 64-row tiles (A/B timing, parity of the two forms). */
 #define DVGR_OPT_NO_HALF_GAT_TILES 1024
+/* The backward completes the running gradient of a layer boundary -- dX += dtau p + the specific GAT's partial, the dX half of
+ * the S1 backward (model/utils.py:92-105) -- inside the next layer's row pass (k_sf_bwd) instead of by a kernel of its own
+ * (layers >= 1, graph_layers 1; round 6).  DVGR_OPT_NO_FOLDED_PUNISH keeps the separate launch (A/B timing, parity of the two forms). */
+#define DVGR_OPT_NO_FOLDED_PUNISH 2048
 
 /* Scope-U loss evaluated by the forward itself (dvgr_opts.loss): the same arithmetic and outputs as
  * dvgr_scope_u_loss below, but the kernels are enqueued as soon as the last layer's list outputs exist and run on the

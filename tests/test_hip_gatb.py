@@ -257,3 +257,32 @@ def test_half_height_tiles_backward_against_oracle():
     what = f"gatb half-height tiles B={B} N={N} L={Lr} bf16x3 train"
     assert_flips_at_kink(stats, what)
     assert_grads(m, t, gin, gw, dbg, Lr, GTOL, what)
+
+
+@pytest.mark.parametrize("B,N,Lr,train,fused", [(7, 20, 3, True, True), (17, 8, 2, False, True), (6, 24, 2, True, False), (3, 64, 2, True, False),
+                                               (33, 20, 2, True, True)])
+def test_folded_punish_equals_the_separate_launch(B, N, Lr, train, fused):
+    """Round 6: the dX half of a layer's S1 backward (dX += dtau p + the specific GAT's partial; model/utils.py:92-105 backward)
+    completed by the NEXT layer's row pass k_sf_bwd (SfBwdArgs::fin_*) against the separate k_punish_bwd launch
+    (DVGR_OPT_NO_FOLDED_PUNISH): the same sums in the same order but for dtau's eight head partials (tree against chain).
+    L = 3 folds two boundaries; N = 24 / 64 run the two-launch attention backward behind the same row pass."""
+    sd_np = synth.xavier_state_dict(O.param_shapes(WD, D, Lr), seed=67, bias_range=0.05)
+    inp = synth.unit_inputs(B, N, T, D, WD, seed=67)
+    R = torch.from_numpy(synth.normal("R_gatb", (B, N, D), 1.0, 67))
+    got = {}
+    for fold in (True, False):
+        m = _module(N, Lr, "bf16x3", sd_np, train, fused)
+        m.folded_punish = fold
+        _, _, got[fold] = _grads(m, inp, R, N, 1234)
+    worst, wk = 0.0, None
+    for k in got[True]:
+        if k.endswith((".fc.bias", ".a.bias")):
+            continue
+        e = rel_err(got[True][k], got[False][k])
+        if k.endswith(".bias"):          # column sums by float atomics: two runs of ONE form differ by ~2e-5 there
+            assert e < 5e-4, (e, k)
+            continue
+        if e > worst:
+            worst, wk = e, k
+    print(f"  folded punish vs separate launch B={B} N={N} L={Lr}: worst rel err {worst:.2e} ({wk})")
+    assert worst < 1e-5, (worst, wk)

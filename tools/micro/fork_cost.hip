@@ -3,6 +3,7 @@
 // stream that actually waits for it and runs a tiny kernel.  Prints the added time per marker.
 //   hipcc --offload-arch=gfx950 -O2 fork_cost.hip -o fork_cost.bin ;  ./fork_cost.bin [K=200] [iters=600]
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -46,10 +47,18 @@ int main(int argc, char** argv) {
       (void)hipDeviceSynchronize();
       (void)hipEventRecord(t0, A);
       for (int k = 0; k < K; ++k) {
+        if (mode == 3) {
+          hipExtLaunchKernelGGL(k_spin, dim3(256), dim3(256), 0, A, nullptr, ev[fset][k], 0, buf + 1024, iters);
+          if (waiter) { (void)hipStreamWaitEvent(B, ev[fset][k], 0); k_tiny<<<1, 64, 0, B>>>(buf); }
+          continue;
+        }
         k_spin<<<256, 256, 0, A>>>(buf + 1024, iters);
         if (mode == 1) {
           (void)hipEventRecord(ev[fset][k], A);
           if (waiter) { (void)hipStreamWaitEvent(B, ev[fset][k], 0); k_tiny<<<1, 64, 0, B>>>(buf); }
+        } else if (mode == 3) {
+          // the marker rides on the kernel's own dispatch packet: hipExtLaunchKernelGGL(..., stopEvent) -- no barrier packet between
+          // this kernel and the next one of the chain
         } else if (mode == 2) {
           ++epoch;
           (void)hipStreamWriteValue32(A, flag, epoch, 0);
@@ -69,6 +78,11 @@ int main(int argc, char** argv) {
   for (int f = 0; f < 3; ++f) {
     const float a = run(1, f, false), b = run(1, f, true);
     printf("  hipEventRecord after every kernel, flags %-34s: +%.2f us per record;  with a waiting stream: +%.2f us\n", flagnames[f],
+           (a - base) / K, (b - base) / K);
+  }
+  for (int f = 0; f < 3; ++f) {
+    const float a = run(3, f, false), b = run(3, f, true);
+    printf("  stop event ON the kernel's launch (hipExtLaunchKernelGGL), flags %-34s: +%.2f us per kernel;  with a waiting stream: +%.2f us\n", flagnames[f],
            (a - base) / K, (b - base) / K);
   }
   {
