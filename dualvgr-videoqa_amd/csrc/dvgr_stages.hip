@@ -399,8 +399,9 @@ __global__ __launch_bounds__(256) void k_sf_bwd(const SfBwdArgs a) {
   const float4* ge = a.g_embed[mod] ? reinterpret_cast<const float4*>(a.g_embed[mod] + r0) : nullptr;
   const float4* z0 = reinterpret_cast<const float4*>(a.z0[mod] + r0);
   const float4* z1 = reinterpret_cast<const float4*>(a.z1[mod] + r0);
-  // the dX half of the layer above's S1 backward, on the row while it is read (SfBwdArgs::fin_*): d = dX + add + dtau p.  Both
-  // passes over the row form d from the SAME inputs (no read of a value this launch stored); the second one stores it.
+  // the dX half of the layer above's S1 backward, on the row while it is read (SfBwdArgs::fin_*): d = dX + add + dtau p.  Where
+  // the row does not stay in registers both passes form d from the SAME inputs (no read of a value this launch stored); the
+  // second pass stores it.
   const bool fin = a.fin_dX[mod] != nullptr;               // (uniform)
   float dtau = 0.f;
   const float4* fadd = nullptr;
@@ -423,13 +424,28 @@ __global__ __launch_bounds__(256) void k_sf_bwd(const SfBwdArgs a) {
     }
     return d;
   };
+  // The row's gradient d stays in registers between the two passes where the row fits (D <= 768: three float4 per lane) --
+  // the second pass then re-reads neither dX nor the folded-in tensors (round 6; until then dX came back from L2).
+  constexpr int KC3 = 3;
+  const bool cached = D4 <= 64 * KC3;                      // (uniform)
+  float4 dreg[KC3];
+#pragma unroll
+  for (int it = 0; it < KC3; ++it) dreg[it] = make_float4(0.f, 0.f, 0.f, 0.f);
   float db0 = 0.f, db1 = 0.f;
-  for (int k = lane; k < D4; k += 64) {
-    float4 d = row_grad(k);
+  auto dots = [&](int k, float4 d) {
     if (ge) { const float4 e = ge[k]; d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w; }
     const float4 u = z0[k], v = z1[k];
     db0 += d.x * u.x + d.y * u.y + d.z * u.z + d.w * u.w;
     db1 += d.x * v.x + d.y * v.y + d.z * v.z + d.w * v.w;
+  };
+  if (cached) {
+#pragma unroll
+    for (int it = 0; it < KC3; ++it) {
+      const int k = lane + 64 * it;
+      if (k < D4) { dreg[it] = row_grad(k); dots(k, dreg[it]); }
+    }
+  } else {
+    for (int k = lane; k < D4; k += 64) dots(k, row_grad(k));
   }
   db0 = wave_sum(db0); db1 = wave_sum(db1);
   const float b0 = a.beta[mod][row * 2], b1 = a.beta[mod][row * 2 + 1];
@@ -447,8 +463,7 @@ __global__ __launch_bounds__(256) void k_sf_bwd(const SfBwdArgs a) {
   float4* dz0 = wdz ? reinterpret_cast<float4*>(a.dz[mod] + r0) : nullptr;
   float4* dz1 = wdz ? reinterpret_cast<float4*>(a.dz[mod] + r1) : nullptr;
   float4* dXf = fin ? reinterpret_cast<float4*>(a.fin_dX[mod] + r0) : nullptr;
-  for (int k = lane; k < D4; k += 64) {
-    float4 d = row_grad(k);
+  auto outputs = [&](int k, float4 d) {
     if (fin) dXf[k] = d;                                   // the completed running gradient (read by the fused backward's B0 and the dX contraction)
     if (ge) { const float4 e = ge[k]; d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w; }
     const float4 ta = t0[k], tb = t1[k], p = p2[k];
@@ -467,6 +482,15 @@ __global__ __launch_bounds__(256) void k_sf_bwd(const SfBwdArgs a) {
       st4(dz0 + k, o0);
       st4(dz1 + k, o1);
     }
+  };
+  if (cached) {
+#pragma unroll
+    for (int it = 0; it < KC3; ++it) {
+      const int k = lane + 64 * it;
+      if (k < D4) outputs(k, dreg[it]);
+    }
+  } else {
+    for (int k = lane; k < D4; k += 64) outputs(k, row_grad(k));
   }
 }
 int sf_bwd(hipStream_t st, const SfBwdArgs& a) {
