@@ -59,11 +59,11 @@ inline hipStream_t shared_side_stream(int dev, int which = 0, bool create = true
     if (!st[dev][2] && hipStreamCreateWithPriority(&st[dev][2], hipStreamNonBlocking, hi) != hipSuccess) st[dev][2] = nullptr;
     return st[dev][2];
   }
-  // (experiment switch, round 6: DVGR_SIDE_PRIO bit 0 = the side stream at the HIGHEST priority instead of the lowest, bit 1 = the
-  // query stream: the forward's query chain S0 on the side stream is on the critical path of layer 0)
-  static const int prio_env = []() { const char* e = getenv("DVGR_SIDE_PRIO"); return e ? atoi(e) : 0; }();
+  // (both at the LOWEST priority.  Round 6 re-measured it -- the forward's query chain S0 on the side stream is on layer 0's
+  // critical path -- with either or both at the highest: C2 0.9218-0.9251 against 0.9250 ms, C4 1.1197-1.1257 against 1.1216:
+  // no difference, experiments_r06.tsv side_stream_priority_*)
   for (int w = 0; w <= which; ++w)             // side before query, always
-    if (!st[dev][w]) st[dev][w] = place_stream(dev, ((prio_env >> w) & 1) ? hi : lo, caller, w == 0 ? kRankSide : kRankQuery, nullptr, nullptr);
+    if (!st[dev][w]) st[dev][w] = place_stream(dev, lo, caller, w == 0 ? kRankSide : kRankQuery, nullptr, nullptr);
   return st[dev][which];
 }
 inline void set_shared_stream(int dev, int which, hipStream_t s) {
