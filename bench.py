@@ -154,7 +154,14 @@ _RESULT_FD = None
 
 
 def emit(obj):
-    """The ONE result line, on the process's original stdout."""
+    """The ONE result line, on the process's original stdout.  A reducer set-up the trials flagged (config.distributed.
+    reducer_trial.suspect_setup) is repeated as a TOP-LEVEL field, where tools/ab.py and the profiles/ consumers look."""
+    try:
+        rt = ((obj.get("config") or {}).get("distributed") or {}).get("reducer_trial") or {}
+        if rt.get("suspect_setup"):
+            obj["suspect_setup"] = True
+    except AttributeError:
+        pass
     line = (json.dumps(obj) + "\n").encode()
     if _RESULT_FD is None:
         sys.stdout.write(line.decode())
@@ -222,6 +229,9 @@ class TrialBoard:
 
     def __init__(self, rank, world):
         self.rank, self.world, self.store = rank, world, None
+        # keys carry the launcher's run id and restart count: after a torchrun restart (--max-restarts), or a second bench through
+        # the same agent store, get() / wait() would otherwise return the previous attempt's ports and outcomes at once
+        self.ns = "dvgr_trial_{}_{}_".format(os.environ.get("TORCHELASTIC_RUN_ID", "run"), os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"))
         if world > 1 and os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") == "True":
             try:
                 import datetime
@@ -239,8 +249,8 @@ class TrialBoard:
             return fixed if self.world > 1 else [free_port() for _ in range(n)]
         try:
             if self.rank == 0:
-                self.store.set("dvgr_trial_ports", json.dumps([free_port() for _ in range(n)]))
-            return json.loads(self.store.get("dvgr_trial_ports").decode())
+                self.store.set(self.ns + "ports", json.dumps([free_port() for _ in range(n)]))
+            return json.loads(self.store.get(self.ns + "ports").decode())
         except Exception as e:                                # noqa: BLE001
             print(f"[bench] trial ports over the agent store failed ({e!r}): fixed port offsets", file=sys.stderr, flush=True)
             self.store = None
@@ -251,8 +261,8 @@ class TrialBoard:
         if self.store is None:         # one rank, or no store: every candidate is tried; several ranks agree afterwards (MAX all-reduce)
             return ms, True
         try:
-            self.store.set(f"dvgr_trial_{kind}_{self.rank}", json.dumps(ms))
-            keys = [f"dvgr_trial_{kind}_{r}" for r in range(self.world)]
+            self.store.set(f"{self.ns}{kind}_{self.rank}", json.dumps(ms))
+            keys = [f"{self.ns}{kind}_{r}" for r in range(self.world)]
             self.store.wait(keys)
             vals = [json.loads(self.store.get(k).decode()) for k in keys]
         except Exception as e:                                # noqa: BLE001
@@ -699,7 +709,7 @@ def main():
     # the optimiser of train.py:158-159 over the unit's flat buffers (clip 12 + Adam, two launches), reported separately:
     # the headline metric is forward + backward
     opt = trainer.ClipAdam(lr=1e-4, max_norm=12.0)
-    seg = [("unit", m.flat_params(), m.last_flat_grad, m.lowp_planes())]
+    seg = [("unit", m.flat_params(), m.last_flat_grad, m.lowp_planes())]    # (one lowp_planes() for 23 rewrites: planes_rewritten() below)
     for _ in range(3):
         opt.step(seg)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -709,6 +719,7 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     optimizer_ms = e0.elapsed_time(e1) / 20
+    m.planes_rewritten()
 
     ms_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt

@@ -121,6 +121,7 @@ SYMBOLS += [
     ("dvgr_dbg_event_destroy", C.c_int, [C.c_void_p]),
     ("dvgr_dbg_launch_count", C.c_longlong, []),
     ("dvgr_dbg_xmap_tags", C.c_int, [C.c_int]),
+    ("dvgr_dbg_plan_xcd_blocks", C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 ]
 
 _lib = None

@@ -1676,6 +1676,10 @@ long long dvgr_dbg_launch_count(void) { return dvgr::g_launch_count.load(std::me
 
 int dvgr_dbg_xmap_tags(int mask) { return dvgr::gemm_xmap_tags(mask); }
 
+int dvgr_dbg_plan_xcd_blocks(int n, const int* M, const int* N, const int* K, int bm, int bn, int max_per_xcd, int* seg_out) {
+  return dvgr::gemm_plan_xcd_blocks(n, M, N, K, bm, bn, max_per_xcd, seg_out);
+}
+
 uint32_t dvgr_dbg_site_key(uint64_t seed, int layer, int mod, int gat, int which) {
   return site_key(seed, drop_site(layer, mod, gat, which));
 }

@@ -103,6 +103,9 @@ int gemm_launch_mixed(hipStream_t stream, const GemmBatch& batch, int tag = TAG_
 
 // Which launch-site tags take the XCD block map (bit per tag); returns the previous mask, mask < 0 = the build's default.
 int gemm_xmap_tags(int mask);
+// The XCD block map's planner for n problems of (M, N, K) on bm x bn tiles: the grid's x extent, 0 when the batch does not fit the
+// scheme, < 0 on bad arguments; seg_out (nullable): 8 x 2 x {problem, m_lo, m_cnt, n_lo, n_cnt}.
+int gemm_plan_xcd_blocks(int n, const int* M, const int* N, const int* K, int bm, int bn, int max_per_xcd, int* seg_out);
 
 // Enqueue the batch on `stream`.  la / lb in {KC, IC}.  Returns hipError_t as int.
 int gemm_launch(hipStream_t stream, int la, int lb, const GemmBatch& batch, int tag = TAG_GENERIC, int prec = DVGR_F32);

@@ -1602,6 +1602,24 @@ static int plan_xcd_blocks(GemmBatch* b, int BM = RT, int BN = RT, int max_per_x
   return 8 * per_xcd;
 }
 
+// The planner behind a plain interface (include/dvgr_debug.h: dvgr_dbg_plan_xcd_blocks; host code only -- tests/test_cabi.py
+// holds it to its invariants without a GPU): seg_out[x][k] = {problem, m_lo, m_cnt, n_lo, n_cnt} as five ints.
+int gemm_plan_xcd_blocks(int n, const int* M, const int* N, const int* K, int bm, int bn, int max_per_xcd, int* seg_out) {
+  if (n < 1 || n > kMaxBatch || !M || !N || !K || bm < 1 || bn < 1) return -1;
+  GemmBatch b{};
+  b.n = n;
+  for (int i = 0; i < n; ++i) { b.p[i].M = M[i]; b.p[i].N = N[i]; b.p[i].K = K[i]; }
+  const int gx = plan_xcd_blocks(&b, bm, bn, max_per_xcd);
+  if (gx && seg_out)
+    for (int x = 0; x < 8; ++x)
+      for (int k = 0; k < 2; ++k) {
+        const XcdSeg g = b.seg[x][k];
+        int* o = seg_out + (x * 2 + k) * 5;
+        o[0] = g.prob; o[1] = g.m_lo; o[2] = g.m_cnt; o[3] = g.n_lo; o[4] = g.n_cnt;
+      }
+  return gx;
+}
+
 template <int LA, int LB, int TAG>
 static int launch_ring(hipStream_t stream, const GemmBatch& b_in, int prec) {
   GemmBatch b = b_in;

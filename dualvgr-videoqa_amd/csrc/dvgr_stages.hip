@@ -493,6 +493,10 @@ __global__ __launch_bounds__(256) void k_sf_bwd(const SfBwdArgs a) {
     for (int k = lane; k < D4; k += 64) outputs(k, row_grad(k));
   }
 }
+// (Round 6 also tried this pass as straight-line code for D = 768 -- FIN / ADD / GE compile-time, every load of a pass issued before
+// the first wait, 2 memory round trips per row instead of ~10 behind the run-time branches above: the launch measures the same,
+// 29.6 against 30.2 us beside the weight-gradient launch (rocprofv3), the step +-0: the kernel runs at the share of the memory
+// system the side stream leaves it, not at its own latency chain.  Not kept.)
 int sf_bwd(hipStream_t st, const SfBwdArgs& a) {
   DVGR_LAUNCH(k_sf_bwd, dim3((a.rows + 3) / 4, 2), dim3(256), 0, st, a);
   DVGR_LAUNCH_CHECK();

@@ -549,12 +549,23 @@ class DualVGRUnit_multiple(nn.Module):
     def lowp_planes(self):
         """The bf16 hi / lo planes tensor of the flat parameter buffer (None in fp32 mode), allocated if need be; for a
         caller that rewrites it together with the parameters in one pass (trainer.ClipAdam: no repack follows such a step
-        because the fused kernel bumps no version counter; anyone else calls params_changed())."""
+        because the fused kernel bumps no version counter; anyone else calls params_changed()).
+
+        CONTRACT: everything derived from the planes -- the transposed P1 planes the fused backward contracts against, the
+        8-bit lo planes -- is rebuilt at the next backward only if this object KNOWS the planes were rewritten.  Each call
+        of lowp_planes() counts as one rewrite (trainer.TrainStep calls it every step).  A caller that keeps the tensor and
+        rewrites it again later must call planes_rewritten() after every such rewrite; otherwise the next backward multiplies
+        dz by LAST step's P1^T without any error."""
         if self.dtype_code == L_.DVGR_F32 or self.no_planes:
             return None
         self.lowp_ptr()
         self._p1t_stale = True              # the caller rewrites the planes: their transposed copies follow at the next backward
         return self._lowp
+
+    def planes_rewritten(self):
+        """The planes tensor handed out by lowp_planes() was rewritten again (see its contract): the derived copies (P1^T,
+        8-bit lo planes) are rebuilt at the next backward."""
+        self._p1t_stale = True
 
     def params_changed(self):
         """The flat parameter buffer was modified behind autograd's back (no `_version` bump, e.g. by a raw kernel): the

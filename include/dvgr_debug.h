@@ -68,6 +68,13 @@ int dvgr_dbg_event_destroy(void *event);
  * parity tests hold the engine to that (tests/test_hip_blocks.py). */
 int dvgr_dbg_xmap_tags(int mask);
 
+/* The planner of that map, host code only (no GPU needed): n (<= 12) problems of M[i] x N[i] outputs and reduction length K[i]
+ * on bm x bn tiles, at most max_per_xcd tiles per XCD.  Returns the launch's grid extent (8 x the tiles of the busiest XCD), 0
+ * when the batch does not fit the scheme (more than two reduction lengths, a class whose problem count does not divide 8, a
+ * tile grid that cannot be cut into equal rectangles), < 0 on bad arguments.  seg_out (nullable, 80 ints): for XCD x and
+ * class k the block {problem, first row tile, row tiles, first column tile, column tiles} at seg_out[(2 x + k) * 5]. */
+int dvgr_dbg_plan_xcd_blocks(int n, const int *M, const int *N, const int *K, int bm, int bn, int max_per_xcd, int *seg_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -275,3 +275,80 @@ def test_clip_layout_and_argument_checks():
     assert lib.dvgr_lstm_forward(C.byref(ok), None, C.byref(io), 0, None, 0, None, 0, 0, 0, None) == -2
     assert lib.dvgr_clip_forward(C.byref(ok), None, None, None, None, 0, None, 0, 0, 0, None) == -2
     assert lib.dvgr_clip_saved_bytes(C.byref(ok)) > 0 and lib.dvgr_clip_workspace_bytes(C.byref(ok)) > 0
+
+
+def _plan(problems, bm=128, bn=128, max_per_xcd=32):
+    lib = L.load()
+    n = len(problems)
+    M = (C.c_int * n)(*[p[0] for p in problems])
+    N = (C.c_int * n)(*[p[1] for p in problems])
+    K = (C.c_int * n)(*[p[2] for p in problems])
+    seg = (C.c_int * 80)()
+    gx = lib.dvgr_dbg_plan_xcd_blocks(n, C.addressof(M), C.addressof(N), C.addressof(K), bm, bn, max_per_xcd, C.addressof(seg))
+    return gx, [[tuple(seg[(2 * x + k) * 5:(2 * x + k) * 5 + 5]) for k in range(2)] for x in range(8)]
+
+
+@pytest.mark.parametrize("name,problems,bm,bn,cap", [
+    ("C2 weight gradients: dP1 x 2 (K = 2 B N) + dWcat x 4 (K = B N)", [(768, 768, 2560)] * 2 + [(768, 768, 1280)] * 4, 128, 128, 32),
+    ("C2 S4: 2 views x 2 modalities", [(1280, 768, 768)] * 4, 128, 128, 32),
+    ("C2 layer-0 projection", [(1280, 1536, 768)] * 2, 128, 128, 32),
+    ("C3 S4", [(1024, 768, 768)] * 4, 128, 128, 32),
+    ("C4 S4 on half-height tiles", [(512, 768, 768)] * 4, 64, 128, 32),
+    ("C5 S4 on 128 x 256 tiles", [(4096, 768, 768)] * 4, 128, 256, 96),
+    ("eval-mode weight gradients", [(768, 768, 2560)] * 2 + [(1536, 768, 1280)] * 2, 128, 128, 32),
+    ("a partial last row tile", [(1200, 768, 768)] * 4, 128, 128, 32),
+])
+def test_xcd_block_map_planner_covers_every_tile_once_and_balances_the_xcds(name, problems, bm, bn, cap):
+    """csrc/dvgr_gemm.hip plan_xcd_blocks (host code; round 6): every output tile of every problem belongs to exactly one XCD's
+    block, the blocks of a class are equal, every XCD gets one block per class (equal work), the grid covers the busiest XCD."""
+    gx, seg = _plan(problems, bm, bn, cap)
+    assert gx > 0, name
+    seen = {}
+    per_xcd = []
+    classes = []                                         # reduction lengths in order of first appearance = the planner's class order
+    for p in problems:
+        if p[2] not in classes:
+            classes.append(p[2])
+    for x in range(8):
+        cnt = 0
+        for k in range(2):
+            pi, m_lo, m_cnt, n_lo, n_cnt = seg[x][k]
+            if m_cnt * n_cnt == 0:
+                continue
+            assert classes.index(problems[pi][2]) == k or len(classes) == 1     # block k of an XCD belongs to class k
+            for mi in range(m_lo, m_lo + m_cnt):
+                for ni in range(n_lo, n_lo + n_cnt):
+                    assert (pi, mi, ni) not in seen, (name, pi, mi, ni)
+                    seen[(pi, mi, ni)] = x
+            cnt += m_cnt * n_cnt
+        per_xcd.append(cnt)
+    want = {(i, mi, ni) for i, (M, N, _) in enumerate(problems) for mi in range(-(-M // bm)) for ni in range(-(-N // bn))}
+    assert set(seen) == want, name
+    assert len(set(per_xcd)) == 1 and gx == 8 * per_xcd[0] and per_xcd[0] <= cap, (name, per_xcd, gx)
+    # equal K-steps per XCD: one block of each class everywhere
+    work = [sum(seg[x][k][2] * seg[x][k][4] * problems[seg[x][k][0]][2] for k in range(2) if seg[x][k][2]) for x in range(8)]
+    assert len(set(work)) == 1, (name, work)
+
+
+@pytest.mark.parametrize("name,problems,bm,bn,cap", [
+    ("three problems: 8 % 3 != 0", [(1280, 768, 768)] * 3, 128, 128, 32),
+    ("three reduction lengths", [(768, 768, 256), (768, 768, 512), (768, 768, 1024)], 128, 128, 32),
+    ("more tiles per XCD than one round", [(4096, 768, 768)] * 4, 128, 128, 32),
+    ("a tile grid that cannot be cut in two equal rectangles", [(640, 384, 768)] * 4, 128, 128, 32),
+    ("unequal problems in one class", [(1280, 768, 768), (640, 768, 768)] * 2, 128, 128, 32),
+])
+def test_xcd_block_map_planner_declines_what_it_cannot_balance(name, problems, bm, bn, cap):
+    gx, _ = _plan(problems, bm, bn, cap)
+    assert gx == 0, (name, gx)
+
+
+def test_xcd_block_map_planner_argument_checks():
+    lib = L.load()
+    assert lib.dvgr_dbg_plan_xcd_blocks(0, None, None, None, 128, 128, 32, None) < 0
+    assert lib.dvgr_dbg_plan_xcd_blocks(13, None, None, None, 128, 128, 32, None) < 0
+    one = (C.c_int * 1)(768)
+    assert lib.dvgr_dbg_plan_xcd_blocks(1, C.addressof(one), C.addressof(one), C.addressof(one), 0, 128, 32, None) < 0
+    # one problem on all eight XCDs: 6 x 6 tiles cannot be cut into 8 equal rectangles, 8 x 6 can (4 x 2 blocks of 2 x 3)
+    assert _plan([(768, 768, 768)])[0] == 0
+    gx, seg = _plan([(1024, 768, 768)])
+    assert gx == 8 * 6 and all(seg[x][0][2] * seg[x][0][4] == 6 for x in range(8))

@@ -181,3 +181,46 @@ def test_adam_pass_keeps_the_units_bf16_planes_in_step():
         m.visual_input_unit.params_changed()            # force dvgr_pack_weights from the fp32 parameters
         b = m(app, mot, q, qlen)[0]
     assert torch.equal(a, b)
+
+
+def test_kept_planes_tensor_needs_planes_rewritten_and_gets_the_right_gradients_with_it():
+    """unit.lowp_planes() contract: a caller that keeps the planes tensor and rewrites it on later steps must call
+    planes_rewritten(), or the fused backward contracts dz against LAST step's transposed P1 planes.  With the call the gradients
+    after two optimizer steps equal those of a fresh module holding the same parameters (planes and P1^T packed from scratch)."""
+    from dualvgr_videoqa_amd import synth
+    from oracle import unit_torch as O       # (shapes and the scalar loss only)
+    B, N, T, D, Wd, Lr = 8, 20, 9, 768, 300, 2
+    sd_np = synth.xavier_state_dict(O.param_shapes(Wd, D, Lr), seed=91, bias_range=0.05)
+    inp = synth.unit_inputs(B, N, T, D, Wd, seed=91)
+
+    def fwd_bwd(m):
+        t = {k: torch.from_numpy(v.copy()).cuda() for k, v in inp.items()}
+        for k in ("A", "M", "dq", "words"):
+            t[k].requires_grad_(True)
+        if m.last_flat_grad is not None:
+            m.zero_grad_flat()
+        O.bench_scalar_loss(m(t["A"], t["M"], t["dq"], t["words"], t["qlen"]), N).backward()
+        torch.cuda.synchronize()
+        return {k: p.grad.detach().clone() for k, p in m.named_parameters()}, t["A"].grad.detach().clone()
+
+    m = dv.DualVGRUnit_multiple(word_dim=Wd, module_dim=D, num_of_nodes=N, unit_layers=Lr, dtype="bf16x3")
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
+    m = m.cuda().eval()
+    m.fused_gat_bwd = "force"
+    fwd_bwd(m)                                              # packs the planes and P1^T once
+    planes = m.lowp_planes()                                # kept across steps
+    opt = trainer.ClipAdam(lr=5e-2, max_norm=12.0)
+    for _ in range(2):
+        opt.step([("unit", m.flat_params(), m.last_flat_grad, planes)])
+        m.planes_rewritten()
+    got_w, got_a = fwd_bwd(m)
+    ref = dv.DualVGRUnit_multiple(word_dim=Wd, module_dim=D, num_of_nodes=N, unit_layers=Lr, dtype="bf16x3")
+    ref.load_state_dict({k: v.detach().cpu().clone() for k, v in m.state_dict().items()})
+    ref = ref.cuda().eval()
+    ref.fused_gat_bwd = "force"
+    want_w, want_a = fwd_bwd(ref)
+    assert float((got_a - want_a).abs().max()) <= 2e-6 * float(want_a.abs().max())
+    for k in want_w:
+        if k.endswith(".bias"):
+            continue
+        assert float((got_w[k] - want_w[k]).abs().max()) <= 1e-5 * float(want_w[k].abs().max()), k

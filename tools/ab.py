@@ -52,6 +52,8 @@ def main():
                 print(out.stderr[-2000:], file=sys.stderr)
                 raise SystemExit(f"variant {name} failed")
             d = json.loads(out.stdout.strip().splitlines()[-1])
+            if d.get("suspect_setup"):       # bench.py: the reducer trials flagged the stream set-up -- not a measurement to log as one
+                raise SystemExit(f"variant {name}: bench.py reports suspect_setup (config.distributed.reducer_trial); refusing to log the row")
             res[name].append(d["ms_per_step"])
             launches[name] = d["config"].get("launches_per_step")
             print(f"round {r} {name}: {d['ms_per_step']:.4f} ms/step", flush=True)
