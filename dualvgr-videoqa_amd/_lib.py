@@ -68,6 +68,8 @@ OPT_NO_LO8 = 256
 OPT_KB32 = 512
 OPT_NO_HALF_GAT_TILES = 1024
 OPT_NO_FOLDED_PUNISH = 2048
+OPT_S0_ON_MAIN = 4096
+OPT_S0_ON_SIDE = 8192
 
 # enum dvgr_probe_site
 (PROBE_NONE, PROBE_FWD_QA_GEMM, PROBE_FWD_GAT_GEMM, PROBE_FWD_GAT_ATTN, PROBE_FWD_SF_GEMM, PROBE_FWD_MFB_GEMM,

@@ -483,39 +483,72 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
     DVGR_TRY(split_planes(st, sb));
   }
 
-  // ---- S0: query side of every layer.  Its contraction (Y_l = dq . W1_l^T, every layer in one launch) runs FIRST and
-  // alone on the main stream -- beside layer 0's Wh contraction each takes twice as long and the punish gate waits for
-  // the slower one (measured: gate at 102 us with the two side by side, 62 us this way); the row kernels and the small
-  // Wq contraction behind it go to the side stream, under layer 0's Wh contraction, and join in front of the gate.
+  // ---- S0: query side of every layer: the contraction Y_l = dq . W1_l^T, the row kernels, the small Wq contraction (below).
   SideStream* side = (O.flags & DVGR_OPT_SINGLE_STREAM) ? nullptr : side_stream(st);
   hipStream_t hs = side ? side->st : st;
   const Probe fprobe{O, st};
-  for (int l0 = 0; l0 < L; l0 += kMaxBatch) {
-    GemmBatch gb{};
-    for (int l = l0; l < L && l < l0 + kMaxBatch; ++l) {
-      gb.p[gb.n] = nt(io->dq, D, lp(l) + P.qa_w1, D, ws + W.Y + (int64_t)l * BT * D, D, lp(l) + P.qa_b1, BT, D, D, ACT_NONE);
-      PM.attach(gb.p[gb.n++]);
+  auto y_gemm = [&](int la, int lb_, hipStream_t on) -> int {   // Y_l = dq W1_l^T + b1_l for the layers [la, lb_)
+    for (int l0 = la; l0 < lb_; l0 += kMaxBatch) {
+      GemmBatch gb{};
+      for (int l = l0; l < lb_ && l < l0 + kMaxBatch; ++l) {
+        gb.p[gb.n] = nt(io->dq, D, lp(l) + P.qa_w1, D, ws + W.Y + (int64_t)l * BT * D, D, lp(l) + P.qa_b1, BT, D, D, ACT_NONE);
+        PM.attach(gb.p[gb.n++]);
+      }
+      const Probe pr{O, on};
+      DVGR_TRY(pr.begin(DVGR_PROBE_FWD_QA_GEMM, l0));
+      DVGR_TRY(gemm_launch(on, KC, KC, gb, TAG_GENERIC, prec));
+      DVGR_TRY(pr.end(DVGR_PROBE_FWD_QA_GEMM, l0));
     }
-    DVGR_TRY(fprobe.begin(DVGR_PROBE_FWD_QA_GEMM, l0));
-    DVGR_TRY(gemm_launch(st, KC, KC, gb, TAG_GENERIC, prec));
-    DVGR_TRY(fprobe.end(DVGR_PROBE_FWD_QA_GEMM, l0));
-  }
-  if (side) DVGR_TRY(side->order(st, hs));
-  {
+    return 0;
+  };
+  auto qa_rows = [&](int la, int cnt, hipStream_t on) -> int {  // the row kernels of the layers [la, la + cnt): every per-layer address is base + l * stride
     QaRowsArgs a{};
-    a.Y = ws + W.Y; a.logit = ws + W.R; a.params = params + P.q_base; a.off_w2 = P.qa_w2; a.off_b2 = P.qa_b2; a.layer_stride = P.q_layer_stride;
-    a.words = io->words; a.qlen = io->qlen; a.saved = saved; a.s_layer_stride = S.layer_stride;
+    a.Y = ws + W.Y + (int64_t)la * BT * D; a.logit = ws + W.R + (int64_t)la * BT;
+    a.params = params + P.q_base + (int64_t)la * P.q_layer_stride; a.off_w2 = P.qa_w2; a.off_b2 = P.qa_b2; a.layer_stride = P.q_layer_stride;
+    a.words = io->words; a.qlen = io->qlen; a.saved = saved + (int64_t)la * S.layer_stride; a.s_layer_stride = S.layer_stride;
     a.s_d = S.qa_d; a.s_nrm = S.qa_nrm; a.s_a = S.qa_a; a.s_ah = S.qa_ah; a.s_S = S.qa_s; a.s_q = S.qa_q;
-    a.B = B; a.T = T; a.D = D; a.Wd = Wd; a.L = L;
-    DVGR_TRY(qa_rows_fwd(hs, a));
-  }
-  {
+    a.B = B; a.T = T; a.D = D; a.Wd = Wd; a.L = cnt;
+    return qa_rows_fwd(on, a);
+  };
+  auto wq_gemm = [&](int la, int lb_, hipStream_t on) -> int {  // p = Wq q + bq of the layers [la, lb_), both modalities
     GemmBatch gb{};
-    for (int l = 0; l < L; ++l)
+    for (int l = la; l < lb_; ++l)
       for (int m = 0; m < 2; ++m) {
         gb.p[gb.n++] = nt(ls(l) + S.qa_q, Wd, qp(l, m) + P.wq, Wd, ms(l, m) + S.p, D, qp(l, m) + P.bq, B, D, Wd, ACT_NONE);
-        if (gb.n == kMaxBatch || (l == L - 1 && m == 1)) { DVGR_TRY(gemm_launch(hs, KC, KC, gb, TAG_GENERIC, prec)); gb.n = 0; }
+        if (gb.n == kMaxBatch || (l == lb_ - 1 && m == 1)) { DVGR_TRY(gemm_launch(on, KC, KC, gb, TAG_GENERIC, prec)); gb.n = 0; }
       }
+    return 0;
+  };
+  // Where S0 runs (two streams):
+  //   DVGR_OPT_S0_ON_SIDE   the form of rounds 1-5: the contraction of all layers on the main stream, rows + Wq on the side stream
+  //                         under layer 0's separate projection, joined in front of the gate (layer 0 = two launches)
+  //   DVGR_OPT_S0_ON_MAIN   everything on the main stream in front of layer 0, which then takes the fused kernel (no fork / join)
+  //   default (round 6)     LAYER 0's share on the main stream in front of the fused layer-0 kernel; the other layers' share on the
+  //                         side stream, forked right behind the input split and needed by layer 0's S5 (the gate of layer 1)
+  const bool s0_side = side && (O.flags & DVGR_OPT_S0_ON_SIDE);
+  const bool s0_all_main = side && !s0_side && ((O.flags & DVGR_OPT_S0_ON_MAIN) || L == 1);
+  const bool s0_main = side && !s0_side;                     // layer 0's gate exists before layer 0 starts: it takes the fused kernel
+  hipEvent_t s0_rest_ev = nullptr;
+  if (!side || s0_all_main) {
+    DVGR_TRY(y_gemm(0, L, st));
+    DVGR_TRY(qa_rows(0, L, st));
+    DVGR_TRY(wq_gemm(0, L, st));
+  } else if (s0_side) {
+    DVGR_TRY(y_gemm(0, L, st));
+    DVGR_TRY(side->order(st, hs));
+    DVGR_TRY(qa_rows(0, L, hs));
+    DVGR_TRY(wq_gemm(0, L, hs));
+  } else {
+    DVGR_TRY(side->order(st, hs));                           // (behind the input split: the planes of dq exist)
+    DVGR_TRY(y_gemm(1, L, hs));
+    DVGR_TRY(qa_rows(1, L - 1, hs));
+    DVGR_TRY(wq_gemm(1, L, hs));
+    s0_rest_ev = side->next();
+    if (!s0_rest_ev) return (int)hipErrorOutOfMemory;
+    { const hipError_t e_ = hipEventRecord(s0_rest_ev, hs); if (e_ != hipSuccess) return (int)e_; }
+    DVGR_TRY(y_gemm(0, 1, st));
+    DVGR_TRY(qa_rows(0, 1, st));
+    DVGR_TRY(wq_gemm(0, 1, st));
   }
 
   // ---- layers ---------------------------------------------------------------------------------------
@@ -528,7 +561,7 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
   // S2 + S3 as one launch (dvgr_gatf.hip) where the shape allows it.  Layer 0 beside the side stream keeps two launches: its
   // gate needs the query chain S0, which runs on the side stream UNDER the separate projection.
   const bool fuse_ok = PM.on && !(O.flags & DVGR_OPT_NO_FUSED_GAT) && gat_fused_supported(B, N, D, prec);
-  auto fuse_gat = [&](int l, int j) { return fuse_ok && !(side && l == 0 && j == 0); };
+  auto fuse_gat = [&](int l, int j) { return fuse_ok && !(side && !s0_main && l == 0 && j == 0); };
   auto gs_ = [&](int l, int m, int j) { return ms(l, m) + S.g_stride * j; };                   // saved block of graph layer j
   int aux_done = 0;                      // unit layers whose list entries have gone to the auxiliary-loss kernels
   for (int l = 0; l < L; ++l) {
@@ -612,7 +645,7 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
       DVGR_TRY(fprobe.end(DVGR_PROBE_FWD_GAT_GEMM, l));
     }
     // S1 (needs p from S0: the side stream joins here)
-    if (l == 0 && j == 0 && side) DVGR_TRY(side->order(hs, st));
+    if (l == 0 && j == 0 && side && !s0_main) DVGR_TRY(side->order(hs, st));
     if (l == 0 && j == 0 && !fuse_gat(l, j))   // layers > 0: gate computed by the previous layer's S5 kernel
       DVGR_TRY(punish_fwd(st, Xin[0], Xin[1], ms(l, 0) + S.p, ms(l, 1) + S.p, ms(l, 0) + S.s, ms(l, 1) + S.s, B, N, D));
     // S3
@@ -720,6 +753,10 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
       DVGR_TRY(fprobe.begin(DVGR_PROBE_FWD_SF_GEMM, l));
       DVGR_TRY(gemm_launch(st, KC, KC, gb4, TAG_FWD_SF, prec));
       DVGR_TRY(fprobe.end(DVGR_PROBE_FWD_SF_GEMM, l));
+      if (l == 0 && s0_rest_ev) {          // S5 of layer 0 computes layer 1's gate from p_1: the other layers' share of S0
+        const hipError_t e_ = hipStreamWaitEvent(st, s0_rest_ev, 0);
+        if (e_ != hipSuccess) return (int)e_;
+      }
       DVGR_TRY(sf_combine_fwd(st, a5));
     }
   }

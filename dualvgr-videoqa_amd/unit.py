@@ -350,6 +350,7 @@ class DualVGRUnit_multiple(nn.Module):
         self.fused_gat_bwd = not bool(int(os.environ.get("DVGR_NO_FUSED_GAT_BWD", "0")))
         if self.fused_gat_bwd and os.environ.get("DVGR_FORCE_FUSED_GAT_BWD", "0") == "1":
             self.fused_gat_bwd = "force"
+        self.s0_where = os.environ.get("DVGR_S0", "split")         # "split" (default) | "main" (DVGR_OPT_S0_ON_MAIN) | "side" (DVGR_OPT_S0_ON_SIDE: rounds 1-5)
         self.folded_punish = not bool(int(os.environ.get("DVGR_NO_FOLDED_PUNISH", "0")))     # False: DVGR_OPT_NO_FOLDED_PUNISH (the S1 backward's dX half as a launch of its own)
         self.half_gat_tiles = not bool(int(os.environ.get("DVGR_NO_HALF_GAT_TILES", "0")))   # False: DVGR_OPT_NO_HALF_GAT_TILES (64-row tiles of the fused kernels at every batch)
         self.kb64 = not bool(int(os.environ.get("DVGR_KB32", "0")))                    # False: DVGR_OPT_KB32 (32-deep K-tiles in the fused kernels)
@@ -660,6 +661,10 @@ class DualVGRUnit_multiple(nn.Module):
             o.flags |= L_.OPT_NO_HALF_GAT_TILES
         if not self.folded_punish:
             o.flags |= L_.OPT_NO_FOLDED_PUNISH
+        if self.s0_where == "main":
+            o.flags |= L_.OPT_S0_ON_MAIN
+        elif self.s0_where == "side":
+            o.flags |= L_.OPT_S0_ON_SIDE
         if not self.lo8_planes:
             o.flags |= L_.OPT_NO_LO8
         if backward and self.fused_gat_bwd and self.hoist_p1t and dims is not None and \

@@ -267,6 +267,13 @@ enum dvgr_probe_site {
  * the S1 backward (model/utils.py:92-105) -- inside the next layer's row pass (k_sf_bwd) instead of by a kernel of its own
  * (layers >= 1, graph_layers 1; round 6).  DVGR_OPT_NO_FOLDED_PUNISH keeps the separate launch (A/B timing, parity of the two forms). */
 #define DVGR_OPT_NO_FOLDED_PUNISH 2048
+/* Where the forward runs the query side S0 (contraction Y = dq W1^T, row kernels, Wq contraction) when it has its side stream.
+ * Default (round 6): LAYER 0's share on the caller's stream in front of layer 0 -- which then takes the fused GAT-view kernel: its
+ * gate exists before it starts, no fork / join on its path -- and the other layers' share on the side stream, needed by layer 0's
+ * S5.  DVGR_OPT_S0_ON_MAIN: all layers' share on the caller's stream.  DVGR_OPT_S0_ON_SIDE: the form of rounds 1-5 (contraction on
+ * the caller's stream, rows + Wq on the side stream under layer 0's separate projection, joined in front of the gate). */
+#define DVGR_OPT_S0_ON_MAIN 4096
+#define DVGR_OPT_S0_ON_SIDE 8192
 
 /* Scope-U loss evaluated by the forward itself (dvgr_opts.loss): the same arithmetic and outputs as
  * dvgr_scope_u_loss below, but the kernels are enqueued as soon as the last layer's list outputs exist and run on the

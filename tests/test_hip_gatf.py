@@ -177,9 +177,33 @@ def test_launch_count_drops_by_one_per_fused_layer():
         n0 = lib.dvgr_dbg_launch_count()
         _forward(m, inp, 3)
         counts[fused] = lib.dvgr_dbg_launch_count() - n0
-    # two-stream mode: layer 0 keeps two launches (its gate waits for the query chain), layers 1 .. L - 1 are fused; the same
-    # flag also selects S6 as one launch (k_mfb_fwd: linear0 / linear1 + ELU + pooling) instead of contraction + pooling kernel
-    assert counts[False] - counts[True] == (Lr - 1) + 1, counts
+    # every layer is fused -- round 6: layer 0 too, its share of the query side S0 runs in front of it on the caller's stream
+    # (DVGR_OPT_S0_ON_SIDE, the form of rounds 1-5, kept two launches for layer 0); the same flag also selects S6 as one launch
+    # (k_mfb_fwd: linear0 / linear1 + ELU + pooling) instead of contraction + pooling kernel
+    assert counts[False] - counts[True] == Lr + 1, counts
+
+
+@pytest.mark.parametrize("B,N,Lr,train", [(9, 20, 3, True), (17, 8, 2, False), (1, 20, 1, True)])
+def test_s0_placements_agree(B, N, Lr, train):
+    """Where the query side S0 runs (include/dvgr.h: default = layer 0's share on the caller's stream, the rest on the side stream;
+    DVGR_OPT_S0_ON_MAIN; DVGR_OPT_S0_ON_SIDE = rounds 1-5) changes streams and the batching of its kernels over the layers, not
+    its arithmetic: saved query tensors and gates bit-identical, outputs equal (layer 0 runs the two-launch form under
+    DVGR_OPT_S0_ON_SIDE: the attention's reductions in another order)."""
+    sd_np = synth.xavier_state_dict(O.param_shapes(WD, D, Lr), seed=49, bias_range=0.05)
+    inp = synth.unit_inputs(B, N, T, D, WD, seed=49)
+    dims = L.make_dims(B, N, T, D, WD, Lr)
+    got = {}
+    for where in ("split", "main", "side"):
+        m = _module(N, Lr, "bf16x3", sd_np, train, True)
+        m.s0_where = where
+        outs = _forward(m, inp, 88)
+        gates = [_saved(m, dims, L.S_S, l, mi, (B, N)) for l in range(Lr) for mi in range(2)]
+        got[where] = ([outs[0].cpu()] + [x.cpu() for x in outs[3]] + [x.cpu() for x in outs[5]], gates)
+    for where in ("main", "side"):
+        for a, b in zip(got["split"][1], got[where][1]):
+            assert torch.equal(a, b), where
+        worst = max(rel_err(a, b) for a, b in zip(got["split"][0], got[where][0]))
+        assert worst < (1e-12 if where == "main" else 5e-6), (where, worst)
 
 
 @pytest.mark.parametrize("B,N,Lr,train", [(64, 20, 2, True), (32, 8, 2, False), (7, 20, 2, True)])
