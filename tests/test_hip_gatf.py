@@ -200,10 +200,17 @@ def test_s0_placements_agree(B, N, Lr, train):
         gates = [_saved(m, dims, L.S_S, l, mi, (B, N)) for l in range(Lr) for mi in range(2)]
         got[where] = ([outs[0].cpu()] + [x.cpu() for x in outs[3]] + [x.cpu() for x in outs[5]], gates)
     for where in ("main", "side"):
-        for a, b in zip(got["split"][1], got[where][1]):
-            assert torch.equal(a, b), where
+        for i, (a, b) in enumerate(zip(got["split"][1], got[where][1])):
+            # layer 0's gates come straight from S0: bit-identical everywhere; the later layers' gates are computed from X', which
+            # under "side" went through layer 0's two-launch attention (another reduction order)
+            if where == "main" or i < 2:
+                assert torch.equal(a, b), (where, i)
+            else:
+                assert rel_err(a, b) < 5e-6, (where, i)
         worst = max(rel_err(a, b) for a, b in zip(got["split"][0], got[where][0]))
-        assert worst < (1e-12 if where == "main" else 5e-6), (where, worst)
+        # ("side": layer 0 in the two-launch form -- below 128 rows its projection runs on the batch-sized exact-fp32 kernels,
+        # equal to the bf16x3 planes' operand rounding only)
+        assert worst < (1e-12 if where == "main" else 2e-5), (where, worst)
 
 
 @pytest.mark.parametrize("B,N,Lr,train", [(64, 20, 2, True), (32, 8, 2, False), (7, 20, 2, True)])
