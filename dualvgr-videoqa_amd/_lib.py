@@ -70,6 +70,7 @@ OPT_NO_HALF_GAT_TILES = 1024
 OPT_NO_FOLDED_PUNISH = 2048
 OPT_S0_ON_MAIN = 4096
 OPT_S0_ON_SIDE = 8192
+OPT_DP_ON_MAIN = 16384
 
 # enum dvgr_probe_site
 (PROBE_NONE, PROBE_FWD_QA_GEMM, PROBE_FWD_GAT_GEMM, PROBE_FWD_GAT_ATTN, PROBE_FWD_SF_GEMM, PROBE_FWD_MFB_GEMM,

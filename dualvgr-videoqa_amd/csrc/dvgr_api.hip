@@ -1202,6 +1202,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
   // ---- layers, last to first -----------------------------------------------------------------------
   hipEvent_t side_done[2] = {nullptr, nullptr};   // side stream finished the layer that used buffer set 0 / 1
   const bool fold_punish = G == 1 && !(O.flags & DVGR_OPT_NO_FOLDED_PUNISH);
+  const bool dp_side = side && fold_punish && !(O.flags & DVGR_OPT_DP_ON_MAIN);
   int fold_layer = -1;                             // the layer whose dX half of the S1 backward the next k_sf_bwd completes
   for (int l = L - 1; l >= 0; --l) {
     const int set = l & 1;
@@ -1423,7 +1424,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       DVGR_TRY(dz_build(st, a));
     }
     if (!fuse_bwd) DVGR_TRY(attn_bwd(0));
-    auto punish = [&](int parts) -> int {   // S1 backward: bit 0 = d p (kept per layer for the query branch), bit 1 = dX
+    auto punish = [&](int parts, hipStream_t on) -> int {   // S1 backward: bit 0 = d p (kept per layer for the query branch), bit 1 = dX
       PunishBwdArgs a{};
       for (int m = 0; m < 2; ++m) {
         a.ds_part[m] = ws + W.ds_part[set][m]; a.s[m] = ms(l, m) + S.s; a.p[m] = ms(l, m) + S.p;
@@ -1433,15 +1434,18 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       a.dp_cat = ws + W.dp_cat + (int64_t)l * B * 2 * D; a.B = B; a.N = N; a.D = D; a.parts = parts;
       a.zero = (parts & 1) ? ws + W.dqbar + (int64_t)l * B * Wd : nullptr; a.zero_cols = Wd;   // dq-bar accumulates split-K partials
       a.copies = G;
-      return punish_bwd(st, a);
+      return punish_bwd(on, a);
     };
-    if (l == 0) DVGR_TRY(punish(1));        // layer 0 is the last one: its query chain must not wait for the dX chain
+    if (l == 0) DVGR_TRY(punish(1, st));        // layer 0 is the last one: its query chain must not wait for the dX chain (both other streams read its d p: it stays in front of their fork)
     // dw, the attention's small partials and (layer 0) d p are final: the side stream takes the column sums of the small
     // vector gradients (p2, a, c) and layer 0's query chain.  The side stream carries NO large contraction: two
     // contractions at once only slow each other down (both are bound by the compute units' global -> LDS path; measured:
     // a weight-gradient launch of 35 us alone took 95-105 us beside the critical path's kernels and slowed those by a
     // third), so every 240-tile contraction stays on the main stream and the side stream fills in latency-bound kernels.
     if (l == 0) DVGR_TRY(to_side_and_query()); else DVGR_TRY(to_side());
+    // d p of a layer >= 1 has one reader, the query branch on the query / side stream: its launch goes to the side stream as well
+    // (round 6; nothing on the caller's stream waits for it -- the dX half of the S1 backward is the next layer's k_sf_bwd)
+    if (l >= 1 && dp_side) DVGR_TRY(punish(1, hs));
     ColsumBatch cb{};
     for (int m = 0; m < 2; ++m) {
       cb.j[cb.n++] = ColsumJob{ms(l, m) + S.tn, nullptr, ws + W.dw[set][m], nullptr, 2 * BN, 0, D, D, gmp(l, m) + P.sf_p2};
@@ -1491,10 +1495,11 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     // Layers >= 1 (graph_layers 1): only d p here; the dX half -- dX += dtau p + the specific GAT's partial -- is done by the NEXT
     // layer's k_sf_bwd on the rows it reads anyway (round 6: one kernel of ~20 us fewer on the critical path per layer >= 1).
     // Layer 0's dX is the call's output: its dX half stays a launch of its own.
-    if (l >= 1 && fold_punish) { DVGR_TRY(punish(1)); fold_layer = l; }
-    else DVGR_TRY(punish(l == 0 ? 2 : 3));
+    if (l >= 1 && fold_punish) { if (!dp_side) DVGR_TRY(punish(1, st)); fold_layer = l; }
+    else DVGR_TRY(punish(l == 0 ? 2 : 3, st));   // (layer 0's dX half on the side stream beside its weight-gradient launch: C2 +2.8 %, C3 -1.0 %, C4 -0.4 %: not kept)
     if (l == 1) {                           // every d p of the layers >= 1 exists: their query branch, under layer 0
       DVGR_TRY(to_query());
+      if (dp_side && qs != hs) DVGR_TRY(side->order(hs, qs));     // (the d p of the layers >= 1 were written on the side stream)
       DVGR_TRY(query_branch(1, L, 1));
     }
     // every weight gradient of the layer as ONE launch: dP1 = sum_v dpre_v^T . z_v (two row segments) and

@@ -274,6 +274,9 @@ enum dvgr_probe_site {
  * the caller's stream, rows + Wq on the side stream under layer 0's separate projection, joined in front of the gate). */
 #define DVGR_OPT_S0_ON_MAIN 4096
 #define DVGR_OPT_S0_ON_SIDE 8192
+/* With the folded S1 backward the d p launch of a layer >= 1 has one reader, the query branch, and runs on the side stream
+ * (round 6).  DVGR_OPT_DP_ON_MAIN keeps it on the caller's stream behind the dX contraction (A/B timing). */
+#define DVGR_OPT_DP_ON_MAIN 16384
 
 /* Scope-U loss evaluated by the forward itself (dvgr_opts.loss): the same arithmetic and outputs as
  * dvgr_scope_u_loss below, but the kernels are enqueued as soon as the last layer's list outputs exist and run on the
