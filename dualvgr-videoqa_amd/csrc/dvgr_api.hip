@@ -461,6 +461,12 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
   const int G = d.G;
   const bool lean = lean_planes(PM.on, BN, G);
   bool loss3_cleared = false;            // the loss scalars were zeroed by the input split kernel (else: a memset of aux_losses)
+  (void)stop_event_rode();               // (no armed stop event survives from an earlier call of this thread that failed half-way)
+  SideStream* side = (O.flags & DVGR_OPT_SINGLE_STREAM) ? nullptr : side_stream(st);
+  hipStream_t hs = side ? side->st : st;
+  // the fork behind the input split (the other layers' share of S0 starts there, below): its event rides on the split kernel's dispatch
+  hipEvent_t split_ev = nullptr;
+  bool split_rode = false;
   if (PM.on) {                           // bf16 hi/lo planes of the caller's inputs
     SplitBatch sb{};
     sb.lo_off = S.total;
@@ -480,12 +486,17 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
         }
     }
     if (O.loss && O.loss->loss3) { sb.zero3 = O.loss->loss3; loss3_cleared = true; }   // before anything adds into them
-    DVGR_TRY(split_planes(st, sb));
+    if (side && L > 1 && !(O.flags & (DVGR_OPT_S0_ON_SIDE | DVGR_OPT_S0_ON_MAIN))) {
+      split_ev = side->next();
+      if (!split_ev) return (int)hipErrorOutOfMemory;
+      arm_stop(split_ev, st);
+    }
+    const int e_split = split_planes(st, sb);
+    split_rode = stop_event_rode();
+    if (e_split) return e_split;
   }
 
   // ---- S0: query side of every layer: the contraction Y_l = dq . W1_l^T, the row kernels, the small Wq contraction (below).
-  SideStream* side = (O.flags & DVGR_OPT_SINGLE_STREAM) ? nullptr : side_stream(st);
-  hipStream_t hs = side ? side->st : st;
   const Probe fprobe{O, st};
   auto y_gemm = [&](int la, int lb_, hipStream_t on) -> int {   // Y_l = dq W1_l^T + b1_l for the layers [la, lb_)
     for (int l0 = la; l0 < lb_; l0 += kMaxBatch) {
@@ -539,7 +550,8 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
     DVGR_TRY(qa_rows(0, L, hs));
     DVGR_TRY(wq_gemm(0, L, hs));
   } else {
-    DVGR_TRY(side->order(st, hs));                           // (behind the input split: the planes of dq exist)
+    if (split_ev) DVGR_TRY(side->order_armed(st, hs, split_ev, split_rode));   // (behind the input split: the planes of dq exist)
+    else DVGR_TRY(side->order(st, hs));
     DVGR_TRY(y_gemm(1, L, hs));
     DVGR_TRY(qa_rows(1, L - 1, hs));
     DVGR_TRY(wq_gemm(1, L, hs));
@@ -564,7 +576,15 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
   auto fuse_gat = [&](int l, int j) { return fuse_ok && !(side && !s0_main && l == 0 && j == 0); };
   auto gs_ = [&](int l, int m, int j) { return ms(l, m) + S.g_stride * j; };                   // saved block of graph layer j
   int aux_done = 0;                      // unit layers whose list entries have gone to the auxiliary-loss kernels
+#ifdef DVGR_TIMING_AIDS
+  static const int aux_group_env = []() { const char* e = getenv("DVGR_AUX_GROUP"); return e ? atoi(e) : 0; }();   // A/B timing aid
+  const int aux_group = aux_group_env > 0 ? aux_group_env : 1;
+#else
+  constexpr int aux_group = 1;           // unit layers per loss group (see below)
+#endif
   for (int l = 0; l < L; ++l) {
+    hipEvent_t aux_ev = nullptr;         // the loss group's fork, when it rides on the layer's fused GAT-view launch
+    bool aux_rode = false;
     const float* Xin[2] = {l == 0 ? io->A : ms(l - 1, 0) + S.x, l == 0 ? io->M : ms(l - 1, 1) + S.x};
     float* outc[2] = {nullptr, nullptr};
     float* outs[2] = {nullptr, nullptr};
@@ -624,7 +644,15 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
       fa.x_lo_off = xlo; fa.w_lo_off = wlo;
       a.B = B; a.N = N; a.D = D;
       DVGR_TRY(fprobe.begin(DVGR_PROBE_FWD_GAT_GEMM, l));
-      DVGR_TRY(gat_fused_fwd(st, fa, prec));
+      // the loss group's fork follows this launch (the layer's last graph step): its event rides on the launch
+      if (side && O.loss && j == G - 1 && ((l + 1) % aux_group == 0 || l == L - 1)) {
+        aux_ev = side->next();
+        if (!aux_ev) return (int)hipErrorOutOfMemory;
+        arm_stop(aux_ev, st);
+      }
+      const int e_gat = gat_fused_fwd(st, fa, prec);
+      aux_rode = stop_event_rode();
+      if (e_gat) return e_gat;
       DVGR_TRY(fprobe.end(DVGR_PROBE_FWD_GAT_GEMM, l));
     } else {
       GemmBatch gb{};
@@ -674,16 +702,11 @@ int dvgr_unit_forward(const dvgr_dims* dp, const float* params, const void* para
     // with S6 as one launch and sum(vis) inside the out contraction the tail is the loss chain (80 us at C2 for all three
     // layers at once, starting 12 us behind the last GAT kernel): one layer per group (experiments_r04.tsv, aux_groups_*:
     // C2 1.0065 ms against 1.0085 for one group of three; C5 9.177 against 9.205 in threes and 9.237 for all twelve at once).
-#ifdef DVGR_TIMING_AIDS
-    static const int aux_group_env = []() { const char* e = getenv("DVGR_AUX_GROUP"); return e ? atoi(e) : 0; }();   // A/B timing aid
-    const int aux_group = aux_group_env > 0 ? aux_group_env : 1;
-#else
-    constexpr int aux_group = 1;
-#endif
     if (O.loss && ((l + 1) % aux_group == 0 || l == L - 1)) {
       const dvgr_loss_spec& Q = *O.loss;
       if (!Q.loss3 || !Q.g_com_app || !Q.g_com_mot || !Q.g_aq_fusion || !Q.g_mq_fusion) return DVGR_E_NULL;
-      if (side) DVGR_TRY(side->order(st, hs));
+      if (side && aux_ev) DVGR_TRY(side->order_armed(st, hs, aux_ev, aux_rode));
+      else if (side) DVGR_TRY(side->order(st, hs));
       dvgr_io lio = *io;
       lio.vis = nullptr;                   // sum(vis) follows at the very end
       float* const gl[4] = {Q.g_com_app, Q.g_com_mot, Q.g_aq_fusion, Q.g_mq_fusion};
@@ -904,13 +927,30 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
   // event calls (C1, B N = 160: 0.43 ms per step without it, 0.48 ms with it).
   const bool use_qs = !(O.flags & DVGR_OPT_NO_QUERY_STREAM) && BND >= (int64_t)512 * 768;
   hipStream_t qs = side ? side->query(use_qs) : st;
-  auto to_side = [&]() -> int { return side ? side->order(st, hs) : 0; };     // hs continues after st's work so far
+  (void)stop_event_rode();               // (no armed stop event survives from an earlier call of this thread that failed half-way)
+  // the per-layer fork behind the fused backward launch (layer 0: behind its d p launch) rides on that launch's dispatch
+  hipEvent_t fork_ev = nullptr;
+  bool fork_rode = false;
+  auto arm_fork = [&]() -> int {
+    fork_ev = nullptr; fork_rode = false;
+    if (!side) return 0;
+    fork_ev = side->next();
+    if (!fork_ev) return (int)hipErrorOutOfMemory;
+    arm_stop(fork_ev, st);
+    return 0;
+  };
+  auto to_side = [&]() -> int {                                               // hs continues after st's work so far
+    if (!side) return 0;
+    if (fork_ev) { const int r = side->order_armed(st, hs, fork_ev, fork_rode); fork_ev = nullptr; return r; }
+    return side->order(st, hs);
+  };
   auto to_main = [&]() -> int { return side ? side->order(hs, st) : 0; };     // st continues after hs's work so far
   auto to_side_and_query = [&]() -> int {                                     // one record on st, both other streams wait
     if (!side) return 0;
-    hipEvent_t e = side->next();
+    hipEvent_t e = fork_ev ? fork_ev : side->next();
     if (!e) return (int)hipErrorOutOfMemory;
-    hipError_t r = hipEventRecord(e, st);
+    hipError_t r = (fork_ev && fork_rode) ? hipSuccess : hipEventRecord(e, st);
+    fork_ev = nullptr;
     if (r == hipSuccess) r = hipStreamWaitEvent(hs, e, 0);
     if (r == hipSuccess && qs != hs) r = hipStreamWaitEvent(qs, e, 0);
     return (int)r;
@@ -1296,7 +1336,10 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       fa.a_lo_off = alo; fa.b_lo_off = p1t_lo;
       a.B = B; a.N = N; a.D = D;
       DVGR_TRY(probe.begin(DVGR_PROBE_BWD_SF_DX, l));
-      DVGR_TRY(gat_fused_bwd(st, fa, prec));
+      if (l > 0) DVGR_TRY(arm_fork());          // (layer 0: its d p launch follows on this stream, the fork rides on that one)
+      const int e_gatb = gat_fused_bwd(st, fa, prec);
+      if (l > 0) fork_rode = stop_event_rode();
+      if (e_gatb) return e_gatb;
       DVGR_TRY(probe.end(DVGR_PROBE_BWD_SF_DX, l));
     } else
     {
@@ -1436,7 +1479,12 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
       a.copies = G;
       return punish_bwd(on, a);
     };
-    if (l == 0) DVGR_TRY(punish(1, st));        // layer 0 is the last one: its query chain must not wait for the dX chain (both other streams read its d p: it stays in front of their fork)
+    if (l == 0) {                               // layer 0 is the last one: its query chain must not wait for the dX chain (both other streams read its d p: it stays in front of their fork)
+      DVGR_TRY(arm_fork());
+      const int e_p = punish(1, st);
+      fork_rode = stop_event_rode();
+      if (e_p) return e_p;
+    }
     // dw, the attention's small partials and (layer 0) d p are final: the side stream takes the column sums of the small
     // vector gradients (p2, a, c) and layer 0's query chain.  The side stream carries NO large contraction: two
     // contractions at once only slow each other down (both are bound by the compute units' global -> LDS path; measured:

@@ -1,6 +1,7 @@
 // dvgr_common.h -- layouts (host) and device helpers shared by every translation unit.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -45,6 +46,38 @@ inline bool launch_skipped(const char* what) {
   do {                                                                      \
     ::dvgr::g_launch_count.fetch_add(1, std::memory_order_relaxed);         \
     hipLaunchKernelGGL(__VA_ARGS__);                                        \
+  } while (0)
+#endif
+
+// A fork right behind ONE kernel (the side stream continues after it) need not put an event-record packet between that kernel and
+// the next one of its stream: the event can ride on the kernel's own dispatch (hipExtLaunchKernelGGL's stopEvent).  Measured
+// (tools/micro/fork_cost.hip, profiles/r06_fork_cost.txt): +1.7 us per fork for the forking stream instead of +2.6.  Protocol, one
+// thread: arm_stop(event, stream) -> call a launch function whose launch is a DVGR_LAUNCH_FORKABLE on that stream ->
+// stop_event_rode() says whether the event went out with it (else the caller records it the ordinary way: the launch was a
+// different one, was skipped, or the function launched nothing).
+struct ArmedStop { hipEvent_t ev; hipStream_t st; bool used; };
+inline thread_local ArmedStop g_armed_stop{nullptr, nullptr, false};
+inline void arm_stop(hipEvent_t e, hipStream_t s) { g_armed_stop = ArmedStop{e, s, false}; }
+inline bool stop_event_rode() { const bool u = g_armed_stop.used; g_armed_stop = ArmedStop{nullptr, nullptr, false}; return u; }
+// (one by-value argument: the kernels of the launch functions this is used in take a single struct)
+#ifdef DVGR_TIMING_AIDS
+#define DVGR_LAUNCH_FORKABLE(kern, grid, block, lds, stream, arg)                                                        \
+  do {                                                                                                                   \
+    if (::dvgr::launch_skipped(#kern)) break;                                                                            \
+    ::dvgr::g_launch_count.fetch_add(1, std::memory_order_relaxed);                                                      \
+    if (::dvgr::g_armed_stop.ev && !::dvgr::g_armed_stop.used && ::dvgr::g_armed_stop.st == (stream)) {                  \
+      hipExtLaunchKernelGGL(kern, grid, block, lds, stream, nullptr, ::dvgr::g_armed_stop.ev, 0, arg);                   \
+      ::dvgr::g_armed_stop.used = true;                                                                                  \
+    } else hipLaunchKernelGGL(kern, grid, block, lds, stream, arg);                                                      \
+  } while (0)
+#else
+#define DVGR_LAUNCH_FORKABLE(kern, grid, block, lds, stream, arg)                                                        \
+  do {                                                                                                                   \
+    ::dvgr::g_launch_count.fetch_add(1, std::memory_order_relaxed);                                                      \
+    if (::dvgr::g_armed_stop.ev && !::dvgr::g_armed_stop.used && ::dvgr::g_armed_stop.st == (stream)) {                  \
+      hipExtLaunchKernelGGL(kern, grid, block, lds, stream, nullptr, ::dvgr::g_armed_stop.ev, 0, arg);                   \
+      ::dvgr::g_armed_stop.used = true;                                                                                  \
+    } else hipLaunchKernelGGL(kern, grid, block, lds, stream, arg);                                                      \
   } while (0)
 #endif
 

@@ -709,7 +709,7 @@ static int gatb_launch(hipStream_t st, const GatFusedBwdArgs& a, const GatfShape
   }
   const int mtiles = (a.at.B + a.spt - 1) / a.spt;
   const int total = mtiles * kHeads * 2;
-  DVGR_LAUNCH((k_gat_fused_bwd<TERMS, MTILES, NT, NTC, FROM_DX, LO8, KB>), dim3(8 * ((total + 7) / 8)), dim3(768), lds, st, a);
+  DVGR_LAUNCH_FORKABLE((k_gat_fused_bwd<TERMS, MTILES, NT, NTC, FROM_DX, LO8, KB>), dim3(8 * ((total + 7) / 8)), dim3(768), lds, st, a);
   DVGR_LAUNCH_CHECK();
 }
 

@@ -388,7 +388,7 @@ static int gatf_launch(hipStream_t st, const GatFusedArgs& a) {
   }
   const int mtiles = (a.at.B + a.spt - 1) / a.spt;
   const int total = mtiles * kHeads * 2;
-  DVGR_LAUNCH((k_gat_fused_fwd<TERMS, MTILES, NT, NTC, LO8, KB>), dim3(8 * ((total + 7) / 8)), dim3(768), lds, st, a);
+  DVGR_LAUNCH_FORKABLE((k_gat_fused_fwd<TERMS, MTILES, NT, NTC, LO8, KB>), dim3(8 * ((total + 7) / 8)), dim3(768), lds, st, a);
   DVGR_LAUNCH_CHECK();
 }
 

@@ -104,6 +104,13 @@ struct SideStream {
     if (!ev[used] && hipEventCreateWithFlags(&ev[used], kEventFlags) != hipSuccess) return nullptr;
     return ev[used++];
   }
+  // order() for a fork right behind ONE launch: `e` was armed (arm_stop) before that launch; if it rode on the kernel's dispatch only
+  // the wait is enqueued, else the ordinary record + wait
+  int order_armed(hipStream_t from, hipStream_t to, hipEvent_t e, bool rode) {
+    hipError_t r = rode ? hipSuccess : hipEventRecord(e, from);
+    if (r == hipSuccess) r = hipStreamWaitEvent(to, e, 0);
+    return (int)r;
+  }
   // everything enqueued on `from` so far happens before whatever is enqueued on `to` from now on
   int order(hipStream_t from, hipStream_t to) {
     hipEvent_t e = next();

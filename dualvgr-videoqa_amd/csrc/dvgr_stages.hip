@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(256) void k_punish_bwd(const PunishBwdArgs a) {
   if (parts & 1) a.dp_cat[(int64_t)b * 2 * D + mod * D + d] = acc;
 }
 int punish_bwd(hipStream_t st, const PunishBwdArgs& a) {
-  DVGR_LAUNCH(k_punish_bwd, dim3(a.B, 2, (a.D + 255) / 256), dim3(256), 0, st, a);
+  DVGR_LAUNCH_FORKABLE(k_punish_bwd, dim3(a.B, 2, (a.D + 255) / 256), dim3(256), 0, st, a);
   DVGR_LAUNCH_CHECK();
 }
 
@@ -1315,7 +1315,7 @@ int split_planes(hipStream_t st, const SplitBatch& b) {
   int64_t mx = 0;
   for (int i = 0; i < b.n; ++i) mx = b.j[i].n > mx ? b.j[i].n : mx;
   const int64_t blocks = (mx / 4 + 255) / 256;
-  DVGR_LAUNCH(k_split_planes, dim3((unsigned)(blocks > 2048 ? 2048 : blocks), b.n), dim3(256), 0, st, b);
+  DVGR_LAUNCH_FORKABLE(k_split_planes, dim3((unsigned)(blocks > 2048 ? 2048 : blocks), b.n), dim3(256), 0, st, b);
   DVGR_LAUNCH_CHECK();
 }
 
