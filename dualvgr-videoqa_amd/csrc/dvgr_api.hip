@@ -1073,7 +1073,16 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
   {
     uint16_t* q0 = PM.out(ws + W.dp0, &plo);
     uint16_t* q1 = PM.out(ws + W.dp1, &plo);
-    DVGR_TRY(mfb_pool_bwd(st, ws + W.dzf, saved + S.mfb_x0, saved + S.mfb_x1, ws + W.dp0, ws + W.dp1, BN, q0, q1, plo));
+    // (two streams: the fork of the MFB weight gradients follows this launch and rides on it)
+    hipEvent_t mfb_ev = nullptr;
+    if (side) {
+      mfb_ev = side->next();
+      if (!mfb_ev) return (int)hipErrorOutOfMemory;
+      arm_stop(mfb_ev, st);
+    }
+    const int e_pool = mfb_pool_bwd(st, ws + W.dzf, saved + S.mfb_x0, saved + S.mfb_x1, ws + W.dp0, ws + W.dp1, BN, q0, q1, plo);
+    const bool mfb_rode = stop_event_rode();
+    if (e_pool) return e_pool;
     // dA = dp0 . W0, dM = dp1 . W1 and the three MFB weight gradients (+ their biases) in ONE launch
     GemmBatch gb{};
     BiasOf bias[kMaxBatch] = {};
@@ -1101,7 +1110,7 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
         if (gb.p[i].layout == LAYOUT_TN) { bt[gt.n] = bias[i]; gt.p[gt.n++] = gb.p[i]; }
         else gn.p[gn.n++] = gb.p[i];
       }
-      DVGR_TRY(side->order(st, hs));
+      DVGR_TRY(side->order_armed(st, hs, mfb_ev, mfb_rode));
       DVGR_TRY(p1_transposed(hs));           // (first thing on the side stream: the last layer's fused kernel waits for it)
       DVGR_TRY(gemm_launch(st, KC, IC, gn, TAG_GENERIC, prec));
       DVGR_TRY(launch_dw(hs, gt, bt, TAG_GENERIC, cb));
@@ -1546,6 +1555,8 @@ int dvgr_unit_backward(const dvgr_dims* dp, const float* params, const void* par
     if (l >= 1 && fold_punish) { if (!dp_side) DVGR_TRY(punish(1, st)); fold_layer = l; }
     else DVGR_TRY(punish(l == 0 ? 2 : 3, st));   // (layer 0's dX half on the side stream beside its weight-gradient launch: C2 +2.8 %, C3 -1.0 %, C4 -0.4 %: not kept)
     if (l == 1) {                           // every d p of the layers >= 1 exists: their query branch, under layer 0
+      // (with d p on the side stream this fork of the caller's stream orders nothing the branch needs -- but without it the branch
+      // starts one contraction earlier, beside the dX launch, and C2 is 1.4 % slower: it stays)
       DVGR_TRY(to_query());
       if (dp_side && qs != hs) DVGR_TRY(side->order(hs, qs));     // (the d p of the layers >= 1 were written on the side stream)
       DVGR_TRY(query_branch(1, L, 1));

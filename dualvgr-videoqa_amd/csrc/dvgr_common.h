@@ -59,25 +59,25 @@ struct ArmedStop { hipEvent_t ev; hipStream_t st; bool used; };
 inline thread_local ArmedStop g_armed_stop{nullptr, nullptr, false};
 inline void arm_stop(hipEvent_t e, hipStream_t s) { g_armed_stop = ArmedStop{e, s, false}; }
 inline bool stop_event_rode() { const bool u = g_armed_stop.used; g_armed_stop = ArmedStop{nullptr, nullptr, false}; return u; }
-// (one by-value argument: the kernels of the launch functions this is used in take a single struct)
+// (the arguments must have the kernel's parameter types exactly: hipExtLaunchKernelGGL deduces them from both sides)
 #ifdef DVGR_TIMING_AIDS
-#define DVGR_LAUNCH_FORKABLE(kern, grid, block, lds, stream, arg)                                                        \
+#define DVGR_LAUNCH_FORKABLE(kern, grid, block, lds, stream, ...)                                                        \
   do {                                                                                                                   \
     if (::dvgr::launch_skipped(#kern)) break;                                                                            \
     ::dvgr::g_launch_count.fetch_add(1, std::memory_order_relaxed);                                                      \
     if (::dvgr::g_armed_stop.ev && !::dvgr::g_armed_stop.used && ::dvgr::g_armed_stop.st == (stream)) {                  \
-      hipExtLaunchKernelGGL(kern, grid, block, lds, stream, nullptr, ::dvgr::g_armed_stop.ev, 0, arg);                   \
+      hipExtLaunchKernelGGL(kern, grid, block, lds, stream, nullptr, ::dvgr::g_armed_stop.ev, 0, __VA_ARGS__);                   \
       ::dvgr::g_armed_stop.used = true;                                                                                  \
-    } else hipLaunchKernelGGL(kern, grid, block, lds, stream, arg);                                                      \
+    } else hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);                                                      \
   } while (0)
 #else
-#define DVGR_LAUNCH_FORKABLE(kern, grid, block, lds, stream, arg)                                                        \
+#define DVGR_LAUNCH_FORKABLE(kern, grid, block, lds, stream, ...)                                                        \
   do {                                                                                                                   \
     ::dvgr::g_launch_count.fetch_add(1, std::memory_order_relaxed);                                                      \
     if (::dvgr::g_armed_stop.ev && !::dvgr::g_armed_stop.used && ::dvgr::g_armed_stop.st == (stream)) {                  \
-      hipExtLaunchKernelGGL(kern, grid, block, lds, stream, nullptr, ::dvgr::g_armed_stop.ev, 0, arg);                   \
+      hipExtLaunchKernelGGL(kern, grid, block, lds, stream, nullptr, ::dvgr::g_armed_stop.ev, 0, __VA_ARGS__);                   \
       ::dvgr::g_armed_stop.used = true;                                                                                  \
-    } else hipLaunchKernelGGL(kern, grid, block, lds, stream, arg);                                                      \
+    } else hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);                                                      \
   } while (0)
 #endif
 

@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void k_mfb_pool_bwd(const float* dz, const flo
 int mfb_pool_bwd(hipStream_t st, const float* dz, const float* x0, const float* x1, float* dp0, float* dp1, int rows,
                  uint16_t* p0, uint16_t* p1, int64_t lo_off) {
   const int64_t n = (int64_t)rows * kMfbPooled;
-  DVGR_LAUNCH(k_mfb_pool_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dz, x0, x1, dp0, dp1, n, p0, p1, lo_off);
+  DVGR_LAUNCH_FORKABLE(k_mfb_pool_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dz, x0, x1, dp0, dp1, n, p0, p1, lo_off);
   DVGR_LAUNCH_CHECK();
 }
 
