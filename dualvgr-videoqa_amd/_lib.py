@@ -71,6 +71,7 @@ OPT_NO_FOLDED_PUNISH = 2048
 OPT_S0_ON_MAIN = 4096
 OPT_S0_ON_SIDE = 8192
 OPT_DP_ON_MAIN = 16384
+OPT_FORKS_BY_RECORD = 32768
 
 # enum dvgr_probe_site
 (PROBE_NONE, PROBE_FWD_QA_GEMM, PROBE_FWD_GAT_GEMM, PROBE_FWD_GAT_ATTN, PROBE_FWD_SF_GEMM, PROBE_FWD_MFB_GEMM,

@@ -350,6 +350,7 @@ class DualVGRUnit_multiple(nn.Module):
         self.fused_gat_bwd = not bool(int(os.environ.get("DVGR_NO_FUSED_GAT_BWD", "0")))
         if self.fused_gat_bwd and os.environ.get("DVGR_FORCE_FUSED_GAT_BWD", "0") == "1":
             self.fused_gat_bwd = "force"
+        self.forks_by_record = bool(int(os.environ.get("DVGR_FORKS_BY_RECORD", "0")))       # True: DVGR_OPT_FORKS_BY_RECORD
         self.dp_on_main = bool(int(os.environ.get("DVGR_DP_ON_MAIN", "0")))                 # True: DVGR_OPT_DP_ON_MAIN (d p launches of the layers >= 1 on the caller's stream)
         self.s0_where = os.environ.get("DVGR_S0", "split")         # "split" (default) | "main" (DVGR_OPT_S0_ON_MAIN) | "side" (DVGR_OPT_S0_ON_SIDE: rounds 1-5)
         self.folded_punish = not bool(int(os.environ.get("DVGR_NO_FOLDED_PUNISH", "0")))     # False: DVGR_OPT_NO_FOLDED_PUNISH (the S1 backward's dX half as a launch of its own)
@@ -662,6 +663,8 @@ class DualVGRUnit_multiple(nn.Module):
             o.flags |= L_.OPT_NO_HALF_GAT_TILES
         if not self.folded_punish:
             o.flags |= L_.OPT_NO_FOLDED_PUNISH
+        if self.forks_by_record:
+            o.flags |= L_.OPT_FORKS_BY_RECORD
         if self.dp_on_main:
             o.flags |= L_.OPT_DP_ON_MAIN
         if self.s0_where == "main":

@@ -277,6 +277,10 @@ enum dvgr_probe_site {
 /* With the folded S1 backward the d p launch of a layer >= 1 has one reader, the query branch, and runs on the side stream
  * (round 6).  DVGR_OPT_DP_ON_MAIN keeps it on the caller's stream behind the dX contraction (A/B timing). */
 #define DVGR_OPT_DP_ON_MAIN 16384
+/* A fork right behind one launch lets its event ride on that launch's dispatch (hipExtLaunchKernelGGL stop event: no record packet
+ * between the kernel and the next one of its stream; round 6).  DVGR_OPT_FORKS_BY_RECORD keeps hipEventRecord + wait everywhere:
+ * A/B timing, and counter collection -- a dispatch that carries an event reads longer by the signal's path in per-kernel timings. */
+#define DVGR_OPT_FORKS_BY_RECORD 32768
 
 /* Scope-U loss evaluated by the forward itself (dvgr_opts.loss): the same arithmetic and outputs as
  * dvgr_scope_u_loss below, but the kernels are enqueued as soon as the last layer's list outputs exist and run on the

@@ -38,8 +38,9 @@ int main(int argc, char** argv) {
   const char* flagnames[3] = {"DisableTiming|DisableSystemFence", "DisableTiming", "default (timing, system fence)"};
   std::vector<hipEvent_t> ev[3];
   for (int f = 0; f < 3; ++f) { ev[f].resize(K); for (int k = 0; k < K; ++k) CK(hipEventCreateWithFlags(&ev[f][k], flagsets[f])); }
-  hipEvent_t t0, t1;
+  hipEvent_t t0, t1, done_ev;
   CK(hipEventCreate(&t0)); CK(hipEventCreate(&t1));
+  CK(hipEventCreateWithFlags(&done_ev, hipEventDisableTiming | hipEventDisableSystemFence));
   uint32_t epoch = 0;
   auto run = [&](int mode, int fset, bool waiter) -> float {
     float best = 1e30f;
@@ -47,6 +48,11 @@ int main(int argc, char** argv) {
       (void)hipDeviceSynchronize();
       (void)hipEventRecord(t0, A);
       for (int k = 0; k < K; ++k) {
+        if (mode == 4) {           // a JOIN: the chain's stream waits for an event of the other stream that completed long ago
+          k_spin<<<256, 256, 0, A>>>(buf + 1024, iters);
+          (void)hipStreamWaitEvent(A, done_ev, 0);
+          continue;
+        }
         if (mode == 3) {
           hipExtLaunchKernelGGL(k_spin, dim3(256), dim3(256), 0, A, nullptr, ev[fset][k], 0, buf + 1024, iters);
           if (waiter) { (void)hipStreamWaitEvent(B, ev[fset][k], 0); k_tiny<<<1, 64, 0, B>>>(buf); }
@@ -73,6 +79,9 @@ int main(int argc, char** argv) {
     }
     return best * 1e3f;
   };
+  k_tiny<<<1, 64, 0, B>>>(buf);
+  CK(hipEventRecord(done_ev, B));
+  CK(hipDeviceSynchronize());
   const float base = run(0, 0, false);
   printf("chain of %d kernels (256 workgroups, %d iterations): %.0f us = %.2f us per kernel\n", K, iters, base, base / K);
   for (int f = 0; f < 3; ++f) {
@@ -84,6 +93,10 @@ int main(int argc, char** argv) {
     const float a = run(3, f, false), b = run(3, f, true);
     printf("  stop event ON the kernel's launch (hipExtLaunchKernelGGL), flags %-34s: +%.2f us per kernel;  with a waiting stream: +%.2f us\n", flagnames[f],
            (a - base) / K, (b - base) / K);
+  }
+  {
+    const float a = run(4, 0, false);
+    printf("  hipStreamWaitEvent on the chain's stream for an event that completed long ago (a join): +%.2f us per wait\n", (a - base) / K);
   }
   {
     const float a = run(2, 0, false), b = run(2, 0, true);

@@ -1,7 +1,8 @@
 #!/bin/bash
 # One GPU call's worth of evidence for a build: every bench configuration, rocprofv3 kernel trace (summary + one step's
 # timeline) and the three separate PMC passes of the default bench (MI355X_MICROARCH.md, rocprofv3 PMC slots), turned into
-# the text / JSON forms kept under profiles/.  Output: gpurun_out/<tag>/ (copy what is to be judged into profiles/).
+# the text / JSON forms kept under profiles/.  (The MFMA-busy pass runs with DVGR_FORKS_BY_RECORD=1: a dispatch that carries a fork's
+# stop event reads longer by the signal's path in GRBM_GUI_ACTIVE -- 0.195 instead of 0.217 at C2 -- while its kernel time is the same.)  Output: gpurun_out/<tag>/ (copy what is to be judged into profiles/).
 #   tools/round_evidence.sh <tag> [notests]
 set -o pipefail
 T=${1:-ev}; R=$PWD; O=$R/gpurun_out/$T; mkdir -p $O
@@ -17,7 +18,7 @@ export TMPDIR=/tmp; cd /tmp
 rocprofv3 --kernel-trace --stats -d $O/stats -o c2 -- python3 $R/bench.py --steps 20 --warmup 5 --min-seconds 0.5 --no-cpu-baseline > $O/stats.log 2>&1 || exit 1
 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o c2 -- python3 $R/bench.py --steps 4 --warmup 1 --min-seconds 0.2 --no-cpu-baseline > $O/pmc_fetch.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o c2 -- python3 $R/bench.py --steps 4 --warmup 1 --min-seconds 0.2 --no-cpu-baseline > $O/pmc_write.log 2>&1 || exit 1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_sq -o c2 -- python3 $R/bench.py --steps 4 --warmup 1 --min-seconds 0.2 --no-cpu-baseline > $O/pmc_sq.log 2>&1 || exit 1
+DVGR_FORKS_BY_RECORD=1 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_sq -o c2 -- python3 $R/bench.py --steps 4 --warmup 1 --min-seconds 0.2 --no-cpu-baseline > $O/pmc_sq.log 2>&1 || exit 1
 cd $R
 DB=$(find $O/stats -name "*.db" | head -1)
 python tools/rocpd_export.py stats $DB $O/kernel_stats.csv $O/summary.txt || exit 1
