@@ -403,6 +403,9 @@ def test_gemm_nn_several_problems_add_into_one_output(M, N, K, count, prec):
                                                   (0, 1280, 1536, 768, 2, 1),     # layer 0's projection: 2 problems, 2 x 2 blocks each
                                                   (0, 1024, 768, 768, 4, 2),      # C3's row count
                                                   (0, 1200, 768, 768, 4, 2),      # a partial last row tile
+                                                  (0, 512, 768, 768, 4, 2),       # C4's S4: 96 tiles -> the half-height (64-row) launch, 24 tiles per XCD
+                                                  (0, 4096, 768, 768, 4, 2),      # C5's S4: 384 tiles of 128 x 256, 48 per XCD (1.5 rounds)
+                                                  (1, 4096, 768, 768, 4, 4),      # C5's dX on the wide tiles
                                                   (0, 1280, 768, 768, 3, 2),      # 8 % 3 != 0: the default map runs
                                                   (2, 1536, 768, 1280, 2, 3)])
 def test_xcd_block_map_is_bit_identical(mode, M, N, K, count, tag):
